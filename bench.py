@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- the north-star hot path on N MI355X of one node.
+
+One "step" = one pass of the PathPlan_City DQN hot path over the whole env batch of a rank:
+    Q(s) for all envs  ->  fused epsilon-greedy  ->  fused HIP env step (update_PathPlan + state_PathPlan,
+    transition written straight into the device replay ring)  ->  device replay sample  ->  one learner update
+    (TD target, MSE, Adam, hard target copy; gradients all-reduced over RCCL when N > 1).
+Workload at --gpus 1: BASELINE.json configs[1] -- 16 384 vectorised envs, DQN, device replay of 1 M transitions.
+Multi-GPU is weak scaling: every rank owns its own 16 384-env shard + ring; the only exchange is the ~26 KB
+gradient bucket per update.
+
+Prints ONE JSON line (rank 0).  `value` = whole-job env-steps/s of the full loop (inputs resident in HBM);
+`roofline` is for the dominant kernel k_step; `cpu_baseline` times the CPU oracle port on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_AGENT_STEP = 604        # 137 B read + 467 B written, obs f32
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--envs", type=int, default=16384, help="envs per GPU (BASELINE configs[1]: 16384)")
+    p.add_argument("--batch", type=int, default=16384, help="learner batch per GPU per update")
+    p.add_argument("--replay", type=int, default=1 << 20, help="replay capacity in transitions per GPU")
+    p.add_argument("--trainer", default="dqn", choices=["dqn", "ddqn", "dueling"])
+    p.add_argument("--obs-dtype", default="f32", choices=["f32", "f16"])
+    p.add_argument("--eps", type=float, default=0.1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--env-only-iters", type=int, default=200)
+    return p.parse_args()
+
+
+def cpu_baseline(envs: int, seconds: float):
+    """The oracle port (oracle/uav_oracle.c, -O3 build) stepping the same workload on all host cores."""
+    from dqn_based_uav_3d_path_planer_amd.data import load_city26
+    from oracle import pyoracle as po
+    c = load_city26()
+    world = po.OracleWorld(c["buildings"], c["len"], c["width"], c["h"], fast=True)
+    params = dict(max_v=float(c["max_v"]), steering_angle=float(c["steering_angle"]), max_step=int(c["max_step"]),
+                  apf_enabled=0)
+    n = min(envs, 4096)
+    batch = po.OracleBatch(world, params, n)
+    head = np.random.default_rng(0).uniform(0, 2 * np.pi, len(c["start_goal"]))
+    batch.load_scenarios(c["start_goal"][:, :3], c["start_goal"][:, 3:], head, c["sub_goals"], c["n_sub"])
+    rng = np.random.default_rng(1)
+    cores = po.lib(fast=True).orc_max_threads()
+    batch.step(rng.uniform(-1, 1, n))          # warm-up (thread pool, page faults)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        a = rng.uniform(-1, 1, n)
+        batch.step(a, want_obs=True, nthreads=cores)
+        steps += n
+        # finished agents keep stepping from their terminal state (empty-list guard): same per-step cost class
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{steps} agent-steps ({n} envs, update_PathPlan + state_PathPlan, random steering, "
+                      f"no learner) in {dt:.1f} s; C port of the reference's Python env path, OpenMP"}
+
+
+def main():
+    args = parse()
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the env hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing, select_actions
+
+    obs_dtype = torch.float16 if args.obs_dtype == "f16" else torch.float32
+    env = make_city26_env(args.envs, device=dev, obs_dtype=obs_dtype)
+    ring = DeviceReplayRing(env, args.replay, discrete=True)
+    ring.reset(seed=1000 + rank)
+    net = "VAnet2" if args.trainer == "dueling" else "Qnet2"
+    torch.manual_seed(42)               # same initial weights on every rank
+    learner = DQNLearner({"NetWork": net, "w": "100", "hiden_dim": "64", "output": "3"}, args.trainer, device=dev,
+                         amp_dtype=torch.float16 if args.obs_dtype == "f16" else None)
+    seed = 7 + rank
+    counter = [0]
+    step_events = []
+
+    def one_step(record=False):
+        q = learner.q_values(ring.current_obs())
+        select_actions(env, q, args.eps, seed, counter[0], index_out=ring.current_action())
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ring.step_env(auto_reset=True)
+            e1.record()
+            step_events.append((e0, e1))
+        else:
+            ring.step_env(auto_reset=True)
+        batch = ring.sample(args.batch, seed, counter[0])
+        learner.learn(batch)
+        counter[0] += 1
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # untimed: a few frames of experience + warm-up of every kernel / allocator path
+    for _ in range(max(args.warmup, 2)):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(record=True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: k_step.  (a) HIP events around each launch inside the timed region, on the launch stream
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in step_events])) if step_events else float("nan")
+    # (b) env-only: back-to-back k_step launches between two events (adds ~1.5 us boundary per launch)
+    it = args.env_only_iters
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(it):
+        ring.step_env(auto_reset=True)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    env_only_ms = e0.elapsed_time(e1) / it
+
+    if rank == 0:
+        n_agents = env.N
+        total_env_steps = args.steps * n_agents * world_size
+        value = total_env_steps / dt
+        algo = ALGO_BYTES_PER_AGENT_STEP if args.obs_dtype == "f32" else 404
+        achieved = algo * n_agents / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec + learner updates/sec, PathPlan_City DQN",
+            "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "learner_updates_per_s": args.steps / dt,
+            "learner_samples_per_s": args.steps * args.batch * world_size / dt,
+            "env_only_steps_per_s": n_agents / (env_only_ms * 1e-3),
+            "config": {"workload": "PathPlan_City 500x500x100, 26 buildings, 1 UAV/env, %d vectorised envs/GPU, %s, "
+                                   "device replay %d transitions/GPU (BASELINE.json configs[1])"
+                                   % (args.envs, args.trainer.upper(), ring.capacity),
+                       "envs_per_gpu": args.envs, "learn_batch_per_gpu": args.batch, "obs_dtype": args.obs_dtype,
+                       "learner_dtype": "f16 autocast" if args.obs_dtype == "f16" else "f32",
+                       "epsilon": args.eps, "parallelism": "env-shard x%d + flat-bucket grad all-reduce" % world_size},
+            "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_agent_step": algo,
+                         "kernel_ms": k_ms, "agents_per_launch": n_agents,
+                         "kernel_ms_env_only_back_to_back": env_only_ms},
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(args.envs, args.cpu_seconds)
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""ctypes binding of include/uavenv.h (libuavenv.so).  Fails loudly: no fallback of any kind."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+OBS_DIM = 100
+MAX_BUILDINGS = 64
+ABI_VERSION = 1
+
+OK, EINVAL, ENOMEM, EHIP, ENODEV = 0, -22, -12, -5, -19
+INFO_NORMAL, INFO_SUCCESS, INFO_LOSE, INFO_SKIPPED = 0, 1, 2, 3
+INFO_NAMES = ("normal", "success", "lose", "skipped")
+ACT_STEER_F32, ACT_STEER_F64, ACT_INDEX_I32 = 0, 1, 2
+OBS_F32, OBS_F16 = 0, 1
+STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS = 1, 2, 4
+
+# every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
+SYMBOLS = (
+    "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
+    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
+    "uavenv_step", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
+    "uavenv_replay_sample", "uavenv_select_actions",
+)
+
+
+class UavEnvConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("n_envs", C.c_int32), ("uav_per_env", C.c_int32),
+        ("max_subgoals", C.c_int32), ("max_step", C.c_int32), ("apf_enabled", C.c_int32), ("obs_dtype", C.c_int32),
+        ("n_actions", C.c_int32), ("reserved0", C.c_int32),
+        ("len", C.c_double), ("width", C.c_double), ("h", C.c_double),
+        ("max_v", C.c_double), ("steering_angle", C.c_double), ("power", C.c_double * 8), ("cell_size", C.c_double),
+    ]
+
+
+class UavReplayRing(C.Structure):
+    _fields_ = [
+        ("obs", C.c_void_p), ("action", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+        ("valid", C.c_void_p), ("frames", C.c_int32), ("n_agents", C.c_int32), ("obs_dtype", C.c_int32),
+        ("action_is_index", C.c_int32),
+    ]
+
+
+class UavEnvError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def load() -> C.CDLL:
+    """Load (building first if the sources are newer) libuavenv.so.  Raises if that is impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if _build.needs_build():
+        _build.build()
+    if not os.path.exists(path):
+        raise UavEnvError(f"{path} is missing and could not be built; the env hot path has no CPU fallback")
+    lib = C.CDLL(path)
+    vp, i32, u32, u64, i64, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_int64, C.c_float
+    lib.uavenv_abi_version.restype = C.c_int
+    lib.uavenv_last_error.restype = C.c_char_p
+    lib.uavenv_create.restype = C.c_int
+    lib.uavenv_create.argtypes = [C.POINTER(UavEnvConfig), C.POINTER(vp)]
+    lib.uavenv_destroy.restype = C.c_int
+    lib.uavenv_destroy.argtypes = [vp]
+    lib.uavenv_num_agents.restype = C.c_int
+    lib.uavenv_num_agents.argtypes = [vp]
+    lib.uavenv_set_buildings.restype = C.c_int
+    lib.uavenv_set_buildings.argtypes = [vp, vp, vp, i32]
+    lib.uavenv_load_scenarios.restype = C.c_int
+    lib.uavenv_load_scenarios.argtypes = [vp, vp, vp, vp, i32]
+    lib.uavenv_reset_all.restype = C.c_int
+    lib.uavenv_reset_all.argtypes = [vp, u64, vp]
+    lib.uavenv_set_state.restype = C.c_int
+    lib.uavenv_set_state.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.uavenv_get_state.restype = C.c_int
+    lib.uavenv_get_state.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.uavenv_step.restype = C.c_int
+    lib.uavenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
+    lib.uavenv_observe.restype = C.c_int
+    lib.uavenv_observe.argtypes = [vp, vp, vp]
+    lib.uavenv_threaten_rate.restype = C.c_int
+    lib.uavenv_threaten_rate.argtypes = [vp, vp, vp, i64, vp]
+    lib.uavenv_threaten_rate_allpairs.restype = C.c_int
+    lib.uavenv_threaten_rate_allpairs.argtypes = [vp, vp, vp, i64, vp]
+    lib.uavenv_replay_sample.restype = C.c_int
+    lib.uavenv_replay_sample.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp]
+    lib.uavenv_select_actions.restype = C.c_int
+    lib.uavenv_select_actions.argtypes = [vp, i32, i32, f32, u64, u64, vp, vp, vp]
+    if lib.uavenv_abi_version() != ABI_VERSION:
+        raise UavEnvError(f"libuavenv ABI {lib.uavenv_abi_version()} != binding {ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().uavenv_last_error().decode("utf-8", "replace")
+        raise UavEnvError(f"{what or 'uavenv call'} failed with code {rc}: {msg}")

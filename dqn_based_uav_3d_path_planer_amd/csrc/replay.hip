@@ -1,0 +1,127 @@
+// replay.hip -- device-resident replay sampling and epsilon-greedy acting (see include/uavenv.h).
+//
+// The replay ring itself is written by k_step (uavenv.hip): the observation of frame t+1 and the
+// reward/done/valid of frame t go straight from the env kernel into the caller's ring tensors, so
+// ReplayMemory.add (BaseClass/replay_buffer.py:41-42) costs no extra HBM traffic.  What is left of
+// ReplayMemory on the learner side is sample2 (replay_buffer.py:48-51): uniform draws + a gather of
+// 2 x 400 B rows per sample, done here as one launch (HBM-bound: 813 B per sample).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uavenv.h"
+#include "uavenv_device.hpp"
+
+using namespace uav;
+
+extern "C" const char *uavenv_last_error(void);
+
+namespace {
+
+// One 16-byte chunk per thread: chunk q of sample s, q in [0, 2*CH) = obs row then next_obs row.
+// CH = 25 (f32 rows, 400 B) or 13 (f16 rows, 200 B = 12.5 chunks -> handled as 8-byte units, CH8 = 25).
+template <int UNIT /*bytes per copy unit*/>
+__global__ void k_sample_gather(UavReplayRing ring, int head, int filled, int batch, uint64_t seed, uint64_t counter,
+                                unsigned char *__restrict__ obs_b, unsigned char *__restrict__ next_b,
+                                unsigned char *__restrict__ act_b, float *__restrict__ rew_b,
+                                float *__restrict__ done_b, float *__restrict__ valid_b)
+{
+    constexpr int ROW_UNITS = 25;                        // 25 x 16 B (f32) or 25 x 8 B (f16)
+    const int row_bytes = ROW_UNITS * UNIT;
+    const int64_t total = (int64_t)batch * (2 * ROW_UNITS);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(t / (2 * ROW_UNITS));
+        const int q = (int)(t - (int64_t)s * (2 * ROW_UNITS));
+        // every thread of a sample re-derives the same draw from the counter-based generator
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)s, (uint32_t)counter, (uint32_t)(counter >> 32), 0x5a3bu),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const int back = 1 + (int)(((uint64_t)r.x * (uint64_t)filled) >> 32);        // 1..filled frames behind head
+        int f = head - back;
+        if (f < 0) f += ring.frames;
+        const int agent = (int)(((uint64_t)r.y * (uint64_t)ring.n_agents) >> 32);
+        int fn = f + 1;
+        if (fn >= ring.frames) fn = 0;
+        const bool is_next = q >= ROW_UNITS;
+        const int u = is_next ? q - ROW_UNITS : q;
+        const size_t src_row = ((size_t)(is_next ? fn : f) * ring.n_agents + agent) * (size_t)row_bytes;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(ring.obs) + src_row + (size_t)u * UNIT;
+        unsigned char *dst = (is_next ? next_b : obs_b) + (size_t)s * row_bytes + (size_t)u * UNIT;
+        if (UNIT == 16) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+        else *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(src);
+        if (q == 0) {
+            const size_t k = (size_t)f * ring.n_agents + agent;
+            reinterpret_cast<uint32_t *>(act_b)[s] = reinterpret_cast<const uint32_t *>(ring.action)[k];
+            rew_b[s] = ring.reward[k];
+            done_b[s] = (float)ring.done[k];
+            if (valid_b) valid_b[s] = ring.valid ? (float)ring.valid[k] : 1.0f;
+        }
+    }
+}
+
+// Trainer/DuelingDQN_Trainer.py:86-97: sample > eps -> argmax_a Q(s,a) (first maximum, as torch.max), else randrange(A).
+__global__ void k_select_actions(const float *__restrict__ q, int n, int A, float eps, uint64_t seed, uint64_t counter,
+                                 int32_t *__restrict__ idx_out, float *__restrict__ steer_out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)counter, (uint32_t)(counter >> 32), 0xac7u),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const float sample = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+        int a;
+        if (sample > eps) {
+            const float *row = q + (size_t)i * A;
+            float best = row[0];
+            a = 0;
+            for (int k = 1; k < A; ++k) {
+                const float v = row[k];
+                if (v > best) { best = v; a = k; }
+            }
+        } else {
+            a = (int)(((uint64_t)r.y * (uint64_t)A) >> 32);
+        }
+        if (idx_out) idx_out[i] = a;
+        if (steer_out) steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(A - 1));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                         uint64_t counter, void *obs_b, void *next_obs_b, void *action_b, float *reward_b,
+                         float *done_b, float *valid_b, void *stream)
+{
+    if (!ring || !ring->obs || !ring->action || !ring->reward || !ring->done || !obs_b || !next_obs_b || !action_b ||
+        !reward_b || !done_b)
+        return UAVENV_EINVAL;
+    if (ring->frames < 2 || ring->n_agents <= 0 || batch <= 0 || filled <= 0 || filled > ring->frames - 1 ||
+        head < 0 || head >= ring->frames)
+        return UAVENV_EINVAL;
+    const int64_t total = (int64_t)batch * 50;
+    const int block = 256;
+    int64_t g = (total + block - 1) / block;
+    const int grid = (int)(g > 4096 ? 4096 : g);
+    hipStream_t s = (hipStream_t)stream;
+    if (ring->obs_dtype == UAVENV_OBS_F32)
+        hipLaunchKernelGGL((k_sample_gather<16>), dim3(grid), dim3(block), 0, s, *ring, head, filled, batch, seed, counter,
+                           (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
+                           done_b, valid_b);
+    else
+        hipLaunchKernelGGL((k_sample_gather<8>), dim3(grid), dim3(block), 0, s, *ring, head, filled, batch, seed, counter,
+                           (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
+                           done_b, valid_b);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_select_actions(const float *q, int32_t n, int32_t n_actions, float eps, uint64_t seed, uint64_t counter,
+                          int32_t *index_out, float *steer_out, void *stream)
+{
+    if (!q || n <= 0 || n_actions < 2 || (!index_out && !steer_out)) return UAVENV_EINVAL;
+    const int block = 256;
+    int grid = (n + block - 1) / block;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_select_actions, dim3(grid), dim3(block), 0, (hipStream_t)stream, q, n, n_actions, eps, seed,
+                       counter, index_out, steer_out);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,888 @@
+// uavenv.hip -- kernels + C ABI of the MI355X-native PathPlan_City env hot path (see include/uavenv.h).
+//
+// Data layout in HBM (per device, N = n_envs * uav_per_env agents)
+//   hot state  : structure-of-arrays, one f64/i32/u8 array of length N per field, so a wavefront's
+//                64 lanes read/write 64 consecutive elements (512 B per f64 field) -- fully coalesced.
+//                Includes a 2-entry window (s0, s1) of the agent's sub-goal list: the step and the
+//                observation only ever read sub_goals[0] and sub_goals[1] (UAV.py:412-440, 519-531).
+//   cold state : sub-goal lists, array-of-structures [N][K][3] f64; touched only when a sub-goal is
+//                popped (one 24 B gather), at reset (copy from the scenario bank) or by APF.
+//   world      : <= 64 cylinders (32 B each) + a gnx x gny grid of candidate bit-masks, staged into
+//                LDS once per workgroup; every occupancy probe is then 1 LDS mask read + ~0-2 LDS
+//                cylinder reads instead of a loop over all buildings.
+//   outputs    : observation rows [N][100] (f32/f16) written straight into the caller's buffer --
+//                point it at replay frame t+1 and the replay append costs no extra bytes.
+// Roofline: HBM-bound by design (604 algorithmic B per agent-step); the f64
+// transcendental chain of the step (4 atan2, 2 sin/cos pairs, ~8 sqrt) is the compute floor.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/uavenv.h"
+#include "uavenv_device.hpp"
+
+using namespace uav;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(UAVENV_EHIP, "%s -> %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device-side state
+// ------------------------------------------------------------------------------------------------
+struct DevState {
+    double *px, *py, *pz, *vx, *vy, *V, *gx, *gy, *gz;
+    double *s0x, *s0y, *s0z, *s1x, *s1y, *s1z;
+    double *score, *total, *path_len;
+    int32_t *step, *sub_idx, *n_total;
+    uint32_t *epoch;
+    uint8_t *done, *alias, *reach;
+    double *sub;   // [N][K][3]
+};
+constexpr int kNumF64 = 18, kNumI32 = 4, kNumU8 = 3;
+
+struct Bank {
+    const double *start_goal;   // [M][6]
+    const double *sub;          // [M][K][3]
+    const int32_t *nsub;        // [M]
+    int32_t m;
+};
+
+struct StepArgs {
+    DevState st;
+    // world
+    const unsigned char *world_blob;   // [BldLds x nb_pad][grid]  (16-byte multiple)
+    int32_t world_bytes, grid_off;
+    int32_t nb, gnx, gny;
+    double inv_cell, W, Hbox;
+    const BldApf *apf_b;
+    // agent params
+    double max_v, steer;
+    PowerParams pw;
+    int32_t max_step, K, U, N, n_actions;
+    // io
+    const void *actions;
+    int32_t action_kind;
+    void *obs;
+    double *reward64;
+    float *reward32;
+    uint8_t *ret_done, *agent_done, *info, *valid;
+    double *energy64;
+    uint32_t flags;
+    // auto reset
+    Bank bank;
+    uint64_t seed, tick;
+};
+
+struct UavEnv {
+    UavEnvConfig cfg;
+    int N;
+    DevState st;
+    void *slab = nullptr;
+    size_t slab_bytes = 0;
+    // world
+    unsigned char *world_blob = nullptr;
+    int world_bytes = 0, grid_off = 0, nb = 0, gnx = 0, gny = 0, mask_bytes = 8;
+    double cell = 10.0;
+    BldApf *apf_b = nullptr;
+    bool have_world = false;
+    // bank
+    double *bank_sg = nullptr, *bank_sub = nullptr;
+    int32_t *bank_nsub = nullptr;
+    int bank_m = 0;
+    uint64_t seed = 0, tick = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+template <typename MaskT>
+__device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, const unsigned char *blob, int bytes,
+                                                       int grid_off, int gnx, int gny, double inv_cell, double W,
+                                                       double Hbox)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(blob);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int k = threadIdx.x; k < bytes / 16; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    WorldLds<MaskT> w;
+    w.b = reinterpret_cast<const BldLds *>(smem);
+    w.grid = reinterpret_cast<const MaskT *>(smem + grid_off);
+    w.gnx = gnx;
+    w.gny = gny;
+    w.inv_cell = inv_cell;
+    w.W = W;
+    w.Hbox = Hbox;
+    return w;
+}
+
+// Agents/UAV.py:174-210  cal_force(point): attraction/repulsion + motion force of every MOVING building
+// within 60 m of its rim.  Returns false where the reference would call Cal_SubTask_Dynamic() (raises).
+__device__ __noinline__ bool cal_force(const BldApf *__restrict__ b, int nb, double x, double y, double z, double &fx,
+                                       double &fy, double &fz)
+{
+    double cum = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
+    bool ok = true;
+    for (int i = 0; i < nb; ++i) {
+        BldApf B = b[i];
+        if (B.vx == 0.0 && B.vy == 0.0 && B.vz == 0.0) continue;
+        double dis = dist3(x, y, z, B.cx, B.cy, B.cz);
+        double d2e = dis - B.R;
+        if (d2e > 60.0) continue;
+        double q = B.R / (d2e * d2e);
+        double f1 = (q < 1.0) ? q : 1.0;
+        double f1_seta = calc_angle(B.cx - x, B.cy - y);
+        double v_seta = calc_angle(B.vx, B.vy);
+        if (d2e < 0.0) f1 = (-d2e > 2.0) ? -d2e : 2.0;
+        double f1x = -f1 * cos(f1_seta), f1y = -f1 * sin(f1_seta);
+        double q2 = B.vnorm * B.R / (d2e * d2e);
+        double f2 = (q2 < 1.0) ? q2 : 1.0;
+        double f2x = f2 * cos(v_seta), f2y = f2 * sin(v_seta);
+        cum += (f1 + f2);
+        tx = (tx + f1x) + f2x;
+        ty = (ty + f1y) + f2y;
+        if (cum > 100.0) { ok = false; break; }
+    }
+    fx = tx; fy = ty; fz = tz;
+    return ok;
+}
+
+__device__ __forceinline__ double load_action(const void *actions, int kind, int i, int n_actions)
+{
+    if (kind == UAVENV_ACT_STEER_F32) return (double)reinterpret_cast<const float *>(actions)[i];
+    if (kind == UAVENV_ACT_STEER_F64) return reinterpret_cast<const double *>(actions)[i];
+    int a = reinterpret_cast<const int32_t *>(actions)[i];
+    return -1.0 + 2.0 * (double)a / (double)(n_actions - 1);
+}
+
+// UAV.reset() from the scenario bank (UAV.py:327-366 with the RRT result pre-planned).
+__device__ __forceinline__ void reset_agent(const StepArgs &a, int i, uint64_t seed, uint64_t tick, ObsIn &o,
+                                            int &sub_idx, int &n_total, int &alias, double &score, double &total,
+                                            double &path_len, int &done, int &reach)
+{
+    uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)tick, (uint32_t)(tick >> 32), 0x5eedu),
+                            make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    double heading = (kTwoPi)*u53(r.x, r.y);             // random.uniform(0, 2*pi)  (a + (b-a)*random(), a = 0)
+    uint32_t scn = (uint32_t)(((uint64_t)r.z * (uint64_t)a.bank.m) >> 32);
+    const double *sg = a.bank.start_goal + (size_t)scn * 6;
+    o.px = sg[0]; o.py = sg[1]; o.pz = sg[2];
+    o.gx = sg[3]; o.gy = sg[4]; o.gz = sg[5];
+    o.vx = a.max_v * cos(heading);
+    o.vy = a.max_v * sin(heading);
+    o.V = calc_v(o.vx, o.vy, a.max_v);
+    o.step = 0;
+    score = 0.0; total = 0.0; path_len = 0.0;
+    done = 0; reach = 0;
+    n_total = a.bank.nsub[scn];
+    sub_idx = 0;
+    alias = n_total >= 2 ? 1 : 0;      // path[0] is the start node == the position object (RRT.py:69)
+    const double *src = a.bank.sub + (size_t)scn * a.K * 3;
+    double *dst = a.st.sub + (size_t)i * a.K * 3;
+    for (int k = 0; k < n_total * 3; ++k) dst[k] = src[k];
+    o.s0x = n_total >= 1 ? src[0] : 0.0; o.s0y = n_total >= 1 ? src[1] : 0.0; o.s0z = n_total >= 1 ? src[2] : 0.0;
+    o.s1x = n_total >= 2 ? src[3] : 0.0; o.s1y = n_total >= 2 ? src[4] : 0.0; o.s1z = n_total >= 2 ? src[5] : 0.0;
+    o.n_rem = n_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused step kernel: update_PathPlan + (auto-reset) + state_PathPlan + output/replay write
+// ------------------------------------------------------------------------------------------------
+template <typename MaskT, bool APF, bool F16>
+__global__ void __launch_bounds__(256) k_step(StepArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const WorldLds<MaskT> w =
+        stage_world<MaskT>(smem, a.world_blob, a.world_bytes, a.grid_off, a.gnx, a.gny, a.inv_cell, a.W, a.Hbox);
+    const DevState &S = a.st;
+    const int N = a.N;
+    const int n_round = (N + 63) & ~63;
+
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        const bool active = i < N;
+        const int ii = active ? i : N - 1;
+
+        ObsIn o;
+        o.px = S.px[ii]; o.py = S.py[ii]; o.pz = S.pz[ii];
+        o.vx = S.vx[ii]; o.vy = S.vy[ii]; o.V = S.V[ii];
+        o.gx = S.gx[ii]; o.gy = S.gy[ii]; o.gz = S.gz[ii];
+        o.s0x = S.s0x[ii]; o.s0y = S.s0y[ii]; o.s0z = S.s0z[ii];
+        o.s1x = S.s1x[ii]; o.s1y = S.s1y[ii]; o.s1z = S.s1z[ii];
+        o.step = S.step[ii];
+        int sub_idx = S.sub_idx[ii], n_total = S.n_total[ii];
+        int done = S.done[ii], alias = S.alias[ii], reach = S.reach[ii];
+        double score = S.score[ii], total = S.total[ii], path_len = S.path_len[ii];
+        uint32_t epoch = S.epoch[ii];
+        const double a0 = load_action(a.actions, a.action_kind, ii, a.n_actions);
+
+        double r = 0.0;
+        int ret_done = 0, info = UAVENV_INFO_NORMAL, valid = 1;
+        const int max_step = a.max_step;
+
+        if ((a.flags & UAVENV_STEP_SKIP_DONE) && done) {
+            ret_done = 1; info = UAVENV_INFO_SKIPPED; valid = 0;                  // PathPlan_City.py:365-366
+        } else if (sub_idx >= n_total) {                                           // UAV.py:400-406
+            done = 1;
+            r += (double)(max_step - o.step);
+            score += r;
+            ret_done = 1; info = UAVENV_INFO_SUCCESS;
+        } else {
+            o.step += 1;                                                           // :408
+            const double ox = o.px, oy = o.py, oz = o.pz;                          // :409
+            const double seta_old = calc_angle(o.vx, o.vy);                        // :411
+            const double dis_old = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);   // :412
+            const double g_old = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);        // :413
+            const double seta_new = seta_old + a0 * a.steer;                       // :414
+            o.vx = a.max_v * cos(seta_new);                                        // :415
+            o.vy = a.max_v * sin(seta_new);                                        // :416
+            o.V = calc_v(o.vx, o.vy, a.max_v);                                     // :417
+            o.px += o.vx;                                                          // :419
+            o.py += o.vy;                                                          // :420
+            if (alias) { o.s0x = o.px; o.s0y = o.py; o.s0z = o.pz; }               // sub_goals[0] IS position after reset
+            double tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);              // :422
+            double tri_V = calc_angle(o.vx, o.vy);                                 // :423
+            if (probe(w, o.px, o.py, o.pz)) {                                      // :425-428
+                r -= 0.3;
+                o.px = ox; o.py = oy; o.pz = oz;
+                alias = 0;
+                tri_V = calc_angle(o.s0x - o.px, o.s0y - o.py);
+            }
+            const double dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);   // :429
+            const double g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);        // :430
+            r -= 0.13 * fabs(a0);                                                  // :434
+            r += 0.2 * cos(fabs(tri_goal - tri_V));                                // :435
+            r += 0.4 * (dis_old - dis_new);                                        // :436
+            r += 0.4 * (g_old - g_new);                                            // :437
+            r -= 0.1;                                                              // :438
+            r -= 0.01 * fabs(o.pz - o.s0z);                                        // :439-440
+            path_len += o.V;                                                       // :443
+            epoch += 1;                                                            // :444
+
+            if (APF) {                                                             // :448-453
+                double *lst = S.sub + (size_t)ii * a.K * 3;
+                if (alias) { lst[sub_idx * 3] = o.s0x; lst[sub_idx * 3 + 1] = o.s0y; lst[sub_idx * 3 + 2] = o.s0z; }
+                for (int k = sub_idx; k < n_total; ++k) {                          // Adjust_subgoal :156-166
+                    double fx, fy, fz;
+                    double sx = lst[k * 3], sy = lst[k * 3 + 1], sz = lst[k * 3 + 2];
+                    cal_force(a.apf_b, a.nb, sx, sy, sz, fx, fy, fz);
+                    lst[k * 3] = sx + fx; lst[k * 3 + 1] = sy + fy; lst[k * 3 + 2] = sz + fz;
+                }
+                alias = 0;
+                o.s0x = lst[sub_idx * 3]; o.s0y = lst[sub_idx * 3 + 1]; o.s0z = lst[sub_idx * 3 + 2];
+                if (sub_idx + 1 < n_total) {
+                    o.s1x = lst[sub_idx * 3 + 3]; o.s1y = lst[sub_idx * 3 + 4]; o.s1z = lst[sub_idx * 3 + 5];
+                }
+                double fx, fy, fz;
+                cal_force(a.apf_b, a.nb, o.px, o.py, o.pz, fx, fy, fz);
+                const double force = sqrt(fx * fx + fy * fy + fz * fz);
+                const double tri_force = calc_angle(fx, fy);
+                r += 0.2 * force * cos(fabs(tri_force - tri_V));
+            }
+
+            const double d_sub = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);
+            if (o.step >= max_step) {                                              // :456-465
+                done = 1;
+                r += (50.0 - d_sub);
+                score += r; total += r;
+                ret_done = 1; info = UAVENV_INFO_LOSE;
+            } else if (d_sub < 7.0 || (dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz) <
+                                       dist3(o.s0x, o.s0y, o.s0z, o.gx, o.gy, o.gz))) {   // :466
+                r += (50.0 - d_sub);                                               // :468
+                sub_idx += 1;                                                      // :469 pop(0)
+                alias = 0;
+                if (sub_idx >= n_total) {                                          // :470-483
+                    r += 50.0;
+                    done = 1;
+                    r += (double)(max_step - o.step);
+                    score += r;
+                    reach = 1;
+                    total += r;
+                    ret_done = 1; info = UAVENV_INFO_SUCCESS;
+                } else {                                                           // :484-495
+                    o.step = 0;                                                    // reset("local reset") :328-332
+                    score = 0.0;
+                    o.V = calc_v(o.vx, o.vy, a.max_v);
+                    o.s0x = o.s1x; o.s0y = o.s1y; o.s0z = o.s1z;
+                    if (sub_idx + 1 < n_total) {
+                        const double *nx = S.sub + ((size_t)ii * a.K + (size_t)(sub_idx + 1)) * 3;
+                        o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
+                    }
+                    tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);             // :488
+                    tri_V = calc_angle(o.vx, o.vy);                                // :489
+                    r += 0.2 * cos(fabs(tri_goal - tri_V));                        // :490
+                    r += (double)(max_step - o.step);                              // :491
+                    score += r; total += r;
+                    ret_done = 1; info = UAVENV_INFO_SUCCESS;                      // returned done; agent NOT done
+                }
+            } else if (dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz) < 7.0) {          // :496-509
+                done = 1;
+                r += 50.0;
+                r += (double)(max_step - o.step);
+                score += r;
+                reach = 1;
+                total += r;
+                ret_done = 1; info = UAVENV_INFO_SUCCESS;
+            } else {                                                               // :510-513
+                score += r; total += r;
+            }
+        }
+        o.n_rem = n_total - sub_idx;
+        const int agent_done = done;
+        const double energy = a.energy64 ? fly_power(a.pw, o.V, ii % a.U) : 0.0;
+
+        // ---- auto reset: the env restarts when ALL of its U agents are done (PathPlan_City.py:252-259,416-417)
+        bool did_reset = false;
+        if (a.flags & UAVENV_STEP_AUTO_RESET) {
+            const unsigned long long dm = __ballot(active && done);
+            const int lane = threadIdx.x & 63;
+            const int g0 = (lane / a.U) * a.U;
+            const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
+            if (active && ((dm & gm) == gm)) {
+                reset_agent(a, ii, a.seed, a.tick, o, sub_idx, n_total, alias, score, total, path_len, done, reach);
+                did_reset = true;
+            }
+        }
+
+        if (active) {
+            // ---- outputs of the transition
+            if (a.reward64) a.reward64[i] = r;
+            if (a.reward32) a.reward32[i] = (float)r;
+            if (a.ret_done) a.ret_done[i] = (uint8_t)ret_done;
+            if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
+            if (a.info) a.info[i] = (uint8_t)info;
+            if (a.valid) a.valid[i] = (uint8_t)valid;
+            if (a.energy64) a.energy64[i] = energy;
+
+            // ---- observation of the (possibly reset) state: state_PathPlan, UAV.py:515-567
+            if (a.obs && !(a.flags & UAVENV_STEP_NO_OBS)) {
+                const double heading = calc_angle(o.vx, o.vy);                     // :526
+                const ObsBits bits = obs_bits(w, o.px, o.py, o.pz);
+                const ObsScalars sc = obs_scalars(o, heading);
+                store_obs_row<F16>(a.obs, i, sc, bits);
+            }
+
+            // ---- state write-back
+            if (valid || did_reset) {
+                S.px[i] = o.px; S.py[i] = o.py; S.pz[i] = o.pz;
+                S.vx[i] = o.vx; S.vy[i] = o.vy; S.V[i] = o.V;
+                S.s0x[i] = o.s0x; S.s0y[i] = o.s0y; S.s0z[i] = o.s0z;
+                S.s1x[i] = o.s1x; S.s1y[i] = o.s1y; S.s1z[i] = o.s1z;
+                S.gx[i] = o.gx; S.gy[i] = o.gy; S.gz[i] = o.gz;
+                S.step[i] = o.step; S.sub_idx[i] = sub_idx; S.n_total[i] = n_total;
+                S.done[i] = (uint8_t)done; S.alias[i] = (uint8_t)alias; S.reach[i] = (uint8_t)reach;
+                S.score[i] = score; S.total[i] = total; S.path_len[i] = path_len;
+                S.epoch[i] = epoch;
+            }
+        }
+    }
+}
+
+// state_PathPlan only
+template <typename MaskT, bool F16>
+__global__ void __launch_bounds__(256) k_observe(StepArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const WorldLds<MaskT> w =
+        stage_world<MaskT>(smem, a.world_blob, a.world_bytes, a.grid_off, a.gnx, a.gny, a.inv_cell, a.W, a.Hbox);
+    const DevState &S = a.st;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x) {
+        ObsIn o;
+        o.px = S.px[i]; o.py = S.py[i]; o.pz = S.pz[i];
+        o.vx = S.vx[i]; o.vy = S.vy[i]; o.V = S.V[i];
+        o.gx = S.gx[i]; o.gy = S.gy[i]; o.gz = S.gz[i];
+        o.s0x = S.s0x[i]; o.s0y = S.s0y[i]; o.s0z = S.s0z[i];
+        o.s1x = S.s1x[i]; o.s1y = S.s1y[i]; o.s1z = S.s1z[i];
+        o.step = S.step[i];
+        o.n_rem = S.n_total[i] - S.sub_idx[i];
+        const double heading = calc_angle(o.vx, o.vy);
+        const ObsBits bits = obs_bits(w, o.px, o.py, o.pz);
+        const ObsScalars sc = obs_scalars(o, heading);
+        store_obs_row<F16>(a.obs, i, sc, bits);
+    }
+}
+
+template <typename MaskT, bool ALLPAIRS>
+__global__ void k_threaten(StepArgs a, const double *__restrict__ xyz, uint8_t *__restrict__ out, int64_t n)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const WorldLds<MaskT> w =
+        stage_world<MaskT>(smem, a.world_blob, a.world_bytes, a.grid_off, a.gnx, a.gny, a.inv_cell, a.W, a.Hbox);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        out[i] = (uint8_t)(ALLPAIRS ? probe_allpairs(w.b, a.nb, a.W, a.Hbox, x, y, z) : probe(w, x, y, z));
+    }
+}
+
+// reset every agent from the bank
+__global__ void k_reset_all(StepArgs a)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x) {
+        ObsIn o;
+        int sub_idx, n_total, alias, done, reach;
+        double score, total, path_len;
+        reset_agent(a, i, a.seed, a.tick, o, sub_idx, n_total, alias, score, total, path_len, done, reach);
+        const DevState &S = a.st;
+        S.px[i] = o.px; S.py[i] = o.py; S.pz[i] = o.pz;
+        S.vx[i] = o.vx; S.vy[i] = o.vy; S.V[i] = o.V;
+        S.gx[i] = o.gx; S.gy[i] = o.gy; S.gz[i] = o.gz;
+        S.s0x[i] = o.s0x; S.s0y[i] = o.s0y; S.s0z[i] = o.s0z;
+        S.s1x[i] = o.s1x; S.s1y[i] = o.s1y; S.s1z[i] = o.s1z;
+        S.step[i] = 0; S.sub_idx[i] = sub_idx; S.n_total[i] = n_total;
+        S.done[i] = 0; S.alias[i] = (uint8_t)alias; S.reach[i] = 0;
+        S.score[i] = 0.0; S.total[i] = 0.0; S.path_len[i] = 0.0;
+        S.epoch[i] = 0;
+    }
+}
+
+// parity injection: scatter host-provided AoS rows into the SoA state
+__global__ void k_set_state(StepArgs a, int first, int count, const double *__restrict__ kin,
+                            const int32_t *__restrict__ step, const int32_t *__restrict__ n_sub,
+                            const int32_t *__restrict__ alias, const double *__restrict__ sub)
+{
+    const DevState &S = a.st;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < count; c += gridDim.x * blockDim.x) {
+        const int i = first + c;
+        const double *k = kin + (size_t)c * 8;
+        double vx = k[3], vy = k[4];
+        const double V = calc_v(vx, vy, a.max_v);       // inject() does uav.V = uav.Calc_V()
+        S.px[i] = k[0]; S.py[i] = k[1]; S.pz[i] = k[2];
+        S.vx[i] = vx; S.vy[i] = vy; S.V[i] = V;
+        S.gx[i] = k[5]; S.gy[i] = k[6]; S.gz[i] = k[7];
+        const int n = n_sub[c];
+        const double *src = sub + (size_t)c * a.K * 3;
+        double *dst = S.sub + (size_t)i * a.K * 3;
+        for (int q = 0; q < n * 3; ++q) dst[q] = src[q];
+        S.s0x[i] = n >= 1 ? src[0] : 0.0; S.s0y[i] = n >= 1 ? src[1] : 0.0; S.s0z[i] = n >= 1 ? src[2] : 0.0;
+        S.s1x[i] = n >= 2 ? src[3] : 0.0; S.s1y[i] = n >= 2 ? src[4] : 0.0; S.s1z[i] = n >= 2 ? src[5] : 0.0;
+        S.step[i] = step[c]; S.sub_idx[i] = 0; S.n_total[i] = n;
+        S.done[i] = 0; S.alias[i] = (uint8_t)(alias ? alias[c] : 0); S.reach[i] = 0;
+        S.score[i] = 0.0; S.total[i] = 0.0; S.path_len[i] = 0.0;
+        S.epoch[i] = 0;
+    }
+}
+
+__global__ void k_get_state(StepArgs a, int first, int count, double *__restrict__ out16, double *__restrict__ out_sub,
+                            int32_t *__restrict__ out_alias)
+{
+    const DevState &S = a.st;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < count; c += gridDim.x * blockDim.x) {
+        const int i = first + c;
+        double *o = out16 + (size_t)c * 16;
+        const int sub_idx = S.sub_idx[i], n_total = S.n_total[i];
+        o[0] = S.px[i]; o[1] = S.py[i]; o[2] = S.pz[i]; o[3] = S.vx[i]; o[4] = S.vy[i]; o[5] = S.V[i];
+        o[6] = S.gx[i]; o[7] = S.gy[i]; o[8] = S.gz[i]; o[9] = (double)S.step[i]; o[10] = (double)S.done[i];
+        o[11] = (double)(n_total - sub_idx); o[12] = S.score[i]; o[13] = S.total[i]; o[14] = S.path_len[i];
+        o[15] = (double)S.reach[i];
+        if (out_alias) out_alias[c] = (int32_t)S.alias[i];
+        if (out_sub) {
+            double *d = out_sub + (size_t)c * a.K * 3;
+            const double *src = S.sub + (size_t)i * a.K * 3;
+            for (int k = 0; k < a.K; ++k) {
+                const int q = sub_idx + k;
+                const bool ok = q < n_total;
+                // the hot window is authoritative for the current sub-goal (it tracks the position alias)
+                d[k * 3] = ok ? (k == 0 ? S.s0x[i] : src[q * 3]) : 0.0;
+                d[k * 3 + 1] = ok ? (k == 0 ? S.s0y[i] : src[q * 3 + 1]) : 0.0;
+                d[k * 3 + 2] = ok ? (k == 0 ? S.s0z[i] : src[q * 3 + 2]) : 0.0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+static StepArgs base_args(const UavEnv *e)
+{
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.st = e->st;
+    a.world_blob = e->world_blob;
+    a.world_bytes = e->world_bytes;
+    a.grid_off = e->grid_off;
+    a.nb = e->nb;
+    a.gnx = e->gnx;
+    a.gny = e->gny;
+    a.inv_cell = 1.0 / e->cell;
+    a.W = e->cfg.width;
+    a.Hbox = e->cfg.h;
+    a.apf_b = e->apf_b;
+    a.max_v = e->cfg.max_v;
+    a.steer = e->cfg.steering_angle;
+    a.pw = PowerParams{e->cfg.power[0], e->cfg.power[1], e->cfg.power[2], e->cfg.power[3],
+                       e->cfg.power[4], e->cfg.power[5], e->cfg.power[6], e->cfg.power[7]};
+    a.max_step = e->cfg.max_step;
+    a.K = e->cfg.max_subgoals;
+    a.U = e->cfg.uav_per_env;
+    a.N = e->N;
+    a.n_actions = e->cfg.n_actions;
+    a.bank.start_goal = e->bank_sg;
+    a.bank.sub = e->bank_sub;
+    a.bank.nsub = e->bank_nsub;
+    a.bank.m = e->bank_m;
+    a.seed = e->seed;
+    a.tick = e->tick;
+    return a;
+}
+
+// Launch geometry: one wavefront per workgroup while that still yields fewer than ~8 workgroups per CU
+// (small N is latency-bound: spread agents over all 256 CUs), 256-thread workgroups with a grid-stride
+// loop beyond that so the LDS staging of the world is amortised.
+static void launch_geometry(int n, int &block, int &grid)
+{
+    if (n <= 131072) {
+        block = 64;
+        grid = (n + 63) / 64;
+    } else {
+        block = 256;
+        grid = (n + 255) / 256;
+        if (grid > 2048) grid = 2048;
+    }
+    if (grid < 1) grid = 1;
+}
+
+template <typename MaskT>
+static void launch_step(const UavEnv *e, const StepArgs &a, hipStream_t s)
+{
+    int block, grid;
+    launch_geometry(e->N, block, grid);
+    const bool f16 = e->cfg.obs_dtype == UAVENV_OBS_F16, apf = e->cfg.apf_enabled == 1;
+    const size_t lds = (size_t)e->world_bytes;
+#define UAV_LAUNCH(APF_, F16_) hipLaunchKernelGGL((k_step<MaskT, APF_, F16_>), dim3(grid), dim3(block), lds, s, a)
+    if (apf) { if (f16) UAV_LAUNCH(true, true); else UAV_LAUNCH(true, false); }
+    else     { if (f16) UAV_LAUNCH(false, true); else UAV_LAUNCH(false, false); }
+#undef UAV_LAUNCH
+}
+
+extern "C" {
+
+int uavenv_abi_version(void) { return UAVENV_ABI_VERSION; }
+const char *uavenv_last_error(void) { return g_err; }
+
+int uavenv_create(const UavEnvConfig *cfg, UavEnv **out)
+{
+    if (!cfg || !out) return fail(UAVENV_EINVAL, "null argument");
+    if (cfg->abi_version != UAVENV_ABI_VERSION)
+        return fail(UAVENV_EINVAL, "abi_version %d != %d", cfg->abi_version, UAVENV_ABI_VERSION);
+    if (cfg->n_envs <= 0 || cfg->max_subgoals < 2 || cfg->max_step <= 0)
+        return fail(UAVENV_EINVAL, "n_envs/max_subgoals/max_step out of range");
+    if (!is_pow2(cfg->uav_per_env) || cfg->uav_per_env > 64)
+        return fail(UAVENV_EINVAL, "uav_per_env must be a power of two <= 64 (got %d)", cfg->uav_per_env);
+    if (cfg->obs_dtype != UAVENV_OBS_F32 && cfg->obs_dtype != UAVENV_OBS_F16)
+        return fail(UAVENV_EINVAL, "obs_dtype");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(UAVENV_ENODEV, "no HIP device visible: libuavenv has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(UAVENV_EINVAL, "device %d of %d", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    UavEnv *e = new (std::nothrow) UavEnv();
+    if (!e) return fail(UAVENV_ENOMEM, "host alloc");
+    e->cfg = *cfg;
+    if (e->cfg.n_actions < 2) e->cfg.n_actions = 3;
+    e->cell = cfg->cell_size > 0 ? cfg->cell_size : 10.0;
+    const long long n64 = (long long)cfg->n_envs * cfg->uav_per_env;
+    if (n64 > (1ll << 30)) { delete e; return fail(UAVENV_EINVAL, "too many agents"); }
+    e->N = (int)n64;
+    const size_t n = (size_t)e->N, npad = (n + 63) & ~(size_t)63;
+    const size_t K = (size_t)cfg->max_subgoals;
+    size_t bytes = npad * 8 * kNumF64 + npad * 4 * kNumI32 + npad * kNumU8 + n * K * 3 * 8 + 256;
+    hipError_t er = hipMalloc(&e->slab, bytes);
+    if (er != hipSuccess) { delete e; return fail(UAVENV_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(er)); }
+    e->slab_bytes = bytes;
+    (void)hipMemset(e->slab, 0, bytes);
+    unsigned char *p = (unsigned char *)e->slab;
+    double **f64s[kNumF64] = {&e->st.px, &e->st.py, &e->st.pz, &e->st.vx, &e->st.vy, &e->st.V, &e->st.gx, &e->st.gy,
+                              &e->st.gz, &e->st.s0x, &e->st.s0y, &e->st.s0z, &e->st.s1x, &e->st.s1y, &e->st.s1z,
+                              &e->st.score, &e->st.total, &e->st.path_len};
+    for (int k = 0; k < kNumF64; ++k) { *f64s[k] = (double *)p; p += npad * 8; }
+    e->st.sub = (double *)p; p += n * K * 3 * 8;
+    p = (unsigned char *)(((uintptr_t)p + 63) & ~(uintptr_t)63);
+    int32_t **i32s[3] = {&e->st.step, &e->st.sub_idx, &e->st.n_total};
+    for (int k = 0; k < 3; ++k) { *i32s[k] = (int32_t *)p; p += npad * 4; }
+    e->st.epoch = (uint32_t *)p; p += npad * 4;
+    uint8_t **u8s[kNumU8] = {&e->st.done, &e->st.alias, &e->st.reach};
+    for (int k = 0; k < kNumU8; ++k) { *u8s[k] = (uint8_t *)p; p += npad; }
+    *out = e;
+    return UAVENV_OK;
+}
+
+int uavenv_destroy(UavEnv *e)
+{
+    if (!e) return UAVENV_OK;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipFree(e->slab);
+    (void)hipFree(e->world_blob);
+    (void)hipFree(e->apf_b);
+    (void)hipFree(e->bank_sg);
+    (void)hipFree(e->bank_sub);
+    (void)hipFree(e->bank_nsub);
+    delete e;
+    return UAVENV_OK;
+}
+
+int uavenv_num_agents(const UavEnv *e) { return e ? e->N : UAVENV_EINVAL; }
+
+int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t nb)
+{
+    if (!e || (nb > 0 && !b5)) return fail(UAVENV_EINVAL, "null argument");
+    if (nb < 0 || nb > UAVENV_MAX_BUILDINGS)
+        return fail(UAVENV_EINVAL, "nb=%d exceeds UAVENV_MAX_BUILDINGS=%d", nb, UAVENV_MAX_BUILDINGS);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const double W = e->cfg.width, cell = e->cell;
+    const int gn = (int)std::ceil(W / cell) > 0 ? (int)std::ceil(W / cell) : 1;
+    const int mask_bytes = nb <= 32 ? 4 : 8;
+    std::vector<BldLds> bl((size_t)(nb > 0 ? nb : 1));
+    std::vector<BldApf> ba((size_t)(nb > 0 ? nb : 1));
+    for (int i = 0; i < nb; ++i) {
+        const double cx = b5[5 * i], cy = b5[5 * i + 1], cz = b5[5 * i + 2], R = b5[5 * i + 3], H = b5[5 * i + 4];
+        // thr = min{ t : sqrt_rn(t) >= R }  =>  (s < thr) <=> (sqrt_rn(s) < R)
+        double t = R * R;
+        if (R > 0) {
+            while (std::sqrt(t) >= R) t = std::nextafter(t, -INFINITY);
+            while (std::sqrt(t) < R) t = std::nextafter(t, INFINITY);
+        } else {
+            t = 0.0;   // sqrt(s) < R<=0 is never true for s >= 0 (R<0) / s<0 impossible
+        }
+        bl[i] = BldLds{cx, cy, t, H};
+        double vx = v3 ? v3[3 * i] : 0.0, vy = v3 ? v3[3 * i + 1] : 0.0, vz = v3 ? v3[3 * i + 2] : 0.0;
+        ba[i] = BldApf{cx, cy, cz, R, vx, vy, vz, std::sqrt(vx * vx + vy * vy + vz * vz)};
+    }
+    // conservative rasterisation: cell rectangle and radius both inflated, so rounding of the cell index
+    // (x * inv_cell) or of the distance can never drop a cylinder that the exact test would hit.
+    std::vector<uint64_t> grid((size_t)gn * gn, 0);
+    const double margin = 1e-6 * (cell > 1.0 ? cell : 1.0);
+    for (int iy = 0; iy < gn; ++iy)
+        for (int ix = 0; ix < gn; ++ix) {
+            const double x0 = ix * cell - margin, x1 = (ix + 1) * cell + margin;
+            const double y0 = iy * cell - margin, y1 = (iy + 1) * cell + margin;
+            uint64_t m = 0;
+            for (int i = 0; i < nb; ++i) {
+                const double qx = bl[i].cx < x0 ? x0 : (bl[i].cx > x1 ? x1 : bl[i].cx);
+                const double qy = bl[i].cy < y0 ? y0 : (bl[i].cy > y1 ? y1 : bl[i].cy);
+                const double d = std::hypot(qx - bl[i].cx, qy - bl[i].cy);
+                if (d < b5[5 * i + 3] + margin) m |= (1ull << i);
+            }
+            grid[(size_t)iy * gn + ix] = m;
+        }
+    const int bld_bytes = (int)(((size_t)(nb > 0 ? nb : 1) * sizeof(BldLds) + 15) & ~(size_t)15);
+    const int grid_bytes = (int)((((size_t)gn * gn * mask_bytes) + 15) & ~(size_t)15);
+    std::vector<unsigned char> blob((size_t)bld_bytes + grid_bytes, 0);
+    memcpy(blob.data(), bl.data(), (size_t)(nb > 0 ? nb : 0) * sizeof(BldLds));
+    if (mask_bytes == 8) {
+        memcpy(blob.data() + bld_bytes, grid.data(), (size_t)gn * gn * 8);
+    } else {
+        uint32_t *g32 = reinterpret_cast<uint32_t *>(blob.data() + bld_bytes);
+        for (size_t k = 0; k < (size_t)gn * gn; ++k) g32[k] = (uint32_t)grid[k];
+    }
+    if (blob.size() > 150 * 1024) return fail(UAVENV_EINVAL, "world blob %zu B does not fit LDS; raise cell_size", blob.size());
+    (void)hipFree(e->world_blob);
+    (void)hipFree(e->apf_b);
+    e->world_blob = nullptr;
+    e->apf_b = nullptr;
+    HIP_TRY(hipMalloc((void **)&e->world_blob, blob.size()));
+    HIP_TRY(hipMemcpy(e->world_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&e->apf_b, ba.size() * sizeof(BldApf)));
+    HIP_TRY(hipMemcpy(e->apf_b, ba.data(), ba.size() * sizeof(BldApf), hipMemcpyHostToDevice));
+    e->world_bytes = (int)blob.size();
+    e->grid_off = bld_bytes;
+    e->nb = nb;
+    e->gnx = gn;
+    e->gny = gn;
+    e->mask_bytes = mask_bytes;
+    e->have_world = true;
+    return UAVENV_OK;
+}
+
+int uavenv_load_scenarios(UavEnv *e, const double *sg, const double *sub, const int32_t *nsub, int32_t m)
+{
+    if (!e || !sg || !sub || !nsub || m <= 0) return fail(UAVENV_EINVAL, "null/empty scenario bank");
+    const int K = e->cfg.max_subgoals;
+    for (int i = 0; i < m; ++i)
+        if (nsub[i] < 0 || nsub[i] > K) return fail(UAVENV_EINVAL, "scenario %d has %d sub-goals > K=%d", i, nsub[i], K);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    (void)hipFree(e->bank_sg); (void)hipFree(e->bank_sub); (void)hipFree(e->bank_nsub);
+    e->bank_sg = e->bank_sub = nullptr; e->bank_nsub = nullptr; e->bank_m = 0;
+    HIP_TRY(hipMalloc((void **)&e->bank_sg, (size_t)m * 6 * 8));
+    HIP_TRY(hipMalloc((void **)&e->bank_sub, (size_t)m * K * 3 * 8));
+    HIP_TRY(hipMalloc((void **)&e->bank_nsub, (size_t)m * 4));
+    HIP_TRY(hipMemcpy(e->bank_sg, sg, (size_t)m * 6 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->bank_sub, sub, (size_t)m * K * 3 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->bank_nsub, nsub, (size_t)m * 4, hipMemcpyHostToDevice));
+    e->bank_m = m;
+    return UAVENV_OK;
+}
+
+int uavenv_reset_all(UavEnv *e, uint64_t seed, void *stream)
+{
+    if (!e) return fail(UAVENV_EINVAL, "null env");
+    if (e->bank_m <= 0) return fail(UAVENV_EINVAL, "uavenv_reset_all: no scenario bank loaded");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    e->seed = seed;
+    e->tick = 0;
+    StepArgs a = base_args(e);
+    const int block = 256, grid = (e->N + block - 1) / block;
+    hipLaunchKernelGGL(k_reset_all, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    e->tick = 1;
+    return UAVENV_OK;
+}
+
+int uavenv_set_state(UavEnv *e, int32_t first, int32_t count, const double *kin, const int32_t *step,
+                     const int32_t *n_sub, const int32_t *alias, const double *sub)
+{
+    if (!e || !kin || !step || !n_sub || !sub) return fail(UAVENV_EINVAL, "null argument");
+    if (first < 0 || count <= 0 || first + count > e->N) return fail(UAVENV_EINVAL, "range [%d,+%d) of %d", first, count, e->N);
+    const int K = e->cfg.max_subgoals;
+    for (int c = 0; c < count; ++c)
+        if (n_sub[c] < 0 || n_sub[c] > K) return fail(UAVENV_EINVAL, "n_sub[%d]=%d > K=%d", c, n_sub[c], K);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    double *d_kin = nullptr, *d_sub = nullptr;
+    int32_t *d_i = nullptr;
+    const size_t c = (size_t)count;
+    HIP_TRY(hipMalloc((void **)&d_kin, c * 8 * 8));
+    HIP_TRY(hipMalloc((void **)&d_sub, c * K * 3 * 8));
+    HIP_TRY(hipMalloc((void **)&d_i, c * 4 * 3));
+    HIP_TRY(hipMemcpy(d_kin, kin, c * 64, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_sub, sub, c * K * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_i, step, c * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_i + c, n_sub, c * 4, hipMemcpyHostToDevice));
+    if (alias) HIP_TRY(hipMemcpy(d_i + 2 * c, alias, c * 4, hipMemcpyHostToDevice));
+    StepArgs a = base_args(e);
+    const int block = 128, grid = (count + block - 1) / block;
+    hipLaunchKernelGGL(k_set_state, dim3(grid), dim3(block), 0, 0, a, first, count, d_kin, d_i, d_i + c,
+                       alias ? d_i + 2 * c : (const int32_t *)nullptr, d_sub);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(d_kin); (void)hipFree(d_sub); (void)hipFree(d_i);
+    return UAVENV_OK;
+}
+
+int uavenv_get_state(UavEnv *e, int32_t first, int32_t count, double *out16, double *out_sub, int32_t *out_alias)
+{
+    if (!e || !out16) return fail(UAVENV_EINVAL, "null argument");
+    if (first < 0 || count <= 0 || first + count > e->N) return fail(UAVENV_EINVAL, "range [%d,+%d) of %d", first, count, e->N);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int K = e->cfg.max_subgoals;
+    const size_t c = (size_t)count;
+    double *d16 = nullptr, *dsub = nullptr;
+    int32_t *dal = nullptr;
+    HIP_TRY(hipMalloc((void **)&d16, c * 16 * 8));
+    if (out_sub) HIP_TRY(hipMalloc((void **)&dsub, c * K * 24));
+    if (out_alias) HIP_TRY(hipMalloc((void **)&dal, c * 4));
+    StepArgs a = base_args(e);
+    const int block = 128, grid = (count + block - 1) / block;
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_get_state, dim3(grid), dim3(block), 0, 0, a, first, count, d16, dsub, dal);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out16, d16, c * 128, hipMemcpyDeviceToHost));
+    if (out_sub) HIP_TRY(hipMemcpy(out_sub, dsub, c * K * 24, hipMemcpyDeviceToHost));
+    if (out_alias) HIP_TRY(hipMemcpy(out_alias, dal, c * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d16); (void)hipFree(dsub); (void)hipFree(dal);
+    return UAVENV_OK;
+}
+
+int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, double *reward64, float *reward32,
+                uint8_t *ret_done, uint8_t *agent_done, uint8_t *info, uint8_t *valid, double *energy64,
+                uint32_t flags, void *stream)
+{
+    if (!e || !actions) return fail(UAVENV_EINVAL, "null env/actions");
+    if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step before uavenv_set_buildings");
+    if (action_kind < 0 || action_kind > 2) return fail(UAVENV_EINVAL, "action_kind %d", action_kind);
+    if ((flags & UAVENV_STEP_AUTO_RESET) && e->bank_m <= 0)
+        return fail(UAVENV_EINVAL, "AUTO_RESET needs a scenario bank (uavenv_load_scenarios)");
+    StepArgs a = base_args(e);
+    a.actions = actions;
+    a.action_kind = action_kind;
+    a.obs = obs;
+    a.reward64 = reward64;
+    a.reward32 = reward32;
+    a.ret_done = ret_done;
+    a.agent_done = agent_done;
+    a.info = info;
+    a.valid = valid;
+    a.energy64 = energy64;
+    a.flags = flags;
+    if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
+    else launch_step<uint64_t>(e, a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    e->tick += 1;
+    return UAVENV_OK;
+}
+
+int uavenv_observe(UavEnv *e, void *obs, void *stream)
+{
+    if (!e || !obs) return fail(UAVENV_EINVAL, "null argument");
+    if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_observe before uavenv_set_buildings");
+    StepArgs a = base_args(e);
+    a.obs = obs;
+    int block, grid;
+    launch_geometry(e->N, block, grid);
+    const size_t lds = (size_t)e->world_bytes;
+    const bool f16 = e->cfg.obs_dtype == UAVENV_OBS_F16;
+    hipStream_t s = (hipStream_t)stream;
+    if (e->mask_bytes == 4) {
+        if (f16) hipLaunchKernelGGL((k_observe<uint32_t, true>), dim3(grid), dim3(block), lds, s, a);
+        else hipLaunchKernelGGL((k_observe<uint32_t, false>), dim3(grid), dim3(block), lds, s, a);
+    } else {
+        if (f16) hipLaunchKernelGGL((k_observe<uint64_t, true>), dim3(grid), dim3(block), lds, s, a);
+        else hipLaunchKernelGGL((k_observe<uint64_t, false>), dim3(grid), dim3(block), lds, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
+static int threaten_impl(UavEnv *e, const double *xyz, uint8_t *out, int64_t n, void *stream, bool allpairs)
+{
+    if (!e || !xyz || !out || n < 0) return fail(UAVENV_EINVAL, "null argument");
+    if (!e->have_world) return fail(UAVENV_EINVAL, "threaten_rate before uavenv_set_buildings");
+    if (n == 0) return UAVENV_OK;
+    StepArgs a = base_args(e);
+    const int block = 256;
+    int64_t g = (n + block - 1) / block;
+    const int grid = (int)(g > 2048 ? 2048 : g);
+    const size_t lds = (size_t)e->world_bytes;
+    hipStream_t s = (hipStream_t)stream;
+    if (e->mask_bytes == 4) {
+        if (allpairs) hipLaunchKernelGGL((k_threaten<uint32_t, true>), dim3(grid), dim3(block), lds, s, a, xyz, out, n);
+        else hipLaunchKernelGGL((k_threaten<uint32_t, false>), dim3(grid), dim3(block), lds, s, a, xyz, out, n);
+    } else {
+        if (allpairs) hipLaunchKernelGGL((k_threaten<uint64_t, true>), dim3(grid), dim3(block), lds, s, a, xyz, out, n);
+        else hipLaunchKernelGGL((k_threaten<uint64_t, false>), dim3(grid), dim3(block), lds, s, a, xyz, out, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
+int uavenv_threaten_rate(UavEnv *e, const double *xyz, uint8_t *out, int64_t n, void *stream)
+{
+    return threaten_impl(e, xyz, out, n, stream, false);
+}
+
+int uavenv_threaten_rate_allpairs(UavEnv *e, const double *xyz, uint8_t *out, int64_t n, void *stream)
+{
+    return threaten_impl(e, xyz, out, n, stream, true);
+}
+
+}  // extern "C"

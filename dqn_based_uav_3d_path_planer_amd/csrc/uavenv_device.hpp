@@ -1,0 +1,258 @@
+// uavenv_device.hpp -- device-side building blocks of the PathPlan_City hot path (gfx950).
+//
+// Numerics contract: everything that decides a reward, a termination or an occupancy bit is
+// IEEE f64 evaluated in the reference's operation order (no FMA contraction: the TU is built
+// with -ffp-contract=off), so that results agree with the CPython reference to last-ulp
+// libm differences (OCML vs glibc atan2/sin/cos), far inside the 1e-5 parity tolerance.
+// Only the stored observation is narrowed (f32 / f16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace uav {
+
+constexpr double kPi = 3.141592653589793;                 // math.pi
+constexpr double kRad2Deg = 180.0 / 3.141592653589793;    // CPython math.degrees factor
+constexpr double kTwoPi = 2.0 * 3.141592653589793;
+
+// One cylinder as the narrow-phase test needs it (LDS resident, 32 B).
+// Obstacles/building.py:20-26:  z > H -> miss;  sqrt(dx^2+dy^2+0) < R -> hit.
+// `thr` is the smallest double t with sqrt_rn(t) >= R, so (s < thr) == (sqrt_rn(s) < R) EXACTLY
+// (sqrt_rn is monotone): the square root leaves the inner loop without changing any result.
+struct BldLds {
+    double cx, cy, thr, H;
+};
+
+// Cylinder as the APF force needs it (Agents/UAV.py:174-210); global memory, uniform index.
+struct BldApf {
+    double cx, cy, cz, R, vx, vy, vz, vnorm;
+};
+
+template <typename MaskT>
+struct WorldLds {
+    const BldLds *b;      // LDS
+    const MaskT *grid;    // LDS: gnx*gny candidate masks
+    int gnx, gny;
+    double inv_cell;
+    double W, Hbox;       // Threaten_rate bounds (x and y both use `width`; PathPlan_City.py:218)
+};
+
+// BaseClass/CalMod.py:89-102  calculate_angle(p1, p2, mod=1) with (dx,dy) = p2 - p1.
+// atan2 -> degrees -> (a + 360) % 360 -> / 180 * pi.  For a in [180, 540] the float modulo is
+// exactly (a >= 360 ? a - 360 : a).
+__device__ __noinline__ double calc_angle(double dx, double dy)
+{
+    double a = atan2(dy, dx) * kRad2Deg;
+    a = a + 360.0;
+    double m = (a >= 360.0) ? (a - 360.0) : a;
+    return m / 180.0 * kPi;
+}
+
+// BaseClass/CalMod.py:64-65  Eu_Loc_distance
+__device__ __forceinline__ double dist3(double ax, double ay, double az, double bx, double by, double bz)
+{
+    double dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+// Agents/UAV.py:246-253  Calc_V: speed with the clamp that rescales (x, y).
+__device__ __forceinline__ double calc_v(double &vx, double &vy, double max_v)
+{
+    double V = sqrt(vx * vx + vy * vy + 0.0);
+    if (V > max_v) {
+        double k = max_v / V;
+        vx = vx * k;
+        vy = vy * k;
+        V = max_v;
+    }
+    return V;
+}
+
+// Agents/UAV.py:239-245  Calc_Fly_Power at speed V (V already clamped).
+struct PowerParams {
+    double P_i, v_0, d_0, rho, s, A, P_b, F_b;
+};
+__device__ __forceinline__ double fly_power(const PowerParams &p, double V, int j)
+{
+    double A = p.A + 0.03 * (double)j;       // UAV.py:55
+    double xi = 0.8 + 0.02 * (double)j;      // UAV.py:58
+    double V2 = V * V, v02 = p.v_0 * p.v_0;
+    double induced = p.P_i * sqrt(sqrt(1.0 + (V2 * V2) / (4.0 * (v02 * v02))) - V2 / (2.0 * v02));
+    double parasite = 0.5 * p.d_0 * p.rho * p.s * A * (V2 * V);
+    double blade = xi * p.P_b * (1.0 + 3.0 * V2 / (p.F_b * p.F_b));
+    return induced + parasite + blade;
+}
+
+// Envs/PathPlan_City.py:215-223  Threaten_rate(p) through the exact broad phase:
+// the cell's mask is a SUPERSET of the cylinders that can hit any point of the cell, so the OR
+// over candidates equals the reference's first-hit loop over all buildings.
+template <typename MaskT>
+__device__ __forceinline__ int probe(const WorldLds<MaskT> &w, double x, double y, double z)
+{
+    if ((x < 0.0) | (x > w.W) | (y < 0.0) | (y > w.W) | (z < 0.0) | (z > w.Hbox)) return 1;
+    int ix = (int)(x * w.inv_cell);
+    int iy = (int)(y * w.inv_cell);
+    ix = ix < w.gnx - 1 ? ix : w.gnx - 1;
+    iy = iy < w.gny - 1 ? iy : w.gny - 1;
+    MaskT m = w.grid[iy * w.gnx + ix];
+    int hit = 0;
+    while (m) {
+        int b = (sizeof(MaskT) == 8) ? __builtin_ctzll((unsigned long long)m) : __builtin_ctz((unsigned)m);
+        m &= (MaskT)(m - 1);
+        BldLds B = w.b[b];
+        double dx = x - B.cx, dy = y - B.cy;
+        double s = dx * dx + dy * dy;       // + (bz-bz)^2 == + 0.0
+        hit |= (int)(!(z > B.H)) & (int)(s < B.thr);
+    }
+    return hit;
+}
+
+// All-pairs variant (no grid): the literal reference loop, for the culling-exactness test.
+__device__ __forceinline__ int probe_allpairs(const BldLds *b, int nb, double W, double Hbox, double x, double y,
+                                              double z)
+{
+    if ((x < 0.0) | (x > W) | (y < 0.0) | (y > W) | (z < 0.0) | (z > Hbox)) return 1;
+    int hit = 0;
+    for (int i = 0; i < nb; ++i) {
+        BldLds B = b[i];
+        double dx = x - B.cx, dy = y - B.cy;
+        double s = dx * dx + dy * dy;
+        hit |= (int)(!(z > B.H)) & (int)(s < B.thr);
+    }
+    return hit;
+}
+
+// The per-agent values an observation is built from.
+struct ObsIn {
+    double px, py, pz, vx, vy, V, gx, gy, gz;
+    double s0x, s0y, s0z, s1x, s1y, s1z;
+    int step, n_rem;   // n_rem = len(sub_goals)
+};
+
+// 5x5 occupancy stencil at `spacing` metres (UAV.py:533-555): bit 5*i+j <- Threaten_rate(px+(i-2)s, py+(j-2)s, pz)
+template <typename MaskT>
+__device__ __forceinline__ uint32_t stencil_bits(const WorldLds<MaskT> &w, double px, double py, double pz,
+                                                 double spacing)
+{
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        double x = px + spacing * (double)(i - 2);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            double y = py + spacing * (double)(j - 2);
+            bits |= (uint32_t)probe(w, x, y, pz) << (5 * i + j);
+        }
+    }
+    return bits;
+}
+
+struct ObsBits {
+    uint32_t s1, s5, s10, below;
+};
+
+template <typename MaskT>
+__device__ __forceinline__ ObsBits obs_bits(const WorldLds<MaskT> &w, double px, double py, double pz)
+{
+    ObsBits o;
+    o.s1 = stencil_bits(w, px, py, pz, 1.0);
+    o.s5 = stencil_bits(w, px, py, pz, 5.0);
+    o.s10 = stencil_bits(w, px, py, pz, 10.0);
+    uint32_t bl = 0;
+#pragma unroll
+    for (int k = 1; k <= 5; ++k) bl |= (uint32_t)probe(w, px, py, pz - (double)k) << (k - 1);   // UAV.py:562-566
+    o.below = bl;
+    return o;
+}
+
+// The 20 scalar features of state_PathPlan (UAV.py:518-531, 557-560), as float.
+struct ObsScalars {
+    float f[20];   // 0..10 -> cols 0..10 ; 11..14 -> cols 86..89
+};
+
+__device__ __forceinline__ ObsScalars obs_scalars(const ObsIn &a, double heading)
+{
+    ObsScalars o;
+    o.f[0] = (float)((double)a.step / 100.0);
+    bool h0 = a.n_rem >= 1, h1 = a.n_rem >= 2;
+    o.f[1] = h0 ? (float)((a.s0x - a.px) / 10.0) : 0.0f;
+    o.f[2] = h0 ? (float)((a.s0y - a.py) / 10.0) : 0.0f;
+    o.f[3] = h0 ? (float)((a.s0z - a.pz) / 10.0) : 0.0f;
+    o.f[4] = (float)a.V;
+    o.f[5] = (float)a.vx;
+    o.f[6] = (float)a.vy;
+    o.f[7] = (float)heading;
+    o.f[8] = h1 ? (float)((a.s1x - a.px) / 10.0) : 0.0f;
+    o.f[9] = h1 ? (float)((a.s1y - a.py) / 10.0) : 0.0f;
+    o.f[10] = h1 ? (float)((a.s1z - a.pz) / 10.0) : 0.0f;
+    o.f[11] = (float)((a.gx - a.px) / 10.0);
+    o.f[12] = (float)((a.gy - a.py) / 10.0);
+    o.f[13] = (float)((a.gz - a.pz) / 10.0);
+    o.f[14] = (float)(a.pz / 10.0);
+    return o;
+}
+
+// Column c (0..99) of the observation row.  `c` is a compile-time
+// constant after unrolling, so this folds to one select per column.
+__device__ __forceinline__ float obs_col(const ObsScalars &s, const ObsBits &b, int c)
+{
+    if (c < 11) return s.f[c];
+    if (c < 36) return (float)((b.s1 >> (c - 11)) & 1u);
+    if (c < 61) return (float)((b.s5 >> (c - 36)) & 1u);
+    if (c < 86) return (float)((b.s10 >> (c - 61)) & 1u);
+    if (c < 90) return s.f[11 + (c - 86)];
+    if (c < 95) return (float)((b.below >> (c - 90)) & 1u);
+    return 0.0f;
+}
+
+// Row-per-lane store of one observation: 25 x 16-byte stores (f32) or 25 x 8-byte (f16).
+template <bool F16>
+__device__ __forceinline__ void store_obs_row(void *obs_base, int64_t agent, const ObsScalars &s, const ObsBits &b)
+{
+    if (!F16) {
+        float4 *row = reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs_base) + agent * 100);
+#pragma unroll
+        for (int k = 0; k < 25; ++k) {
+            float4 v;
+            v.x = obs_col(s, b, 4 * k + 0);
+            v.y = obs_col(s, b, 4 * k + 1);
+            v.z = obs_col(s, b, 4 * k + 2);
+            v.w = obs_col(s, b, 4 * k + 3);
+            row[k] = v;
+        }
+    } else {
+        uint2 *row = reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(obs_base) + agent * 100);
+#pragma unroll
+        for (int k = 0; k < 25; ++k) {
+            __half2 lo = __floats2half2_rn(obs_col(s, b, 4 * k + 0), obs_col(s, b, 4 * k + 1));
+            __half2 hi = __floats2half2_rn(obs_col(s, b, 4 * k + 2), obs_col(s, b, 4 * k + 3));
+            uint2 v;
+            v.x = *reinterpret_cast<uint32_t *>(&lo);
+            v.y = *reinterpret_cast<uint32_t *>(&hi);
+            row[k] = v;
+        }
+    }
+}
+
+// Philox4x32-10 (counter-based; one independent stream per (seed, agent, tick)).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// 53-bit uniform in [0,1) from two words (same construction as CPython's random()).
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace uav

@@ -1,0 +1,167 @@
+/*
+ * uavenv.h -- C ABI of the MI355X-native PathPlan_City hot path (libuavenv.so).
+ *
+ * The reference (young-how/DQN-based-UAV-3D_path_planer) is pure Python and has
+ * NO FFI of its own: its plugin boundary is reflection (FactoryClass/EnvFactory.py:12-25,
+ * AgentFactory.py:11-27, TrainerFactory.py:10-22) over duck-typed Env/Agent/Trainer
+ * objects.  This header is the boundary the build adds UNDER that surface; each entry
+ * point names the reference interface it replaces.  The Python plugin classes in
+ * dqn_based_uav_3d_path_planer_amd/plugins/ (PathPlan_City, UAV, building, *_Trainer) bind
+ * these symbols with ctypes -- see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative UAVENV_E* code; nothing throws
+ *     across the ABI; uavenv_last_error() gives a message for the last failure.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()); "host" pointers are ordinary host memory, copied synchronously.
+ *   - hot-path calls only ENQUEUE work on the caller's stream (void* == hipStream_t,
+ *     NULL = default stream); they never synchronise and create no threads.
+ *   - agents are indexed i = env * uav_per_env + j  (PathPlan_City.py:59-62: UAV_j of env).
+ */
+#ifndef UAVENV_H
+#define UAVENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVENV_ABI_VERSION 1
+#define UAVENV_OBS_DIM 100          /* Agents/UAV.py:517  state_map = zeros(1,1,1,100) */
+#define UAVENV_MAX_BUILDINGS 64     /* broad-phase masks are 64-bit */
+
+/* error codes */
+#define UAVENV_OK 0
+#define UAVENV_EINVAL (-22)
+#define UAVENV_ENOMEM (-12)
+#define UAVENV_EHIP (-5)            /* a HIP runtime call failed; see uavenv_last_error() */
+#define UAVENV_ENODEV (-19)         /* no gfx950 device visible -- there is no CPU fallback */
+
+/* info codes written by uavenv_step (Agents/UAV.py:406,465,483,495,509,513) */
+#define UAVENV_INFO_NORMAL 0
+#define UAVENV_INFO_SUCCESS 1
+#define UAVENV_INFO_LOSE 2
+#define UAVENV_INFO_SKIPPED 3       /* agent was already done and UAVENV_STEP_SKIP_DONE was set */
+
+/* action encodings accepted by uavenv_step */
+#define UAVENV_ACT_STEER_F32 0      /* action[0] in [-1,1] as float  (SAC continuous, Trainer/SAC_Trainer.py:444-448) */
+#define UAVENV_ACT_STEER_F64 1      /* same as double (parity tests) */
+#define UAVENV_ACT_INDEX_I32 2      /* discrete a in [0,A): steer = -1 + 2a/(A-1)  (the
+                                       reference leaves the discrete->steering map undefined; this is ours) */
+
+/* observation storage */
+#define UAVENV_OBS_F32 0
+#define UAVENV_OBS_F16 1
+
+/* uavenv_step flags */
+#define UAVENV_STEP_AUTO_RESET 1u   /* env whose agents are all done is reset from the scenario bank in the same
+                                       launch (replaces PathPlan_City.py:416-417 Scene_Random_Reset per episode) */
+#define UAVENV_STEP_SKIP_DONE 2u    /* agents with done==1 do not move (PathPlan_City.py:365-366) */
+#define UAVENV_STEP_NO_OBS 4u       /* do not compute/write the observation */
+
+typedef struct UavEnv UavEnv;       /* opaque; owns the per-agent state in HBM */
+
+/* Construction parameters: BaseClass/BaseEnv.py:17-22, Agents/UAV.py:22-59, config/UAV.xml. */
+typedef struct UavEnvConfig {
+    int32_t abi_version;        /* UAVENV_ABI_VERSION */
+    int32_t device;             /* HIP device ordinal */
+    int32_t n_envs;             /* independent environments resident on this device */
+    int32_t uav_per_env;        /* num_UAV (PathPlan_City.py:55); power of two <= 64 */
+    int32_t max_subgoals;       /* K: capacity of each agent's sub-goal list (reference: unbounded, observed <= 34) */
+    int32_t max_step;           /* Max_Step */
+    int32_t apf_enabled;        /* APF_Enabled (UAV.py:142,448) */
+    int32_t obs_dtype;          /* UAVENV_OBS_F32 / UAVENV_OBS_F16 */
+    int32_t n_actions;          /* A for UAVENV_ACT_INDEX_I32 (>=2) */
+    int32_t reserved0;
+    double len, width, h;       /* world box; NOTE Threaten_rate bounds x AND y by `width` (PathPlan_City.py:218) */
+    double max_v;               /* int(Max_V) */
+    double steering_angle;      /* radians: Steering_angle/180*pi */
+    double power[8];            /* P_i v_0 d_0 rho s A P_b F_b  (A gets +0.03 j, xi = 0.8+0.02 j per UAV j) */
+    double cell_size;           /* broad-phase grid cell in metres; 0 -> 10 */
+} UavEnvConfig;
+
+/* ---- lifetime --------------------------------------------------------------------- */
+int uavenv_abi_version(void);
+const char *uavenv_last_error(void);
+/* replaces PathPlan_City.__init__ + UAV.__init__ state allocation (PathPlan_City.py:31-69) */
+int uavenv_create(const UavEnvConfig *cfg, UavEnv **out);
+int uavenv_destroy(UavEnv *env);
+int uavenv_num_agents(const UavEnv *env);
+
+/* replaces the building list built from buildings.xml (PathPlan_City.py:41-51, building.py:6-11).
+ * host_cxcyczRH: nb x 5 doubles; host_vxyz: nb x 3 doubles or NULL (static, stock config). */
+int uavenv_set_buildings(UavEnv *env, const double *host_cxcyczRH, const double *host_vxyz, int32_t nb);
+
+/* ---- reset ------------------------------------------------------------------------- */
+/* Scenario bank = the part of UAV.reset() that cannot run per step on device yet: start/goal
+ * and the RRT sub-goal list (UAV.py:353-360, PathPlan/RRT.py:63-105).
+ * host_start_goal: M x 6 (sx,sy,sz,gx,gy,gz); host_subgoals: M x K x 3; host_nsub: M. */
+int uavenv_load_scenarios(UavEnv *env, const double *host_start_goal, const double *host_subgoals,
+                          const int32_t *host_nsub, int32_t m);
+/* UAV.reset() (UAV.py:327-366) for every agent: heading ~ U(0,2pi), scenario ~ U{0..M-1} from a
+ * counter-based Philox stream keyed by (seed, agent); sub_goals[0] aliases the position as in the reference. */
+int uavenv_reset_all(UavEnv *env, uint64_t seed, void *stream);
+
+/* ---- parity injection (tests; synchronous, host pointers) ------------------------- */
+/* kin: count x 8 doubles (px,py,pz,vx,vy,gx,gy,gz); V is recomputed with Calc_V semantics (UAV.py:246-253).
+ * step/n_sub/alias: count int32 each (alias may be NULL = 0); sub: count x K x 3 doubles. */
+int uavenv_set_state(UavEnv *env, int32_t first, int32_t count, const double *kin, const int32_t *step,
+                     const int32_t *n_sub, const int32_t *alias, const double *sub);
+/* out16: count x 16 doubles = [px,py,pz,vx,vy,V,gx,gy,gz,Step,done,n_sub,score,total_score,path_len,reach_goal];
+ * out_sub (nullable): count x K x 3 remaining sub-goals, current first; out_alias (nullable): count int32. */
+int uavenv_get_state(UavEnv *env, int32_t first, int32_t count, double *out16, double *out_sub, int32_t *out_alias);
+
+/* ---- hot path ---------------------------------------------------------------------- */
+/* One UAV.update_PathPlan(action) (UAV.py:397-513) + UAV.state_PathPlan() (UAV.py:515-567) for every
+ * agent, i.e. BaseEnv.Move_Agent (BaseEnv.py:123-137) vectorised.  All output pointers are nullable.
+ *   actions_dev   N elements of the type selected by action_kind
+ *   obs_dev       N x 100 (f32 or f16 per cfg.obs_dtype): the state AFTER the step (after the reset if
+ *                 AUTO_RESET fired) -- point it at replay frame t+1 to fuse ReplayMemory.add (replay_buffer.py:41-42)
+ *   reward64/32   global_r as double / float (the reference stores FloatTensor([[reward]]), PathPlan_City.py:377)
+ *   ret_done      the `done` RETURNED by update (goes into replay); agent_done = self.done (ends the episode)
+ *   valid         0 for skipped agents, else 1
+ *   energy64      Calc_Fly_Power at the post-step speed (UAV.py:239-245), J per unit-time step
+ */
+int uavenv_step(UavEnv *env, const void *actions_dev, int32_t action_kind, void *obs_dev, double *reward64_dev,
+                float *reward32_dev, uint8_t *ret_done_dev, uint8_t *agent_done_dev, uint8_t *info_dev,
+                uint8_t *valid_dev, double *energy64_dev, uint32_t flags, void *stream);
+/* UAV.state_PathPlan() only (UAV.py:515-567), e.g. the first observation after a reset. */
+int uavenv_observe(UavEnv *env, void *obs_dev, void *stream);
+/* PathPlan_City.Threaten_rate (PathPlan_City.py:215-223) for n points: xyz_dev n x 3 doubles -> out_dev n bytes. */
+int uavenv_threaten_rate(UavEnv *env, const double *xyz_dev, uint8_t *out_dev, int64_t n, void *stream);
+/* Same, bypassing the broad-phase grid (all-pairs); used to prove the culling is exact. */
+int uavenv_threaten_rate_allpairs(UavEnv *env, const double *xyz_dev, uint8_t *out_dev, int64_t n, void *stream);
+
+/* ---- device replay ring + acting (BaseClass/replay_buffer.py:28-54) ----------------- */
+/* The ring is caller-owned HBM, frame-major: frame t holds obs[t] = state BEFORE action t, plus
+ * action/reward/done/valid of transition t; next_state of (t,i) is obs[(t+1) % frames][i]. */
+typedef struct UavReplayRing {
+    void *obs;            /* frames x N x 100, f32 or f16 */
+    void *action;         /* frames x N, float steer or int32 index */
+    float *reward;        /* frames x N */
+    uint8_t *done;        /* frames x N  (returned done) */
+    uint8_t *valid;       /* frames x N */
+    int32_t frames;
+    int32_t n_agents;
+    int32_t obs_dtype;
+    int32_t action_is_index;
+} UavReplayRing;
+
+/* ReplayMemory.sample2 (replay_buffer.py:48-51) on device: draw `batch` (frame, agent) pairs uniformly (with
+ * replacement, Philox(seed, counter)) from the `filled` frames preceding `head` and gather them into
+ * contiguous batch buffers: obs_b/next_obs_b batch x 100 (ring dtype), action_b batch (ring type),
+ * reward_b batch f32, done_b batch f32 (0/1), valid_b batch f32 (0/1). */
+int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                         uint64_t counter, void *obs_b, void *next_obs_b, void *action_b, float *reward_b,
+                         float *done_b, float *valid_b, void *stream);
+
+/* epsilon-greedy over Q-values (Trainer/DuelingDQN_Trainer.py:86-97): q_dev N x A f32 (row-major).
+ * Writes the chosen index (int32, nullable) and its steering value (f32, nullable). */
+int uavenv_select_actions(const float *q_dev, int32_t n, int32_t n_actions, float eps, uint64_t seed,
+                          uint64_t counter, int32_t *index_out_dev, float *steer_out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVENV_H */

@@ -206,9 +206,23 @@ class OracleBatch:
     def __init__(self, world: OracleWorld, params: dict, n: int):
         self.world, self.lib, self.n = world, world.lib, n
         self.arr = (Uav * n)()
-        for i in range(n):
-            for k, v in params.items():
-                setattr(self.arr[i], k, v)
+        self.view = np.frombuffer(self.arr, dtype=np.dtype(Uav))   # structured view: vectorised field access
+        for k, v in params.items():
+            self.view[k] = v
+
+    def set_from_state16(self, st, sub, alias):
+        """Load agents from the [n,16] layout of uavenv_get_state / gen_golden.uav_state_vec (+ sub-goals)."""
+        v = self.view
+        for k, name in enumerate(("px", "py", "pz", "vx", "vy", "V", "gx", "gy", "gz")):
+            v[name] = st[:, k]
+        v["vz"] = 0.0
+        v["step"], v["done"], v["n_sub"] = st[:, 9].astype(np.int32), st[:, 10].astype(np.int32), st[:, 11].astype(np.int32)
+        v["score"], v["total_score"], v["path_len"] = st[:, 12], st[:, 13], st[:, 14]
+        v["reach_goal"] = st[:, 15].astype(np.int32)
+        v["sub0_alias"] = np.asarray(alias, dtype=np.int32)
+        v["error"] = 0
+        k = min(sub.shape[1], KMAX)
+        v["sub"][:, :k] = sub[:, :k]
 
     def load_scenarios(self, start, goal, heading, sub_goals, n_sub, max_v=1.0):
         m = len(start)

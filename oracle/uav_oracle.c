@@ -191,6 +191,7 @@ void orc_update_pathplan(const orc_world *w, orc_uav *u, double a0,
             if (orc_cal_force(w, u, u->sub[k][0], u->sub[k][1], u->sub[k][2], f)) u->error = 2;
             u->sub[k][0] += f[0]; u->sub[k][1] += f[1]; u->sub[k][2] += f[2];
         }
+        u->sub0_alias = 0;   /* Adjust_subgoal rebuilds the list from NEW Loc objects (:162-165): the alias ends */
         double f[3];
         if (orc_cal_force(w, u, u->px, u->py, u->pz, f)) u->error = 2;
         double force = orc_distance(0, 0, 0, f[0], f[1], f[2]);

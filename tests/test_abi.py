@@ -1,0 +1,67 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol include/uavenv.h declares.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from dqn_based_uav_3d_path_planer_amd import _build, _lib
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "uavenv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(uavenv_\w+)\s*\(", text)))
+
+
+def test_library_builds_and_loads():
+    path = _build.build()
+    assert os.path.exists(path)
+    lib = _lib.load()
+    assert lib.uavenv_abi_version() == _lib.ABI_VERSION
+
+
+def test_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = header_symbols()
+    assert len(declared) >= 16
+    assert sorted(_lib.SYMBOLS) == declared, "ctypes binding and header disagree"
+    for name in declared:
+        assert hasattr(lib, name), f"libuavenv.so does not export {name}"
+
+
+def test_config_struct_layout_matches_header():
+    # 10 int32 + 5 doubles + 8 doubles + 1 double, naturally aligned
+    assert ctypes.sizeof(_lib.UavEnvConfig) == 10 * 4 + 14 * 8
+    assert ctypes.sizeof(_lib.UavReplayRing) == 5 * 8 + 4 * 4
+
+
+def test_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    cfg = _lib.UavEnvConfig()
+    cfg.abi_version = _lib.ABI_VERSION
+    cfg.n_envs, cfg.uav_per_env, cfg.max_subgoals, cfg.max_step = 4, 1, 8, 150
+    h = ctypes.c_void_p()
+    rc = lib.uavenv_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == _lib.ENODEV
+    assert b"no CPU fallback" in lib.uavenv_last_error()
+    from dqn_based_uav_3d_path_planer_amd.env import VecPathPlanEnv
+    with pytest.raises(_lib.UavEnvError):
+        VecPathPlanEnv(4, [[1.0, 2.0, 0.0, 3.0, 4.0]])
+
+
+def test_rejects_bad_config():
+    lib = _lib.load()
+    cfg = _lib.UavEnvConfig()
+    cfg.abi_version = 999
+    h = ctypes.c_void_p()
+    assert lib.uavenv_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.EINVAL
+    cfg.abi_version = _lib.ABI_VERSION
+    cfg.n_envs, cfg.uav_per_env, cfg.max_subgoals, cfg.max_step = 4, 3, 8, 150   # 3 is not a power of two
+    assert lib.uavenv_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.EINVAL
+    assert lib.uavenv_create(None, ctypes.byref(h)) == _lib.EINVAL
