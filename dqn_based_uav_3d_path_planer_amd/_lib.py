@@ -56,6 +56,9 @@ def load() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch first: it bundles its own libamdhip64/libhsa-runtime64; if libuavenv.so pulled /opt/rocm's copies in
+    # before torch loads, the process ends up with two HSA runtimes and the second sees no device.
+    import torch  # noqa: F401
     path = _build.LIB_PATH
     if _build.needs_build():
         _build.build()

@@ -51,16 +51,24 @@ static int fail(int code, const char *fmt, ...)
 // ------------------------------------------------------------------------------------------------
 // device-side state
 // ------------------------------------------------------------------------------------------------
+// One slab, three typed planes; field k of a plane is the npad-element array at base + k*npad.  Only the
+// three base pointers (+ npad, sub) travel as kernel arguments: 25 separate pointers would not fit the SGPR
+// budget and the compiler would spill them through v_writelane/v_readlane.
+enum F64Field { F_PX, F_PY, F_PZ, F_VX, F_VY, F_V, F_GX, F_GY, F_GZ, F_S0X, F_S0Y, F_S0Z, F_S1X, F_S1Y, F_S1Z,
+                F_SCORE, F_TOTAL, F_PATHLEN, F_HEAD };
+enum I32Field { I_STEP, I_SUBIDX, I_NTOTAL, I_EPOCH, I_SCN, I_FLAGS };
+// I_FLAGS packs done (bit 0), alias (bit 1), reach_goal (bit 2) in ONE dword: byte-sized planes made the compiler
+// zero-extend each byte right after its load, i.e. wait for every earlier load before the LDS staging could start.
+constexpr int kFlagDone = 1, kFlagAlias = 2, kFlagReach = 4;
 struct DevState {
-    double *px, *py, *pz, *vx, *vy, *V, *gx, *gy, *gz;
-    double *s0x, *s0y, *s0z, *s1x, *s1y, *s1z;
-    double *score, *total, *path_len;
-    int32_t *step, *sub_idx, *n_total;
-    uint32_t *epoch;
-    uint8_t *done, *alias, *reach;
-    double *sub;   // [N][K][3]
+    double *f64;     // [19][npad]
+    int32_t *i32;    // [6][npad]
+    size_t npad;
+    double *sub;     // [N][K][3]
+    __host__ __device__ double *F(int k) const { return f64 + (size_t)k * npad; }
+    __host__ __device__ int32_t *I(int k) const { return i32 + (size_t)k * npad; }
 };
-constexpr int kNumF64 = 18, kNumI32 = 4, kNumU8 = 3;
+constexpr int kNumF64 = 19, kNumI32 = 6;
 
 struct Bank {
     const double *start_goal;   // [M][6]
@@ -72,9 +80,9 @@ struct Bank {
 struct StepArgs {
     DevState st;
     // world
-    const unsigned char *world_blob;   // [BldLds x nb_pad][grid]  (16-byte multiple)
-    int32_t world_bytes, grid_off;
-    int32_t nb, gnx, gny;
+    const unsigned char *world_blob;   // [BldLds x nb][grid halo 2][grid halo 10][grid halo 20]  (16-byte multiples)
+    int32_t world_bytes, grid_off, grid_stride;
+    int32_t nb, gn;
     double inv_cell, W, Hbox;
     const BldApf *apf_b;
     // agent params
@@ -103,7 +111,7 @@ struct UavEnv {
     size_t slab_bytes = 0;
     // world
     unsigned char *world_blob = nullptr;
-    int world_bytes = 0, grid_off = 0, nb = 0, gnx = 0, gny = 0, mask_bytes = 8;
+    int world_bytes = 0, grid_off = 0, grid_stride = 0, nb = 0, gn = 0, mask_bytes = 8;
     double cell = 10.0;
     BldApf *apf_b = nullptr;
     bool have_world = false;
@@ -118,22 +126,38 @@ struct UavEnv {
 // device helpers
 // ------------------------------------------------------------------------------------------------
 template <typename MaskT>
-__device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, const unsigned char *blob, int bytes,
-                                                       int grid_off, int gnx, int gny, double inv_cell, double W,
-                                                       double Hbox)
+__device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, const StepArgs &a)
 {
-    const uint4 *src = reinterpret_cast<const uint4 *>(blob);
+    // global -> registers -> LDS with up to kInFlight 16-byte loads per lane in flight (a one-load-per-iteration
+    // loop serialises one L2 round trip per KiB and was ~20 % of the kernel at 16 384 envs)
+    constexpr int kInFlight = 12;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.world_blob);
     uint4 *dst = reinterpret_cast<uint4 *>(smem);
-    for (int k = threadIdx.x; k < bytes / 16; k += blockDim.x) dst[k] = src[k];
+    const int n16 = a.world_bytes / 16;
+    for (int base = 0; base < n16; base += (int)blockDim.x * kInFlight) {
+        uint4 tmp[kInFlight];
+#pragma unroll
+        for (int r = 0; r < kInFlight; ++r) {
+            const int k = base + r * (int)blockDim.x + (int)threadIdx.x;
+            tmp[r] = src[k < n16 ? k : n16 - 1];      // unconditional (clamped) so all loads issue back to back
+        }
+#pragma unroll
+        for (int r = 0; r < kInFlight; ++r)           // pin the loads here: keeps hipcc from sinking each one into
+            asm volatile("" : "+v"(tmp[r].x), "+v"(tmp[r].y), "+v"(tmp[r].z), "+v"(tmp[r].w));   // its guarded store
+#pragma unroll
+        for (int r = 0; r < kInFlight; ++r) {
+            const int k = base + r * (int)blockDim.x + (int)threadIdx.x;
+            if (k < n16) dst[k] = tmp[r];
+        }
+    }
     __syncthreads();
     WorldLds<MaskT> w;
     w.b = reinterpret_cast<const BldLds *>(smem);
-    w.grid = reinterpret_cast<const MaskT *>(smem + grid_off);
-    w.gnx = gnx;
-    w.gny = gny;
-    w.inv_cell = inv_cell;
-    w.W = W;
-    w.Hbox = Hbox;
+    for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(smem + a.grid_off + h * a.grid_stride);
+    w.gn = a.gn;
+    w.inv_cell = a.inv_cell;
+    w.W = a.W;
+    w.Hbox = a.Hbox;
     return w;
 }
 
@@ -168,41 +192,245 @@ __device__ __noinline__ bool cal_force(const BldApf *__restrict__ b, int nb, dou
     return ok;
 }
 
-__device__ __forceinline__ double load_action(const void *actions, int kind, int i, int n_actions)
+// Actions are fetched as raw bits (so the load can be issued early, with no dependent conversion) and decoded
+// at first use.
+struct RawAction {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ RawAction load_action_raw(const void *actions, int kind, int i)
 {
-    if (kind == UAVENV_ACT_STEER_F32) return (double)reinterpret_cast<const float *>(actions)[i];
-    if (kind == UAVENV_ACT_STEER_F64) return reinterpret_cast<const double *>(actions)[i];
-    int a = reinterpret_cast<const int32_t *>(actions)[i];
-    return -1.0 + 2.0 * (double)a / (double)(n_actions - 1);
+    RawAction r;
+    r.hi = 0;
+    if (kind == UAVENV_ACT_STEER_F64) {
+        const uint2 v = reinterpret_cast<const uint2 *>(actions)[i];
+        r.lo = v.x;
+        r.hi = v.y;
+    } else {
+        r.lo = reinterpret_cast<const uint32_t *>(actions)[i];
+    }
+    return r;
+}
+__device__ __forceinline__ double decode_action(RawAction r, int kind, int n_actions)
+{
+    if (kind == UAVENV_ACT_STEER_F32) return (double)__uint_as_float(r.lo);
+    if (kind == UAVENV_ACT_STEER_F64) return __longlong_as_double((long long)(((unsigned long long)r.hi << 32) | r.lo));
+    return -1.0 + 2.0 * (double)(int)r.lo / (double)(n_actions - 1);
 }
 
-// UAV.reset() from the scenario bank (UAV.py:327-366 with the RRT result pre-planned).
-__device__ __forceinline__ void reset_agent(const StepArgs &a, int i, uint64_t seed, uint64_t tick, ObsIn &o,
-                                            int &sub_idx, int &n_total, int &alias, double &score, double &total,
-                                            double &path_len, int &done, int &reach)
+// The registers an agent lives in during a step.
+struct Agent {
+    ObsIn o;
+    double head;                 // cached calculate_angle(0, V_vector) of the CURRENT velocity
+    double score, total, path_len;
+    int sub_idx, n_total, scn;   // scn >= 0: the sub-goal list is bank scenario scn (read-only); -1: private list
+    int done, alias, reach;      // unpacked from I_FLAGS by unpack_flags() at first use
+    int flags_raw;
+    uint32_t epoch;
+};
+
+__device__ __forceinline__ void load_agent(const DevState &S, int i, Agent &g)
 {
-    uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)tick, (uint32_t)(tick >> 32), 0x5eedu),
-                            make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    double heading = (kTwoPi)*u53(r.x, r.y);             // random.uniform(0, 2*pi)  (a + (b-a)*random(), a = 0)
-    uint32_t scn = (uint32_t)(((uint64_t)r.z * (uint64_t)a.bank.m) >> 32);
+    ObsIn &o = g.o;
+    o.px = S.F(F_PX)[i]; o.py = S.F(F_PY)[i]; o.pz = S.F(F_PZ)[i];
+    o.vx = S.F(F_VX)[i]; o.vy = S.F(F_VY)[i]; o.V = S.F(F_V)[i];
+    o.gx = S.F(F_GX)[i]; o.gy = S.F(F_GY)[i]; o.gz = S.F(F_GZ)[i];
+    o.s0x = S.F(F_S0X)[i]; o.s0y = S.F(F_S0Y)[i]; o.s0z = S.F(F_S0Z)[i];
+    o.s1x = S.F(F_S1X)[i]; o.s1y = S.F(F_S1Y)[i]; o.s1z = S.F(F_S1Z)[i];
+    g.head = S.F(F_HEAD)[i];
+    g.score = S.F(F_SCORE)[i]; g.total = S.F(F_TOTAL)[i]; g.path_len = S.F(F_PATHLEN)[i];
+    o.step = S.I(I_STEP)[i];
+    g.sub_idx = S.I(I_SUBIDX)[i]; g.n_total = S.I(I_NTOTAL)[i]; g.scn = S.I(I_SCN)[i];
+    g.epoch = (uint32_t)S.I(I_EPOCH)[i];
+    g.flags_raw = S.I(I_FLAGS)[i];
+}
+
+__device__ __forceinline__ void unpack_flags(Agent &g)
+{
+    g.done = g.flags_raw & kFlagDone ? 1 : 0;
+    g.alias = g.flags_raw & kFlagAlias ? 1 : 0;
+    g.reach = g.flags_raw & kFlagReach ? 1 : 0;
+    g.o.n_rem = g.n_total - g.sub_idx;
+}
+
+__device__ __forceinline__ void store_agent(const DevState &S, int i, const Agent &g)
+{
+    const ObsIn &o = g.o;
+    S.F(F_PX)[i] = o.px; S.F(F_PY)[i] = o.py; S.F(F_PZ)[i] = o.pz;
+    S.F(F_VX)[i] = o.vx; S.F(F_VY)[i] = o.vy; S.F(F_V)[i] = o.V;
+    S.F(F_GX)[i] = o.gx; S.F(F_GY)[i] = o.gy; S.F(F_GZ)[i] = o.gz;
+    S.F(F_S0X)[i] = o.s0x; S.F(F_S0Y)[i] = o.s0y; S.F(F_S0Z)[i] = o.s0z;
+    S.F(F_S1X)[i] = o.s1x; S.F(F_S1Y)[i] = o.s1y; S.F(F_S1Z)[i] = o.s1z;
+    S.F(F_HEAD)[i] = g.head;
+    S.F(F_SCORE)[i] = g.score; S.F(F_TOTAL)[i] = g.total; S.F(F_PATHLEN)[i] = g.path_len;
+    S.I(I_STEP)[i] = o.step; S.I(I_SUBIDX)[i] = g.sub_idx; S.I(I_NTOTAL)[i] = g.n_total; S.I(I_SCN)[i] = g.scn;
+    S.I(I_EPOCH)[i] = (int32_t)g.epoch;
+    S.I(I_FLAGS)[i] = (g.done ? kFlagDone : 0) | (g.alias ? kFlagAlias : 0) | (g.reach ? kFlagReach : 0);
+}
+
+// Where agent i's sub-goal list lives: a bank scenario (shared, read-only) or its private [K][3] slot.
+__device__ __forceinline__ const double *list_of(const StepArgs &a, int i, int scn)
+{
+    return scn >= 0 ? a.bank.sub + (size_t)scn * a.K * 3 : a.st.sub + (size_t)i * a.K * 3;
+}
+
+// UAV.reset() from the scenario bank (UAV.py:327-366 with the RRT result pre-planned).  The sub-goal list is
+// NOT copied: the agent just remembers the scenario id (APF mutates sub-goals, so there it is copied).
+template <bool APF>
+__device__ __forceinline__ void reset_agent(const StepArgs &a, int i, Agent &g)
+{
+    ObsIn &o = g.o;
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), 0x5eedu),
+                                  make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
+    const double heading = (kTwoPi)*u53(r.x, r.y);       // random.uniform(0, 2*pi)  (a + (b-a)*random(), a = 0)
+    const uint32_t scn = (uint32_t)(((uint64_t)r.z * (uint64_t)a.bank.m) >> 32);
     const double *sg = a.bank.start_goal + (size_t)scn * 6;
+    const double *src = a.bank.sub + (size_t)scn * a.K * 3;
+    const int n_total = a.bank.nsub[scn];
     o.px = sg[0]; o.py = sg[1]; o.pz = sg[2];
     o.gx = sg[3]; o.gy = sg[4]; o.gz = sg[5];
-    o.vx = a.max_v * cos(heading);
-    o.vy = a.max_v * sin(heading);
+    // bank rows are always K x 3 doubles (zero padded): load unconditionally, no dependent branches
+    o.s0x = src[0]; o.s0y = src[1]; o.s0z = src[2];
+    o.s1x = src[3]; o.s1y = src[4]; o.s1z = src[5];
+    double sn, cs;
+    sincos(heading, &sn, &cs);
+    o.vx = a.max_v * cs;
+    o.vy = a.max_v * sn;
     o.V = calc_v(o.vx, o.vy, a.max_v);
+    g.head = calc_angle(o.vx, o.vy);
     o.step = 0;
-    score = 0.0; total = 0.0; path_len = 0.0;
-    done = 0; reach = 0;
-    n_total = a.bank.nsub[scn];
-    sub_idx = 0;
-    alias = n_total >= 2 ? 1 : 0;      // path[0] is the start node == the position object (RRT.py:69)
-    const double *src = a.bank.sub + (size_t)scn * a.K * 3;
-    double *dst = a.st.sub + (size_t)i * a.K * 3;
-    for (int k = 0; k < n_total * 3; ++k) dst[k] = src[k];
-    o.s0x = n_total >= 1 ? src[0] : 0.0; o.s0y = n_total >= 1 ? src[1] : 0.0; o.s0z = n_total >= 1 ? src[2] : 0.0;
-    o.s1x = n_total >= 2 ? src[3] : 0.0; o.s1y = n_total >= 2 ? src[4] : 0.0; o.s1z = n_total >= 2 ? src[5] : 0.0;
+    g.score = 0.0; g.total = 0.0; g.path_len = 0.0;
+    g.done = 0; g.reach = 0; g.epoch = 0;
+    g.n_total = n_total;
+    g.sub_idx = 0;
+    g.alias = n_total >= 2 ? 1 : 0;      // path[0] is the start node == the position object (RRT.py:69)
+    if (APF) {
+        double *dst = a.st.sub + (size_t)i * a.K * 3;
+        for (int k = 0; k < n_total * 3; ++k) dst[k] = src[k];
+        g.scn = -1;
+    } else {
+        g.scn = (int)scn;
+    }
     o.n_rem = n_total;
+}
+
+// Agents/UAV.py:397-513  update_PathPlan(action) on the register copy of one agent.
+template <typename MaskT, bool APF>
+__device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
+                                           double &r, int &ret_done, int &info)
+{
+    ObsIn &o = g.o;
+    const int max_step = a.max_step;
+    r = 0.0; ret_done = 0; info = UAVENV_INFO_NORMAL;
+    if (g.sub_idx >= g.n_total) {                                              // :400-406
+        g.done = 1;
+        r += (double)(max_step - o.step);
+        g.score += r;
+        ret_done = 1; info = UAVENV_INFO_SUCCESS;
+        return;
+    }
+    o.step += 1;                                                               // :408
+    const double ox = o.px, oy = o.py, oz = o.pz;                              // :409
+    const double seta_old = g.head;                                            // :411 (cached: same V_vector)
+    const double dis_old = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);       // :412
+    const double g_old = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);            // :413
+    const double seta_new = seta_old + a0 * a.steer;                           // :414
+    double sn, cs;
+    sincos(seta_new, &sn, &cs);
+    o.vx = a.max_v * cs;                                                       // :415
+    o.vy = a.max_v * sn;                                                       // :416
+    o.V = calc_v(o.vx, o.vy, a.max_v);                                         // :417
+    o.px += o.vx;                                                              // :419
+    o.py += o.vy;                                                              // :420
+    if (g.alias) { o.s0x = o.px; o.s0y = o.py; o.s0z = o.pz; }                 // sub_goals[0] IS position after reset
+    double tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);                  // :422
+    g.head = calc_angle(o.vx, o.vy);                                           // :423 (and obs[7], and next :411)
+    double tri_V = g.head;
+    if (probe(w, o.px, o.py, o.pz)) {                                          // :425-428
+        r -= 0.3;
+        o.px = ox; o.py = oy; o.pz = oz;
+        g.alias = 0;
+        tri_V = calc_angle(o.s0x - o.px, o.s0y - o.py);
+    }
+    const double dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);       // :429
+    const double g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);            // :430
+    r -= 0.13 * fabs(a0);                                                      // :434
+    r += 0.2 * cos(fabs(tri_goal - tri_V));                                    // :435
+    r += 0.4 * (dis_old - dis_new);                                            // :436
+    r += 0.4 * (g_old - g_new);                                                // :437
+    r -= 0.1;                                                                  // :438
+    r -= 0.01 * fabs(o.pz - o.s0z);                                            // :439-440
+    g.path_len += o.V;                                                         // :443
+    g.epoch += 1;                                                              // :444
+
+    if (APF) {                                                                 // :448-453 (private list only)
+        double *lst = a.st.sub + (size_t)ii * a.K * 3;
+        if (g.alias) { lst[g.sub_idx * 3] = o.s0x; lst[g.sub_idx * 3 + 1] = o.s0y; lst[g.sub_idx * 3 + 2] = o.s0z; }
+        for (int k = g.sub_idx; k < g.n_total; ++k) {                          // Adjust_subgoal :156-166
+            double fx, fy, fz;
+            const double sx = lst[k * 3], sy = lst[k * 3 + 1], sz = lst[k * 3 + 2];
+            cal_force(a.apf_b, a.nb, sx, sy, sz, fx, fy, fz);
+            lst[k * 3] = sx + fx; lst[k * 3 + 1] = sy + fy; lst[k * 3 + 2] = sz + fz;
+        }
+        g.alias = 0;
+        o.s0x = lst[g.sub_idx * 3]; o.s0y = lst[g.sub_idx * 3 + 1]; o.s0z = lst[g.sub_idx * 3 + 2];
+        if (g.sub_idx + 1 < g.n_total) {
+            o.s1x = lst[g.sub_idx * 3 + 3]; o.s1y = lst[g.sub_idx * 3 + 4]; o.s1z = lst[g.sub_idx * 3 + 5];
+        }
+        double fx, fy, fz;
+        cal_force(a.apf_b, a.nb, o.px, o.py, o.pz, fx, fy, fz);
+        const double force = sqrt(fx * fx + fy * fy + fz * fz);
+        const double tri_force = calc_angle(fx, fy);
+        r += 0.2 * force * cos(fabs(tri_force - tri_V));
+    }
+
+    const double d_sub = APF ? dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z) : dis_new;   // same operands when !APF
+    const double d_goal = g_new;
+    if (o.step >= max_step) {                                                  // :456-465
+        g.done = 1;
+        r += (50.0 - d_sub);
+        g.score += r; g.total += r;
+        ret_done = 1; info = UAVENV_INFO_LOSE;
+    } else if (d_sub < 7.0 || (d_goal < dist3(o.s0x, o.s0y, o.s0z, o.gx, o.gy, o.gz))) {   // :466
+        r += (50.0 - d_sub);                                                   // :468
+        g.sub_idx += 1;                                                        // :469 pop(0)
+        g.alias = 0;
+        if (g.sub_idx >= g.n_total) {                                          // :470-483
+            r += 50.0;
+            g.done = 1;
+            r += (double)(max_step - o.step);
+            g.score += r;
+            g.reach = 1;
+            g.total += r;
+            ret_done = 1; info = UAVENV_INFO_SUCCESS;
+        } else {                                                               // :484-495
+            o.step = 0;                                                        // reset("local reset") :328-332
+            g.score = 0.0;
+            const double vx0 = o.vx, vy0 = o.vy;
+            o.V = calc_v(o.vx, o.vy, a.max_v);
+            o.s0x = o.s1x; o.s0y = o.s1y; o.s0z = o.s1z;
+            if (g.sub_idx + 1 < g.n_total) {
+                const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
+                o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
+            }
+            tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);                 // :488
+            if (o.vx != vx0 || o.vy != vy0) g.head = calc_angle(o.vx, o.vy);   // :489 (Calc_V rescaled again)
+            tri_V = g.head;
+            r += 0.2 * cos(fabs(tri_goal - tri_V));                            // :490
+            r += (double)(max_step - o.step);                                  // :491
+            g.score += r; g.total += r;
+            ret_done = 1; info = UAVENV_INFO_SUCCESS;                          // returned done; agent NOT done
+        }
+    } else if (d_goal < 7.0) {                                                 // :496-509
+        g.done = 1;
+        r += 50.0;
+        r += (double)(max_step - o.step);
+        g.score += r;
+        g.reach = 1;
+        g.total += r;
+        ret_done = 1; info = UAVENV_INFO_SUCCESS;
+    } else {                                                                   // :510-513
+        g.score += r; g.total += r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,158 +440,61 @@ template <typename MaskT, bool APF, bool F16>
 __global__ void __launch_bounds__(256) k_step(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const WorldLds<MaskT> w =
-        stage_world<MaskT>(smem, a.world_blob, a.world_bytes, a.grid_off, a.gnx, a.gny, a.inv_cell, a.W, a.Hbox);
     const DevState &S = a.st;
     const int N = a.N;
     const int n_round = (N + 63) & ~63;
+    const int stride = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
 
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+    // issue the first tile's state loads BEFORE the world is staged: their HBM latency overlaps the LDS fill
+    Agent g;
+    RawAction ra = {0u, 0u};
+    if (i < n_round) {
+        const int ii = i < N ? i : N - 1;
+        load_agent(S, ii, g);
+        ra = load_action_raw(a.actions, a.action_kind, ii);
+    }
+    const WorldLds<MaskT> w = stage_world<MaskT>(smem, a);
+
+    while (i < n_round) {
         const bool active = i < N;
         const int ii = active ? i : N - 1;
-
-        ObsIn o;
-        o.px = S.px[ii]; o.py = S.py[ii]; o.pz = S.pz[ii];
-        o.vx = S.vx[ii]; o.vy = S.vy[ii]; o.V = S.V[ii];
-        o.gx = S.gx[ii]; o.gy = S.gy[ii]; o.gz = S.gz[ii];
-        o.s0x = S.s0x[ii]; o.s0y = S.s0y[ii]; o.s0z = S.s0z[ii];
-        o.s1x = S.s1x[ii]; o.s1y = S.s1y[ii]; o.s1z = S.s1z[ii];
-        o.step = S.step[ii];
-        int sub_idx = S.sub_idx[ii], n_total = S.n_total[ii];
-        int done = S.done[ii], alias = S.alias[ii], reach = S.reach[ii];
-        double score = S.score[ii], total = S.total[ii], path_len = S.path_len[ii];
-        uint32_t epoch = S.epoch[ii];
-        const double a0 = load_action(a.actions, a.action_kind, ii, a.n_actions);
-
+        unpack_flags(g);
+        const double a0 = decode_action(ra, a.action_kind, a.n_actions);
         double r = 0.0;
         int ret_done = 0, info = UAVENV_INFO_NORMAL, valid = 1;
-        const int max_step = a.max_step;
-
-        if ((a.flags & UAVENV_STEP_SKIP_DONE) && done) {
+        if ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done) {
             ret_done = 1; info = UAVENV_INFO_SKIPPED; valid = 0;                  // PathPlan_City.py:365-366
-        } else if (sub_idx >= n_total) {                                           // UAV.py:400-406
-            done = 1;
-            r += (double)(max_step - o.step);
-            score += r;
-            ret_done = 1; info = UAVENV_INFO_SUCCESS;
         } else {
-            o.step += 1;                                                           // :408
-            const double ox = o.px, oy = o.py, oz = o.pz;                          // :409
-            const double seta_old = calc_angle(o.vx, o.vy);                        // :411
-            const double dis_old = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);   // :412
-            const double g_old = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);        // :413
-            const double seta_new = seta_old + a0 * a.steer;                       // :414
-            o.vx = a.max_v * cos(seta_new);                                        // :415
-            o.vy = a.max_v * sin(seta_new);                                        // :416
-            o.V = calc_v(o.vx, o.vy, a.max_v);                                     // :417
-            o.px += o.vx;                                                          // :419
-            o.py += o.vy;                                                          // :420
-            if (alias) { o.s0x = o.px; o.s0y = o.py; o.s0z = o.pz; }               // sub_goals[0] IS position after reset
-            double tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);              // :422
-            double tri_V = calc_angle(o.vx, o.vy);                                 // :423
-            if (probe(w, o.px, o.py, o.pz)) {                                      // :425-428
-                r -= 0.3;
-                o.px = ox; o.py = oy; o.pz = oz;
-                alias = 0;
-                tri_V = calc_angle(o.s0x - o.px, o.s0y - o.py);
-            }
-            const double dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);   // :429
-            const double g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);        // :430
-            r -= 0.13 * fabs(a0);                                                  // :434
-            r += 0.2 * cos(fabs(tri_goal - tri_V));                                // :435
-            r += 0.4 * (dis_old - dis_new);                                        // :436
-            r += 0.4 * (g_old - g_new);                                            // :437
-            r -= 0.1;                                                              // :438
-            r -= 0.01 * fabs(o.pz - o.s0z);                                        // :439-440
-            path_len += o.V;                                                       // :443
-            epoch += 1;                                                            // :444
-
-            if (APF) {                                                             // :448-453
-                double *lst = S.sub + (size_t)ii * a.K * 3;
-                if (alias) { lst[sub_idx * 3] = o.s0x; lst[sub_idx * 3 + 1] = o.s0y; lst[sub_idx * 3 + 2] = o.s0z; }
-                for (int k = sub_idx; k < n_total; ++k) {                          // Adjust_subgoal :156-166
-                    double fx, fy, fz;
-                    double sx = lst[k * 3], sy = lst[k * 3 + 1], sz = lst[k * 3 + 2];
-                    cal_force(a.apf_b, a.nb, sx, sy, sz, fx, fy, fz);
-                    lst[k * 3] = sx + fx; lst[k * 3 + 1] = sy + fy; lst[k * 3 + 2] = sz + fz;
-                }
-                alias = 0;
-                o.s0x = lst[sub_idx * 3]; o.s0y = lst[sub_idx * 3 + 1]; o.s0z = lst[sub_idx * 3 + 2];
-                if (sub_idx + 1 < n_total) {
-                    o.s1x = lst[sub_idx * 3 + 3]; o.s1y = lst[sub_idx * 3 + 4]; o.s1z = lst[sub_idx * 3 + 5];
-                }
-                double fx, fy, fz;
-                cal_force(a.apf_b, a.nb, o.px, o.py, o.pz, fx, fy, fz);
-                const double force = sqrt(fx * fx + fy * fy + fz * fz);
-                const double tri_force = calc_angle(fx, fy);
-                r += 0.2 * force * cos(fabs(tri_force - tri_V));
-            }
-
-            const double d_sub = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);
-            if (o.step >= max_step) {                                              // :456-465
-                done = 1;
-                r += (50.0 - d_sub);
-                score += r; total += r;
-                ret_done = 1; info = UAVENV_INFO_LOSE;
-            } else if (d_sub < 7.0 || (dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz) <
-                                       dist3(o.s0x, o.s0y, o.s0z, o.gx, o.gy, o.gz))) {   // :466
-                r += (50.0 - d_sub);                                               // :468
-                sub_idx += 1;                                                      // :469 pop(0)
-                alias = 0;
-                if (sub_idx >= n_total) {                                          // :470-483
-                    r += 50.0;
-                    done = 1;
-                    r += (double)(max_step - o.step);
-                    score += r;
-                    reach = 1;
-                    total += r;
-                    ret_done = 1; info = UAVENV_INFO_SUCCESS;
-                } else {                                                           // :484-495
-                    o.step = 0;                                                    // reset("local reset") :328-332
-                    score = 0.0;
-                    o.V = calc_v(o.vx, o.vy, a.max_v);
-                    o.s0x = o.s1x; o.s0y = o.s1y; o.s0z = o.s1z;
-                    if (sub_idx + 1 < n_total) {
-                        const double *nx = S.sub + ((size_t)ii * a.K + (size_t)(sub_idx + 1)) * 3;
-                        o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
-                    }
-                    tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);             // :488
-                    tri_V = calc_angle(o.vx, o.vy);                                // :489
-                    r += 0.2 * cos(fabs(tri_goal - tri_V));                        // :490
-                    r += (double)(max_step - o.step);                              // :491
-                    score += r; total += r;
-                    ret_done = 1; info = UAVENV_INFO_SUCCESS;                      // returned done; agent NOT done
-                }
-            } else if (dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz) < 7.0) {          // :496-509
-                done = 1;
-                r += 50.0;
-                r += (double)(max_step - o.step);
-                score += r;
-                reach = 1;
-                total += r;
-                ret_done = 1; info = UAVENV_INFO_SUCCESS;
-            } else {                                                               // :510-513
-                score += r; total += r;
-            }
+            step_agent<MaskT, APF>(a, w, ii, a0, g, r, ret_done, info);
         }
-        o.n_rem = n_total - sub_idx;
-        const int agent_done = done;
-        const double energy = a.energy64 ? fly_power(a.pw, o.V, ii % a.U) : 0.0;
+        g.o.n_rem = g.n_total - g.sub_idx;
+        const int agent_done = g.done;
+        const double energy = a.energy64 ? fly_power(a.pw, g.o.V, ii % a.U) : 0.0;
 
         // ---- auto reset: the env restarts when ALL of its U agents are done (PathPlan_City.py:252-259,416-417)
         bool did_reset = false;
         if (a.flags & UAVENV_STEP_AUTO_RESET) {
-            const unsigned long long dm = __ballot(active && done);
+            const unsigned long long dm = __ballot(active && g.done);
             const int lane = threadIdx.x & 63;
             const int g0 = (lane / a.U) * a.U;
             const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
             if (active && ((dm & gm) == gm)) {
-                reset_agent(a, ii, a.seed, a.tick, o, sub_idx, n_total, alias, score, total, path_len, done, reach);
+                reset_agent<APF>(a, ii, g);
                 did_reset = true;
             }
         }
 
         if (active) {
+            // ---- observation of the (possibly reset) state: state_PathPlan, UAV.py:515-567.  Computed BEFORE any
+            // store is issued: a wait on a later load would otherwise also wait for the stores in flight.
+            const bool want_obs = a.obs && !(a.flags & UAVENV_STEP_NO_OBS);
+            ObsBits bits;
+            ObsScalars sc;
+            if (want_obs) {
+                bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);
+                sc = obs_scalars(g.o, g.head);                                     // :526 heading == cached angle
+            }
             // ---- outputs of the transition
             if (a.reward64) a.reward64[i] = r;
             if (a.reward32) a.reward32[i] = (float)r;
@@ -372,27 +503,16 @@ __global__ void __launch_bounds__(256) k_step(StepArgs a)
             if (a.info) a.info[i] = (uint8_t)info;
             if (a.valid) a.valid[i] = (uint8_t)valid;
             if (a.energy64) a.energy64[i] = energy;
-
-            // ---- observation of the (possibly reset) state: state_PathPlan, UAV.py:515-567
-            if (a.obs && !(a.flags & UAVENV_STEP_NO_OBS)) {
-                const double heading = calc_angle(o.vx, o.vy);                     // :526
-                const ObsBits bits = obs_bits(w, o.px, o.py, o.pz);
-                const ObsScalars sc = obs_scalars(o, heading);
-                store_obs_row<F16>(a.obs, i, sc, bits);
-            }
-
             // ---- state write-back
-            if (valid || did_reset) {
-                S.px[i] = o.px; S.py[i] = o.py; S.pz[i] = o.pz;
-                S.vx[i] = o.vx; S.vy[i] = o.vy; S.V[i] = o.V;
-                S.s0x[i] = o.s0x; S.s0y[i] = o.s0y; S.s0z[i] = o.s0z;
-                S.s1x[i] = o.s1x; S.s1y[i] = o.s1y; S.s1z[i] = o.s1z;
-                S.gx[i] = o.gx; S.gy[i] = o.gy; S.gz[i] = o.gz;
-                S.step[i] = o.step; S.sub_idx[i] = sub_idx; S.n_total[i] = n_total;
-                S.done[i] = (uint8_t)done; S.alias[i] = (uint8_t)alias; S.reach[i] = (uint8_t)reach;
-                S.score[i] = score; S.total[i] = total; S.path_len[i] = path_len;
-                S.epoch[i] = epoch;
-            }
+            if (valid || did_reset) store_agent(S, i, g);
+            if (want_obs) store_obs_row<F16>(a.obs, i, sc, bits);
+        }
+
+        i += stride;
+        if (i < n_round) {
+            const int in = i < N ? i : N - 1;
+            load_agent(S, in, g);
+            ra = load_action_raw(a.actions, a.action_kind, in);
         }
     }
 }
@@ -402,21 +522,13 @@ template <typename MaskT, bool F16>
 __global__ void __launch_bounds__(256) k_observe(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const WorldLds<MaskT> w =
-        stage_world<MaskT>(smem, a.world_blob, a.world_bytes, a.grid_off, a.gnx, a.gny, a.inv_cell, a.W, a.Hbox);
-    const DevState &S = a.st;
+    const WorldLds<MaskT> w = stage_world<MaskT>(smem, a);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x) {
-        ObsIn o;
-        o.px = S.px[i]; o.py = S.py[i]; o.pz = S.pz[i];
-        o.vx = S.vx[i]; o.vy = S.vy[i]; o.V = S.V[i];
-        o.gx = S.gx[i]; o.gy = S.gy[i]; o.gz = S.gz[i];
-        o.s0x = S.s0x[i]; o.s0y = S.s0y[i]; o.s0z = S.s0z[i];
-        o.s1x = S.s1x[i]; o.s1y = S.s1y[i]; o.s1z = S.s1z[i];
-        o.step = S.step[i];
-        o.n_rem = S.n_total[i] - S.sub_idx[i];
-        const double heading = calc_angle(o.vx, o.vy);
-        const ObsBits bits = obs_bits(w, o.px, o.py, o.pz);
-        const ObsScalars sc = obs_scalars(o, heading);
+        Agent g;
+        load_agent(a.st, i, g);
+        unpack_flags(g);
+        const ObsBits bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);
+        const ObsScalars sc = obs_scalars(g.o, g.head);
         store_obs_row<F16>(a.obs, i, sc, bits);
     }
 }
@@ -425,8 +537,7 @@ template <typename MaskT, bool ALLPAIRS>
 __global__ void k_threaten(StepArgs a, const double *__restrict__ xyz, uint8_t *__restrict__ out, int64_t n)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const WorldLds<MaskT> w =
-        stage_world<MaskT>(smem, a.world_blob, a.world_bytes, a.grid_off, a.gnx, a.gny, a.inv_cell, a.W, a.Hbox);
+    const WorldLds<MaskT> w = stage_world<MaskT>(smem, a);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
         out[i] = (uint8_t)(ALLPAIRS ? probe_allpairs(w.b, a.nb, a.W, a.Hbox, x, y, z) : probe(w, x, y, z));
@@ -434,23 +545,28 @@ __global__ void k_threaten(StepArgs a, const double *__restrict__ xyz, uint8_t *
 }
 
 // reset every agent from the bank
+template <bool APF>
 __global__ void k_reset_all(StepArgs a)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x) {
-        ObsIn o;
-        int sub_idx, n_total, alias, done, reach;
-        double score, total, path_len;
-        reset_agent(a, i, a.seed, a.tick, o, sub_idx, n_total, alias, score, total, path_len, done, reach);
-        const DevState &S = a.st;
-        S.px[i] = o.px; S.py[i] = o.py; S.pz[i] = o.pz;
-        S.vx[i] = o.vx; S.vy[i] = o.vy; S.V[i] = o.V;
-        S.gx[i] = o.gx; S.gy[i] = o.gy; S.gz[i] = o.gz;
-        S.s0x[i] = o.s0x; S.s0y[i] = o.s0y; S.s0z[i] = o.s0z;
-        S.s1x[i] = o.s1x; S.s1y[i] = o.s1y; S.s1z[i] = o.s1z;
-        S.step[i] = 0; S.sub_idx[i] = sub_idx; S.n_total[i] = n_total;
-        S.done[i] = 0; S.alias[i] = (uint8_t)alias; S.reach[i] = 0;
-        S.score[i] = 0.0; S.total[i] = 0.0; S.path_len[i] = 0.0;
-        S.epoch[i] = 0;
+        Agent g;
+        reset_agent<APF>(a, i, g);
+        store_agent(a.st, i, g);
+    }
+}
+
+// Detach every agent from the scenario bank (copy its list into the private slot) -- run before a bank is replaced.
+__global__ void k_privatize(StepArgs a)
+{
+    const DevState &S = a.st;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x) {
+        const int scn = S.I(I_SCN)[i];
+        if (scn < 0) continue;
+        const double *src = a.bank.sub + (size_t)scn * a.K * 3;
+        double *dst = S.sub + (size_t)i * a.K * 3;
+        const int n = S.I(I_NTOTAL)[i];
+        for (int q = 0; q < n * 3; ++q) dst[q] = src[q];
+        S.I(I_SCN)[i] = -1;
     }
 }
 
@@ -463,21 +579,24 @@ __global__ void k_set_state(StepArgs a, int first, int count, const double *__re
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < count; c += gridDim.x * blockDim.x) {
         const int i = first + c;
         const double *k = kin + (size_t)c * 8;
-        double vx = k[3], vy = k[4];
-        const double V = calc_v(vx, vy, a.max_v);       // inject() does uav.V = uav.Calc_V()
-        S.px[i] = k[0]; S.py[i] = k[1]; S.pz[i] = k[2];
-        S.vx[i] = vx; S.vy[i] = vy; S.V[i] = V;
-        S.gx[i] = k[5]; S.gy[i] = k[6]; S.gz[i] = k[7];
+        Agent g;
+        ObsIn &o = g.o;
+        o.px = k[0]; o.py = k[1]; o.pz = k[2];
+        o.vx = k[3]; o.vy = k[4];
+        o.V = calc_v(o.vx, o.vy, a.max_v);              // inject() does uav.V = uav.Calc_V()
+        g.head = calc_angle(o.vx, o.vy);
+        o.gx = k[5]; o.gy = k[6]; o.gz = k[7];
         const int n = n_sub[c];
         const double *src = sub + (size_t)c * a.K * 3;
         double *dst = S.sub + (size_t)i * a.K * 3;
         for (int q = 0; q < n * 3; ++q) dst[q] = src[q];
-        S.s0x[i] = n >= 1 ? src[0] : 0.0; S.s0y[i] = n >= 1 ? src[1] : 0.0; S.s0z[i] = n >= 1 ? src[2] : 0.0;
-        S.s1x[i] = n >= 2 ? src[3] : 0.0; S.s1y[i] = n >= 2 ? src[4] : 0.0; S.s1z[i] = n >= 2 ? src[5] : 0.0;
-        S.step[i] = step[c]; S.sub_idx[i] = 0; S.n_total[i] = n;
-        S.done[i] = 0; S.alias[i] = (uint8_t)(alias ? alias[c] : 0); S.reach[i] = 0;
-        S.score[i] = 0.0; S.total[i] = 0.0; S.path_len[i] = 0.0;
-        S.epoch[i] = 0;
+        o.s0x = n >= 1 ? src[0] : 0.0; o.s0y = n >= 1 ? src[1] : 0.0; o.s0z = n >= 1 ? src[2] : 0.0;
+        o.s1x = n >= 2 ? src[3] : 0.0; o.s1y = n >= 2 ? src[4] : 0.0; o.s1z = n >= 2 ? src[5] : 0.0;
+        o.step = step[c];
+        g.sub_idx = 0; g.n_total = n; g.scn = -1;
+        g.done = 0; g.alias = alias ? alias[c] : 0; g.reach = 0;
+        g.score = 0.0; g.total = 0.0; g.path_len = 0.0; g.epoch = 0;
+        store_agent(S, i, g);
     }
 }
 
@@ -488,22 +607,22 @@ __global__ void k_get_state(StepArgs a, int first, int count, double *__restrict
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < count; c += gridDim.x * blockDim.x) {
         const int i = first + c;
         double *o = out16 + (size_t)c * 16;
-        const int sub_idx = S.sub_idx[i], n_total = S.n_total[i];
-        o[0] = S.px[i]; o[1] = S.py[i]; o[2] = S.pz[i]; o[3] = S.vx[i]; o[4] = S.vy[i]; o[5] = S.V[i];
-        o[6] = S.gx[i]; o[7] = S.gy[i]; o[8] = S.gz[i]; o[9] = (double)S.step[i]; o[10] = (double)S.done[i];
-        o[11] = (double)(n_total - sub_idx); o[12] = S.score[i]; o[13] = S.total[i]; o[14] = S.path_len[i];
-        o[15] = (double)S.reach[i];
-        if (out_alias) out_alias[c] = (int32_t)S.alias[i];
+        const int sub_idx = S.I(I_SUBIDX)[i], n_total = S.I(I_NTOTAL)[i];
+        o[0] = S.F(F_PX)[i]; o[1] = S.F(F_PY)[i]; o[2] = S.F(F_PZ)[i]; o[3] = S.F(F_VX)[i]; o[4] = S.F(F_VY)[i]; o[5] = S.F(F_V)[i];
+        o[6] = S.F(F_GX)[i]; o[7] = S.F(F_GY)[i]; o[8] = S.F(F_GZ)[i]; o[9] = (double)S.I(I_STEP)[i]; o[10] = (double)((S.I(I_FLAGS)[i] & kFlagDone) ? 1 : 0);
+        o[11] = (double)(n_total - sub_idx); o[12] = S.F(F_SCORE)[i]; o[13] = S.F(F_TOTAL)[i]; o[14] = S.F(F_PATHLEN)[i];
+        o[15] = (double)((S.I(I_FLAGS)[i] & kFlagReach) ? 1 : 0);
+        if (out_alias) out_alias[c] = (S.I(I_FLAGS)[i] & kFlagAlias) ? 1 : 0;
         if (out_sub) {
             double *d = out_sub + (size_t)c * a.K * 3;
-            const double *src = S.sub + (size_t)i * a.K * 3;
+            const double *src = list_of(a, i, S.I(I_SCN)[i]);
             for (int k = 0; k < a.K; ++k) {
                 const int q = sub_idx + k;
                 const bool ok = q < n_total;
                 // the hot window is authoritative for the current sub-goal (it tracks the position alias)
-                d[k * 3] = ok ? (k == 0 ? S.s0x[i] : src[q * 3]) : 0.0;
-                d[k * 3 + 1] = ok ? (k == 0 ? S.s0y[i] : src[q * 3 + 1]) : 0.0;
-                d[k * 3 + 2] = ok ? (k == 0 ? S.s0z[i] : src[q * 3 + 2]) : 0.0;
+                d[k * 3] = ok ? (k == 0 ? S.F(F_S0X)[i] : src[q * 3]) : 0.0;
+                d[k * 3 + 1] = ok ? (k == 0 ? S.F(F_S0Y)[i] : src[q * 3 + 1]) : 0.0;
+                d[k * 3 + 2] = ok ? (k == 0 ? S.F(F_S0Z)[i] : src[q * 3 + 2]) : 0.0;
             }
         }
     }
@@ -522,9 +641,9 @@ static StepArgs base_args(const UavEnv *e)
     a.world_blob = e->world_blob;
     a.world_bytes = e->world_bytes;
     a.grid_off = e->grid_off;
+    a.grid_stride = e->grid_stride;
     a.nb = e->nb;
-    a.gnx = e->gnx;
-    a.gny = e->gny;
+    a.gn = e->gn;
     a.inv_cell = 1.0 / e->cell;
     a.W = e->cfg.width;
     a.Hbox = e->cfg.h;
@@ -601,29 +720,24 @@ int uavenv_create(const UavEnvConfig *cfg, UavEnv **out)
     if (!e) return fail(UAVENV_ENOMEM, "host alloc");
     e->cfg = *cfg;
     if (e->cfg.n_actions < 2) e->cfg.n_actions = 3;
-    e->cell = cfg->cell_size > 0 ? cfg->cell_size : 10.0;
+    e->cell = cfg->cell_size > 0 ? cfg->cell_size : 20.0;
     const long long n64 = (long long)cfg->n_envs * cfg->uav_per_env;
     if (n64 > (1ll << 30)) { delete e; return fail(UAVENV_EINVAL, "too many agents"); }
     e->N = (int)n64;
     const size_t n = (size_t)e->N, npad = (n + 63) & ~(size_t)63;
     const size_t K = (size_t)cfg->max_subgoals;
-    size_t bytes = npad * 8 * kNumF64 + npad * 4 * kNumI32 + npad * kNumU8 + n * K * 3 * 8 + 256;
+    size_t bytes = npad * 8 * kNumF64 + npad * 4 * kNumI32 + n * K * 3 * 8 + 256;
     hipError_t er = hipMalloc(&e->slab, bytes);
     if (er != hipSuccess) { delete e; return fail(UAVENV_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(er)); }
     e->slab_bytes = bytes;
     (void)hipMemset(e->slab, 0, bytes);
     unsigned char *p = (unsigned char *)e->slab;
-    double **f64s[kNumF64] = {&e->st.px, &e->st.py, &e->st.pz, &e->st.vx, &e->st.vy, &e->st.V, &e->st.gx, &e->st.gy,
-                              &e->st.gz, &e->st.s0x, &e->st.s0y, &e->st.s0z, &e->st.s1x, &e->st.s1y, &e->st.s1z,
-                              &e->st.score, &e->st.total, &e->st.path_len};
-    for (int k = 0; k < kNumF64; ++k) { *f64s[k] = (double *)p; p += npad * 8; }
+    e->st.npad = npad;
+    e->st.f64 = (double *)p; p += npad * 8 * kNumF64;
     e->st.sub = (double *)p; p += n * K * 3 * 8;
     p = (unsigned char *)(((uintptr_t)p + 63) & ~(uintptr_t)63);
-    int32_t **i32s[3] = {&e->st.step, &e->st.sub_idx, &e->st.n_total};
-    for (int k = 0; k < 3; ++k) { *i32s[k] = (int32_t *)p; p += npad * 4; }
-    e->st.epoch = (uint32_t *)p; p += npad * 4;
-    uint8_t **u8s[kNumU8] = {&e->st.done, &e->st.alias, &e->st.reach};
-    for (int k = 0; k < kNumU8; ++k) { *u8s[k] = (uint8_t *)p; p += npad; }
+    e->st.i32 = (int32_t *)p; p += npad * 4 * kNumI32;
+    (void)hipMemset(e->st.I(I_SCN), 0xff, npad * 4);   // scn = -1: private (empty) list
     *out = e;
     return UAVENV_OK;
 }
@@ -669,32 +783,32 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
         double vx = v3 ? v3[3 * i] : 0.0, vy = v3 ? v3[3 * i + 1] : 0.0, vz = v3 ? v3[3 * i + 2] : 0.0;
         ba[i] = BldApf{cx, cy, cz, R, vx, vy, vz, std::sqrt(vx * vx + vy * vy + vz * vz)};
     }
-    // conservative rasterisation: cell rectangle and radius both inflated, so rounding of the cell index
-    // (x * inv_cell) or of the distance can never drop a cylinder that the exact test would hit.
-    std::vector<uint64_t> grid((size_t)gn * gn, 0);
+    // conservative rasterisation: for halo h the cell rectangle is grown by h (+ margin) on every side and the
+    // radius by a margin, so rounding of the cell index (x * inv_cell) or of the distance can never drop a
+    // cylinder that the exact test would hit for any point within L-inf distance h of the cell.
+    static const double kHalo[3] = {2.0, 10.0, 20.0};
     const double margin = 1e-6 * (cell > 1.0 ? cell : 1.0);
-    for (int iy = 0; iy < gn; ++iy)
-        for (int ix = 0; ix < gn; ++ix) {
-            const double x0 = ix * cell - margin, x1 = (ix + 1) * cell + margin;
-            const double y0 = iy * cell - margin, y1 = (iy + 1) * cell + margin;
-            uint64_t m = 0;
-            for (int i = 0; i < nb; ++i) {
-                const double qx = bl[i].cx < x0 ? x0 : (bl[i].cx > x1 ? x1 : bl[i].cx);
-                const double qy = bl[i].cy < y0 ? y0 : (bl[i].cy > y1 ? y1 : bl[i].cy);
-                const double d = std::hypot(qx - bl[i].cx, qy - bl[i].cy);
-                if (d < b5[5 * i + 3] + margin) m |= (1ull << i);
-            }
-            grid[(size_t)iy * gn + ix] = m;
-        }
     const int bld_bytes = (int)(((size_t)(nb > 0 ? nb : 1) * sizeof(BldLds) + 15) & ~(size_t)15);
     const int grid_bytes = (int)((((size_t)gn * gn * mask_bytes) + 15) & ~(size_t)15);
-    std::vector<unsigned char> blob((size_t)bld_bytes + grid_bytes, 0);
+    std::vector<unsigned char> blob((size_t)bld_bytes + 3 * (size_t)grid_bytes, 0);
     memcpy(blob.data(), bl.data(), (size_t)(nb > 0 ? nb : 0) * sizeof(BldLds));
-    if (mask_bytes == 8) {
-        memcpy(blob.data() + bld_bytes, grid.data(), (size_t)gn * gn * 8);
-    } else {
-        uint32_t *g32 = reinterpret_cast<uint32_t *>(blob.data() + bld_bytes);
-        for (size_t k = 0; k < (size_t)gn * gn; ++k) g32[k] = (uint32_t)grid[k];
+    for (int h = 0; h < 3; ++h) {
+        unsigned char *gdst = blob.data() + bld_bytes + (size_t)h * grid_bytes;
+        for (int iy = 0; iy < gn; ++iy)
+            for (int ix = 0; ix < gn; ++ix) {
+                const double x0 = ix * cell - kHalo[h] - margin, x1 = (ix + 1) * cell + kHalo[h] + margin;
+                const double y0 = iy * cell - kHalo[h] - margin, y1 = (iy + 1) * cell + kHalo[h] + margin;
+                uint64_t m = 0;
+                for (int i = 0; i < nb; ++i) {
+                    const double qx = bl[i].cx < x0 ? x0 : (bl[i].cx > x1 ? x1 : bl[i].cx);
+                    const double qy = bl[i].cy < y0 ? y0 : (bl[i].cy > y1 ? y1 : bl[i].cy);
+                    const double d = std::hypot(qx - bl[i].cx, qy - bl[i].cy);
+                    if (d < b5[5 * i + 3] + margin) m |= (1ull << i);
+                }
+                const size_t k = (size_t)iy * gn + ix;
+                if (mask_bytes == 8) reinterpret_cast<uint64_t *>(gdst)[k] = m;
+                else reinterpret_cast<uint32_t *>(gdst)[k] = (uint32_t)m;
+            }
     }
     if (blob.size() > 150 * 1024) return fail(UAVENV_EINVAL, "world blob %zu B does not fit LDS; raise cell_size", blob.size());
     (void)hipFree(e->world_blob);
@@ -707,9 +821,9 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
     HIP_TRY(hipMemcpy(e->apf_b, ba.data(), ba.size() * sizeof(BldApf), hipMemcpyHostToDevice));
     e->world_bytes = (int)blob.size();
     e->grid_off = bld_bytes;
+    e->grid_stride = grid_bytes;
     e->nb = nb;
-    e->gnx = gn;
-    e->gny = gn;
+    e->gn = gn;
     e->mask_bytes = mask_bytes;
     e->have_world = true;
     return UAVENV_OK;
@@ -722,6 +836,13 @@ int uavenv_load_scenarios(UavEnv *e, const double *sg, const double *sub, const 
     for (int i = 0; i < m; ++i)
         if (nsub[i] < 0 || nsub[i] > K) return fail(UAVENV_EINVAL, "scenario %d has %d sub-goals > K=%d", i, nsub[i], K);
     HIP_TRY(hipSetDevice(e->cfg.device));
+    if (e->bank_m > 0) {      // agents may still point into the old bank: give them private copies first
+        StepArgs a = base_args(e);
+        HIP_TRY(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_privatize, dim3((e->N + 255) / 256), dim3(256), 0, 0, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
     (void)hipFree(e->bank_sg); (void)hipFree(e->bank_sub); (void)hipFree(e->bank_nsub);
     e->bank_sg = e->bank_sub = nullptr; e->bank_nsub = nullptr; e->bank_m = 0;
     HIP_TRY(hipMalloc((void **)&e->bank_sg, (size_t)m * 6 * 8));
@@ -743,7 +864,8 @@ int uavenv_reset_all(UavEnv *e, uint64_t seed, void *stream)
     e->tick = 0;
     StepArgs a = base_args(e);
     const int block = 256, grid = (e->N + block - 1) / block;
-    hipLaunchKernelGGL(k_reset_all, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
+    if (e->cfg.apf_enabled == 1) hipLaunchKernelGGL(k_reset_all<true>, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_reset_all<false>, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     e->tick = 1;
     return UAVENV_OK;

@@ -29,13 +29,19 @@ struct BldApf {
     double cx, cy, cz, R, vx, vy, vz, vnorm;
 };
 
+// The world as a workgroup sees it in LDS: the cylinder table and three candidate grids.
+// grid h (h = 2, 10, 20 m) stores, per cell, the bit-mask of cylinders that can hit ANY point within an
+// L-infinity distance h of the cell: one mask read then serves a whole 5x5 stencil of spacing h/2 centred in
+// the cell (or, for h = 2, any single point of the cell).  Masks are conservative supersets (host side,
+// uavenv_set_buildings), every candidate still takes the exact narrow-phase test, so the result is identical to
+// the reference's loop over all buildings.
 template <typename MaskT>
 struct WorldLds {
-    const BldLds *b;      // LDS
-    const MaskT *grid;    // LDS: gnx*gny candidate masks
-    int gnx, gny;
+    const BldLds *b;       // LDS
+    const MaskT *g[3];     // LDS: halo 2 m / 10 m / 20 m, gn*gn masks each
+    int gn;
     double inv_cell;
-    double W, Hbox;       // Threaten_rate bounds (x and y both use `width`; PathPlan_City.py:218)
+    double W, Hbox;        // Threaten_rate bounds (x and y both use `width`; PathPlan_City.py:218)
 };
 
 // BaseClass/CalMod.py:89-102  calculate_angle(p1, p2, mod=1) with (dx,dy) = p2 - p1.
@@ -84,25 +90,36 @@ __device__ __forceinline__ double fly_power(const PowerParams &p, double V, int 
     return induced + parasite + blade;
 }
 
-// Envs/PathPlan_City.py:215-223  Threaten_rate(p) through the exact broad phase:
-// the cell's mask is a SUPERSET of the cylinders that can hit any point of the cell, so the OR
-// over candidates equals the reference's first-hit loop over all buildings.
+template <typename MaskT>
+__device__ __forceinline__ int ctz_mask(MaskT m)
+{
+    return (sizeof(MaskT) == 8) ? __builtin_ctzll((unsigned long long)m) : __builtin_ctz((unsigned)m);
+}
+
+// Cell of (x, y), clamped into the grid.  For a point outside the box the clamped cell is the cell of its
+// projection onto the box, which is within the same L-infinity halo of every in-bounds stencil point.
+template <typename MaskT>
+__device__ __forceinline__ int cell_of(const WorldLds<MaskT> &w, double x, double y)
+{
+    int ix = (int)(x * w.inv_cell), iy = (int)(y * w.inv_cell);
+    ix = ix < 0 ? 0 : (ix > w.gn - 1 ? w.gn - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > w.gn - 1 ? w.gn - 1 : iy);
+    return iy * w.gn + ix;
+}
+
+// Envs/PathPlan_City.py:215-223  Threaten_rate(p) for one point through the exact broad phase.
 template <typename MaskT>
 __device__ __forceinline__ int probe(const WorldLds<MaskT> &w, double x, double y, double z)
 {
     if ((x < 0.0) | (x > w.W) | (y < 0.0) | (y > w.W) | (z < 0.0) | (z > w.Hbox)) return 1;
-    int ix = (int)(x * w.inv_cell);
-    int iy = (int)(y * w.inv_cell);
-    ix = ix < w.gnx - 1 ? ix : w.gnx - 1;
-    iy = iy < w.gny - 1 ? iy : w.gny - 1;
-    MaskT m = w.grid[iy * w.gnx + ix];
+    MaskT m = w.g[0][cell_of(w, x, y)];
     int hit = 0;
     while (m) {
-        int b = (sizeof(MaskT) == 8) ? __builtin_ctzll((unsigned long long)m) : __builtin_ctz((unsigned)m);
+        const int b = ctz_mask(m);
         m &= (MaskT)(m - 1);
-        BldLds B = w.b[b];
-        double dx = x - B.cx, dy = y - B.cy;
-        double s = dx * dx + dy * dy;       // + (bz-bz)^2 == + 0.0
+        const BldLds B = w.b[b];
+        const double dx = x - B.cx, dy = y - B.cy;
+        const double s = dx * dx + dy * dy;       // + (bz-bz)^2 == + 0.0
         hit |= (int)(!(z > B.H)) & (int)(s < B.thr);
     }
     return hit;
@@ -130,19 +147,43 @@ struct ObsIn {
     int step, n_rem;   // n_rem = len(sub_goals)
 };
 
-// 5x5 occupancy stencil at `spacing` metres (UAV.py:533-555): bit 5*i+j <- Threaten_rate(px+(i-2)s, py+(j-2)s, pz)
+// 5x5 occupancy stencil at `sp` metres (UAV.py:533-555): bit 5*i+j <- Threaten_rate(px+(i-2)sp, py+(j-2)sp, pz).
+// One candidate mask (grid with halo 2*sp) serves all 25 points; per candidate the 25 exact tests share the
+// 5 dx^2 and 5 dy^2 terms and run branch-free.
 template <typename MaskT>
-__device__ __forceinline__ uint32_t stencil_bits(const WorldLds<MaskT> &w, double px, double py, double pz,
-                                                 double spacing)
+__device__ __forceinline__ uint32_t stencil_bits(const WorldLds<MaskT> &w, const MaskT *grid, int cell, double px,
+                                                 double py, double pz, double sp)
 {
+    double x[5], y[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        x[i] = px + sp * (double)(i - 2);
+        y[i] = py + sp * (double)(i - 2);
+    }
     uint32_t bits = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        double x = px + spacing * (double)(i - 2);
+        bits |= ((x[i] < 0.0) | (x[i] > w.W)) ? (0x1Fu << (5 * i)) : 0u;        // whole row i out of the box
+        bits |= ((y[i] < 0.0) | (y[i] > w.W)) ? (0x108421u << i) : 0u;          // whole column j=i out of the box
+    }
+    if ((pz < 0.0) | (pz > w.Hbox)) bits = 0x1FFFFFFu;
+    MaskT m = grid[cell];
+    while (m) {
+        const int b = ctz_mask(m);
+        m &= (MaskT)(m - 1);
+        const BldLds B = w.b[b];
+        if (!(pz > B.H)) {
+            double dx2[5], dy2[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            double y = py + spacing * (double)(j - 2);
-            bits |= (uint32_t)probe(w, x, y, pz) << (5 * i + j);
+            for (int i = 0; i < 5; ++i) {
+                const double dx = x[i] - B.cx, dy = y[i] - B.cy;
+                dx2[i] = dx * dx;
+                dy2[i] = dy * dy;
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bits |= ((dx2[i] + dy2[j]) < B.thr) ? (1u << (5 * i + j)) : 0u;
         }
     }
     return bits;
@@ -156,12 +197,30 @@ template <typename MaskT>
 __device__ __forceinline__ ObsBits obs_bits(const WorldLds<MaskT> &w, double px, double py, double pz)
 {
     ObsBits o;
-    o.s1 = stencil_bits(w, px, py, pz, 1.0);
-    o.s5 = stencil_bits(w, px, py, pz, 5.0);
-    o.s10 = stencil_bits(w, px, py, pz, 10.0);
+    const int cell = cell_of(w, px, py);
+    o.s1 = stencil_bits(w, w.g[0], cell, px, py, pz, 1.0);
+    o.s5 = stencil_bits(w, w.g[1], cell, px, py, pz, 5.0);
+    o.s10 = stencil_bits(w, w.g[2], cell, px, py, pz, 10.0);
+    // UAV.py:562-566: Threaten_rate(px, py, pz - k), k = 1..5
     uint32_t bl = 0;
+    const bool xy_out = (px < 0.0) | (px > w.W) | (py < 0.0) | (py > w.W);
 #pragma unroll
-    for (int k = 1; k <= 5; ++k) bl |= (uint32_t)probe(w, px, py, pz - (double)k) << (k - 1);   // UAV.py:562-566
+    for (int k = 1; k <= 5; ++k) {
+        const double z = pz - (double)k;
+        bl |= (xy_out | (z < 0.0) | (z > w.Hbox)) ? (1u << (k - 1)) : 0u;
+    }
+    if (bl != 0x1Fu) {      // only when the UAV flies above ground level
+        MaskT m = w.g[0][cell];
+        while (m) {
+            const int b = ctz_mask(m);
+            m &= (MaskT)(m - 1);
+            const BldLds B = w.b[b];
+            const double dx = px - B.cx, dy = py - B.cy;
+            const bool in_disc = (dx * dx + dy * dy) < B.thr;
+#pragma unroll
+            for (int k = 1; k <= 5; ++k) bl |= (in_disc & !((pz - (double)k) > B.H)) ? (1u << (k - 1)) : 0u;
+        }
+    }
     o.below = bl;
     return o;
 }
@@ -171,25 +230,27 @@ struct ObsScalars {
     float f[20];   // 0..10 -> cols 0..10 ; 11..14 -> cols 86..89
 };
 
+// The divisions by 10 / 100 of the reference are multiplications by the f64 reciprocal here: the <= 1 ulp(f64)
+// difference vanishes in the f32 / f16 store (an f64 division costs ~15 dependent instructions, there are 14).
 __device__ __forceinline__ ObsScalars obs_scalars(const ObsIn &a, double heading)
 {
     ObsScalars o;
-    o.f[0] = (float)((double)a.step / 100.0);
+    o.f[0] = (float)((double)a.step * 0.01);
     bool h0 = a.n_rem >= 1, h1 = a.n_rem >= 2;
-    o.f[1] = h0 ? (float)((a.s0x - a.px) / 10.0) : 0.0f;
-    o.f[2] = h0 ? (float)((a.s0y - a.py) / 10.0) : 0.0f;
-    o.f[3] = h0 ? (float)((a.s0z - a.pz) / 10.0) : 0.0f;
+    o.f[1] = h0 ? (float)((a.s0x - a.px) * 0.1) : 0.0f;
+    o.f[2] = h0 ? (float)((a.s0y - a.py) * 0.1) : 0.0f;
+    o.f[3] = h0 ? (float)((a.s0z - a.pz) * 0.1) : 0.0f;
     o.f[4] = (float)a.V;
     o.f[5] = (float)a.vx;
     o.f[6] = (float)a.vy;
     o.f[7] = (float)heading;
-    o.f[8] = h1 ? (float)((a.s1x - a.px) / 10.0) : 0.0f;
-    o.f[9] = h1 ? (float)((a.s1y - a.py) / 10.0) : 0.0f;
-    o.f[10] = h1 ? (float)((a.s1z - a.pz) / 10.0) : 0.0f;
-    o.f[11] = (float)((a.gx - a.px) / 10.0);
-    o.f[12] = (float)((a.gy - a.py) / 10.0);
-    o.f[13] = (float)((a.gz - a.pz) / 10.0);
-    o.f[14] = (float)(a.pz / 10.0);
+    o.f[8] = h1 ? (float)((a.s1x - a.px) * 0.1) : 0.0f;
+    o.f[9] = h1 ? (float)((a.s1y - a.py) * 0.1) : 0.0f;
+    o.f[10] = h1 ? (float)((a.s1z - a.pz) * 0.1) : 0.0f;
+    o.f[11] = (float)((a.gx - a.px) * 0.1);
+    o.f[12] = (float)((a.gy - a.py) * 0.1);
+    o.f[13] = (float)((a.gz - a.pz) * 0.1);
+    o.f[14] = (float)(a.pz * 0.1);
     return o;
 }
 

@@ -78,7 +78,7 @@ typedef struct UavEnvConfig {
     double max_v;               /* int(Max_V) */
     double steering_angle;      /* radians: Steering_angle/180*pi */
     double power[8];            /* P_i v_0 d_0 rho s A P_b F_b  (A gets +0.03 j, xi = 0.8+0.02 j per UAV j) */
-    double cell_size;           /* broad-phase grid cell in metres; 0 -> 10 */
+    double cell_size;           /* broad-phase grid cell in metres; 0 -> 20 */
 } UavEnvConfig;
 
 /* ---- lifetime --------------------------------------------------------------------- */
