@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
+    p.add_argument("--learner", default="fused", choices=["fused", "torch"],
+                   help="fused = hand-written HIP kernels (csrc/learner.hip); torch = PyTorch-ROCm ops")
     return p.parse_args()
 
 
@@ -92,7 +94,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
-    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
     from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing, select_actions
 
     obs_dtype = torch.float16 if args.obs_dtype == "f16" else torch.float32
@@ -101,15 +103,23 @@ def main():
     ring.reset(seed=1000 + rank)
     net = "VAnet2" if args.trainer == "dueling" else "Qnet2"
     torch.manual_seed(42)               # same initial weights on every rank
-    learner = DQNLearner({"NetWork": net, "w": "100", "hiden_dim": "64", "output": "3"}, args.trainer, device=dev,
-                         amp_dtype=torch.float16 if args.obs_dtype == "f16" else None)
+    net_param = {"NetWork": net, "w": "100", "hiden_dim": "64", "output": "3"}
+    fused = args.learner == "fused"
+    if fused:
+        learner = FusedDQNLearner(net_param, args.trainer, device=dev)
+    else:
+        learner = DQNLearner(net_param, args.trainer, device=dev,
+                             amp_dtype=torch.float16 if args.obs_dtype == "f16" else None)
     seed = 7 + rank
     counter = [0]
     step_events = []
 
     def one_step(record=False):
-        q = learner.q_values(ring.current_obs())
-        select_actions(env, q, args.eps, seed, counter[0], index_out=ring.current_action())
+        if fused:
+            learner.act(ring.current_obs(), args.eps, seed, counter[0], index_out=ring.current_action())
+        else:
+            q = learner.q_values(ring.current_obs())
+            select_actions(env, q, args.eps, seed, counter[0], index_out=ring.current_action())
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -118,8 +128,10 @@ def main():
             step_events.append((e0, e1))
         else:
             ring.step_env(auto_reset=True)
-        batch = ring.sample(args.batch, seed, counter[0])
-        learner.learn(batch)
+        if fused:
+            learner.learn_from_ring(ring, args.batch, seed, counter[0])
+        else:
+            learner.learn(ring.sample(args.batch, seed, counter[0]))
         counter[0] += 1
 
     def fence():
@@ -173,7 +185,8 @@ def main():
                                    "device replay %d transitions/GPU (BASELINE.json configs[1])"
                                    % (args.envs, args.trainer.upper(), ring.capacity),
                        "envs_per_gpu": args.envs, "learn_batch_per_gpu": args.batch, "obs_dtype": args.obs_dtype,
-                       "learner_dtype": "f16 autocast" if args.obs_dtype == "f16" else "f32",
+                       "learner": "fused HIP kernels (f32 MFMA)" if fused else "PyTorch-ROCm ops",
+                       "learner_dtype": "f32" if fused or args.obs_dtype == "f32" else "f16 autocast",
                        "epsilon": args.eps, "parallelism": "env-shard x%d + flat-bucket grad all-reduce" % world_size},
             "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -23,6 +23,7 @@ SYMBOLS = (
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_select_actions",
+    "uavenv_dqn_num_params", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_act",
 )
 
 
@@ -42,6 +43,11 @@ class UavReplayRing(C.Structure):
         ("valid", C.c_void_p), ("frames", C.c_int32), ("n_agents", C.c_int32), ("obs_dtype", C.c_int32),
         ("action_is_index", C.c_int32),
     ]
+
+
+class UavDqnNet(C.Structure):
+    _fields_ = [("local", C.c_void_p), ("target", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("w", C.c_int32), ("hid", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32)]
 
 
 class UavEnvError(RuntimeError):
@@ -96,6 +102,17 @@ def load() -> C.CDLL:
     lib.uavenv_replay_sample.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp]
     lib.uavenv_select_actions.restype = C.c_int
     lib.uavenv_select_actions.argtypes = [vp, i32, i32, f32, u64, u64, vp, vp, vp]
+    net = C.POINTER(UavDqnNet)
+    lib.uavenv_dqn_num_params.restype = C.c_int
+    lib.uavenv_dqn_num_params.argtypes = [net]
+    lib.uavenv_dqn_grad.restype = C.c_int
+    lib.uavenv_dqn_grad.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, net, i32, f32, i32, vp, vp]
+    lib.uavenv_dqn_reduce.restype = C.c_int
+    lib.uavenv_dqn_reduce.argtypes = [net, vp, i32, vp, vp]
+    lib.uavenv_dqn_adam.restype = C.c_int
+    lib.uavenv_dqn_adam.argtypes = [net, vp, f32, f32, f32, f32, i32, i32, vp, vp]
+    lib.uavenv_dqn_act.restype = C.c_int
+    lib.uavenv_dqn_act.argtypes = [net, vp, i32, i32, f32, u64, u64, vp, vp, vp, vp]
     if lib.uavenv_abi_version() != ABI_VERSION:
         raise UavEnvError(f"libuavenv ABI {lib.uavenv_abi_version()} != binding {ABI_VERSION}")
     _LIB = lib

@@ -1,0 +1,549 @@
+// learner.hip -- fused DQN / DDQN / Dueling-DQN update for the reference's Q-MLPs (100-64-A) on gfx950.
+//
+// Replaces, per update, the ~45 PyTorch launches of  sample -> q_local(s), q_target(s') [, q_local(s')] ->
+// TD target -> MSE -> backward -> Adam -> hard target copy  (Trainer/DQN_Trainer.py:85-136,
+// DDQN_Trainer.py:72-117, DuelingDQN_Trainer.py:99-190, nets BaseClass/BaseCNN.py:93-139) by three kernels:
+//
+//   k_dqn_grad   one workgroup per 64 sampled transitions: draws the samples (same Philox stream as
+//                uavenv_replay_sample), gathers the two 400 B rows straight from the replay ring into LDS,
+//                runs the three 64x64x100 layer-1 products and the 64x100x64 weight-gradient product on the
+//                f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 FMA chains, 157 TF class), everything else
+//                (layer 2 with A <= 15 outputs, TD target, ReLU masks, bias/W2 gradients) on the VALU, and
+//                writes ONE partial-gradient row per workgroup -- no atomics, deterministic.
+//   k_dqn_reduce sums the partial rows -> raw[P+2] = gradient sums, loss sum, valid count (this flat vector is
+//                what multi-GPU all-reduces over RCCL: the mean is then over the valid samples of ALL ranks).
+//   k_dqn_adam   normalises by the valid count, torch.optim.Adam step (+ hard target copy every Update_loop).
+//   k_dqn_act    Q(s) for all N envs + epsilon-greedy in one launch (same MFMA forward).
+//
+// The generic PyTorch-ROCm learner (learner.py) remains for other shapes and as the numerical cross-check.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/uavenv.h"
+#include "uavenv_device.hpp"
+
+using namespace uav;
+
+namespace {
+
+constexpr int kW = 100;        // input width   (config/Trainer.xml <w>)
+constexpr int kHid = 64;       // hidden width  (<hiden_dim>)
+constexpr int kTile = 64;      // samples per workgroup
+constexpr int kLdx = 101;      // LDS leading dim of the 64 x 100 tiles: odd -> the 32 rows a wave reads hit 32 banks
+constexpr int kLdh = 65;
+constexpr int kMaxOut = 16;    // layer-2 outputs: A (+1 for the dueling value head)
+constexpr int kXTile = kTile * kLdx + 32;   // + pad: the dW1 product reads 28 columns past the last row
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct NetDev {
+    const float *W1, *b1, *W2, *b2;
+};
+
+__device__ __forceinline__ NetDev net_view(const float *flat, int n2)
+{
+    NetDev n;
+    n.W1 = flat;
+    n.b1 = flat + kHid * kW;
+    n.W2 = n.b1 + kHid;
+    n.b2 = n.W2 + n2 * kHid;
+    return n;
+}
+
+// 64 rows x 100 floats -> LDS tile [64][kLdx].  Rows are given by a per-row base pointer (gathered from the ring)
+// or are consecutive (weights).  16-byte global loads, all issued before the LDS writes.
+template <typename T>
+__device__ __forceinline__ void stage_rows(float *dst, const T *const *row_ptr_lds, const T *base_consecutive)
+{
+    constexpr int kChunks = kTile * 25;    // 25 chunks of 4 elements per row
+#pragma unroll
+    for (int it = 0; it < (kChunks + 255) / 256; ++it) {
+        const int c = it * 256 + (int)threadIdx.x;
+        if (c < kChunks) {
+            const int row = c / 25, q = c - row * 25;
+            const T *src = row_ptr_lds ? row_ptr_lds[row] : base_consecutive + (size_t)row * kW;
+            float4 v;
+            if (sizeof(T) == 4) {
+                v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + 4 * q);
+            } else {
+                const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(src) + 4 * q);
+                const __half2 lo = *reinterpret_cast<const __half2 *>(&raw.x);
+                const __half2 hi = *reinterpret_cast<const __half2 *>(&raw.y);
+                v = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+            }
+            float *d = dst + row * kLdx + 4 * q;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+}
+
+// One wave: acc(32x32) += A(32 x K) * B(K x 32) with  A[i][k] = a[(i)*lda + k],  B[k][j] = b[(j)*ldb + k]
+// (both operands stored "row = output index, contiguous k"): lane l feeds A[l&31][k + (l>>5)], B[k + (l>>5)][l&31].
+__device__ __forceinline__ floatx16 mfma_rows(const float *a, int lda, const float *b, int ldb, int K)
+{
+    const int l = (int)threadIdx.x & 63;
+    const float *ap = a + (l & 31) * lda + (l >> 5);
+    const float *bp = b + (l & 31) * ldb + (l >> 5);
+    floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 10
+    for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
+    return acc;
+}
+
+// H[64][kLdh] = relu(X[64][kLdx] * W1^T + b1): wave w owns the 32x32 quadrant (w>>1, w&1).
+__device__ __forceinline__ void layer1(const float *X, const float *W1, const float *b1, float *H)
+{
+    const int wv = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
+    const int r0 = (wv >> 1) * 32, c0 = (wv & 1) * 32;
+    const floatx16 acc = mfma_rows(X + r0 * kLdx, kLdx, W1 + c0 * kLdx, kLdx, kW);
+    const int col = c0 + (l & 31);
+    const float bias = b1[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+        const float v = acc[reg] + bias;
+        H[row * kLdh + col] = v > 0.0f ? v : 0.0f;
+    }
+}
+
+// layer 2 for one sample: out[n2] = W2 h + b2, then Q (dueling: V + A - mean A, BaseCNN.py:131-138)
+__device__ __forceinline__ void layer2(const float *h, const float *W2, const float *b2, int n_actions, int dueling,
+                                       float *q /*[n_actions]*/)
+{
+    const int n2 = n_actions + (dueling ? 1 : 0);
+    float out[kMaxOut];
+    for (int a = 0; a < n2; ++a) {
+        float s = 0.0f;
+        for (int j = 0; j < kHid; ++j) s = fmaf(h[j], W2[a * kHid + j], s);
+        out[a] = s + b2[a];
+    }
+    if (dueling) {
+        float mean = 0.0f;
+        for (int a = 0; a < n_actions; ++a) mean += out[a];
+        mean /= (float)n_actions;
+        for (int a = 0; a < n_actions; ++a) q[a] = out[n_actions] + out[a] - mean;
+    } else {
+        for (int a = 0; a < n_actions; ++a) q[a] = out[a];
+    }
+}
+
+struct GradArgs {
+    UavReplayRing ring;
+    int head, filled, batch;
+    uint64_t seed, counter;
+    const int32_t *explicit_idx;     // nullable: batch x (frame, agent) overriding the Philox draws
+    const float *local, *target;     // flat parameter blocks
+    int n_actions, dueling, kind;    // kind 0: max_a Q_target(s')   1: Q_target(s', argmax_a Q_local(s'))
+    float gamma;
+    int huber;
+    float *partials;                 // [gridDim.x][P + 2]
+    int P;
+};
+
+template <typename ObsT>
+__global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
+{
+    extern __shared__ __align__(16) float lds[];
+    float *Xs = lds;                       // states       [64][101]
+    float *Xn = Xs + kXTile;               // next states
+    float *W1 = Xn + kXTile;               // local fc1
+    float *W1t = W1 + kXTile;              // target fc1
+    float *Hs = W1t + kXTile;              // relu(fc1(s)) -> later dH
+    float *Ht = Hs + kTile * kLdh;         // scratch hidden (local(s') then target(s'))
+    float *small = Ht + kTile * kLdh;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    float *b1 = small;                     // [64]
+    float *b1t = b1 + kHid;                // [64]
+    float *W2 = b1t + kHid;                // [16][64]
+    float *W2t = W2 + kMaxOut * kHid;      // [16][64]
+    float *b2 = W2t + kMaxOut * kHid;      // [16]
+    float *b2t = b2 + kMaxOut;             // [16]
+    float *dout = b2t + kMaxOut;           // [64][16]  dL/d(layer-2 output) per sample
+    float *red = dout + kTile * kMaxOut;   // [64] per-sample loss, [64] per-sample weight
+    const ObsT **rows_s = reinterpret_cast<const ObsT **>(red + 2 * kTile);   // [64] row pointers
+    const ObsT **rows_n = rows_s + kTile;
+    int *aux = reinterpret_cast<int *>(rows_n + kTile);                       // [64] action, [64] argmax, [64] slot
+    const int tid = (int)threadIdx.x;
+    const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
+
+    // ---- P0: draw / look up the 64 transitions of this tile, then stage everything
+    if (tid < kTile) {
+        const int s = (int)blockIdx.x * kTile + tid;
+        int f, agent;
+        if (g.explicit_idx) {
+            f = g.explicit_idx[2 * s];
+            agent = g.explicit_idx[2 * s + 1];
+        } else {
+            const uint4 r = philox4x32_10(make_uint4((uint32_t)s, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0x5a3bu),
+                                          make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
+            const int back = 1 + (int)(((uint64_t)r.x * (uint64_t)g.filled) >> 32);
+            f = g.head - back;
+            if (f < 0) f += g.ring.frames;
+            agent = (int)(((uint64_t)r.y * (uint64_t)g.ring.n_agents) >> 32);
+        }
+        int fn = f + 1;
+        if (fn >= g.ring.frames) fn = 0;
+        const ObsT *obs = reinterpret_cast<const ObsT *>(g.ring.obs);
+        rows_s[tid] = obs + ((size_t)f * g.ring.n_agents + agent) * kW;
+        rows_n[tid] = obs + ((size_t)fn * g.ring.n_agents + agent) * kW;
+        aux[2 * kTile + tid] = f * g.ring.n_agents + agent;
+    }
+    for (int k = tid; k < kHid; k += 256) { b1[k] = nl.b1[k]; b1t[k] = nt.b1[k]; }
+    for (int k = tid; k < n2 * kHid; k += 256) { W2[k] = nl.W2[k]; W2t[k] = nt.W2[k]; }
+    if (tid < n2) { b2[tid] = nl.b2[tid]; b2t[tid] = nt.b2[tid]; }
+    if (tid < 32) {       // zero the pad the dW1 product over-reads
+        Xs[kTile * kLdx + tid] = 0.0f;
+        Xn[kTile * kLdx + tid] = 0.0f;
+    }
+    stage_rows<float>(W1, nullptr, nl.W1);
+    stage_rows<float>(W1t, nullptr, nt.W1);
+    __syncthreads();
+    stage_rows<ObsT>(Xs, rows_s, nullptr);
+    stage_rows<ObsT>(Xn, rows_n, nullptr);
+    __syncthreads();
+
+    // ---- P1: hidden layers on the matrix cores
+    layer1(Xs, W1, b1, Hs);
+    if (g.kind == 1) layer1(Xn, W1, b1, Ht);         // local net on s' (double-DQN action choice)
+    __syncthreads();
+    if (g.kind == 1) {
+        if (tid < kTile) {
+            float q[kMaxOut];
+            layer2(Ht + tid * kLdh, W2, b2, g.n_actions, g.dueling, q);
+            int best = 0;
+            for (int a = 1; a < g.n_actions; ++a) if (q[a] > q[best]) best = a;     // torch.max: first maximum
+            aux[kTile + tid] = best;
+        }
+        __syncthreads();
+    }
+    layer1(Xn, W1t, b1t, Ht);                        // target net on s'
+    __syncthreads();
+
+    // ---- P4: TD target, loss, dL/dout per sample (Trainer/DQN_Trainer.py:107-119)
+    if (tid < kTile) {
+        const int slot = aux[2 * kTile + tid];
+        const int act = g.ring.action_is_index ? reinterpret_cast<const int32_t *>(g.ring.action)[slot] : 0;
+        const float r = g.ring.reward[slot];
+        const float d = (float)g.ring.done[slot];
+        const float v = g.ring.valid ? (float)g.ring.valid[slot] : 1.0f;
+        float ql[kMaxOut], qt[kMaxOut];
+        layer2(Hs + tid * kLdh, W2, b2, g.n_actions, g.dueling, ql);
+        layer2(Ht + tid * kLdh, W2t, b2t, g.n_actions, g.dueling, qt);
+        float qn;
+        if (g.kind == 1) {
+            qn = qt[aux[kTile + tid]];
+        } else {
+            qn = qt[0];
+            for (int a = 1; a < g.n_actions; ++a) qn = qt[a] > qn ? qt[a] : qn;
+        }
+        const float y = r + (g.gamma * qn * (1.0f - d));
+        const float delta = ql[act] - y;
+        float per, dq;
+        if (g.huber) {
+            const float ad = fabsf(delta);
+            per = ad < 1.0f ? 0.5f * delta * delta : ad - 0.5f;
+            dq = ad < 1.0f ? delta : (delta > 0.0f ? 1.0f : -1.0f);
+        } else {
+            per = delta * delta;                      // MSELoss (BaseTrainer.py:40)
+            dq = 2.0f * delta;
+        }
+        dq *= v;
+        red[tid] = per * v;
+        red[kTile + tid] = v;
+        for (int a = 0; a < kMaxOut; ++a) dout[tid * kMaxOut + a] = 0.0f;
+        if (g.dueling) {                              // Q = V + A - mean(A)
+            for (int a = 0; a < g.n_actions; ++a)
+                dout[tid * kMaxOut + a] = dq * ((a == act ? 1.0f : 0.0f) - 1.0f / (float)g.n_actions);
+            dout[tid * kMaxOut + g.n_actions] = dq;
+        } else {
+            dout[tid * kMaxOut + act] = dq;
+        }
+    }
+    __syncthreads();
+
+    // ---- P5: layer-2 gradients (needs the forward Hs), then dH in place
+    float *out = g.partials + (size_t)blockIdx.x * (g.P + 2);
+    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
+    for (int k = tid; k < n2 * kHid; k += 256) {
+        const int a = k / kHid, j = k - a * kHid;
+        float s = 0.0f;
+        for (int smp = 0; smp < kTile; ++smp) s = fmaf(dout[smp * kMaxOut + a], Hs[smp * kLdh + j], s);
+        out[oW2 + k] = s;
+    }
+    if (tid < n2) {
+        float s = 0.0f;
+        for (int smp = 0; smp < kTile; ++smp) s += dout[smp * kMaxOut + tid];
+        out[ob2 + tid] = s;
+    }
+    if (tid == 0) {
+        float ls = 0.0f, cnt = 0.0f;
+        for (int smp = 0; smp < kTile; ++smp) { ls += red[smp]; cnt += red[kTile + smp]; }
+        out[g.P] = ls;
+        out[g.P + 1] = cnt;
+    }
+    __syncthreads();
+    for (int k = tid; k < kTile * kHid; k += 256) {
+        const int smp = k / kHid, j = k - smp * kHid;
+        float s = 0.0f;
+        for (int a = 0; a < n2; ++a) s = fmaf(dout[smp * kMaxOut + a], W2[a * kHid + j], s);
+        Hs[smp * kLdh + j] = Hs[smp * kLdh + j] > 0.0f ? s : 0.0f;        // ReLU mask
+    }
+    __syncthreads();
+
+    // ---- P6: dW1[j][k] = sum_s dH[s][j] X[s][k] on the matrix cores; db1[j] = sum_s dH[s][j]
+    {
+        const int wv = tid >> 6, l = tid & 63;
+        const int m0 = (wv & 1) * 32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n0 = ((wv >> 1) * 2 + t) * 32;
+            // A[m = j][kk = s] = dH[s][j]  (address s*kLdh + j);  B[kk = s][n = k] = Xs[s][k]
+            const float *ap = Hs + (l >> 5) * kLdh + m0 + (l & 31);
+            const float *bp = Xs + (l >> 5) * kLdx + n0 + (l & 31);
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+            for (int kk = 0; kk < kTile; kk += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * kLdh], bp[kk * kLdx], acc, 0, 0, 0);
+            const int n = n0 + (l & 31);
+            if (n < kW) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
+                    out[m * kW + n] = acc[reg];
+                }
+            }
+        }
+    }
+    if (tid < kHid) {
+        float s = 0.0f;
+        for (int smp = 0; smp < kTile; ++smp) s += Hs[smp * kLdh + tid];
+        out[kHid * kW + tid] = s;
+    }
+}
+
+// raw[p] = sum_b partial[b][p] for p in [0, P+2): gradient sums, loss sum, valid count.  32 columns x 8 row-groups
+// per workgroup so that each lane keeps nblk/8 independent, coalesced loads in flight (a one-thread-per-column loop
+// over 256 partial rows was latency-bound at 63 us).
+__global__ void __launch_bounds__(256) k_dqn_reduce(const float *__restrict__ partials, int nblk, int P,
+                                                    float *__restrict__ raw)
+{
+    __shared__ float red[8][33];
+    const int stride = P + 2;
+    const int px = (int)threadIdx.x & 31, gy = (int)threadIdx.x >> 5;
+    const int p = (int)blockIdx.x * 32 + px;
+    float s = 0.0f;
+    if (p < stride) {
+        int b = gy;
+        for (; b + 24 < nblk; b += 32) {
+            const float v0 = partials[(size_t)b * stride + p], v1 = partials[(size_t)(b + 8) * stride + p];
+            const float v2 = partials[(size_t)(b + 16) * stride + p], v3 = partials[(size_t)(b + 24) * stride + p];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; b < nblk; b += 8) s += partials[(size_t)b * stride + p];
+    }
+    red[gy][px] = s;
+    __syncthreads();
+    if (gy == 0 && p < stride) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][px];
+        raw[p] = t;
+    }
+}
+
+// torch.optim.Adam (amsgrad off, weight_decay 0) on grad = raw / max(valid count, 1), + optional hard target copy
+// (DQN_Trainer.py:121-130,138-141).  raw[P] = loss sum, raw[P+1] = valid count.
+__global__ void k_dqn_adam(float *__restrict__ local, float *__restrict__ target, float *__restrict__ m,
+                           float *__restrict__ v, const float *__restrict__ raw, int P, float lr, float beta1,
+                           float beta2, float eps, float bc1, float bc2_sqrt, int hard_update, float *__restrict__ loss)
+{
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const float cnt = raw[P + 1];
+    const float inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
+    if (p == 0 && loss) *loss = raw[P] * inv;
+    if (p >= P) return;
+    const float gp = raw[p] * inv;
+    const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;      // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    m[p] = mp;
+    v[p] = vp;
+    const float denom = sqrtf(vp) / bc2_sqrt + eps;
+    const float np = local[p] - (lr / bc1) * (mp / denom);
+    local[p] = np;
+    if (hard_update) target[p] = np;
+}
+
+struct ActArgs {
+    const void *obs;       // [n][100]
+    int n, n_actions, dueling;
+    const float *local;
+    float eps;
+    uint64_t seed, counter;
+    int32_t *index_out;
+    float *steer_out;
+    float *q_out;          // nullable [n][A]
+};
+
+// Q(s) + epsilon-greedy for a tile of 64 envs (Trainer/DuelingDQN_Trainer.py:86-97)
+template <typename ObsT>
+__global__ void __launch_bounds__(256) k_dqn_act(ActArgs g)
+{
+    extern __shared__ __align__(16) float lds[];
+    float *Xs = lds;
+    float *W1 = Xs + kXTile;
+    float *Hs = W1 + kXTile;
+    float *b1 = Hs + kTile * kLdh;
+    float *W2 = b1 + kHid;
+    float *b2 = W2 + kMaxOut * kHid;
+    const ObsT **rows = reinterpret_cast<const ObsT **>(b2 + kMaxOut);
+    const int tid = (int)threadIdx.x;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    const NetDev nl = net_view(g.local, n2);
+    if (tid < kTile) {
+        int i = (int)blockIdx.x * kTile + tid;
+        if (i >= g.n) i = g.n - 1;
+        rows[tid] = reinterpret_cast<const ObsT *>(g.obs) + (size_t)i * kW;
+    }
+    for (int k = tid; k < kHid; k += 256) b1[k] = nl.b1[k];
+    for (int k = tid; k < n2 * kHid; k += 256) W2[k] = nl.W2[k];
+    if (tid < n2) b2[tid] = nl.b2[tid];
+    stage_rows<float>(W1, nullptr, nl.W1);
+    __syncthreads();
+    stage_rows<ObsT>(Xs, rows, nullptr);
+    __syncthreads();
+    layer1(Xs, W1, b1, Hs);
+    __syncthreads();
+    if (tid < kTile) {
+        const int i = (int)blockIdx.x * kTile + tid;
+        if (i < g.n) {
+            float q[kMaxOut];
+            layer2(Hs + tid * kLdh, W2, b2, g.n_actions, g.dueling, q);
+            if (g.q_out)
+                for (int a = 0; a < g.n_actions; ++a) g.q_out[(size_t)i * g.n_actions + a] = q[a];
+            const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
+                                          make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
+            const float sample = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+            int a;
+            if (sample > g.eps) {
+                a = 0;
+                for (int k = 1; k < g.n_actions; ++k) if (q[k] > q[a]) a = k;
+            } else {
+                a = (int)(((uint64_t)r.y * (uint64_t)g.n_actions) >> 32);
+            }
+            if (g.index_out) g.index_out[i] = a;
+            if (g.steer_out) g.steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(g.n_actions - 1));
+        }
+    }
+}
+
+constexpr size_t kGradLds = (size_t)(4 * kXTile + 2 * kTile * kLdh + 2 * kHid + 2 * kMaxOut * kHid + 2 * kMaxOut +
+                                     kTile * kMaxOut + 2 * kTile) * 4 + 2 * kTile * 8 + 3 * kTile * 4;
+constexpr size_t kActLds = (size_t)(2 * kXTile + kTile * kLdh + kHid + kMaxOut * kHid + kMaxOut) * 4 + kTile * 8;
+
+bool net_ok(const UavDqnNet *n)
+{
+    return n && n->local && n->w == kW && n->hid == kHid && n->n_actions >= 2 &&
+           n->n_actions + (n->dueling ? 1 : 0) <= kMaxOut;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uavenv_dqn_num_params(const UavDqnNet *net)
+{
+    if (!net) return UAVENV_EINVAL;
+    const int n2 = net->n_actions + (net->dueling ? 1 : 0);
+    return net->hid * net->w + net->hid + n2 * net->hid + n2;
+}
+
+int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                    uint64_t counter, const int32_t *explicit_idx, const UavDqnNet *net, int32_t kind, float gamma,
+                    int32_t huber, float *partials, void *stream)
+{
+    if (!ring || !ring->obs || !ring->action || !ring->reward || !ring->done || !partials || !net_ok(net) || !net->target)
+        return UAVENV_EINVAL;
+    if (batch <= 0 || batch % kTile != 0 || ring->frames < 2 || head < 0 || head >= ring->frames) return UAVENV_EINVAL;
+    if (!explicit_idx && (filled <= 0 || filled > ring->frames - 1)) return UAVENV_EINVAL;
+    if (!ring->action_is_index) return UAVENV_EINVAL;
+    GradArgs g;
+    g.ring = *ring;
+    g.head = head; g.filled = filled; g.batch = batch;
+    g.seed = seed; g.counter = counter;
+    g.explicit_idx = explicit_idx;
+    g.local = net->local; g.target = net->target;
+    g.n_actions = net->n_actions; g.dueling = net->dueling; g.kind = kind;
+    g.gamma = gamma; g.huber = huber;
+    g.partials = partials;
+    g.P = uavenv_dqn_num_params(net);
+    const int grid = batch / kTile;
+    hipStream_t s = (hipStream_t)stream;
+    if (ring->obs_dtype == UAVENV_OBS_F32) {
+        static bool attr32 = false;
+        if (!attr32) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad<float>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradLds) != hipSuccess)
+                return UAVENV_EHIP;
+            attr32 = true;
+        }
+        hipLaunchKernelGGL((k_dqn_grad<float>), dim3(grid), dim3(256), kGradLds, s, g);
+    } else {
+        static bool attr16 = false;
+        if (!attr16) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad<__half>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradLds) != hipSuccess)
+                return UAVENV_EHIP;
+            attr16 = true;
+        }
+        hipLaunchKernelGGL((k_dqn_grad<__half>), dim3(grid), dim3(256), kGradLds, s, g);
+    }
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials, int32_t n_partials, float *raw_out, void *stream)
+{
+    if (!net_ok(net) || !partials || !raw_out || n_partials <= 0) return UAVENV_EINVAL;
+    const int P = uavenv_dqn_num_params(net);
+    hipLaunchKernelGGL(k_dqn_reduce, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials, P,
+                       raw_out);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_dqn_adam(const UavDqnNet *net, const float *raw, float lr, float beta1, float beta2, float eps, int32_t step_t,
+                    int32_t hard_update, float *loss_out, void *stream)
+{
+    if (!net_ok(net) || !net->target || !net->m || !net->v || !raw || step_t <= 0) return UAVENV_EINVAL;
+    const int P = uavenv_dqn_num_params(net);
+    const float bc1 = 1.0f - powf(beta1, (float)step_t);
+    const float bc2 = 1.0f - powf(beta2, (float)step_t);
+    hipLaunchKernelGGL(k_dqn_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, net->local, net->target,
+                       net->m, net->v, raw, P, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update, loss_out);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype, int32_t n, float eps, uint64_t seed,
+                   uint64_t counter, int32_t *index_out, float *steer_out, float *q_out, void *stream)
+{
+    if (!net_ok(net) || !obs_dev || n <= 0) return UAVENV_EINVAL;
+    ActArgs g;
+    g.obs = obs_dev; g.n = n; g.n_actions = net->n_actions; g.dueling = net->dueling;
+    g.local = net->local; g.eps = eps; g.seed = seed; g.counter = counter;
+    g.index_out = index_out; g.steer_out = steer_out; g.q_out = q_out;
+    const int grid = (n + kTile - 1) / kTile;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_act<float>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_act<__half>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLds) != hipSuccess)
+            return UAVENV_EHIP;
+        attr = true;
+    }
+    if (obs_dtype == UAVENV_OBS_F32) hipLaunchKernelGGL((k_dqn_act<float>), dim3(grid), dim3(256), kActLds, s, g);
+    else hipLaunchKernelGGL((k_dqn_act<__half>), dim3(grid), dim3(256), kActLds, s, g);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+}  // extern "C"

@@ -161,6 +161,36 @@ int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled
 int uavenv_select_actions(const float *q_dev, int32_t n, int32_t n_actions, float eps, uint64_t seed,
                           uint64_t counter, int32_t *index_out_dev, float *steer_out_dev, void *stream);
 
+/* ---- fused DQN-family learner for the reference's Q-MLPs (BaseClass/BaseCNN.py:93-139, w=100, hid=64) ---------- */
+/* Flat f32 parameter blocks in HBM, layout [W1 hid*w][b1 hid][W2 n2*hid][b2 n2] with n2 = n_actions (+1 value row
+ * for the dueling VAnet2: rows 0..A-1 = fc_A, row A = fc_V).  m / v are Adam's moments (same layout). */
+typedef struct UavDqnNet {
+    float *local;     /* q_local  */
+    float *target;    /* q_target */
+    float *m, *v;
+    int32_t w, hid, n_actions, dueling;
+} UavDqnNet;
+
+int uavenv_dqn_num_params(const UavDqnNet *net);
+/* One learn_off_policy() gradient (Trainer/DQN_Trainer.py:93-121, DDQN_Trainer.py:84-105): draws `batch` transitions
+ * (batch % 64 == 0) with the SAME Philox stream as uavenv_replay_sample (or takes explicit (frame, agent) pairs),
+ * gathers them from the ring, forward/backward on the f32 MFMA.  kind 0: max_a Q_target(s'); 1: double-DQN.
+ * Writes batch/64 partial rows of (num_params + 2) floats (gradient sums, loss sum, valid count). */
+int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                    uint64_t counter, const int32_t *explicit_idx_dev, const UavDqnNet *net, int32_t kind, float gamma,
+                    int32_t huber, float *partials_dev, void *stream);
+/* Sum the partial rows -> raw_out_dev[num_params + 2] = gradient sums, loss sum, valid-sample count.  This flat vector
+ * is the RCCL all-reduce(sum) payload for multi-GPU (the mean is then over the valid samples of all ranks). */
+int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, float *raw_out_dev,
+                      void *stream);
+/* grad = raw / max(count, 1); torch.optim.Adam step t (1-based) on q_local; hard_update != 0 also copies the new
+ * weights into q_target (DQN_Trainer.py:121-130,138-141); loss_out_dev (nullable) receives the mean loss. */
+int uavenv_dqn_adam(const UavDqnNet *net, const float *raw_dev, float lr, float beta1, float beta2, float eps,
+                    int32_t step_t, int32_t hard_update, float *loss_out_dev, void *stream);
+/* Q(s) for n envs + epsilon-greedy in one launch (DuelingDQN_Trainer.py:86-97); q_out_dev nullable [n][A]. */
+int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype, int32_t n, float eps, uint64_t seed,
+                   uint64_t counter, int32_t *index_out_dev, float *steer_out_dev, float *q_out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
