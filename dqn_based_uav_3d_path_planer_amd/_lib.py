@@ -91,7 +91,7 @@ def load() -> C.CDLL:
     lib.uavenv_get_state.restype = C.c_int
     lib.uavenv_get_state.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.uavenv_step.restype = C.c_int
-    lib.uavenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
+    lib.uavenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.uavenv_observe.restype = C.c_int
     lib.uavenv_observe.argtypes = [vp, vp, vp]
     lib.uavenv_threaten_rate.restype = C.c_int

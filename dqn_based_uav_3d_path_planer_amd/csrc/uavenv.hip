@@ -97,6 +97,7 @@ struct StepArgs {
     float *reward32;
     uint8_t *ret_done, *agent_done, *info, *valid;
     double *energy64;
+    const uint8_t *active;             // nullable per-agent mask: 0 -> the agent is left untouched (valid = 0)
     uint32_t flags;
     // auto reset
     Bank bank;
@@ -463,8 +464,9 @@ __global__ void __launch_bounds__(256) k_step(StepArgs a)
         const double a0 = decode_action(ra, a.action_kind, a.n_actions);
         double r = 0.0;
         int ret_done = 0, info = UAVENV_INFO_NORMAL, valid = 1;
-        if ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done) {
-            ret_done = 1; info = UAVENV_INFO_SKIPPED; valid = 0;                  // PathPlan_City.py:365-366
+        const bool masked = a.active && a.active[ii] == 0;
+        if (masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done)) {
+            ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
         } else {
             step_agent<MaskT, APF>(a, w, ii, a0, g, r, ret_done, info);
         }
@@ -927,7 +929,7 @@ int uavenv_get_state(UavEnv *e, int32_t first, int32_t count, double *out16, dou
 
 int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, double *reward64, float *reward32,
                 uint8_t *ret_done, uint8_t *agent_done, uint8_t *info, uint8_t *valid, double *energy64,
-                uint32_t flags, void *stream)
+                const uint8_t *active, uint32_t flags, void *stream)
 {
     if (!e || !actions) return fail(UAVENV_EINVAL, "null env/actions");
     if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step before uavenv_set_buildings");
@@ -945,6 +947,7 @@ int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, 
     a.info = info;
     a.valid = valid;
     a.energy64 = energy64;
+    a.active = active;
     a.flags = flags;
     if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
     else launch_step<uint64_t>(e, a, (hipStream_t)stream);

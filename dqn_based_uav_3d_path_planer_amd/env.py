@@ -163,7 +163,7 @@ class VecPathPlanEnv:
                        energy=torch.empty(n, dtype=torch.float64, device=d) if want_energy else None)
 
     def step(self, actions: torch.Tensor, out: Optional[StepOut] = None, *, auto_reset: bool = False,
-             skip_done: bool = False, want_energy: bool = False) -> StepOut:
+             skip_done: bool = False, want_energy: bool = False, active: Optional[torch.Tensor] = None) -> StepOut:
         """One update_PathPlan + state_PathPlan for every agent.  actions: [N] float32/float64 steer or int32 index."""
         if out is None:
             out = self.alloc_out(want_energy)
@@ -182,14 +182,15 @@ class VecPathPlanEnv:
             flags |= _lib.STEP_NO_OBS
         _lib.check(self.lib.uavenv_step(self._h, actions.data_ptr(), kind, _ptr(out.obs), _ptr(out.reward),
                                         _ptr(out.reward32), _ptr(out.ret_done), _ptr(out.agent_done), _ptr(out.info),
-                                        _ptr(out.valid), _ptr(out.energy), flags, self._stream()), "uavenv_step")
+                                        _ptr(out.valid), _ptr(out.energy), _ptr(active), flags, self._stream()),
+                   "uavenv_step")
         return out
 
     def step_raw(self, actions_ptr: int, kind: int, obs_ptr, reward32_ptr, ret_done_ptr, valid_ptr, flags: int,
                  agent_done_ptr=None, info_ptr=None, reward64_ptr=None):
         """Pointer-level step used by the replay-fused rollout (no tensor bookkeeping on the hot loop)."""
         _lib.check(self.lib.uavenv_step(self._h, actions_ptr, kind, obs_ptr, reward64_ptr, reward32_ptr, ret_done_ptr,
-                                        agent_done_ptr, info_ptr, valid_ptr, None, flags, self._stream()),
+                                        agent_done_ptr, info_ptr, valid_ptr, None, None, flags, self._stream()),
                    "uavenv_step")
 
     def threaten_rate(self, points: torch.Tensor, allpairs: bool = False) -> torch.Tensor:

@@ -1,0 +1,247 @@
+"""Drop-in for Envs/PathPlan_City.py on the MI355X hot path: same constructor contract (the <env> XML dict),
+same duck type simulator.py touches (run_eposide, Agents, Trainer, run_XML_scene, Threaten_rate, Move_Agent,
+update, Check_uav_Done, result-dict keys), backed by `num_envs` vectorised envs in HBM.  Optional new tags
+(all default to the reference's behaviour): <num_envs>, <device>, <obs_dtype>, <scenario_bank>, <seed>.
+Out of scope and therefore absent: rendering, MySQL, federated averaging."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+import _backend
+from dqn_based_uav_3d_path_planer_amd.compat import Loc, None2Value, XML2Dict
+from dqn_based_uav_3d_path_planer_amd.factories import AgentFactory, ThreatenFactory, TrainerFactory
+
+
+class PathPlan_City:
+    def __init__(self, param: dict) -> None:
+        # ---- BaseEnv.__init__ (BaseClass/BaseEnv.py:17-34)
+        self.len = int(None2Value(param.get("len"), 100))
+        self.width = int(None2Value(param.get("width"), 100))
+        self.h = int(None2Value(param.get("h"), 20))
+        self.Agents, self.Threatens, self.Trainer = [], [], None
+        self.AgentFactory, self.ThreatenFactory, self.TrainerFactory = AgentFactory(), ThreatenFactory(), TrainerFactory()
+        self.Is_AC = int(None2Value(param.get("Is_AC"), 0))
+        # ---- PathPlan_City.__init__ (Envs/PathPlan_City.py:31-103)
+        self.eps = float(None2Value(param.get("eps"), 0.1))
+        self.Is_On_Policy = int(None2Value(param.get("Is_On_Policy"), 0))
+        self.param = param
+        self.buildings = []
+        threaten_params = param.get("Obstacles")
+        self.buildings_param = None
+        if threaten_params is not None:
+            cfg = XML2Dict(os.path.normpath(threaten_params.get("buildings")))
+            self.buildings_param = cfg.get("buildings")
+        if self.buildings_param is not None:
+            items = self.buildings_param["Threaten"]
+            for p in (items if isinstance(items, list) else [items]):
+                self.buildings.append(self.ThreatenFactory.Create_Threaten(p))
+        self.num_UAV = int(param.get("num_UAV"))
+        agents_params = param.get("Agent")
+        uav_params = XML2Dict(os.path.normpath(agents_params["xml_path_agent"])).get("Agent")
+        self.num_envs = int(None2Value(param.get("num_envs"), 1))
+        self.seed = int(None2Value(param.get("seed"), 42))
+        b = np.array([[t.position.x, t.position.y, t.position.z, t._R, t._H] for t in self.buildings], dtype=np.float64)
+        obs_dtype = torch.float16 if (param.get("obs_dtype") or "f32") == "f16" else torch.float32
+        trainer_xml = os.path.normpath(agents_params["Trainer"].get("Trainer_path"))
+        n_actions = int(None2Value(XML2Dict(trainer_xml).get("Trainer").get("output"), 3))
+        fp = (uav_params.get("Power_param") or {}).get("Fly_power") or {}
+        power = tuple(float(fp.get(k)) for k in ("P_i", "v_0", "d_0", "rho", "s", "A", "P_b", "F_b")) \
+            if all(fp.get(k) is not None for k in ("P_i", "v_0", "d_0", "rho", "s", "A", "P_b", "F_b")) else None
+        kw = dict(uav_per_env=self.num_UAV, max_step=int(uav_params.get("Max_Step")),
+                  apf_enabled=int(uav_params.get("APF_Enabled") or 0), obs_dtype=obs_dtype, n_actions=n_actions,
+                  length=float(self.len), width=float(self.width), h=float(self.h), max_v=float(int(uav_params.get("Max_V"))),
+                  steering_angle=float(uav_params.get("Steering_angle")) / 180 * np.pi)
+        if power is not None:
+            kw["power"] = power
+        if param.get("device"):
+            kw["device"] = param.get("device")
+        self.backend = _backend.make_backend(self.num_envs, b, **kw)
+        self._load_bank(param.get("scenario_bank"), b)
+        for i in range(self.num_UAV):
+            up = dict(uav_params)
+            up["name"] = "UAV_" + str(i)
+            up["j"] = i
+            agent = self.AgentFactory.Create_Agent(up, self)
+            tp = dict(XML2Dict(trainer_xml).get("Trainer"))
+            tp["name"] = agent.name
+            if param.get("device") and not tp.get("device"):
+                tp["device"] = param.get("device")
+            agent.Trainer = self.TrainerFactory.Create_Trainer(tp)
+            self.Agents.append(agent)
+        self.result = {"success": 0, "failed:": 0, "meet_threaten": 0, "normal": 0, "loss": None, "sum_epoch": 0, "eps": 0.1}
+        self.epoch = 0
+        self.print_loop = int(None2Value(param.get("print_loop"), 2))
+        self.Is_FL = int(None2Value(param.get("Is_FL"), 0))
+        self.FL_Loop = int(None2Value(param.get("FL_Loop"), 3))
+        self.executed_time = 0
+        self._state_cache = None
+        self._obs = None
+        self._episode = 0
+        self.Scene_Random_Reset()
+
+    # ---- scenario bank (the RRT part of UAV.reset, pre-planned) ------------------------------------------
+    def _load_bank(self, path, b):
+        if path:
+            z = np.load(os.path.normpath(path))
+            self.backend.load_scenarios(z["start_goal"], z["sub_goals"], z["n_sub"])
+            return
+        from dqn_based_uav_3d_path_planer_amd.data import load_city26
+        c = load_city26()
+        if c["buildings"].shape != b.shape or not np.allclose(c["buildings"], b, rtol=0, atol=1e-9):
+            raise ValueError("no <scenario_bank> given and the buildings differ from the packaged city26 world: "
+                             "plan a bank for this world first (see oracle/gen_bank.py)")
+        self.backend.load_scenarios(c["start_goal"], c["sub_goals"], c["n_sub"])
+
+    # ---- helpers used by the UAV views -------------------------------------------------------------------
+    def _invalidate(self):
+        self._state_cache = None
+
+    def _states(self):
+        if self._state_cache is None:
+            self._state_cache = self.backend.get_state(0, self.backend.N, want_sub=True)
+        return self._state_cache
+
+    def _state_row(self, e, j):
+        return self._states()[0][e * self.num_UAV + j]
+
+    def _subgoals(self, e, j):
+        st, sub, _ = self._states()
+        i = e * self.num_UAV + j
+        return sub[i][: int(st[i][11])]
+
+    def _obs_slot(self, j) -> torch.Tensor:
+        return self._obs.view(self.num_envs, self.num_UAV, -1)[:, j]
+
+    def _obs_rows(self, j) -> np.ndarray:
+        return self._obs_slot(j).float().cpu().numpy()
+
+    def _slot_mask(self, j) -> torch.Tensor:
+        m = torch.zeros((self.num_envs, self.num_UAV), dtype=torch.uint8, device=self._obs.device)
+        m[:, j] = 1
+        return m.reshape(-1).contiguous()
+
+    def _step_slot(self, j, action):
+        """Move UAV_j of every env (BaseEnv.Move_Agent semantics for a batch); other slots are left untouched."""
+        dev = self._obs.device
+        a = torch.as_tensor(np.asarray(action.cpu() if torch.is_tensor(action) else action))
+        if a.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8) or isinstance(action, int):
+            kind_int = True
+            col = a.reshape(-1).to(torch.int32)
+        else:
+            kind_int = False
+            col = a.reshape(-1)[:1].to(torch.float64) if a.numel() in (1, 2) and self.num_envs == 1 else a.reshape(-1).to(torch.float64)
+        if col.numel() == 1:
+            col = col.expand(self.num_envs)
+        full = torch.zeros((self.num_envs, self.num_UAV), dtype=torch.int32 if kind_int else torch.float64, device=dev)
+        full[:, j] = col.to(dev)
+        out = self.backend.step(full.reshape(-1).contiguous(), active=self._slot_mask(j), skip_done=False)
+        self._obs = out.obs
+        self._invalidate()
+        sl = slice(j, None, self.num_UAV)
+        return (out.reward.cpu().numpy()[sl], out.ret_done.cpu().numpy()[sl], out.info.cpu().numpy()[sl])
+
+    # ---- reference methods ---------------------------------------------------------------------------------
+    def Threaten_rate(self, p: Loc):
+        """PathPlan_City.py:215-223 on the device broad phase + exact narrow phase."""
+        pts = torch.tensor([[float(p.x), float(p.y), float(p.z)]], dtype=torch.float64)
+        return int(self.backend.threaten_rate(pts)[0])
+
+    def Scene_Random_Reset(self):
+        self._episode += 1
+        self._obs = self.backend.reset(self.seed + self._episode)
+        self._invalidate()
+
+    def Check_uav_Done(self):
+        return bool(self._states()[0][:, 10].all())
+
+    def Move_Agent(self, index: int, action):
+        """BaseEnv.py:123-137 -> (next_state, reward, done, info) of env 0."""
+        reward, done, info = self.Agents[index].update(action)
+        return self.Agents[index].state(), reward, done, info
+
+    def run(self):
+        pass
+
+    def run_XML_scene(self):
+        pass
+
+    def Choose_Action2(self, index: int, eps=0.2):
+        state = self.Agents[index].state()
+        return self.Agents[index].Trainer.get_action(state, eps)
+
+    def Reset_Result(self, eps_rate):
+        self.result = {"success": 0, "lose": 0, "meet_threaten": 0, "normal": 0, "loss": 0, "sum_epoch": 0,
+                       "eps": eps_rate, "score": 0, "average_score": 0, "step": 0}
+
+    def Run_statistics(self, info):
+        self.result[info] = self.result[info] + 1
+
+    def update(self):
+        """PathPlan_City.py:757-776: every agent trains on its current transition_dict."""
+        re = []
+        for uav in self.Agents:
+            item = dict(uav.Train_nn())
+            item["score"] = uav.score
+            item["average_score"] = uav.score
+            item["step"] = uav.Step
+            item["energy_cost"] = uav.energy_cost_total
+            item["task_collect"] = uav.task_collect
+            item["Energy_Efficent"] = uav.task_collect / (uav.energy_cost_total + 0.001)
+            item["UE_waiting_time"] = 0
+            re.append(item)
+        return re
+
+    def Train_statistics(self, train_info):
+        for info in train_info:
+            loss = info["loss"]
+            self.result["loss"] += float(loss.item()) if torch.is_tensor(loss) else float(loss)
+            self.result["sum_epoch"] += info["sum_epoch"]
+            self.result["score"] += info["score"]
+            self.result["average_score"] += info["average_score"] / max(len(train_info), 1)
+            self.result["step"] += info["step"]
+
+    def run_eposide(self, eps_rate=0.1):
+        """PathPlan_City.py:410-478 (off-policy branch) for all vectorised envs at once: reset, then
+        act -> step -> store -> sample -> learn per time step until every agent of every env is done."""
+        self.Reset_Result(eps_rate)
+        self.Scene_Random_Reset()
+        names = ("normal", "success", "lose")
+        train_info = []
+        while True:
+            self.run()
+            states = self._obs
+            s_view = states.view(self.num_envs, self.num_UAV, -1)
+            actions = torch.zeros((self.num_envs, self.num_UAV), dtype=torch.int32, device=states.device)
+            for j, uav in enumerate(self.Agents):
+                uav.transition_dict = {"states": [], "actions": [], "next_states": [], "rewards": [], "dones": []}
+                actions[:, j] = uav.Trainer.get_action_batch(s_view[:, j], eps_rate).to(states.device)
+            out = self.backend.step(actions.reshape(-1).contiguous(), skip_done=True)     # done agents wait (:365-366)
+            self._obs = out.obs
+            self._invalidate()
+            info = out.info.view(self.num_envs, self.num_UAV)
+            valid = out.valid.view(self.num_envs, self.num_UAV).bool()
+            for k, nm in enumerate(names):
+                self.result[nm] += int(((info == k) & valid).sum().item())
+            n_view = out.obs.view(self.num_envs, self.num_UAV, -1)
+            r_view = out.reward32.view(self.num_envs, self.num_UAV)
+            d_view = out.ret_done.view(self.num_envs, self.num_UAV)
+            for j, uav in enumerate(self.Agents):
+                mem = uav.Trainer.replay_memory
+                mem.add_batch(s_view[:, j].float(), actions[:, j], r_view[:, j], n_view[:, j].float(), d_view[:, j],
+                              valid=valid[:, j])
+                if len(mem.buffer) > uav.Trainer.Batch_Size:                                  # :383-385
+                    b = mem.sample_tensors(uav.Trainer.Batch_Size)
+                    uav.transition_dict = {"states": b["states"], "actions": b["actions"], "next_states": b["next_states"],
+                                           "rewards": b["rewards"], "dones": b["dones"], "idx": None, "weights": None}
+            train_info = self.update()                                                        # :456
+            if self.Check_uav_Done():
+                break
+        self.Train_statistics(train_info)
+        self.epoch += 1
+        if self.epoch % self.print_loop == 0:
+            for uav in self.Agents:
+                uav.record_list()
+        return self.result

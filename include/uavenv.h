@@ -122,10 +122,12 @@ int uavenv_get_state(UavEnv *env, int32_t first, int32_t count, double *out16, d
  *   ret_done      the `done` RETURNED by update (goes into replay); agent_done = self.done (ends the episode)
  *   valid         0 for skipped agents, else 1
  *   energy64      Calc_Fly_Power at the post-step speed (UAV.py:239-245), J per unit-time step
+ *   active        nullable N-byte mask; agents with 0 are left untouched (info SKIPPED, valid 0) -- this is how
+ *                 BaseEnv.Move_Agent(index, action) moves ONE agent of the batch
  */
 int uavenv_step(UavEnv *env, const void *actions_dev, int32_t action_kind, void *obs_dev, double *reward64_dev,
                 float *reward32_dev, uint8_t *ret_done_dev, uint8_t *agent_done_dev, uint8_t *info_dev,
-                uint8_t *valid_dev, double *energy64_dev, uint32_t flags, void *stream);
+                uint8_t *valid_dev, double *energy64_dev, const uint8_t *active_dev, uint32_t flags, void *stream);
 /* UAV.state_PathPlan() only (UAV.py:515-567), e.g. the first observation after a reset. */
 int uavenv_observe(UavEnv *env, void *obs_dev, void *stream);
 /* PathPlan_City.Threaten_rate (PathPlan_City.py:215-223) for n points: xyz_dev n x 3 doubles -> out_dev n bytes. */
