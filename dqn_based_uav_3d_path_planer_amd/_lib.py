@@ -21,7 +21,7 @@ STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS = 1, 2, 4
 SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
-    "uavenv_step", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
+    "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_act",
 )
@@ -92,6 +92,8 @@ def load() -> C.CDLL:
     lib.uavenv_get_state.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.uavenv_step.restype = C.c_int
     lib.uavenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
+    lib.uavenv_set_debug_buffer.restype = C.c_int
+    lib.uavenv_set_debug_buffer.argtypes = [vp, vp]
     lib.uavenv_observe.restype = C.c_int
     lib.uavenv_observe.argtypes = [vp, vp, vp]
     lib.uavenv_threaten_rate.restype = C.c_int

@@ -296,6 +296,44 @@ __device__ __forceinline__ void store_obs_row(void *obs_base, int64_t agent, con
     }
 }
 
+// Wave-cooperative, fully coalesced store of 64 observation rows (one workgroup == one wavefront).
+// Each lane drops its own row into an LDS tile (row stride 101 dwords -> the 64 column writes of one instruction hit
+// 32 distinct banks), then the wave streams the 64 x 100 tile out as 25 contiguous 1 KiB (f32) / 512 B (f16)
+// stores.  The row-per-lane form costs 25 store instructions of 64 separate 16-byte segments each (~64 TA cycles
+// per instruction instead of ~16) -- measured 3.6 k cycles of a 24 k-cycle wave at 16 384 envs.
+constexpr int kTileLd = 101;
+constexpr int kTileBytes = 64 * kTileLd * 4;
+template <bool F16>
+__device__ __forceinline__ void store_obs_tile(void *obs_base, int64_t first_agent, int n_valid, float *tile,
+                                               const ObsScalars &s, const ObsBits &b)
+{
+    const int lane = (int)threadIdx.x & 63;
+    float *row = tile + lane * kTileLd;
+#pragma unroll
+    for (int c = 0; c < 100; ++c) row[c] = obs_col(s, b, c);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 25; ++it) {
+        const int e = it * 256 + lane * 4;            // flat element index inside the 64 x 100 tile
+        const int r = e / 100, c = e - r * 100;
+        if (r < n_valid) {
+            const float *src = tile + r * kTileLd + c;
+            if (!F16) {
+                float4 v = make_float4(src[0], src[1], src[2], src[3]);
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs_base) + first_agent * 100 + e) = v;
+            } else {
+                __half2 lo = __floats2half2_rn(src[0], src[1]);
+                __half2 hi = __floats2half2_rn(src[2], src[3]);
+                uint2 v;
+                v.x = *reinterpret_cast<uint32_t *>(&lo);
+                v.y = *reinterpret_cast<uint32_t *>(&hi);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(obs_base) + first_agent * 100 + e) = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // Philox4x32-10 (counter-based; one independent stream per (seed, agent, tick)).
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
 {

@@ -128,6 +128,9 @@ int uavenv_get_state(UavEnv *env, int32_t first, int32_t count, double *out16, d
 int uavenv_step(UavEnv *env, const void *actions_dev, int32_t action_kind, void *obs_dev, double *reward64_dev,
                 float *reward32_dev, uint8_t *ret_done_dev, uint8_t *agent_done_dev, uint8_t *info_dev,
                 uint8_t *valid_dev, double *energy64_dev, const uint8_t *active_dev, uint32_t flags, void *stream);
+/* Diagnostics: when dev_buf != NULL, wave w of uavenv_step writes 8 s_memtime stamps to dev_buf[8*w .. 8*w+7]
+ * (start, world staged, state landed, step done, reset done, obs computed, stores issued, stores retired). */
+int uavenv_set_debug_buffer(UavEnv *env, unsigned long long *dev_buf);
 /* UAV.state_PathPlan() only (UAV.py:515-567), e.g. the first observation after a reset. */
 int uavenv_observe(UavEnv *env, void *obs_dev, void *stream);
 /* PathPlan_City.Threaten_rate (PathPlan_City.py:215-223) for n points: xyz_dev n x 3 doubles -> out_dev n bytes. */
