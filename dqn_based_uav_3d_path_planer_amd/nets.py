@@ -43,3 +43,47 @@ NETWORKS = {"Qnet2": Qnet2, "VAnet2": VAnet2}
 def create_network(param):
     """FactoryClass/NetworkFactory.py:10-22 -- look the class up by its `NetWork` name."""
     return NETWORKS[param.get("NetWork")](param)
+
+
+class PolicyNetContinuous_SAC(torch.nn.Module):
+    """BaseCNN.py:459-483 incl. its quirks: std = tanh(softplus(.)), and the log-prob correction applies tanh to the
+    already squashed action (`1 - tanh(action)^2`).  `eps` (optional) replaces Normal.rsample()'s N(0,1) draw so the
+    same update can be replayed on another device."""
+
+    def __init__(self, param):
+        super().__init__()
+        w, hid, out = int(param.get("w")), int(param.get("hiden_dim")), int(param.get("output"))
+        self.fc1 = torch.nn.Linear(w, hid)
+        self.fc_mu = torch.nn.Linear(hid, out)
+        self.fc_std = torch.nn.Linear(hid, out)
+        self.action_bound = float(param.get("action_bound"))
+
+    def forward(self, x, eps=None):
+        x = F.relu(self.fc1(x))
+        mu = torch.tanh(self.fc_mu(x))
+        std = torch.tanh(F.softplus(self.fc_std(x)))
+        dist = torch.distributions.Normal(mu, std)
+        normal_sample = dist.rsample() if eps is None else mu + std * eps
+        log_prob = dist.log_prob(normal_sample)
+        action = torch.tanh(normal_sample)
+        log_prob = log_prob - torch.log(1 - torch.tanh(action).pow(2) + 1e-7)
+        return action * self.action_bound, log_prob
+
+
+class QValueNetContinuous_SAC(torch.nn.Module):
+    """BaseCNN.py:486-500: Q(s, a) MLP whose output width is action_dim (2 values, as in the reference)."""
+
+    def __init__(self, param):
+        super().__init__()
+        w, hid, ad = int(param.get("w")), int(param.get("hiden_dim")), int(param.get("action_dim"))
+        self.fc1 = torch.nn.Linear(w + ad, hid)
+        self.fc2 = torch.nn.Linear(hid, hid)
+        self.fc_out = torch.nn.Linear(hid, ad)
+
+    def forward(self, x, a):
+        x = F.relu(self.fc1(torch.cat([x, a], dim=-1)))
+        x = F.relu(self.fc2(x))
+        return self.fc_out(x)
+
+
+NETWORKS.update(PolicyNetContinuous_SAC=PolicyNetContinuous_SAC, QValueNetContinuous_SAC=QValueNetContinuous_SAC)

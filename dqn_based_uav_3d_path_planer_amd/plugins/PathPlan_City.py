@@ -214,10 +214,20 @@ class PathPlan_City:
             self.run()
             states = self._obs
             s_view = states.view(self.num_envs, self.num_UAV, -1)
-            actions = torch.zeros((self.num_envs, self.num_UAV), dtype=torch.int32, device=states.device)
+            chosen = []
             for j, uav in enumerate(self.Agents):
                 uav.transition_dict = {"states": [], "actions": [], "next_states": [], "rewards": [], "dones": []}
-                actions[:, j] = uav.Trainer.get_action_batch(s_view[:, j], eps_rate).to(states.device)
+                chosen.append(uav.Trainer.get_action_batch(s_view[:, j], eps_rate).to(states.device))
+            continuous = any(c.dim() == 2 for c in chosen)          # SAC: [n, action_dim], only [:, 0] steers (UAV.py:414)
+            actions = torch.zeros((self.num_envs, self.num_UAV), dtype=torch.float32 if continuous else torch.int32,
+                                  device=states.device)
+            for j, c in enumerate(chosen):
+                if c.dim() == 2:
+                    actions[:, j] = c[:, 0].float()
+                elif continuous:                                     # mixed: index -> steer with the documented table
+                    actions[:, j] = -1.0 + 2.0 * c.float() / (self.Agents[j].Trainer.act_num - 1)
+                else:
+                    actions[:, j] = c.to(torch.int32)
             out = self.backend.step(actions.reshape(-1).contiguous(), skip_done=True)     # done agents wait (:365-366)
             self._obs = out.obs
             self._invalidate()
@@ -230,7 +240,7 @@ class PathPlan_City:
             d_view = out.ret_done.view(self.num_envs, self.num_UAV)
             for j, uav in enumerate(self.Agents):
                 mem = uav.Trainer.replay_memory
-                mem.add_batch(s_view[:, j].float(), actions[:, j], r_view[:, j], n_view[:, j].float(), d_view[:, j],
+                mem.add_batch(s_view[:, j].float(), chosen[j], r_view[:, j], n_view[:, j].float(), d_view[:, j],
                               valid=valid[:, j])
                 if len(mem.buffer) > uav.Trainer.Batch_Size:                                  # :383-385
                     b = mem.sample_tensors(uav.Trainer.Batch_Size)

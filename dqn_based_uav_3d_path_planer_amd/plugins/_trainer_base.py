@@ -52,7 +52,8 @@ class VecReplayMemory:
     def add_batch(self, states, actions, rewards, next_states, dones, valid=None):
         t = lambda x, dt: torch.as_tensor(x, device=self.device).to(dt)   # noqa: E731
         s, ns = t(states, torch.float32).reshape(-1, self.obs_dim), t(next_states, torch.float32).reshape(-1, self.obs_dim)
-        a, r, d = t(actions, torch.int64).reshape(-1), t(rewards, torch.float32).reshape(-1), t(dones, torch.float32).reshape(-1)
+        a = t(actions, self.actions.dtype).reshape(len(s), *self.actions.shape[1:])      # [n] indices or [n, action_dim]
+        r, d = t(rewards, torch.float32).reshape(-1), t(dones, torch.float32).reshape(-1)
         if valid is not None:
             keep = torch.as_tensor(valid, device=self.device).reshape(-1).bool()
             s, ns, a, r, d = s[keep], ns[keep], a[keep], r[keep], d[keep]

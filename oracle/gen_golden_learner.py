@@ -86,6 +86,7 @@ def main():
         gen(s, "DQN_Trainer", "Qnet2")
         gen(s, "DDQN_Trainer", "Qnet2")
         gen(s, "DuelingDQN_Trainer", "VAnet2")
+        gen_sac(s)
         # epsilon schedule, simulator.py:141-145
         sim = s.sim
         eps = []
@@ -98,5 +99,77 @@ def main():
         s.close()
 
 
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SAC continuous (Trainer/SAC_Trainer.py:325-379, nets BaseClass/BaseCNN.py:459-500): BASELINE config 4's trainer.
+# The update is stochastic (Normal.rsample); torch.manual_seed(SEED + k) before update k pins the two draws
+# (actor(next_states) in calc_target, then actor(states)); the noise itself is recorded too.
+def gen_sac(s):
+    from FactoryClass.TrainerFactory import TrainerFactory
+    param = {"Trainer_Type": "SAC_Trainer", "Is_Train": "1", "IsPriority_Replay": "0",
+             "actor": {"NetWork": "PolicyNetContinuous_SAC", "h": "1", "w": "100", "channel": "1", "action_bound": "1",
+                       "hiden_dim": "64", "output": "2", "lr": "0.0001"},
+             "critic": {"NetWork": "QValueNetContinuous_SAC", "h": "1", "w": "100", "channel": "1", "hiden_dim": "64",
+                        "action_dim": "2", "lr": "0.001"},
+             "SAC_param": {"IS_Continuous": "1", "alpha_lr": "0.0001", "target_entropy": "1", "gamma": "0.99", "tau": "0.05"},
+             "Priority_Replay": "0", "replay_size": "10000", "LEARNING_RATE": "0.0005", "Batch_Size": "64",
+             "max_epoch": "100", "save_loop": str(10 ** 9), "name": "golden"}
+    tr = TrainerFactory().Create_Trainer(param)
+    assert tr is not None
+    tr.save = lambda *a, **k: None
+    g = torch.Generator().manual_seed(4321)
+    nets = {"actor": tr.actor, "critic_1": tr.critic_1, "critic_2": tr.critic_2}
+    for net in nets.values():
+        with torch.no_grad():
+            for p in net.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    tr.target_critic_1.load_state_dict(tr.critic_1.state_dict())
+    tr.target_critic_2.load_state_dict(tr.critic_2.state_dict())
+    out = {}
+    for name, net in nets.items():
+        for k, v in sd_to_np(net.state_dict()).items():
+            out[f"{name}0_{k}"] = v
+    rng = np.random.default_rng(7)
+    B = 64
+    states = rng.normal(0, 1, (B, 100)).astype(np.float32)
+    next_states = rng.normal(0, 1, (B, 100)).astype(np.float32)
+    actions = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+    rewards = (rng.normal(0, 1, B) * np.where(rng.random(B) < 0.1, 150.0, 1.0)).astype(np.float32)
+    dones = (rng.random(B) < 0.25).astype(np.float32)
+    for i in range(B):
+        tr.replay_memory.push((0, 0, 0, 0, 0), 0)     # update() only checks len(memory) >= Batch_Size (:333)
+    td = {"states": states.tolist(), "actions": actions.tolist(), "rewards": rewards.tolist(),
+          "next_states": next_states.tolist(), "dones": dones.tolist()}
+    SEED, K = 1000, 5
+    losses, alphas, noise = [], [], []
+    for k in range(K):
+        torch.manual_seed(SEED + k)
+        n1, n2 = torch.randn(B, 2), torch.randn(B, 2)     # what the two rsample() calls will draw
+        noise.append(np.stack([n1.numpy(), n2.numpy()]))
+        torch.manual_seed(SEED + k)
+        res = tr.update(td)
+        losses.append(float(res["loss"]))
+        alphas.append(float(tr.log_alpha))
+    # deterministic acting check: get_action under a seed
+    torch.manual_seed(77)
+    act = tr.get_action(states[0].tolist(), 0.0)
+    out.update(states=states, next_states=next_states, actions=actions, rewards=rewards, dones=dones,
+               losses=np.array(losses), log_alpha=np.array(alphas), noise=np.array(noise), seed=SEED,
+               act_seed77=np.array(act), epoch=int(tr.epoch))
+    for name, net in {**nets, "target_critic_1": tr.target_critic_1, "target_critic_2": tr.target_critic_2}.items():
+        for k, v in sd_to_np(net.state_dict()).items():
+            out[f"{name}1_{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "learner_SAC_Trainer.npz"), **out)
+    print("SAC_Trainer losses", losses, "log_alpha", alphas, "act", act)
+
+
 if __name__ == "__main__":
-    main()
+    if "--sac" in sys.argv:
+        _s = RefSession()
+        try:
+            gen_sac(_s)
+        finally:
+            _s.close()
+    else:
+        main()

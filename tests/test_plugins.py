@@ -146,6 +146,22 @@ def test_run_eposide_contract_vectorised(cfg_dir):
     assert sim.epoch == 10 and len(sim.infos) == 10 and sim.Max_score >= max(i["average_score"] for i in sim.infos) - 1e-9
 
 
+def test_run_eposide_with_sac_continuous_actions(cfg_dir):
+    """BASELINE config 4's trainer (and the reference's shipped default) through the same episode loop."""
+    xml = driver.make_config_dir(str(cfg_dir), "SAC", num_envs=6, num_uav=4)
+    # Trainer.xml has no <output> at top level for SAC: n_actions falls back to 3 (unused for steer actions)
+    sim = driver.simulator(xml)
+    env = sim.env
+    assert env is not None and type(env.Agents[0].Trainer).__name__ == "SAC_Trainer" and env.backend.N == 24
+    torch.manual_seed(3)
+    res = env.run_eposide(0.1)
+    assert res["lose"] + res["success"] >= 24 and env.Check_uav_Done()
+    tr = env.Agents[2].Trainer
+    assert tr.replay_memory.actions.shape[1] == 2 and len(tr.replay_memory) > 150
+    assert float(tr.replay_memory.actions[: len(tr.replay_memory)].abs().max()) <= 1.0
+    assert tr.epoch > 150 and np.isfinite(float(res["loss"]))
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout")
 def test_unmodified_reference_simulator_drives_our_plugins(cfg_dir, monkeypatch):
     """Drop-in proof: the reference's own simulator.py + factories (scratch copy), our plugin dir first on
