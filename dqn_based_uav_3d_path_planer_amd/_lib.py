@@ -23,7 +23,7 @@ SYMBOLS = (
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_select_actions",
-    "uavenv_dqn_num_params", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_act",
+    "uavenv_dqn_num_params", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
 )
 
 
@@ -113,6 +113,8 @@ def load() -> C.CDLL:
     lib.uavenv_dqn_reduce.argtypes = [net, vp, i32, vp, vp]
     lib.uavenv_dqn_adam.restype = C.c_int
     lib.uavenv_dqn_adam.argtypes = [net, vp, f32, f32, f32, f32, i32, i32, vp, vp]
+    lib.uavenv_dqn_reduce_adam.restype = C.c_int
+    lib.uavenv_dqn_reduce_adam.argtypes = [net, vp, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp]
     lib.uavenv_dqn_act.restype = C.c_int
     lib.uavenv_dqn_act.argtypes = [net, vp, i32, i32, f32, u64, u64, vp, vp, vp, vp]
     if lib.uavenv_abi_version() != ABI_VERSION:

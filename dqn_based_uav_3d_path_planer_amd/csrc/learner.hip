@@ -57,23 +57,41 @@ template <typename T>
 __device__ __forceinline__ void stage_rows(float *dst, const T *const *row_ptr_lds, const T *base_consecutive)
 {
     constexpr int kChunks = kTile * 25;    // 25 chunks of 4 elements per row
+    constexpr int kIters = (kChunks + 255) / 256;
+    float4 v[kIters];
+    // phase 1: every global load of this tile in flight at once (a load -> wait -> LDS-write loop serialises
+    // seven memory round trips per tile, four tiles per workgroup)
 #pragma unroll
-    for (int it = 0; it < (kChunks + 255) / 256; ++it) {
+    for (int it = 0; it < kIters; ++it) {
+        int c = it * 256 + (int)threadIdx.x;
+        c = c < kChunks ? c : kChunks - 1;
+        const int row = c / 25, q = c - row * 25;
+        const T *src = row_ptr_lds ? row_ptr_lds[row] : base_consecutive + (size_t)row * kW;
+        if (sizeof(T) == 4) {
+            v[it] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + 4 * q);
+        } else {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(src) + 4 * q);
+            v[it] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f);   // decoded in phase 2
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; ++it)
+        asm volatile("" : "+v"(v[it].x), "+v"(v[it].y), "+v"(v[it].z), "+v"(v[it].w));
+    // phase 2: LDS writes
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
         const int c = it * 256 + (int)threadIdx.x;
         if (c < kChunks) {
             const int row = c / 25, q = c - row * 25;
-            const T *src = row_ptr_lds ? row_ptr_lds[row] : base_consecutive + (size_t)row * kW;
-            float4 v;
-            if (sizeof(T) == 4) {
-                v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + 4 * q);
-            } else {
-                const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(src) + 4 * q);
-                const __half2 lo = *reinterpret_cast<const __half2 *>(&raw.x);
-                const __half2 hi = *reinterpret_cast<const __half2 *>(&raw.y);
-                v = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+            float4 w = v[it];
+            if (sizeof(T) != 4) {
+                const uint32_t rx = __float_as_uint(v[it].x), ry = __float_as_uint(v[it].y);
+                const __half2 lo = *reinterpret_cast<const __half2 *>(&rx);
+                const __half2 hi = *reinterpret_cast<const __half2 *>(&ry);
+                w = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
             }
             float *d = dst + row * kLdx + 4 * q;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
         }
     }
 }
@@ -201,6 +219,7 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
     __syncthreads();
     stage_rows<ObsT>(Xs, rows_s, nullptr);
     stage_rows<ObsT>(Xn, rows_n, nullptr);
+    if (tid < kTile) Xs[tid * kLdx + kW] = 1.0f;     // ones column: the dW1 product then yields db1 as its column 100
     __syncthreads();
 
     // ---- P1: hidden layers on the matrix cores
@@ -249,38 +268,51 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
             dq = 2.0f * delta;
         }
         dq *= v;
-        red[tid] = per * v;
-        red[kTile + tid] = v;
-        for (int a = 0; a < kMaxOut; ++a) dout[tid * kMaxOut + a] = 0.0f;
-        if (g.dueling) {                              // Q = V + A - mean(A)
-            for (int a = 0; a < g.n_actions; ++a)
-                dout[tid * kMaxOut + a] = dq * ((a == act ? 1.0f : 0.0f) - 1.0f / (float)g.n_actions);
-            dout[tid * kMaxOut + g.n_actions] = dq;
-        } else {
-            dout[tid * kMaxOut + act] = dq;
+        float dvals[kMaxOut];                         // compile-time indexed only (stays in registers)
+        const float inv_a = 1.0f / (float)g.n_actions;
+#pragma unroll
+        for (int a = 0; a < kMaxOut; ++a) {
+            float dv = 0.0f;
+            if (g.dueling) {                          // Q = V + A - mean(A)
+                if (a < g.n_actions) dv = dq * ((a == act ? 1.0f : 0.0f) - inv_a);
+                else if (a == g.n_actions) dv = dq;
+            } else if (a == act) {
+                dv = dq;
+            }
+            dvals[a] = dv;
+            dout[tid * kMaxOut + a] = dv;
+        }
+        // wave-level sums over the 64 samples (threads 0..63 are exactly wave 0): db2, loss sum, valid count
+        float *outp = g.partials + (size_t)blockIdx.x * (g.P + 2);
+        const int ob2w = kHid * kW + kHid + n2 * kHid;
+#pragma unroll
+        for (int a = 0; a < kMaxOut; ++a) {
+            if (a < n2) {                              // uniform branch: __shfl_down is a ds_bpermute (~100 cycles)
+                float t = dvals[a];
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+                if (tid == 0) outp[ob2w + a] = t;
+            }
+        }
+        float ls = per * v, cn = v;
+        for (int off = 32; off > 0; off >>= 1) {
+            ls += __shfl_down(ls, off, 64);
+            cn += __shfl_down(cn, off, 64);
+        }
+        if (tid == 0) {
+            outp[g.P] = ls;
+            outp[g.P + 1] = cn;
         }
     }
     __syncthreads();
 
     // ---- P5: layer-2 gradients (needs the forward Hs), then dH in place
     float *out = g.partials + (size_t)blockIdx.x * (g.P + 2);
-    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
+    const int oW2 = kHid * kW + kHid;
     for (int k = tid; k < n2 * kHid; k += 256) {
         const int a = k / kHid, j = k - a * kHid;
         float s = 0.0f;
         for (int smp = 0; smp < kTile; ++smp) s = fmaf(dout[smp * kMaxOut + a], Hs[smp * kLdh + j], s);
         out[oW2 + k] = s;
-    }
-    if (tid < n2) {
-        float s = 0.0f;
-        for (int smp = 0; smp < kTile; ++smp) s += dout[smp * kMaxOut + tid];
-        out[ob2 + tid] = s;
-    }
-    if (tid == 0) {
-        float ls = 0.0f, cnt = 0.0f;
-        for (int smp = 0; smp < kTile; ++smp) { ls += red[smp]; cnt += red[kTile + smp]; }
-        out[g.P] = ls;
-        out[g.P + 1] = cnt;
     }
     __syncthreads();
     for (int k = tid; k < kTile * kHid; k += 256) {
@@ -306,19 +338,15 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
             for (int kk = 0; kk < kTile; kk += 2)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * kLdh], bp[kk * kLdx], acc, 0, 0, 0);
             const int n = n0 + (l & 31);
-            if (n < kW) {
+            if (n <= kW) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int m = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
-                    out[m * kW + n] = acc[reg];
+                    if (n < kW) out[m * kW + n] = acc[reg];
+                    else out[kHid * kW + m] = acc[reg];          // column 100 = X's ones column -> db1[m]
                 }
             }
         }
-    }
-    if (tid < kHid) {
-        float s = 0.0f;
-        for (int smp = 0; smp < kTile; ++smp) s += Hs[smp * kLdh + tid];
-        out[kHid * kW + tid] = s;
     }
 }
 
@@ -372,6 +400,62 @@ __global__ void k_dqn_adam(float *__restrict__ local, float *__restrict__ target
     const float np = local[p] - (lr / bc1) * (mp / denom);
     local[p] = np;
     if (hard_update) target[p] = np;
+}
+
+// Single-GPU fast path: k_dqn_reduce + k_dqn_adam in one launch (each workgroup owns 32 parameters end to end; the
+// valid count is re-derived per workgroup from the nblk count cells, 1 load per thread).
+__global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict__ partials, int nblk, int P,
+                                                         float *__restrict__ local, float *__restrict__ target,
+                                                         float *__restrict__ m, float *__restrict__ v, float lr,
+                                                         float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                                         int hard_update, float *__restrict__ loss, float *__restrict__ raw)
+{
+    __shared__ float red[8][33];
+    __shared__ float cnt_part[4];
+    __shared__ float s_inv;
+    const int stride = P + 2;
+    const int tid = (int)threadIdx.x;
+    float c = 0.0f;
+    for (int b = tid; b < nblk; b += 256) c += partials[(size_t)b * stride + P + 1];
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((tid & 63) == 0) cnt_part[tid >> 6] = c;
+    const int px = tid & 31, gy = tid >> 5;
+    const int p = (int)blockIdx.x * 32 + px;
+    float s = 0.0f;
+    if (p < stride) {
+        int b = gy;
+        for (; b + 24 < nblk; b += 32) {
+            const float v0 = partials[(size_t)b * stride + p], v1 = partials[(size_t)(b + 8) * stride + p];
+            const float v2 = partials[(size_t)(b + 16) * stride + p], v3 = partials[(size_t)(b + 24) * stride + p];
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; b < nblk; b += 8) s += partials[(size_t)b * stride + p];
+    }
+    red[gy][px] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float cnt = (cnt_part[0] + cnt_part[1]) + (cnt_part[2] + cnt_part[3]);
+        s_inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
+    }
+    __syncthreads();
+    if (gy == 0 && p < stride) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][px];
+        if (raw) raw[p] = t;
+        if (p < P) {
+            const float gp = t * s_inv;
+            const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);
+            const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;
+            m[p] = mp;
+            v[p] = vp;
+            const float np = local[p] - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
+            local[p] = np;
+            if (hard_update) target[p] = np;
+        } else if (p == P && loss) {
+            *loss = t * s_inv;
+        }
+    }
 }
 
 struct ActArgs {
@@ -519,6 +603,21 @@ int uavenv_dqn_adam(const UavDqnNet *net, const float *raw, float lr, float beta
     const float bc2 = 1.0f - powf(beta2, (float)step_t);
     hipLaunchKernelGGL(k_dqn_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, net->local, net->target,
                        net->m, net->v, raw, P, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update, loss_out);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials, int32_t n_partials, float lr, float beta1,
+                           float beta2, float eps, int32_t step_t, int32_t hard_update, float *loss_out, float *raw_out,
+                           void *stream)
+{
+    if (!net_ok(net) || !net->target || !net->m || !net->v || !partials || n_partials <= 0 || step_t <= 0)
+        return UAVENV_EINVAL;
+    const int P = uavenv_dqn_num_params(net);
+    const float bc1 = 1.0f - powf(beta1, (float)step_t);
+    const float bc2 = 1.0f - powf(beta2, (float)step_t);
+    hipLaunchKernelGGL(k_dqn_reduce_adam, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
+                       P, net->local, net->target, net->m, net->v, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update,
+                       loss_out, raw_out);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

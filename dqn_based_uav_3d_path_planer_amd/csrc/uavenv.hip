@@ -444,11 +444,17 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
 // ------------------------------------------------------------------------------------------------
 // the fused step kernel: update_PathPlan + (auto-reset) + state_PathPlan + output/replay write
 // ------------------------------------------------------------------------------------------------
+#ifdef UAVENV_PHASE_PROFILE   // diagnostic build only (scripts/phase_profile.py): the stamps perturb scheduling
 #define UAV_STAMP(slot)                                                                                       \
     do {                                                                                                     \
         if (a.dbg && (threadIdx.x & 63) == 0)                                                                \
             a.dbg[((size_t)blockIdx.x * (a.block >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#define UAV_DRAIN() do { if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } } while (0)
+#else
+#define UAV_STAMP(slot) do { } while (0)
+#define UAV_DRAIN() do { } while (0)
+#endif
 
 template <typename MaskT, bool APF, bool F16, bool TILE>
 __global__ void __launch_bounds__(256) k_step(StepArgs a)
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(256) k_step(StepArgs a)
         const int ii = active ? i : N - 1;
         unpack_flags(g);
         const double a0 = decode_action(ra, a.action_kind, a.n_actions);
-        if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        UAV_DRAIN();
         UAV_STAMP(2);
         double r = 0.0;
         int ret_done = 0, info = UAVENV_INFO_NORMAL, valid = 1;
@@ -529,7 +535,7 @@ __global__ void __launch_bounds__(256) k_step(StepArgs a)
             if (valid || did_reset) store_agent(S, i, g);
             if (want_obs && !TILE) store_obs_row<F16>(a.obs, i, sc, bits);
             UAV_STAMP(6);
-            if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            UAV_DRAIN();
             UAV_STAMP(7);
         }
         if (TILE && want_obs) {      // one wavefront per workgroup: wave-cooperative coalesced tile store

@@ -146,6 +146,7 @@ class FusedDQNLearner:
         self.raw = torch.zeros(self.P + 2, dtype=torch.float32, device=self.device)   # grad sums, loss sum, count
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self._partials = None
+        self.force_split = False       # tests: take the multi-GPU (reduce -> all-reduce -> adam) path on one GPU
 
     def _bind(self, net, flat, hid, w):
         """Move the module's parameters into the flat block (kernel layout) and make them views of it."""
@@ -202,13 +203,20 @@ class FusedDQNLearner:
                                       None if explicit_idx is None else explicit_idx.data_ptr(), C.byref(self.net),
                                       kind, self.gamma, self.huber, self._partials.data_ptr(), s)
         _lib.check(rc, "uavenv_dqn_grad")
+        hard = 1 if self.epoch % self.update_loop == 0 else 0
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi and not self.force_split:      # reduce + Adam (+ hard target copy) in one launch
+            rc = self.lib.uavenv_dqn_reduce_adam(C.byref(self.net), self._partials.data_ptr(), nblk, self.lr,
+                                                 self.betas[0], self.betas[1], self.eps, self.epoch, hard,
+                                                 self.loss.data_ptr(), None, s)
+            _lib.check(rc, "uavenv_dqn_reduce_adam")
+            return self.loss
         rc = self.lib.uavenv_dqn_reduce(C.byref(self.net), self._partials.data_ptr(), nblk, self.raw.data_ptr(), s)
         _lib.check(rc, "uavenv_dqn_reduce")
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # one ~26 KB bucket over RCCL / xGMI: gradient SUMS + loss sum + valid count, so the update is the
-            # mean over the valid samples of all ranks (== single-GPU on the concatenated batch)
+        # one ~26 KB bucket over RCCL / xGMI: gradient SUMS + loss sum + valid count, so the update is the mean over
+        # the valid samples of all ranks (== single-GPU on the concatenated batch)
+        if multi:
             dist.all_reduce(self.raw, op=dist.ReduceOp.SUM)
-        hard = 1 if self.epoch % self.update_loop == 0 else 0
         rc = self.lib.uavenv_dqn_adam(C.byref(self.net), self.raw.data_ptr(), self.lr, self.betas[0], self.betas[1],
                                       self.eps, self.epoch, hard, self.loss.data_ptr(), s)
         _lib.check(rc, "uavenv_dqn_adam")

@@ -192,6 +192,10 @@ int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials_dev, int32_t n
  * weights into q_target (DQN_Trainer.py:121-130,138-141); loss_out_dev (nullable) receives the mean loss. */
 int uavenv_dqn_adam(const UavDqnNet *net, const float *raw_dev, float lr, float beta1, float beta2, float eps,
                     int32_t step_t, int32_t hard_update, float *loss_out_dev, void *stream);
+/* Single-GPU fast path: uavenv_dqn_reduce + uavenv_dqn_adam in ONE launch (raw_out_dev nullable). */
+int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, float lr, float beta1,
+                           float beta2, float eps, int32_t step_t, int32_t hard_update, float *loss_out_dev,
+                           float *raw_out_dev, void *stream);
 /* Q(s) for n envs + epsilon-greedy in one launch (DuelingDQN_Trainer.py:86-97); q_out_dev nullable [n][A]. */
 int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype, int32_t n, float eps, uint64_t seed,
                    uint64_t counter, int32_t *index_out_dev, float *steer_out_dev, float *q_out_dev, void *stream);

@@ -74,12 +74,19 @@ def test_fused_matches_torch_learner_on_a_real_ring(kind, net):
     F = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
     F.q_local.load_state_dict(T.q_local.state_dict())
     F.q_target.load_state_dict(T.q_target.state_dict())
+    F2 = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")      # the split (multi-GPU) kernel path
+    F2.q_local.load_state_dict(T.q_local.state_dict())
+    F2.q_target.load_state_dict(T.q_target.state_dict())
+    F2.force_split = True
     B = 4096
     for it in range(4):
         batch = ring.sample(B, seed=11, counter=it)
         lt = float(T.learn(batch))
         lf = float(F.learn_from_ring(ring, B, seed=11, counter=it))
+        lf2 = float(F2.learn_from_ring(ring, B, seed=11, counter=it))
         assert abs(lt - lf) <= 2e-5 * abs(lt), (it, lt, lf)
+        assert abs(lf2 - lf) <= 1e-6 * abs(lf), (it, lf, lf2)
+    assert (F.flat[:2] - F2.flat[:2]).abs().max().item() <= 1e-6
     for (k, a), (_, b) in zip(T.q_local.state_dict().items(), F.q_local.state_dict().items()):
         assert (a - b).abs().max().item() <= 2e-5, k
     for (k, a), (_, b) in zip(T.q_target.state_dict().items(), F.q_target.state_dict().items()):
