@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
+    p.add_argument("--bank", default="gpu", choices=["gpu", "packaged"],
+                   help="reset scenarios: planned on the GPU at start-up (csrc/rrt.hip) or the packaged reference resets")
     p.add_argument("--learner", default="fused", choices=["fused", "torch"],
                    help="fused = hand-written HIP kernels (csrc/learner.hip); torch = PyTorch-ROCm ops")
     return p.parse_args()
@@ -98,7 +100,11 @@ def main():
     from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing, select_actions
 
     obs_dtype = torch.float16 if args.obs_dtype == "f16" else torch.float32
-    env = make_city26_env(args.envs, device=dev, obs_dtype=obs_dtype, cell_size=args.cell)
+    t_plan = time.perf_counter()
+    env = make_city26_env(args.envs, bank=args.bank, bank_size=max(args.envs, 4096), bank_seed=42 + rank, device=dev,
+                          obs_dtype=obs_dtype, cell_size=args.cell)
+    torch.cuda.synchronize(dev)
+    t_plan = time.perf_counter() - t_plan
     ring = DeviceReplayRing(env, args.replay, discrete=True)
     ring.reset(seed=1000 + rank)
     net = "VAnet2" if args.trainer == "dueling" else "Qnet2"
@@ -198,6 +204,9 @@ def main():
                        "envs_per_gpu": args.envs, "learn_batch_per_gpu": args.batch, "obs_dtype": args.obs_dtype,
                        "learner": "fused HIP kernels (f32 MFMA)" if fused else "PyTorch-ROCm ops",
                        "learner_dtype": "f32" if fused or args.obs_dtype == "f32" else "f16 autocast",
+                       "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
+                                      % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
+                       else "1024 packaged reference resets",
                        "epsilon": args.eps, "parallelism": "env-shard x%d + flat-bucket grad all-reduce" % world_size},
             "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -1,0 +1,280 @@
+// rrt.hip -- the sub-goal planner of UAV.reset() on the GPU.
+//
+// Reference: Agents/UAV.py:353-360 (start / goal draws, Cal_SubTask) -> PathPlan/RRT.py:63-105 (RRTPlanner.getPath:
+// 50 % goal bias, nearest node, steer by step 30 m, obstacle test every 5 m, one rewire pass over all nodes, stop when
+// within 30 m of the goal, path = start .. goal).  The algorithm is sequential in its iterations, so ONE WAVEFRONT
+// plans one scenario and spreads each iteration's inner loops over its 64 lanes:
+//   nearest node     lanes stride the node list (LDS), wave arg-min with first-index tie break (python min());
+//   obstacle_free    the <= 7 sample points of a segment are tested by 7 lanes at once through the same LDS broad
+//                    phase + exact narrow phase as the env kernels (probe());
+//   rewire           lanes test "d < step" for 64 nodes at a time, the surviving candidates are then visited in list
+//                    order (the reference's sequential cost update).
+// Thousands of scenarios plan concurrently (one per wavefront), which is what feeds the auto-reset of the env kernels
+// without a host-side bank.  Random numbers: a counter-based Philox stream per scenario, or -- for parity tests against
+// the CPU oracle -- an explicit U[0,1) stream per scenario.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uavenv.h"
+#include "uavenv_device.hpp"
+
+using namespace uav;
+
+namespace {
+
+struct RrtArgs {
+    const unsigned char *world_blob;
+    int32_t world_bytes, grid_off, grid_stride, gn;
+    double inv_cell, W, Hbox;        // Threaten_rate bounds
+    double len, width, h;            // sampling box (RRT.py:26-32)
+    int32_t m, K, max_iter, max_nodes;
+    double step_size, obstacle_step;
+    const double *start_goal_in;     // nullable [m][6]
+    const double *uniforms;          // nullable [m][stream_len]
+    int32_t stream_len;
+    uint64_t seed;
+    double *out_start_goal;          // [m][6]
+    double *out_sub;                 // [m][K][3]
+    int32_t *out_nsub;               // [m]  (<0: -needed when the path does not fit K; 1: planner gave up -> [goal])
+    int32_t *out_iters;              // nullable [m]
+};
+
+struct Node {
+    double x, y, z, cost;
+};
+
+struct Stream {
+    const double *ext;
+    int ext_n, t;
+    uint64_t seed;
+    uint32_t scn, attempt;
+    __device__ double next()
+    {
+        const int k = t++;
+        if (ext) return k < ext_n ? ext[k] : 0.75;
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)k, scn, attempt, 0x7272u),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        return u53(r.x, r.y);
+    }
+    __device__ double uniform(double a, double b) { return a + (b - a) * next(); }    // random.uniform
+};
+
+// Loc.distance (BaseClass/CalMod.py:41-42)
+__device__ __forceinline__ double ldist(double ax, double ay, double az, double bx, double by, double bz)
+{
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+// RRT.obstacle_free (RRT.py:48-56): sample points a + (b-a)*i/(steps+1), i = 0..steps, one lane each.
+template <typename MaskT>
+__device__ __forceinline__ bool obstacle_free(const WorldLds<MaskT> &w, double ax, double ay, double az, double bx,
+                                              double by, double bz, double obstacle_step)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int steps = (int)(ldist(ax, ay, az, bx, by, bz) / obstacle_step);
+    bool hit_any = false;
+    for (int base = 0; base <= steps; base += 64) {
+        const int i = base + lane;
+        int hit = 0;
+        if (i <= steps) {
+            const double x = ax + (bx - ax) * (double)i / (double)(steps + 1);
+            const double y = ay + (by - ay) * (double)i / (double)(steps + 1);
+            const double z = az + (bz - az) * (double)i / (double)(steps + 1);
+            hit = probe(w, x, y, z);
+        }
+        if (__ballot(hit) != 0ull) hit_any = true;
+    }
+    return !hit_any;
+}
+
+template <typename MaskT>
+__global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = (int)threadIdx.x;
+    {   // stage the world (same blob as the env kernels)
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.world_blob);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (int k = lane; k < a.world_bytes / 16; k += 64) dst[k] = src[k];
+    }
+    __syncthreads();
+    WorldLds<MaskT> w;
+    w.b = reinterpret_cast<const BldLds *>(smem);
+    for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(smem + a.grid_off + h * a.grid_stride);
+    w.gn = a.gn; w.inv_cell = a.inv_cell; w.W = a.W; w.Hbox = a.Hbox;
+    const int node_off = (a.world_bytes + 15) & ~15;
+    Node *nodes = reinterpret_cast<Node *>(smem + node_off);
+    int *parent = reinterpret_cast<int *>(smem + node_off + (size_t)a.max_nodes * sizeof(Node));
+
+    for (int scn = (int)blockIdx.x; scn < a.m; scn += (int)gridDim.x) {
+        Stream rs;
+        rs.ext = a.uniforms ? a.uniforms + (size_t)scn * a.stream_len : nullptr;
+        rs.ext_n = a.stream_len; rs.t = 0; rs.seed = a.seed; rs.scn = (uint32_t)scn; rs.attempt = 0;
+        int n_path = 0, iters = 0;
+        double sx, sy, sz, gx, gy, gz;
+        const int max_attempts = a.uniforms ? 1 : 4;
+        for (int attempt = 0; attempt < max_attempts; ++attempt) {
+            rs.attempt = (uint32_t)attempt;
+            rs.t = 0;
+            if (a.start_goal_in) {
+                const double *sg = a.start_goal_in + (size_t)scn * 6;
+                sx = sg[0]; sy = sg[1]; sz = sg[2]; gx = sg[3]; gy = sg[4]; gz = sg[5];
+            } else {      // UAV.py:344,353-358 (the heading draw comes first in UAV.reset; it is not part of a scenario)
+                (void)rs.uniform(0, kTwoPi);
+                sx = rs.uniform(10, 210); sy = rs.uniform(1, 10); sz = 0.0;
+                gx = rs.uniform(330, 490); gy = rs.uniform(420, 490); gz = 0.0;
+            }
+            if (lane == 0) { nodes[0] = Node{sx, sy, sz, 0.0}; parent[0] = -1; }
+            __syncthreads();
+            int nn = 1, goal_parent = -1;
+            int it = 0;
+            for (; it < a.max_iter && nn < a.max_nodes; ++it) {
+                // ---- get_random_point (RRT.py:26-34)
+                double rx, ry, rz;
+                if (rs.uniform(0, 1) > 0.5) {
+                    rx = rs.uniform(0, a.len); ry = rs.uniform(0, a.width); rz = rs.uniform(0, a.h);
+                } else {
+                    rx = gx; ry = gy; rz = gz;
+                }
+                // ---- nearest_node (RRT.py:36-37): first minimum
+                double bd = 1e300;
+                int bi = 0x7fffffff;
+                for (int k = lane; k < nn; k += 64) {
+                    const Node q = nodes[k];
+                    const double d = ldist(q.x, q.y, q.z, rx, ry, rz);
+                    if (d < bd) { bd = d; bi = k; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double od = __shfl_xor(bd, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                }
+                const Node nr = nodes[bi];
+                // ---- steer (RRT.py:39-46); np.linalg.norm == sqrt(ddot) == an FMA chain on the reference platform
+                double dx = rx - nr.x, dy = ry - nr.y, dz = rz - nr.z;
+                const double length = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+                double nx, ny, nz;
+                if (length < a.step_size) {
+                    nx = rx; ny = ry; nz = rz;
+                } else {
+                    dx = dx / length; dy = dy / length; dz = dz / length;
+                    nx = nr.x + dx * a.step_size; ny = nr.y + dy * a.step_size; nz = nr.z + dz * a.step_size;
+                }
+                if (!obstacle_free(w, nr.x, nr.y, nr.z, nx, ny, nz, a.obstacle_step)) continue;     // :77-78
+                const int me = nn;
+                double my_cost = nr.cost + ldist(nr.x, nr.y, nr.z, nx, ny, nz);
+                int my_parent = bi;
+                // ---- rewire (RRT.py:84-90), sequential over the list, 64 distance tests at a time
+                for (int base = 0; base < nn; base += 64) {
+                    const int k = base + lane;
+                    bool near = false;
+                    if (k < nn) {
+                        const Node q = nodes[k];
+                        near = ldist(q.x, q.y, q.z, nx, ny, nz) < a.step_size;
+                    }
+                    unsigned long long mask = __ballot(near);
+                    while (mask) {
+                        const int b = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const Node q = nodes[base + b];
+                        const double d = ldist(q.x, q.y, q.z, nx, ny, nz);
+                        if (my_cost > q.cost + d) {
+                            if (obstacle_free(w, q.x, q.y, q.z, nx, ny, nz, a.obstacle_step)) {
+                                my_parent = base + b;
+                                my_cost = q.cost + d;
+                            }
+                        }
+                    }
+                }
+                if (lane == 0) { nodes[me] = Node{nx, ny, nz, my_cost}; parent[me] = my_parent; }
+                nn += 1;
+                __syncthreads();
+                if (ldist(nx, ny, nz, gx, gy, gz) <= a.step_size) {                       // :92-94
+                    goal_parent = me;
+                    ++it;
+                    break;
+                }
+            }
+            iters = it;
+            // ---- path = [start .. new_node, goal] (RRT.py:96-103)
+            int count = 1;
+            for (int p = goal_parent; p >= 0; p = parent[p]) count++;
+            n_path = count;
+            if ((count >= 2 && count <= a.K) || attempt + 1 == max_attempts) {
+                if (count <= a.K) {
+                    double *out = a.out_sub + (size_t)scn * a.K * 3;
+                    if (lane == 0) {
+                        int k = count - 1;
+                        out[3 * k] = gx; out[3 * k + 1] = gy; out[3 * k + 2] = gz;
+                        for (int p = goal_parent; p >= 0; p = parent[p]) {
+                            --k;
+                            out[3 * k] = nodes[p].x; out[3 * k + 1] = nodes[p].y; out[3 * k + 2] = nodes[p].z;
+                        }
+                    }
+                    for (int q = count * 3 + lane; q < a.K * 3; q += 64) out[q] = 0.0;
+                }
+                break;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) {
+            a.out_nsub[scn] = n_path <= a.K ? n_path : -n_path;
+            if (a.out_iters) a.out_iters[scn] = iters;
+            double *sg = a.out_start_goal + (size_t)scn * 6;
+            sg[0] = sx; sg[1] = sy; sg[2] = sz; sg[3] = gx; sg[4] = gy; sg[5] = gz;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// declared in uavenv.hip (shares the env's world blob)
+extern "C" int uavenv__world_view(const UavEnv *env, const unsigned char **blob, int32_t *bytes, int32_t *grid_off,
+                                  int32_t *grid_stride, int32_t *gn, double *inv_cell, double *W, double *Hbox,
+                                  double *len, int32_t *mask_bytes, int32_t *K);
+
+extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
+                               int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
+                               double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev,
+                               int32_t *out_iters_dev, void *stream)
+{
+    if (!env || m <= 0 || !out_start_goal_dev || !out_sub_dev || !out_nsub_dev || max_iter <= 0 || step_size <= 0 ||
+        obstacle_step <= 0 || (uniforms_dev && stream_len <= 0))
+        return UAVENV_EINVAL;
+    RrtArgs a;
+    int32_t mask_bytes = 8;
+    double len = 0;
+    if (uavenv__world_view(env, &a.world_blob, &a.world_bytes, &a.grid_off, &a.grid_stride, &a.gn, &a.inv_cell, &a.W,
+                           &a.Hbox, &len, &mask_bytes, &a.K) != UAVENV_OK)
+        return UAVENV_EINVAL;
+    a.len = len; a.width = a.W; a.h = a.Hbox;
+    a.m = m; a.max_iter = max_iter;
+    a.max_nodes = 2048;
+    a.step_size = step_size; a.obstacle_step = obstacle_step;
+    a.start_goal_in = start_goal_dev; a.uniforms = uniforms_dev; a.stream_len = stream_len; a.seed = seed;
+    a.out_start_goal = out_start_goal_dev; a.out_sub = out_sub_dev; a.out_nsub = out_nsub_dev; a.out_iters = out_iters_dev;
+    const size_t lds = (size_t)((a.world_bytes + 15) & ~15) + (size_t)a.max_nodes * (sizeof(Node) + sizeof(int));
+    const int grid = m < 4096 ? m : 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (mask_bytes == 4) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rrt_plan<uint32_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UAVENV_EHIP;
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_rrt_plan<uint32_t>), dim3(grid), dim3(64), lds, s, a);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rrt_plan<uint64_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UAVENV_EHIP;
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_rrt_plan<uint64_t>), dim3(grid), dim3(64), lds, s, a);
+    }
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}

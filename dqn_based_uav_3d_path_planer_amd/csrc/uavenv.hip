@@ -29,6 +29,11 @@
 
 using namespace uav;
 
+extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
+                               int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
+                               double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev,
+                               int32_t *out_iters_dev, void *stream);
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -901,6 +906,72 @@ int uavenv_load_scenarios(UavEnv *e, const double *sg, const double *sub, const 
     HIP_TRY(hipMemcpy(e->bank_sub, sub, (size_t)m * K * 3 * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->bank_nsub, nsub, (size_t)m * 4, hipMemcpyHostToDevice));
     e->bank_m = m;
+    return UAVENV_OK;
+}
+
+// internal: lets rrt.hip stage the same world blob
+int uavenv__world_view(const UavEnv *e, const unsigned char **blob, int32_t *bytes, int32_t *grid_off, int32_t *grid_stride,
+                       int32_t *gn, double *inv_cell, double *W, double *Hbox, double *len, int32_t *mask_bytes, int32_t *K)
+{
+    if (!e || !e->have_world) return fail(UAVENV_EINVAL, "planner before uavenv_set_buildings");
+    *blob = e->world_blob; *bytes = e->world_bytes; *grid_off = e->grid_off; *grid_stride = e->grid_stride;
+    *gn = e->gn; *inv_cell = 1.0 / e->cell; *W = e->cfg.width; *Hbox = e->cfg.h; *len = e->cfg.len;
+    *mask_bytes = e->mask_bytes; *K = e->cfg.max_subgoals;
+    return UAVENV_OK;
+}
+
+// Scenarios the planner could not fit (n_sub outside [2, K]) take the next valid scenario's row.
+__global__ void k_bank_fix(double *sg, double *sub, int32_t *nsub, int m, int K)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int n = nsub[i];
+        if (n >= 2 && n <= K) continue;
+        int j = -1;
+        for (int d = 1; d < m; ++d) {
+            const int c = (i + d) % m;
+            const int nc = nsub[c];
+            if (nc >= 2 && nc <= K) { j = c; break; }      // valid rows are never written by this kernel
+        }
+        if (j < 0) continue;
+        for (int q = 0; q < 6; ++q) sg[(size_t)i * 6 + q] = sg[(size_t)j * 6 + q];
+        for (int q = 0; q < K * 3; ++q) sub[(size_t)i * K * 3 + q] = sub[(size_t)j * K * 3 + q];
+        nsub[i] = -1000000 - j;      // marker; resolved below
+    }
+}
+__global__ void k_bank_fix2(int32_t *nsub, int m)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int n = nsub[i];
+        if (n <= -1000000) nsub[i] = nsub[-1000000 - n];
+    }
+}
+
+int uavenv_plan_scenarios(UavEnv *e, int32_t m, uint64_t seed, int32_t max_iter, void *stream)
+{
+    if (!e || m <= 0 || max_iter <= 0) return fail(UAVENV_EINVAL, "uavenv_plan_scenarios: bad argument");
+    if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_plan_scenarios before uavenv_set_buildings");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int K = e->cfg.max_subgoals;
+    if (e->bank_m > 0) {      // agents may still point into the old bank
+        StepArgs a = base_args(e);
+        HIP_TRY(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_privatize, dim3((e->N + 255) / 256), dim3(256), 0, 0, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    double *sg = nullptr, *sub = nullptr;
+    int32_t *ns = nullptr;
+    HIP_TRY(hipMalloc((void **)&sg, (size_t)m * 6 * 8));
+    HIP_TRY(hipMalloc((void **)&sub, (size_t)m * K * 3 * 8));
+    HIP_TRY(hipMalloc((void **)&ns, (size_t)m * 4));
+    // UAV.py:216-218: RRTPlanner(step = sub_granularity = 30, obstacle_step 5)
+    int rc = uavenv_rrt_plan(e, m, nullptr, nullptr, 0, seed, max_iter, 30.0, 5.0, sg, sub, ns, nullptr, stream);
+    if (rc != UAVENV_OK) { (void)hipFree(sg); (void)hipFree(sub); (void)hipFree(ns); return fail(rc, "uavenv_rrt_plan failed"); }
+    hipLaunchKernelGGL(k_bank_fix, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, sg, sub, ns, m, K);
+    hipLaunchKernelGGL(k_bank_fix2, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, ns, m);
+    HIP_TRY(hipGetLastError());
+    (void)hipFree(e->bank_sg); (void)hipFree(e->bank_sub); (void)hipFree(e->bank_nsub);   // hipFree waits for the device
+    e->bank_sg = sg; e->bank_sub = sub; e->bank_nsub = ns; e->bank_m = m;
     return UAVENV_OK;
 }
 

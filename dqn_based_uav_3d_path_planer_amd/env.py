@@ -113,6 +113,27 @@ class VecPathPlanEnv:
                    "uavenv_load_scenarios")
         self.n_scenarios = m
 
+    def plan_scenarios(self, m: int, seed: int = 0, max_iter: int = 10000):
+        """Plan a fresh bank of m reset scenarios on the GPU (start/goal draws + RRT, one wavefront each)."""
+        _lib.check(self.lib.uavenv_plan_scenarios(self._h, int(m), int(seed), int(max_iter), self._stream()),
+                   "uavenv_plan_scenarios")
+        self.n_scenarios = int(m)
+
+    def rrt_plan(self, m: int, *, start_goal=None, uniforms=None, seed: int = 0, max_iter: int = 10000,
+                 step_size: float = 30.0, obstacle_step: float = 5.0):
+        """The GPU planner alone -> (start_goal [m,6], sub_goals [m,K,3], n_sub [m], iters [m]) device tensors."""
+        d = self.device
+        sg_in = None if start_goal is None else torch.as_tensor(start_goal, dtype=torch.float64, device=d).contiguous()
+        u = None if uniforms is None else torch.as_tensor(uniforms, dtype=torch.float64, device=d).contiguous()
+        sg = torch.zeros((m, 6), dtype=torch.float64, device=d)
+        sub = torch.zeros((m, self.K, 3), dtype=torch.float64, device=d)
+        ns = torch.zeros(m, dtype=torch.int32, device=d)
+        it = torch.zeros(m, dtype=torch.int32, device=d)
+        _lib.check(self.lib.uavenv_rrt_plan(self._h, int(m), _ptr(sg_in), _ptr(u), 0 if u is None else u.shape[1], int(seed),
+                                            int(max_iter), float(step_size), float(obstacle_step), sg.data_ptr(),
+                                            sub.data_ptr(), ns.data_ptr(), it.data_ptr(), self._stream()), "uavenv_rrt_plan")
+        return sg, sub, ns, it
+
     def reset(self, seed: int = 0, obs: Optional[torch.Tensor] = None) -> torch.Tensor:
         _lib.check(self.lib.uavenv_reset_all(self._h, int(seed), self._stream()), "uavenv_reset_all")
         return self.observe(obs)

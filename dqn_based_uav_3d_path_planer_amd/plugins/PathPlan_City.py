@@ -90,10 +90,13 @@ class PathPlan_City:
             return
         from dqn_based_uav_3d_path_planer_amd.data import load_city26
         c = load_city26()
-        if c["buildings"].shape != b.shape or not np.allclose(c["buildings"], b, rtol=0, atol=1e-9):
-            raise ValueError("no <scenario_bank> given and the buildings differ from the packaged city26 world: "
-                             "plan a bank for this world first (see oracle/gen_bank.py)")
-        self.backend.load_scenarios(c["start_goal"], c["sub_goals"], c["n_sub"])
+        if c["buildings"].shape == b.shape and np.allclose(c["buildings"], b, rtol=0, atol=1e-9):
+            self.backend.load_scenarios(c["start_goal"], c["sub_goals"], c["n_sub"])
+        elif hasattr(self.backend, "plan_scenarios"):
+            # any other world: plan the bank on the GPU (UAV.reset's draws + RRT, csrc/rrt.hip)
+            self.backend.plan_scenarios(max(1024, min(65536, self.num_envs)), seed=self.seed)
+        else:
+            raise ValueError("no <scenario_bank> given and no planner available for this world")
 
     # ---- helpers used by the UAV views -------------------------------------------------------------------
     def _invalidate(self):

@@ -99,6 +99,16 @@ int uavenv_set_buildings(UavEnv *env, const double *host_cxcyczRH, const double 
  * host_start_goal: M x 6 (sx,sy,sz,gx,gy,gz); host_subgoals: M x K x 3; host_nsub: M. */
 int uavenv_load_scenarios(UavEnv *env, const double *host_start_goal, const double *host_subgoals,
                           const int32_t *host_nsub, int32_t m);
+/* The same bank planned ON THE GPU: m scenarios, each = UAV.reset()'s start/goal draws (UAV.py:353-358) + the RRT
+ * sub-goal planner (PathPlan/RRT.py:63-105, step 30 m, obstacle test every 5 m), one wavefront per scenario, Philox
+ * stream (seed, scenario).  Replaces the env's bank; scenarios whose path does not fit K take a neighbour's. */
+int uavenv_plan_scenarios(UavEnv *env, int32_t m, uint64_t seed, int32_t max_iter, void *stream);
+/* The planner itself, for callers that bring their own start/goal (m x 6, nullable) and/or their own U[0,1) stream
+ * (m x stream_len, nullable; parity tests replay CPython's Mersenne stream).  out_nsub < 0: path needs -n > K slots. */
+int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
+                    int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
+                    double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev, int32_t *out_iters_dev,
+                    void *stream);
 /* UAV.reset() (UAV.py:327-366) for every agent: heading ~ U(0,2pi), scenario ~ U{0..M-1} from a
  * counter-based Philox stream keyed by (seed, agent); sub_goals[0] aliases the position as in the reference. */
 int uavenv_reset_all(UavEnv *env, uint64_t seed, void *stream);

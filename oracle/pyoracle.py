@@ -27,7 +27,8 @@ class World(C.Structure):
 
 
 class Rng(C.Structure):
-    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int32)]
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int32), ("ext_n", C.c_int32), ("ext_i", C.c_int32),
+                ("ext", C.POINTER(C.c_double))]
 
 
 class Uav(C.Structure):
@@ -75,6 +76,8 @@ def _load(name: str) -> C.CDLL:
     lib.orc_state_pathplan.argtypes = [C.POINTER(World), C.POINTER(Uav), C.c_void_p]
     lib.orc_rng_seed.restype = None
     lib.orc_rng_seed.argtypes = [C.POINTER(Rng), C.c_uint64]
+    lib.orc_rng_external.restype = None
+    lib.orc_rng_external.argtypes = [C.POINTER(Rng), C.c_void_p, C.c_int32]
     lib.orc_rng_random.restype = d
     lib.orc_rng_random.argtypes = [C.POINTER(Rng)]
     lib.orc_rng_uniform.restype = d
@@ -193,11 +196,29 @@ class OracleRng:
         self.r = Rng()
         self.lib.orc_rng_seed(C.byref(self.r), int(seed))
 
+    def replay(self, uniforms: np.ndarray):
+        """Make random() return the given U[0,1) values in order (keeps a reference to the array)."""
+        self._ext = np.ascontiguousarray(uniforms, dtype=np.float64)
+        self.lib.orc_rng_external(C.byref(self.r), self._ext.ctypes.data, len(self._ext))
+        return self
+
     def random(self) -> float:
         return float(self.lib.orc_rng_random(C.byref(self.r)))
 
     def uniform(self, a, b) -> float:
         return float(self.lib.orc_rng_uniform(C.byref(self.r), float(a), float(b)))
+
+
+def rrt_get_path(world: "OracleWorld", rng: "OracleRng", start, goal, step_size=30.0, max_iter=10000, obstacle_step=5.0,
+                 cap=KMAX):
+    """PathPlan/RRT.py:63-105 -> (path [n,3], iterations)."""
+    s = np.ascontiguousarray(start, dtype=np.float64)
+    g = np.ascontiguousarray(goal, dtype=np.float64)
+    out = np.zeros((cap, 3))
+    it = C.c_int(0)
+    n = world.lib.orc_rrt_get_path(C.byref(world.w), C.byref(rng.r), float(step_size), int(max_iter), float(obstacle_step),
+                                   s.ctypes.data, g.ctypes.data, out.ctypes.data, cap, C.byref(it))
+    return (out[:n].copy() if n >= 0 else None), it.value
 
 
 class OracleBatch:

@@ -324,6 +324,7 @@ void orc_rng_seed(orc_rng *r, uint64_t seed)
     key[1] = (uint32_t)(seed >> 32);
     if (key[1]) len = 2;
     mt_init_by_array(r, key, len);
+    r->ext = 0; r->ext_n = 0; r->ext_i = 0;
 }
 
 static uint32_t mt_genrand(orc_rng *r)
@@ -352,8 +353,16 @@ static uint32_t mt_genrand(orc_rng *r)
     return y;
 }
 
+void orc_rng_external(orc_rng *r, const double *u, int32_t n)
+{
+    r->ext = u;
+    r->ext_n = n;
+    r->ext_i = 0;
+}
+
 double orc_rng_random(orc_rng *r)
 {
+    if (r->ext) return r->ext_i < r->ext_n ? r->ext[r->ext_i++] : 0.75;   /* exhausted stream: keep sampling space */
     uint32_t a = mt_genrand(r) >> 5, b = mt_genrand(r) >> 6;
     return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
 }

@@ -49,6 +49,8 @@ typedef struct {
 typedef struct {
     uint32_t mt[624];
     int32_t idx;
+    int32_t ext_n, ext_i;      /* when ext != NULL random() replays ext[0..ext_n) instead of the twister */
+    const double *ext;
 } orc_rng;
 
 /* Agents/UAV.py per-agent parameters + state touched by the hot path. */
@@ -96,6 +98,7 @@ void orc_state_pathplan(const orc_world *w, const orc_uav *u, double *obs);   /*
 
 /* ---- reset + RRT ---- */
 void orc_rng_seed(orc_rng *r, uint64_t seed);          /* random.seed(int) */
+void orc_rng_external(orc_rng *r, const double *u, int32_t n);  /* replay a given U[0,1) stream (GPU-planner parity) */
 double orc_rng_random(orc_rng *r);                     /* random.random() */
 double orc_rng_uniform(orc_rng *r, double a, double b);/* random.uniform(a,b) */
 /* PathPlan/RRT.py:63-105; returns the number of path nodes written (<= cap), or -needed if cap too small */
