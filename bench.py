@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
+    p.add_argument("--env-only", action="store_true", help="diagnostic: time only back-to-back k_step launches")
     p.add_argument("--bank", default="gpu", choices=["gpu", "packaged"],
                    help="reset scenarios: planned on the GPU at start-up (csrc/rrt.hip) or the packaged reference resets")
     p.add_argument("--learner", default="fused", choices=["fused", "torch"],
@@ -107,6 +108,28 @@ def main():
     t_plan = time.perf_counter() - t_plan
     ring = DeviceReplayRing(env, args.replay, discrete=True)
     ring.reset(seed=1000 + rank)
+    if args.env_only:      # diagnostic mode (not the benchmark contract): k_step alone, random actions, steady state
+        gen = torch.Generator(device=dev).manual_seed(0)
+        for _ in range(max(args.warmup, 260)):        # run past the first resets so episodes are desynchronised
+            ring.current_action().copy_(torch.randint(0, 3, (env.N,), generator=gen, device=dev, dtype=torch.int32))
+            ring.step_env(auto_reset=True)
+        for f in range(ring.frames):
+            ring.action[f].copy_(torch.randint(0, 3, (env.N,), generator=gen, device=dev, dtype=torch.int32))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(args.steps):
+            ring.step_env(auto_reset=True)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / args.steps
+        algo = ALGO_BYTES_PER_AGENT_STEP if args.obs_dtype == "f32" else 404
+        gbs = algo * env.N / (ms * 1e-3) / 1e9
+        print(json.dumps({"mode": "env-only", "envs": env.N, "k_step_ms_back_to_back": ms,
+                          "env_steps_per_s": env.N / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS,
+                          "obs_dtype": args.obs_dtype, "replay_frames": ring.frames}))
+        env.close()
+        return
     net = "VAnet2" if args.trainer == "dueling" else "Qnet2"
     torch.manual_seed(42)               # same initial weights on every rank
     net_param = {"NetWork": net, "w": "100", "hiden_dim": "64", "output": "3"}

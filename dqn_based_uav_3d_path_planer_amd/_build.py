@@ -39,6 +39,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     extra = ["-DUAVENV_PHASE_PROFILE"] if os.environ.get("UAVENV_PHASE_PROFILE") else []   # diagnostics build
+    extra += os.environ.get("UAVENV_EXTRA_FLAGS", "").split()                              # A/B experiments
     cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -327,7 +327,7 @@ __device__ __forceinline__ void reset_agent(const StepArgs &a, int i, Agent &g)
 }
 
 // Agents/UAV.py:397-513  update_PathPlan(action) on the register copy of one agent.
-template <typename MaskT, bool APF>
+template <typename MaskT, bool APF, bool INL>
 __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
                                            double &r, int &ret_done, int &info)
 {
@@ -355,14 +355,14 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
     o.px += o.vx;                                                              // :419
     o.py += o.vy;                                                              // :420
     if (g.alias) { o.s0x = o.px; o.s0y = o.py; o.s0z = o.pz; }                 // sub_goals[0] IS position after reset
-    double tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);                  // :422
-    g.head = calc_angle(o.vx, o.vy);                                           // :423 (and obs[7], and next :411)
+    double tri_goal = angle_of<INL>(o.s0x - o.px, o.s0y - o.py);                  // :422
+    g.head = angle_of<INL>(o.vx, o.vy);                                           // :423 (and obs[7], and next :411)
     double tri_V = g.head;
     if (probe(w, o.px, o.py, o.pz)) {                                          // :425-428
         r -= 0.3;
         o.px = ox; o.py = oy; o.pz = oz;
         g.alias = 0;
-        tri_V = calc_angle(o.s0x - o.px, o.s0y - o.py);
+        tri_V = angle_of<INL>(o.s0x - o.px, o.s0y - o.py);
     }
     const double dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);       // :429
     const double g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);            // :430
@@ -392,7 +392,7 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
         double fx, fy, fz;
         cal_force(a.apf_b, a.nb, o.px, o.py, o.pz, fx, fy, fz);
         const double force = sqrt(fx * fx + fy * fy + fz * fz);
-        const double tri_force = calc_angle(fx, fy);
+        const double tri_force = angle_of<INL>(fx, fy);
         r += 0.2 * force * cos(fabs(tri_force - tri_V));
     }
 
@@ -425,8 +425,8 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
                 const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
                 o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
             }
-            tri_goal = calc_angle(o.s0x - o.px, o.s0y - o.py);                 // :488
-            if (o.vx != vx0 || o.vy != vy0) g.head = calc_angle(o.vx, o.vy);   // :489 (Calc_V rescaled again)
+            tri_goal = angle_of<INL>(o.s0x - o.px, o.s0y - o.py);                 // :488
+            if (o.vx != vx0 || o.vy != vy0) g.head = angle_of<INL>(o.vx, o.vy);   // :489 (Calc_V rescaled again)
             tri_V = g.head;
             r += 0.2 * cos(fabs(tri_goal - tri_V));                            // :490
             r += (double)(max_step - o.step);                                  // :491
@@ -461,8 +461,11 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
 #define UAV_DRAIN() do { } while (0)
 #endif
 
+#ifndef UAVENV_KSTEP_WAVES
+#define UAVENV_KSTEP_WAVES 1      // min waves per SIMD the register allocator must leave room for (A/B knob)
+#endif
 template <typename MaskT, bool APF, bool F16, bool TILE>
-__global__ void __launch_bounds__(256) k_step(StepArgs a)
+__global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevState &S = a.st;
@@ -483,6 +486,9 @@ __global__ void __launch_bounds__(256) k_step(StepArgs a)
     const WorldLds<MaskT> w = stage_world<MaskT>(smem, a);
     UAV_STAMP(1);
 
+    // TILE launches cover N with exactly one tile per thread: a straight-line body (no loop) keeps the compiler from
+    // hoisting ~25 plane addresses out of a loop that runs once (they did not fit the SGPR file and were spilled
+    // through ~100 v_writelane right after the staging barrier: ~2.5 k cycles of a 24 k-cycle wave).
     while (i < n_round) {
         const bool active = i < N;
         const int ii = active ? i : N - 1;
@@ -496,7 +502,7 @@ __global__ void __launch_bounds__(256) k_step(StepArgs a)
         if (masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done)) {
             ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
         } else {
-            step_agent<MaskT, APF>(a, w, ii, a0, g, r, ret_done, info);
+            step_agent<MaskT, APF, TILE>(a, w, ii, a0, g, r, ret_done, info);
         }
         UAV_STAMP(3);
         g.o.n_rem = g.n_total - g.sub_idx;
@@ -538,16 +544,17 @@ __global__ void __launch_bounds__(256) k_step(StepArgs a)
             if (a.energy64) a.energy64[i] = energy;
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);
-            if (want_obs && !TILE) store_obs_row<F16>(a.obs, i, sc, bits);
+            if (want_obs && !(TILE && a.tile_off >= 0)) store_obs_row<F16>(a.obs, i, sc, bits);
             UAV_STAMP(6);
             UAV_DRAIN();
             UAV_STAMP(7);
         }
-        if (TILE && want_obs) {      // one wavefront per workgroup: wave-cooperative coalesced tile store
+        if (TILE && a.tile_off >= 0 && want_obs) {      // wave-cooperative coalesced tile store (opt-in)
             const int first = i - ((int)threadIdx.x & 63);
             store_obs_tile<F16>(a.obs, first, N - first, reinterpret_cast<float *>(smem + a.tile_off), sc, bits);
         }
 
+        if (TILE) break;
         i += stride;
         if (i < n_round) {
             const int in = i < N ? i : N - 1;
@@ -736,9 +743,10 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     // MEASURED (round 1, 16 384 envs): the tile path removes 2.5 k cycles of store issue per wave but the launch got
     // 3 us SLOWER (18.4 vs 15.4 us back-to-back), so it is opt-in (UAVENV_TILE_STORE=1) until that is understood.
     static const bool tile_enabled = getenv("UAVENV_TILE_STORE") && atoi(getenv("UAVENV_TILE_STORE")) != 0;
-    const bool tile = tile_enabled && block == 64;
-    a.tile_off = (e->world_bytes + 15) & ~15;
-    const size_t lds = tile ? (size_t)a.tile_off + kTileBytes : (size_t)e->world_bytes;
+    const bool tile = block == 64;                 // the single-wave-workgroup variant (inline angle chains)
+    const bool tile_store = tile_enabled && tile;
+    a.tile_off = tile_store ? (e->world_bytes + 15) & ~15 : -1;
+    const size_t lds = tile_store ? (size_t)a.tile_off + kTileBytes : (size_t)e->world_bytes;
 #define UAV_LAUNCH(APF_, F16_)                                                                                   \
     do {                                                                                                         \
         if (tile) hipLaunchKernelGGL((k_step<MaskT, APF_, F16_, true>), dim3(grid), dim3(block), lds, s, a);       \
