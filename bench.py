@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
+    p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
     p.add_argument("--env-only", action="store_true", help="diagnostic: time only back-to-back k_step launches")
     p.add_argument("--bank", default="gpu", choices=["gpu", "packaged"],
                    help="reset scenarios: planned on the GPU at start-up (csrc/rrt.hip) or the packaged reference resets")
@@ -108,6 +109,9 @@ def main():
     t_plan = time.perf_counter() - t_plan
     ring = DeviceReplayRing(env, args.replay, discrete=True)
     ring.reset(seed=1000 + rank)
+    if args.no_obs:
+        from dqn_based_uav_3d_path_planer_amd import _lib as _l
+        ring.extra_flags = _l.STEP_NO_OBS
     if args.env_only:      # diagnostic mode (not the benchmark contract): k_step alone, random actions, steady state
         gen = torch.Generator(device=dev).manual_seed(0)
         for _ in range(max(args.warmup, 260)):        # run past the first resets so episodes are desynchronised

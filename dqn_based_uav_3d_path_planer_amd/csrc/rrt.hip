@@ -24,7 +24,7 @@ namespace {
 
 struct RrtArgs {
     const unsigned char *world_blob;
-    int32_t world_bytes, grid_off, grid_stride, gn;
+    int32_t world_bytes, aux_off, grid_off, grid_stride, gn;
     double inv_cell, W, Hbox;        // Threaten_rate bounds
     double len, width, h;            // sampling box (RRT.py:26-32)
     int32_t m, K, max_iter, max_nodes;
@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
     __syncthreads();
     WorldLds<MaskT> w;
     w.b = reinterpret_cast<const BldLds *>(smem);
+    w.aux = reinterpret_cast<const BldAux *>(smem + a.aux_off);
     for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(smem + a.grid_off + h * a.grid_stride);
     w.gn = a.gn; w.inv_cell = a.inv_cell; w.W = a.W; w.Hbox = a.Hbox;
     const int node_off = (a.world_bytes + 15) & ~15;
@@ -232,8 +233,8 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
 }  // namespace
 
 // declared in uavenv.hip (shares the env's world blob)
-extern "C" int uavenv__world_view(const UavEnv *env, const unsigned char **blob, int32_t *bytes, int32_t *grid_off,
-                                  int32_t *grid_stride, int32_t *gn, double *inv_cell, double *W, double *Hbox,
+extern "C" int uavenv__world_view(const UavEnv *env, const unsigned char **blob, int32_t *bytes, int32_t *aux_off,
+                                  int32_t *grid_off, int32_t *grid_stride, int32_t *gn, double *inv_cell, double *W, double *Hbox,
                                   double *len, int32_t *mask_bytes, int32_t *K);
 
 extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
@@ -247,7 +248,7 @@ extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_
     RrtArgs a;
     int32_t mask_bytes = 8;
     double len = 0;
-    if (uavenv__world_view(env, &a.world_blob, &a.world_bytes, &a.grid_off, &a.grid_stride, &a.gn, &a.inv_cell, &a.W,
+    if (uavenv__world_view(env, &a.world_blob, &a.world_bytes, &a.aux_off, &a.grid_off, &a.grid_stride, &a.gn, &a.inv_cell, &a.W,
                            &a.Hbox, &len, &mask_bytes, &a.K) != UAVENV_OK)
         return UAVENV_EINVAL;
     a.len = len; a.width = a.W; a.h = a.Hbox;

@@ -87,7 +87,7 @@ struct StepArgs {
     DevState st;
     // world
     const unsigned char *world_blob;   // [BldLds x nb][grid halo 2][grid halo 10][grid halo 20]  (16-byte multiples)
-    int32_t world_bytes, grid_off, grid_stride;
+    int32_t world_bytes, aux_off, grid_off, grid_stride;
     int32_t nb, gn;
     double inv_cell, W, Hbox;
     const BldApf *apf_b;
@@ -96,6 +96,7 @@ struct StepArgs {
     PowerParams pw;
     int32_t max_step, K, U, N, n_actions;
     int32_t tile_off;                  // LDS byte offset of the obs tile (TILE kernels)
+    int32_t obsq_off;                  // LDS byte offset of the per-wave observation work queues (ObsWaveLds[waves])
     int32_t block;                     // workgroup size, passed as an argument: reading blockDim.x costs a vector load
                                        // from the dispatch packet + s_waitcnt vmcnt(0) in front of the staging barrier
     // io
@@ -122,7 +123,7 @@ struct UavEnv {
     size_t slab_bytes = 0;
     // world
     unsigned char *world_blob = nullptr;
-    int world_bytes = 0, grid_off = 0, grid_stride = 0, nb = 0, gn = 0, mask_bytes = 8;
+    int world_bytes = 0, aux_off = 0, grid_off = 0, grid_stride = 0, nb = 0, gn = 0, mask_bytes = 8;
     double cell = 10.0;
     BldApf *apf_b = nullptr;
     bool have_world = false;
@@ -166,6 +167,7 @@ __device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, cons
     __syncthreads();
     WorldLds<MaskT> w;
     w.b = reinterpret_cast<const BldLds *>(smem);
+    w.aux = reinterpret_cast<const BldAux *>(smem + a.aux_off);
     for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(smem + a.grid_off + h * a.grid_stride);
     w.gn = a.gn;
     w.inv_cell = a.inv_cell;
@@ -526,13 +528,15 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         const bool want_obs = a.obs && !(a.flags & UAVENV_STEP_NO_OBS);
         ObsBits bits;
         ObsScalars sc;
+        // ---- observation of the (possibly reset) state: state_PathPlan, UAV.py:515-567.  Computed BEFORE any store is
+        // issued (a wait on a later load would also wait for the stores in flight); wave-cooperative (work queue), so
+        // every lane of the wavefront takes part, active or not.
+        if (want_obs) {
+            ObsWaveLds *L = reinterpret_cast<ObsWaveLds *>(smem + a.obsq_off) + (threadIdx.x >> 6);
+            bits = obs_bits_queued(w, L, g.o.px, g.o.py, g.o.pz, active);
+            sc = obs_scalars(g.o, g.head);                                         // :526 heading == cached angle
+        }
         if (active) {
-            // ---- observation of the (possibly reset) state: state_PathPlan, UAV.py:515-567.  Computed BEFORE any
-            // store is issued: a wait on a later load would otherwise also wait for the stores in flight.
-            if (want_obs) {
-                bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);
-                sc = obs_scalars(g.o, g.head);                                     // :526 heading == cached angle
-            }
             UAV_STAMP(5);
             // ---- outputs of the transition
             if (a.reward64) a.reward64[i] = r;
@@ -544,14 +548,15 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
             if (a.energy64) a.energy64[i] = energy;
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);
-            if (want_obs && !(TILE && a.tile_off >= 0)) store_obs_row<F16>(a.obs, i, sc, bits);
+            if (want_obs && a.tile_off < 0) store_obs_row<F16>(a.obs, i, sc, bits);
             UAV_STAMP(6);
             UAV_DRAIN();
             UAV_STAMP(7);
         }
-        if (TILE && a.tile_off >= 0 && want_obs) {      // wave-cooperative coalesced tile store (opt-in)
+        if (a.tile_off >= 0 && want_obs) {      // wave-cooperative coalesced tile store (opt-in)
             const int first = i - ((int)threadIdx.x & 63);
-            store_obs_tile<F16>(a.obs, first, N - first, reinterpret_cast<float *>(smem + a.tile_off), sc, bits);
+            float *tile = reinterpret_cast<float *>(smem + a.tile_off + (threadIdx.x >> 6) * kTileBytes);
+            store_obs_tile<F16>(a.obs, first, N - first, tile, sc, bits);
         }
 
         if (TILE) break;
@@ -574,7 +579,7 @@ __global__ void __launch_bounds__(256) k_observe(StepArgs a)
         Agent g;
         load_agent(a.st, i, g);
         unpack_flags(g);
-        const ObsBits bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);
+        const ObsBits bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);      // lane-per-agent form (reference for the queue)
         const ObsScalars sc = obs_scalars(g.o, g.head);
         store_obs_row<F16>(a.obs, i, sc, bits);
     }
@@ -687,6 +692,7 @@ static StepArgs base_args(const UavEnv *e)
     a.st = e->st;
     a.world_blob = e->world_blob;
     a.world_bytes = e->world_bytes;
+    a.aux_off = e->aux_off;
     a.grid_off = e->grid_off;
     a.grid_stride = e->grid_stride;
     a.nb = e->nb;
@@ -740,13 +746,17 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     const bool f16 = e->cfg.obs_dtype == UAVENV_OBS_F16, apf = e->cfg.apf_enabled == 1;
     // single-wave workgroups (small, latency-bound N) stage their 64 observation rows through LDS and store them
     // coalesced; 256-thread workgroups (large N, throughput-bound) keep LDS for occupancy and store row-per-lane.
-    // MEASURED (round 1, 16 384 envs): the tile path removes 2.5 k cycles of store issue per wave but the launch got
-    // 3 us SLOWER (18.4 vs 15.4 us back-to-back), so it is opt-in (UAVENV_TILE_STORE=1) until that is understood.
-    static const bool tile_enabled = getenv("UAVENV_TILE_STORE") && atoi(getenv("UAVENV_TILE_STORE")) != 0;
-    const bool tile = block == 64;                 // the single-wave-workgroup variant (inline angle chains)
-    const bool tile_store = tile_enabled && tile;
-    a.tile_off = tile_store ? (e->world_bytes + 15) & ~15 : -1;
-    const size_t lds = tile_store ? (size_t)a.tile_off + kTileBytes : (size_t)e->world_bytes;
+    // MEASURED (round 1): the wave-cooperative tile store pays off when the launch is throughput-bound (256-thread
+    // workgroups, N > 131 072: 1 M envs 318 -> 242 us, +30 %; the row-per-lane form issues 64 separate 16-byte
+    // segments per store instruction) and costs ~2 us when it is latency-bound (single-wave workgroups at 16 384
+    // envs: 12.4 -> 14.3 us).  Default accordingly; UAVENV_TILE_STORE=0/1 forces it off/on for A/B runs.
+    static const char *tile_env = getenv("UAVENV_TILE_STORE");
+    const bool tile_enabled = tile_env ? atoi(tile_env) != 0 : block == 256;
+    const bool tile_store = tile_enabled;
+    a.obsq_off = (e->world_bytes + 15) & ~15;
+    const int obsq_end = a.obsq_off + (block / 64) * (int)sizeof(ObsWaveLds);
+    a.tile_off = tile_store ? (obsq_end + 15) & ~15 : -1;
+    const size_t lds = tile_store ? (size_t)a.tile_off + (size_t)(block / 64) * kTileBytes : (size_t)obsq_end;
 #define UAV_LAUNCH(APF_, F16_)                                                                                   \
     do {                                                                                                         \
         if (tile) hipLaunchKernelGGL((k_step<MaskT, APF_, F16_, true>), dim3(grid), dim3(block), lds, s, a);       \
@@ -850,10 +860,23 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
     // cylinder that the exact test would hit for any point within L-inf distance h of the cell.
     static const double kHalo[3] = {2.0, 10.0, 20.0};
     const double margin = 1e-6 * (cell > 1.0 ? cell : 1.0);
-    const int bld_bytes = (int)(((size_t)(nb > 0 ? nb : 1) * sizeof(BldLds) + 15) & ~(size_t)15);
+    const int bld_only = (int)(((size_t)(nb > 0 ? nb : 1) * sizeof(BldLds) + 15) & ~(size_t)15);
+    const int aux_bytes = (int)(((size_t)(nb > 0 ? nb : 1) * sizeof(BldAux) + 15) & ~(size_t)15);
+    const int bld_bytes = bld_only + aux_bytes;            // [BldLds x nb][BldAux x nb] then the three grids
     const int grid_bytes = (int)((((size_t)gn * gn * mask_bytes) + 15) & ~(size_t)15);
     std::vector<unsigned char> blob((size_t)bld_bytes + 3 * (size_t)grid_bytes, 0);
     memcpy(blob.data(), bl.data(), (size_t)(nb > 0 ? nb : 0) * sizeof(BldLds));
+    {
+        static const double kSpacing[3] = {1.0, 5.0, 10.0};
+        BldAux *aux = reinterpret_cast<BldAux *>(blob.data() + bld_only);
+        for (int i = 0; i < nb; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const double R = b5[5 * i + 3], diag = 2.0 * std::sqrt(2.0) * kSpacing[k], guard = 1e-6;
+                const double ro = R + diag + guard, ri = R - diag - guard;
+                aux[i].rej2[k] = ro > 0 ? ro * ro : 0.0;
+                aux[i].acc2[k] = ri > 0 ? ri * ri : -1.0;      // -1: never "entirely inside"
+            }
+    }
     for (int h = 0; h < 3; ++h) {
         unsigned char *gdst = blob.data() + bld_bytes + (size_t)h * grid_bytes;
         for (int iy = 0; iy < gn; ++iy)
@@ -882,6 +905,7 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
     HIP_TRY(hipMalloc((void **)&e->apf_b, ba.size() * sizeof(BldApf)));
     HIP_TRY(hipMemcpy(e->apf_b, ba.data(), ba.size() * sizeof(BldApf), hipMemcpyHostToDevice));
     e->world_bytes = (int)blob.size();
+    e->aux_off = bld_only;
     e->grid_off = bld_bytes;
     e->grid_stride = grid_bytes;
     e->nb = nb;
@@ -918,11 +942,11 @@ int uavenv_load_scenarios(UavEnv *e, const double *sg, const double *sub, const 
 }
 
 // internal: lets rrt.hip stage the same world blob
-int uavenv__world_view(const UavEnv *e, const unsigned char **blob, int32_t *bytes, int32_t *grid_off, int32_t *grid_stride,
+int uavenv__world_view(const UavEnv *e, const unsigned char **blob, int32_t *bytes, int32_t *aux_off, int32_t *grid_off, int32_t *grid_stride,
                        int32_t *gn, double *inv_cell, double *W, double *Hbox, double *len, int32_t *mask_bytes, int32_t *K)
 {
     if (!e || !e->have_world) return fail(UAVENV_EINVAL, "planner before uavenv_set_buildings");
-    *blob = e->world_blob; *bytes = e->world_bytes; *grid_off = e->grid_off; *grid_stride = e->grid_stride;
+    *blob = e->world_blob; *bytes = e->world_bytes; *aux_off = e->aux_off; *grid_off = e->grid_off; *grid_stride = e->grid_stride;
     *gn = e->gn; *inv_cell = 1.0 / e->cell; *W = e->cfg.width; *Hbox = e->cfg.h; *len = e->cfg.len;
     *mask_bytes = e->mask_bytes; *K = e->cfg.max_subgoals;
     return UAVENV_OK;

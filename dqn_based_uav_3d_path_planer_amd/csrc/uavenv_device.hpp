@@ -24,6 +24,16 @@ struct BldLds {
     double cx, cy, thr, H;
 };
 
+// Per-cylinder quick-accept / quick-reject radii for the three stencils (LDS resident, 48 B).  With c the stencil
+// centre and diag_k = 2*sqrt(2)*spacing_k the farthest stencil point:
+//   |c - centre_b|^2 >= rej2[k] = (R + diag_k + 1e-6)^2  =>  NO stencil point can be inside the disc  -> skip;
+//   |c - centre_b|^2 <  acc2[k] = (R - diag_k - 1e-6)^2  =>  EVERY stencil point is inside           -> all 25 bits.
+// Both are implications with a 1e-6 m guard band (>> f64 rounding), so they never change a result of the exact
+// 25-point test; they only skip it.  A 20 m cell + halo lists every cylinder that MIGHT touch the stencil; most do not.
+struct BldAux {
+    double rej2[3], acc2[3];
+};
+
 // Cylinder as the APF force needs it (Agents/UAV.py:174-210); global memory, uniform index.
 struct BldApf {
     double cx, cy, cz, R, vx, vy, vz, vnorm;
@@ -38,6 +48,7 @@ struct BldApf {
 template <typename MaskT>
 struct WorldLds {
     const BldLds *b;       // LDS
+    const BldAux *aux;     // LDS
     const MaskT *g[3];     // LDS: halo 2 m / 10 m / 20 m, gn*gn masks each
     int gn;
     double inv_cell;
@@ -96,6 +107,14 @@ __device__ __forceinline__ double fly_power(const PowerParams &p, double V, int 
     double parasite = 0.5 * p.d_0 * p.rho * p.s * A * (V2 * V);
     double blade = xi * p.P_b * (1.0 + 3.0 * V2 / (p.F_b * p.F_b));
     return induced + parasite + blade;
+}
+
+// LDS hand-off between the lanes of ONE wavefront (DS operations of a wave complete in order; this only has to stop
+// the compiler from reordering across it).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <typename MaskT>
@@ -159,8 +178,8 @@ struct ObsIn {
 // One candidate mask (grid with halo 2*sp) serves all 25 points; per candidate the 25 exact tests share the
 // 5 dx^2 and 5 dy^2 terms and run branch-free.
 template <typename MaskT>
-__device__ __forceinline__ uint32_t stencil_bits(const WorldLds<MaskT> &w, const MaskT *grid, int cell, double px,
-                                                 double py, double pz, double sp)
+__device__ __forceinline__ uint32_t stencil_bits(const WorldLds<MaskT> &w, int k, int cell, double px, double py,
+                                                 double pz, double sp)
 {
     double x[5], y[5];
 #pragma unroll
@@ -175,24 +194,27 @@ __device__ __forceinline__ uint32_t stencil_bits(const WorldLds<MaskT> &w, const
         bits |= ((y[i] < 0.0) | (y[i] > w.W)) ? (0x108421u << i) : 0u;          // whole column j=i out of the box
     }
     if ((pz < 0.0) | (pz > w.Hbox)) bits = 0x1FFFFFFu;
-    MaskT m = grid[cell];
+    MaskT m = w.g[k][cell];
     while (m) {
         const int b = ctz_mask(m);
         m &= (MaskT)(m - 1);
         const BldLds B = w.b[b];
-        if (!(pz > B.H)) {
-            double dx2[5], dy2[5];
+        const double dcx = px - B.cx, dcy = py - B.cy;
+        const double dc2 = dcx * dcx + dcy * dcy;
+        const double rej2 = w.aux[b].rej2[k], acc2 = w.aux[b].acc2[k];
+        if ((dc2 >= rej2) | (pz > B.H)) continue;          // cannot touch this stencil / UAV above the roof
+        if (dc2 < acc2) { bits = 0x1FFFFFFu; continue; }   // stencil entirely inside the disc
+        double dx2[5], dy2[5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const double dx = x[i] - B.cx, dy = y[i] - B.cy;
-                dx2[i] = dx * dx;
-                dy2[i] = dy * dy;
-            }
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int j = 0; j < 5; ++j) bits |= ((dx2[i] + dy2[j]) < B.thr) ? (1u << (5 * i + j)) : 0u;
+        for (int i = 0; i < 5; ++i) {
+            const double dx = x[i] - B.cx, dy = y[i] - B.cy;
+            dx2[i] = dx * dx;
+            dy2[i] = dy * dy;
         }
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) bits |= ((dx2[i] + dy2[j]) < B.thr) ? (1u << (5 * i + j)) : 0u;
     }
     return bits;
 }
@@ -201,14 +223,27 @@ struct ObsBits {
     uint32_t s1, s5, s10, below;
 };
 
+// All 80 occupancy probes of state_PathPlan (UAV.py:533-566) in ONE pass over the candidate cylinders of the widest
+// (halo 20 m) mask, which contains the candidates of the two narrower stencils: each candidate costs one LDS round
+// trip (its 80 bytes) and then feeds three independent quick-reject / quick-accept / 25-point tests, instead of three
+// separate mask -> cylinder -> test dependency chains (the observation was LDS-latency bound, not ALU bound).
 template <typename MaskT>
 __device__ __forceinline__ ObsBits obs_bits(const WorldLds<MaskT> &w, double px, double py, double pz)
 {
-    ObsBits o;
-    const int cell = cell_of(w, px, py);
-    o.s1 = stencil_bits(w, w.g[0], cell, px, py, pz, 1.0);
-    o.s5 = stencil_bits(w, w.g[1], cell, px, py, pz, 5.0);
-    o.s10 = stencil_bits(w, w.g[2], cell, px, py, pz, 10.0);
+    const double kSp[3] = {1.0, 5.0, 10.0};
+    uint32_t bits[3];
+    const bool z_out = (pz < 0.0) | (pz > w.Hbox);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t bk = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const double xi = px + kSp[k] * (double)(i - 2), yi = py + kSp[k] * (double)(i - 2);
+            bk |= ((xi < 0.0) | (xi > w.W)) ? (0x1Fu << (5 * i)) : 0u;        // whole row i out of the box
+            bk |= ((yi < 0.0) | (yi > w.W)) ? (0x108421u << i) : 0u;          // whole column j=i out of the box
+        }
+        bits[k] = z_out ? 0x1FFFFFFu : bk;
+    }
     // UAV.py:562-566: Threaten_rate(px, py, pz - k), k = 1..5
     uint32_t bl = 0;
     const bool xy_out = (px < 0.0) | (px > w.W) | (py < 0.0) | (py > w.W);
@@ -217,18 +252,168 @@ __device__ __forceinline__ ObsBits obs_bits(const WorldLds<MaskT> &w, double px,
         const double z = pz - (double)k;
         bl |= (xy_out | (z < 0.0) | (z > w.Hbox)) ? (1u << (k - 1)) : 0u;
     }
-    if (bl != 0x1Fu) {      // only when the UAV flies above ground level
-        MaskT m = w.g[0][cell];
-        while (m) {
-            const int b = ctz_mask(m);
-            m &= (MaskT)(m - 1);
-            const BldLds B = w.b[b];
-            const double dx = px - B.cx, dy = py - B.cy;
-            const bool in_disc = (dx * dx + dy * dy) < B.thr;
+    const bool need_below = bl != 0x1Fu;      // only when the UAV flies above ground level
+
+    MaskT m = w.g[2][cell_of(w, px, py)];
+    while (m) {
+        const int b = ctz_mask(m);
+        m &= (MaskT)(m - 1);
+        const BldLds B = w.b[b];
+        const BldAux X = w.aux[b];
+        const double dcx = px - B.cx, dcy = py - B.cy;
+        const double dc2 = dcx * dcx + dcy * dcy;
+        if (need_below & (dc2 < B.thr)) {
 #pragma unroll
-            for (int k = 1; k <= 5; ++k) bl |= (in_disc & !((pz - (double)k) > B.H)) ? (1u << (k - 1)) : 0u;
+            for (int k = 1; k <= 5; ++k) bl |= !((pz - (double)k) > B.H) ? (1u << (k - 1)) : 0u;
+        }
+        if (pz > B.H) continue;                                   // UAV above this roof: no stencil point can hit
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (dc2 >= X.rej2[k]) continue;                       // cannot touch this stencil
+            if (dc2 < X.acc2[k]) { bits[k] = 0x1FFFFFFu; continue; }   // stencil entirely inside the disc
+            double dx2[5], dy2[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double dx = (px + kSp[k] * (double)(i - 2)) - B.cx, dy = (py + kSp[k] * (double)(i - 2)) - B.cy;
+                dx2[i] = dx * dx;
+                dy2[i] = dy * dy;
+            }
+            uint32_t bk = bits[k];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bk |= ((dx2[i] + dy2[j]) < B.thr) ? (1u << (5 * i + j)) : 0u;
+            bits[k] = bk;
         }
     }
+    ObsBits o;
+    o.s1 = bits[0];
+    o.s5 = bits[1];
+    o.s10 = bits[2];
+    o.below = bl;
+    return o;
+}
+
+// ---- the same 80 probes with a wave-level WORK QUEUE -----------------------------------------------------------
+// With lane == agent, the 25-point test of a (cylinder, stencil) pair is needed by only ~1 lane in 3 per candidate
+// iteration, but a divergent branch makes the whole wavefront pay for it every time.  Here phase A only CLASSIFIES
+// each (agent, candidate, stencil) as reject / accept / "needs the 25 tests" and pushes the latter as packed items
+// into a per-wave LDS queue (ballot + mbcnt prefix, no atomics); phase B runs the 25 tests with one ITEM per lane
+// -- dense, no divergence -- and ORs the result into the owner's bit words in LDS; phase C reads them back.
+// Same tests on the same operands => bit-identical to obs_bits().
+constexpr int kObsQueueCap = 512;
+struct ObsWaveLds {
+    double pxy[64][2];
+    uint32_t bits[64][3];
+    uint32_t queue[kObsQueueCap];
+};
+
+template <typename MaskT>
+__device__ __forceinline__ void obs_queue_drain(const WorldLds<MaskT> &w, ObsWaveLds *L, int count)
+{
+    const int lane = (int)threadIdx.x & 63;
+    wave_lds_sync();
+    for (int base = 0; base < count; base += 64) {
+        const int it = base + lane;
+        if (it < count) {
+            const uint32_t item = L->queue[it];
+            const int owner = (int)(item & 63u), b = (int)((item >> 6) & 63u), k = (int)(item >> 12);
+            const double sp = k == 0 ? 1.0 : (k == 1 ? 5.0 : 10.0);
+            const double px = L->pxy[owner][0], py = L->pxy[owner][1];
+            const BldLds B = w.b[b];
+            double dx2[5], dy2[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double dx = (px + sp * (double)(i - 2)) - B.cx, dy = (py + sp * (double)(i - 2)) - B.cy;
+                dx2[i] = dx * dx;
+                dy2[i] = dy * dy;
+            }
+            uint32_t bk = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bk |= ((dx2[i] + dy2[j]) < B.thr) ? (1u << (5 * i + j)) : 0u;
+            if (bk) atomicOr(&L->bits[owner][k], bk);
+        }
+    }
+    wave_lds_sync();
+}
+
+template <typename MaskT>
+__device__ __forceinline__ ObsBits obs_bits_queued(const WorldLds<MaskT> &w, ObsWaveLds *L, double px, double py,
+                                                   double pz, bool active)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const double kSp[3] = {1.0, 5.0, 10.0};
+    uint32_t bits[3];
+    const bool z_out = (pz < 0.0) | (pz > w.Hbox);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t bk = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const double xi = px + kSp[k] * (double)(i - 2), yi = py + kSp[k] * (double)(i - 2);
+            bk |= ((xi < 0.0) | (xi > w.W)) ? (0x1Fu << (5 * i)) : 0u;
+            bk |= ((yi < 0.0) | (yi > w.W)) ? (0x108421u << i) : 0u;
+        }
+        bits[k] = z_out ? 0x1FFFFFFu : bk;
+    }
+    uint32_t bl = 0;
+    const bool xy_out = (px < 0.0) | (px > w.W) | (py < 0.0) | (py > w.W);
+#pragma unroll
+    for (int k = 1; k <= 5; ++k) {
+        const double z = pz - (double)k;
+        bl |= (xy_out | (z < 0.0) | (z > w.Hbox)) ? (1u << (k - 1)) : 0u;
+    }
+    const bool need_below = bl != 0x1Fu;
+
+    L->pxy[lane][0] = px;
+    L->pxy[lane][1] = py;
+    L->bits[lane][0] = 0u; L->bits[lane][1] = 0u; L->bits[lane][2] = 0u;
+    MaskT m = active ? w.g[2][cell_of(w, px, py)] : (MaskT)0;
+    int count = 0;                                   // wave-uniform
+    while (__ballot(m != 0) != 0ull) {
+        if (count > kObsQueueCap - 192) {            // room for one more iteration's worst case (64 lanes x 3)
+            obs_queue_drain(w, L, count);
+            count = 0;
+        }
+        const bool have = m != 0;
+        const int b = have ? ctz_mask(m) : 0;
+        if (have) m &= (MaskT)(m - 1);
+        bool full[3] = {false, false, false};
+        if (have) {
+            const BldLds B = w.b[b];
+            const BldAux X = w.aux[b];
+            const double dcx = px - B.cx, dcy = py - B.cy;
+            const double dc2 = dcx * dcx + dcy * dcy;
+            if (need_below & (dc2 < B.thr)) {
+#pragma unroll
+                for (int k = 1; k <= 5; ++k) bl |= !((pz - (double)k) > B.H) ? (1u << (k - 1)) : 0u;
+            }
+            if (!(pz > B.H)) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (dc2 < X.acc2[k]) bits[k] = 0x1FFFFFFu;          // stencil entirely inside the disc
+                    else if (dc2 < X.rej2[k]) full[k] = true;           // can touch: needs the 25 exact tests
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long bm = __ballot(full[k]);
+            if (bm) {
+                const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                if (full[k]) L->queue[pos] = (uint32_t)lane | ((uint32_t)b << 6) | ((uint32_t)k << 12);
+                count += __builtin_popcountll(bm);
+            }
+        }
+    }
+    obs_queue_drain(w, L, count);
+    ObsBits o;
+    o.s1 = bits[0] | L->bits[lane][0];
+    o.s5 = bits[1] | L->bits[lane][1];
+    o.s10 = bits[2] | L->bits[lane][2];
     o.below = bl;
     return o;
 }
@@ -319,7 +504,7 @@ __device__ __forceinline__ void store_obs_tile(void *obs_base, int64_t first_age
     float *row = tile + lane * kTileLd;
 #pragma unroll
     for (int c = 0; c < 100; ++c) row[c] = obs_col(s, b, c);
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 25; ++it) {
         const int e = it * 256 + lane * 4;            // flat element index inside the 64 x 100 tile
@@ -339,7 +524,7 @@ __device__ __forceinline__ void store_obs_tile(void *obs_base, int64_t first_age
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // Philox4x32-10 (counter-based; one independent stream per (seed, agent, tick)).

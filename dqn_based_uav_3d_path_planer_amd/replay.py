@@ -36,6 +36,7 @@ class DeviceReplayRing:
                                      1 if discrete else 0)
         self._obs_stride = n * _lib.OBS_DIM * self.obs.element_size()
         self._batch_bufs = {}
+        self.extra_flags = 0           # diagnostics (e.g. _lib.STEP_NO_OBS to time the step without the observation)
 
     @property
     def capacity(self) -> int:
@@ -59,7 +60,7 @@ class DeviceReplayRing:
         """Apply action[head] with the fused kernel; the transition lands in the ring in the same launch."""
         t, nxt = self.head, (self.head + 1) % self.frames
         n = self.env.N
-        flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0)
+        flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | self.extra_flags
         kind = _lib.ACT_INDEX_I32 if self.discrete else _lib.ACT_STEER_F32
         self.env.step_raw(self.action.data_ptr() + t * n * 4, kind, self.obs.data_ptr() + nxt * self._obs_stride,
                           self.reward.data_ptr() + t * n * 4, self.done.data_ptr() + t * n,
