@@ -750,6 +750,7 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     // workgroups, N > 131 072: 1 M envs 318 -> 242 us, +30 %; the row-per-lane form issues 64 separate 16-byte
     // segments per store instruction) and costs ~2 us when it is latency-bound (single-wave workgroups at 16 384
     // envs: 12.4 -> 14.3 us).  Default accordingly; UAVENV_TILE_STORE=0/1 forces it off/on for A/B runs.
+    const bool tile = block == 64;                 // the single-wave-workgroup variant (straight-line, inline angles)
     static const char *tile_env = getenv("UAVENV_TILE_STORE");
     const bool tile_enabled = tile_env ? atoi(tile_env) != 0 : block == 256;
     const bool tile_store = tile_enabled;
