@@ -532,8 +532,17 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         // issued (a wait on a later load would also wait for the stores in flight); wave-cooperative (work queue), so
         // every lane of the wavefront takes part, active or not.
         if (want_obs) {
-            ObsWaveLds *L = reinterpret_cast<ObsWaveLds *>(smem + a.obsq_off) + (threadIdx.x >> 6);
-            bits = obs_bits_queued(w, L, g.o.px, g.o.py, g.o.pz, active);
+#ifdef UAVENV_QUEUE_ALWAYS
+            constexpr bool kQueue = true;
+#else
+            constexpr bool kQueue = TILE;      // measured: the queue wins on single-wave launches, the plain form at large N
+#endif
+            if (kQueue) {
+                ObsWaveLds *L = reinterpret_cast<ObsWaveLds *>(smem + a.obsq_off) + (threadIdx.x >> 6);
+                bits = obs_bits_queued(w, L, g.o.px, g.o.py, g.o.pz, active);
+            } else {
+                bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);
+            }
             sc = obs_scalars(g.o, g.head);                                         // :526 heading == cached angle
         }
         if (active) {
