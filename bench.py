@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
+    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) | gloo (test: several ranks on one GPU)")
+    p.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
     p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
     p.add_argument("--env-only", action="store_true", help="diagnostic: time only back-to-back k_step launches")
     p.add_argument("--bank", default="gpu", choices=["gpu", "packaged"],
@@ -91,11 +93,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the env hot path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
 
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
     from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
@@ -188,8 +195,8 @@ def main():
         dt = float(t.item())
 
     # dominant kernel: k_step.  (a) HIP events around each launch inside the timed region, on the launch stream,
-    # minus the cost of an EMPTY event pair on the same stream (two marker packets, ~3 us): without that correction
-    # the event figure sits ~20 % above rocprofv3's kernel-trace average for a 15 us kernel.
+    # minus half the cost of an EMPTY event pair on the same stream: without that correction the event figure sits
+    # ~20 % above rocprofv3's kernel-trace average for a 13 us kernel.
     empty = []
     for _ in range(50):
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -199,7 +206,9 @@ def main():
     torch.cuda.synchronize(dev)
     pair_ms = float(np.median([a.elapsed_time(b) for a, b in empty]))
     k_raw_ms = float(np.mean([a.elapsed_time(b) for a, b in step_events])) if step_events else float("nan")
-    k_ms = k_raw_ms - pair_ms
+    # an empty pair costs two marker packets back to back; a pair around a kernel carries ONE of them inside the
+    # interval (measured: raw 15.54 us, empty pair 5.54 us, rocprofv3 12.76 us -> raw - pair/2 = 12.77 us)
+    k_ms = k_raw_ms - 0.5 * pair_ms
     # (b) env-only: back-to-back k_step launches between two events (adds ~1.5 us boundary per launch)
     it = args.env_only_iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -211,6 +220,13 @@ def main():
     torch.cuda.synchronize(dev)
     env_only_ms = e0.elapsed_time(e1) / it
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_kstep_traffic.json")     # PMC passes cannot run inside this process:
+    if os.path.exists(tpath) and args.envs == 16384 and args.obs_dtype == "f32":   # last committed rocprofv3 --pmc result
+        try:
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
     if rank == 0:
         n_agents = env.N
         total_env_steps = args.steps * n_agents * world_size
@@ -237,7 +253,8 @@ def main():
                        "epsilon": args.eps, "parallelism": "env-shard x%d + flat-bucket grad all-reduce" % world_size},
             "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_agent_step": algo,
+                         "traffic": traffic, "traffic_source": "profiles/r01_kstep_traffic.json (rocprofv3 --pmc "
+                         "FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None, "algorithmic_bytes_per_agent_step": algo,
                          "kernel_ms": k_ms, "kernel_ms_raw_event_pair": k_raw_ms, "empty_event_pair_ms": pair_ms,
                          "agents_per_launch": n_agents,
                          "kernel_ms_env_only_back_to_back": env_only_ms},
