@@ -23,7 +23,7 @@ SYMBOLS = (
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_select_actions",
-    "uavenv_dqn_num_params", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
+    "uavenv_dqn_num_params", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
 )
 
 
@@ -111,6 +111,8 @@ def load() -> C.CDLL:
     net = C.POINTER(UavDqnNet)
     lib.uavenv_dqn_num_params.restype = C.c_int
     lib.uavenv_dqn_num_params.argtypes = [net]
+    lib.uavenv_dqn_set_debug_buffer.restype = C.c_int
+    lib.uavenv_dqn_set_debug_buffer.argtypes = [vp]
     lib.uavenv_dqn_grad.restype = C.c_int
     lib.uavenv_dqn_grad.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, net, i32, f32, i32, vp, vp]
     lib.uavenv_dqn_reduce.restype = C.c_int

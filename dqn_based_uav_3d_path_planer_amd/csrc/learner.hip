@@ -53,35 +53,40 @@ __device__ __forceinline__ NetDev net_view(const float *flat, int n2)
 
 // 64 rows x 100 floats -> LDS tile [64][kLdx].  Rows are given by a per-row base pointer (gathered from the ring)
 // or are consecutive (weights).  16-byte global loads, all issued before the LDS writes.
+constexpr int kStageChunks = kTile * 25;                 // 25 chunks of 4 elements per row
+constexpr int kStageIters = (kStageChunks + 255) / 256;  // 7 per thread
+
+// Phase 1 of staging a 64 x 100 tile: put this thread's 7 global loads in flight (no wait).  Rows come from a
+// per-row pointer table in LDS (gathered replay rows) or are consecutive (weights).
 template <typename T>
-__device__ __forceinline__ void stage_rows(float *dst, const T *const *row_ptr_lds, const T *base_consecutive)
+__device__ __forceinline__ void stage_issue(float4 (&v)[kStageIters], const T *const *row_ptr_lds, const T *base_consecutive)
 {
-    constexpr int kChunks = kTile * 25;    // 25 chunks of 4 elements per row
-    constexpr int kIters = (kChunks + 255) / 256;
-    float4 v[kIters];
-    // phase 1: every global load of this tile in flight at once (a load -> wait -> LDS-write loop serialises
-    // seven memory round trips per tile, four tiles per workgroup)
 #pragma unroll
-    for (int it = 0; it < kIters; ++it) {
+    for (int it = 0; it < kStageIters; ++it) {
         int c = it * 256 + (int)threadIdx.x;
-        c = c < kChunks ? c : kChunks - 1;
+        c = c < kStageChunks ? c : kStageChunks - 1;
         const int row = c / 25, q = c - row * 25;
         const T *src = row_ptr_lds ? row_ptr_lds[row] : base_consecutive + (size_t)row * kW;
         if (sizeof(T) == 4) {
             v[it] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + 4 * q);
         } else {
             const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(src) + 4 * q);
-            v[it] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f);   // decoded in phase 2
+            v[it] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f);   // decoded at commit
         }
     }
+}
+
+// Phase 2: LDS writes (the first use of v[] is where the compiler waits for the loads).
+template <typename T>
+__device__ __forceinline__ void stage_commit(float *dst, float4 (&v)[kStageIters])
+{
 #pragma unroll
-    for (int it = 0; it < kIters; ++it)
+    for (int it = 0; it < kStageIters; ++it)
         asm volatile("" : "+v"(v[it].x), "+v"(v[it].y), "+v"(v[it].z), "+v"(v[it].w));
-    // phase 2: LDS writes
 #pragma unroll
-    for (int it = 0; it < kIters; ++it) {
+    for (int it = 0; it < kStageIters; ++it) {
         const int c = it * 256 + (int)threadIdx.x;
-        if (c < kChunks) {
+        if (c < kStageChunks) {
             const int row = c / 25, q = c - row * 25;
             float4 w = v[it];
             if (sizeof(T) != 4) {
@@ -94,6 +99,14 @@ __device__ __forceinline__ void stage_rows(float *dst, const T *const *row_ptr_l
             d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
         }
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_rows(float *dst, const T *const *row_ptr_lds, const T *base_consecutive)
+{
+    float4 v[kStageIters];
+    stage_issue<T>(v, row_ptr_lds, base_consecutive);
+    stage_commit<T>(dst, v);
 }
 
 // One wave: acc(32x32) += A(32 x K) * B(K x 32) with  A[i][k] = a[(i)*lda + k],  B[k][j] = b[(j)*ldb + k]
@@ -146,6 +159,40 @@ __device__ __forceinline__ void layer2(const float *h, const float *W2, const fl
     }
 }
 
+// Layer 2 for a whole 64-sample tile with ALL threads of the workgroup: one (sample, output) dot product per thread
+// (consecutive threads -> consecutive samples -> conflict-free H reads; W2 row broadcast), four accumulators so the
+// LDS latency overlaps.  out2[s][a] = W2[a] . H[s] + b2[a].  (A thread-per-sample loop over all outputs ran on 64
+// lanes only and cost 11 k cycles per tile.)
+__device__ __forceinline__ void layer2_block(const float *H, const float *W2, const float *b2, int n2, float *out2)
+{
+    for (int item = (int)threadIdx.x; item < kTile * n2; item += 256) {
+        const int smp = item & (kTile - 1), a = item >> 6;
+        const float *h = H + smp * kLdh, *wr = W2 + a * kHid;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kHid; j += 4) {
+            s0 = fmaf(h[j], wr[j], s0);
+            s1 = fmaf(h[j + 1], wr[j + 1], s1);
+            s2 = fmaf(h[j + 2], wr[j + 2], s2);
+            s3 = fmaf(h[j + 3], wr[j + 3], s3);
+        }
+        out2[smp * kMaxOut + a] = ((s0 + s1) + (s2 + s3)) + b2[a];
+    }
+}
+
+// Q from the layer-2 outputs of one sample (dueling: V + A - mean A, BaseCNN.py:131-138)
+__device__ __forceinline__ void q_from_out(const float *o, int n_actions, int dueling, float *q)
+{
+    if (dueling) {
+        float mean = 0.0f;
+        for (int a = 0; a < n_actions; ++a) mean += o[a];
+        mean /= (float)n_actions;
+        for (int a = 0; a < n_actions; ++a) q[a] = o[n_actions] + o[a] - mean;
+    } else {
+        for (int a = 0; a < n_actions; ++a) q[a] = o[a];
+    }
+}
+
 struct GradArgs {
     UavReplayRing ring;
     int head, filled, batch;
@@ -157,7 +204,14 @@ struct GradArgs {
     int huber;
     float *partials;                 // [gridDim.x][P + 2]
     int P;
+    unsigned long long *dbg;         // diagnostics build: 8 s_memtime stamps per workgroup
 };
+
+#ifdef UAVENV_PHASE_PROFILE
+#define L_STAMP(slot) do { if (g.dbg && threadIdx.x == 0) g.dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define L_STAMP(slot) do { } while (0)
+#endif
 
 template <typename ObsT>
 __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
@@ -185,6 +239,7 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
     const int tid = (int)threadIdx.x;
     const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
 
+    L_STAMP(0);
     // ---- P0: draw / look up the 64 transitions of this tile, then stage everything
     if (tid < kTile) {
         const int s = (int)blockIdx.x * kTile + tid;
@@ -207,29 +262,59 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
         rows_n[tid] = obs + ((size_t)fn * g.ring.n_agents + agent) * kW;
         aux[2 * kTile + tid] = f * g.ring.n_agents + agent;
     }
-    for (int k = tid; k < kHid; k += 256) { b1[k] = nl.b1[k]; b1t[k] = nt.b1[k]; }
-    for (int k = tid; k < n2 * kHid; k += 256) { W2[k] = nl.W2[k]; W2t[k] = nt.W2[k]; }
-    if (tid < n2) { b2[tid] = nl.b2[tid]; b2t[tid] = nt.b2[tid]; }
+    __syncthreads();      // row pointers visible
+    // every global load of the tile in flight at once: 4 x 7 wide loads + the small vectors, ONE memory round trip
+    float4 vW1[kStageIters], vW1t[kStageIters], vXs[kStageIters], vXn[kStageIters];
+    stage_issue<float>(vW1, nullptr, nl.W1);
+    stage_issue<float>(vW1t, nullptr, nt.W1);
+    stage_issue<ObsT>(vXs, rows_s, nullptr);
+    stage_issue<ObsT>(vXn, rows_n, nullptr);
+    const int kb = tid < kHid ? tid : kHid - 1;
+    const float pb1 = nl.b1[kb], pb1t = nt.b1[kb];
+    const int k0 = tid < n2 * kHid ? tid : 0, k1 = tid + 256 < n2 * kHid ? tid + 256 : 0;
+    const int k2 = tid + 512 < n2 * kHid ? tid + 512 : 0, k3 = tid + 768 < n2 * kHid ? tid + 768 : 0;
+    const float pw0 = nl.W2[k0], pw1 = nl.W2[k1], pw2 = nl.W2[k2], pw3 = nl.W2[k3];
+    const float pt0 = nt.W2[k0], pt1 = nt.W2[k1], pt2 = nt.W2[k2], pt3 = nt.W2[k3];
+    const int kq = tid < n2 ? tid : 0;
+    const float pb2 = nl.b2[kq], pb2t = nt.b2[kq];
+    // this sample's scalar fields (needed only in P4: fetched now so their latency is long gone by then)
+    int p_act = 0;
+    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f;
+    if (tid < kTile) {
+        const int slot = aux[2 * kTile + tid];
+        p_act = g.ring.action_is_index ? reinterpret_cast<const int32_t *>(g.ring.action)[slot] : 0;
+        p_rew = g.ring.reward[slot];
+        p_done = (float)g.ring.done[slot];
+        p_valid = g.ring.valid ? (float)g.ring.valid[slot] : 1.0f;
+    }
+    stage_commit<float>(W1, vW1);
+    stage_commit<float>(W1t, vW1t);
+    stage_commit<ObsT>(Xs, vXs);
+    stage_commit<ObsT>(Xn, vXn);
+    if (tid < kHid) { b1[tid] = pb1; b1t[tid] = pb1t; }
+    if (tid < n2 * kHid) { W2[tid] = pw0; W2t[tid] = pt0; }
+    if (tid + 256 < n2 * kHid) { W2[tid + 256] = pw1; W2t[tid + 256] = pt1; }
+    if (tid + 512 < n2 * kHid) { W2[tid + 512] = pw2; W2t[tid + 512] = pt2; }
+    if (tid + 768 < n2 * kHid) { W2[tid + 768] = pw3; W2t[tid + 768] = pt3; }
+    if (tid < n2) { b2[tid] = pb2; b2t[tid] = pb2t; }
     if (tid < 32) {       // zero the pad the dW1 product over-reads
         Xs[kTile * kLdx + tid] = 0.0f;
         Xn[kTile * kLdx + tid] = 0.0f;
     }
-    stage_rows<float>(W1, nullptr, nl.W1);
-    stage_rows<float>(W1t, nullptr, nt.W1);
-    __syncthreads();
-    stage_rows<ObsT>(Xs, rows_s, nullptr);
-    stage_rows<ObsT>(Xn, rows_n, nullptr);
     if (tid < kTile) Xs[tid * kLdx + kW] = 1.0f;     // ones column: the dW1 product then yields db1 as its column 100
     __syncthreads();
 
+    L_STAMP(1);
     // ---- P1: hidden layers on the matrix cores
     layer1(Xs, W1, b1, Hs);
     if (g.kind == 1) layer1(Xn, W1, b1, Ht);         // local net on s' (double-DQN action choice)
     __syncthreads();
     if (g.kind == 1) {
+        layer2_block(Ht, W2, b2, n2, dout);           // dout is free until P4: scratch for Q_local(s')
+        __syncthreads();
         if (tid < kTile) {
             float q[kMaxOut];
-            layer2(Ht + tid * kLdh, W2, b2, g.n_actions, g.dueling, q);
+            q_from_out(dout + tid * kMaxOut, g.n_actions, g.dueling, q);
             int best = 0;
             for (int a = 1; a < g.n_actions; ++a) if (q[a] > q[best]) best = a;     // torch.max: first maximum
             aux[kTile + tid] = best;
@@ -238,17 +323,19 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
     }
     layer1(Xn, W1t, b1t, Ht);                        // target net on s'
     __syncthreads();
+    float *outl = Xn, *outt = Xn + kTile * kMaxOut;  // Xn (and W1t) are dead from here on: 2 x [64][16] scratch
+    layer2_block(Hs, W2, b2, n2, outl);
+    layer2_block(Ht, W2t, b2t, n2, outt);
+    __syncthreads();
 
+    L_STAMP(2);
     // ---- P4: TD target, loss, dL/dout per sample (Trainer/DQN_Trainer.py:107-119)
     if (tid < kTile) {
-        const int slot = aux[2 * kTile + tid];
-        const int act = g.ring.action_is_index ? reinterpret_cast<const int32_t *>(g.ring.action)[slot] : 0;
-        const float r = g.ring.reward[slot];
-        const float d = (float)g.ring.done[slot];
-        const float v = g.ring.valid ? (float)g.ring.valid[slot] : 1.0f;
+        const int act = p_act;
+        const float r = p_rew, d = p_done, v = p_valid;
         float ql[kMaxOut], qt[kMaxOut];
-        layer2(Hs + tid * kLdh, W2, b2, g.n_actions, g.dueling, ql);
-        layer2(Ht + tid * kLdh, W2t, b2t, g.n_actions, g.dueling, qt);
+        q_from_out(outl + tid * kMaxOut, g.n_actions, g.dueling, ql);
+        q_from_out(outt + tid * kMaxOut, g.n_actions, g.dueling, qt);
         float qn;
         if (g.kind == 1) {
             qn = qt[aux[kTile + tid]];
@@ -282,37 +369,34 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
             dvals[a] = dv;
             dout[tid * kMaxOut + a] = dv;
         }
-        // wave-level sums over the 64 samples (threads 0..63 are exactly wave 0): db2, loss sum, valid count
-        float *outp = g.partials + (size_t)blockIdx.x * (g.P + 2);
-        const int ob2w = kHid * kW + kHid + n2 * kHid;
-#pragma unroll
-        for (int a = 0; a < kMaxOut; ++a) {
-            if (a < n2) {                              // uniform branch: __shfl_down is a ds_bpermute (~100 cycles)
-                float t = dvals[a];
-                for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-                if (tid == 0) outp[ob2w + a] = t;
-            }
-        }
-        float ls = per * v, cn = v;
-        for (int off = 32; off > 0; off >>= 1) {
-            ls += __shfl_down(ls, off, 64);
-            cn += __shfl_down(cn, off, 64);
-        }
-        if (tid == 0) {
-            outp[g.P] = ls;
-            outp[g.P + 1] = cn;
-        }
+        // db2, the loss sum and the valid count ride along with the dW2 reduction below: two extra dout columns and a
+        // ones column in Hs (its pad column 64) turn them into three more dot products over the 64 samples
+        dout[tid * kMaxOut + n2] = per * v;
+        dout[tid * kMaxOut + n2 + 1] = v;
+        Hs[tid * kLdh + kHid] = 1.0f;
     }
     __syncthreads();
 
+    L_STAMP(3);
     // ---- P5: layer-2 gradients (needs the forward Hs), then dH in place
     float *out = g.partials + (size_t)blockIdx.x * (g.P + 2);
-    const int oW2 = kHid * kW + kHid;
-    for (int k = tid; k < n2 * kHid; k += 256) {
-        const int a = k / kHid, j = k - a * kHid;
-        float s = 0.0f;
-        for (int smp = 0; smp < kTile; ++smp) s = fmaf(dout[smp * kMaxOut + a], Hs[smp * kLdh + j], s);
-        out[oW2 + k] = s;
+    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
+    for (int k = tid; k < n2 * (kHid + 1) + 2; k += 256) {
+        int a, j;
+        if (k < n2 * (kHid + 1)) { a = k / (kHid + 1); j = k - a * (kHid + 1); }
+        else { a = n2 + (k - n2 * (kHid + 1)); j = kHid; }          // loss sum, valid count
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int smp = 0; smp < kTile; smp += 4) {
+            s0 = fmaf(dout[smp * kMaxOut + a], Hs[smp * kLdh + j], s0);
+            s1 = fmaf(dout[(smp + 1) * kMaxOut + a], Hs[(smp + 1) * kLdh + j], s1);
+            s2 = fmaf(dout[(smp + 2) * kMaxOut + a], Hs[(smp + 2) * kLdh + j], s2);
+            s3 = fmaf(dout[(smp + 3) * kMaxOut + a], Hs[(smp + 3) * kLdh + j], s3);
+        }
+        const float t = (s0 + s1) + (s2 + s3);
+        if (a >= n2) out[g.P + (a - n2)] = t;
+        else if (j == kHid) out[ob2 + a] = t;
+        else out[oW2 + a * kHid + j] = t;
     }
     __syncthreads();
     for (int k = tid; k < kTile * kHid; k += 256) {
@@ -323,6 +407,7 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
     }
     __syncthreads();
 
+    L_STAMP(4);
     // ---- P6: dW1[j][k] = sum_s dH[s][j] X[s][k] on the matrix cores; db1[j] = sum_s dH[s][j]
     {
         const int wv = tid >> 6, l = tid & 63;
@@ -348,6 +433,7 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
             }
         }
     }
+    L_STAMP(5);
 }
 
 // raw[p] = sum_b partial[b][p] for p in [0, P+2): gradient sums, loss sum, valid count.  32 columns x 8 row-groups
@@ -498,11 +584,14 @@ __global__ void __launch_bounds__(256) k_dqn_act(ActArgs g)
     __syncthreads();
     layer1(Xs, W1, b1, Hs);
     __syncthreads();
+    float *out2 = Xs;                                 // the staged observations are dead after layer 1
+    layer2_block(Hs, W2, b2, n2, out2);
+    __syncthreads();
     if (tid < kTile) {
         const int i = (int)blockIdx.x * kTile + tid;
         if (i < g.n) {
             float q[kMaxOut];
-            layer2(Hs + tid * kLdh, W2, b2, g.n_actions, g.dueling, q);
+            q_from_out(out2 + tid * kMaxOut, g.n_actions, g.dueling, q);
             if (g.q_out)
                 for (int a = 0; a < g.n_actions; ++a) g.q_out[(size_t)i * g.n_actions + a] = q[a];
             const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
@@ -525,15 +614,23 @@ constexpr size_t kGradLds = (size_t)(4 * kXTile + 2 * kTile * kLdh + 2 * kHid + 
                                      kTile * kMaxOut + 2 * kTile) * 4 + 2 * kTile * 8 + 3 * kTile * 4;
 constexpr size_t kActLds = (size_t)(2 * kXTile + kTile * kLdh + kHid + kMaxOut * kHid + kMaxOut) * 4 + kTile * 8;
 
+unsigned long long *g_learner_dbg = nullptr;
+
 bool net_ok(const UavDqnNet *n)
 {
     return n && n->local && n->w == kW && n->hid == kHid && n->n_actions >= 2 &&
-           n->n_actions + (n->dueling ? 1 : 0) <= kMaxOut;
+           n->n_actions + (n->dueling ? 1 : 0) + 2 <= kMaxOut;     // + 2 spare dout columns (loss sum, valid count)
 }
 
 }  // namespace
 
 extern "C" {
+
+int uavenv_dqn_set_debug_buffer(unsigned long long *dev_buf)
+{
+    g_learner_dbg = dev_buf;
+    return UAVENV_OK;
+}
 
 int uavenv_dqn_num_params(const UavDqnNet *net)
 {
@@ -561,6 +658,7 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
     g.gamma = gamma; g.huber = huber;
     g.partials = partials;
     g.P = uavenv_dqn_num_params(net);
+    g.dbg = g_learner_dbg;
     const int grid = batch / kTile;
     hipStream_t s = (hipStream_t)stream;
     if (ring->obs_dtype == UAVENV_OBS_F32) {

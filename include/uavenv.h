@@ -187,6 +187,8 @@ typedef struct UavDqnNet {
 } UavDqnNet;
 
 int uavenv_dqn_num_params(const UavDqnNet *net);
+/* Diagnostics (UAVENV_PHASE_PROFILE builds): 8 s_memtime stamps per workgroup of uavenv_dqn_grad; NULL disables. */
+int uavenv_dqn_set_debug_buffer(unsigned long long *dev_buf);
 /* One learn_off_policy() gradient (Trainer/DQN_Trainer.py:93-121, DDQN_Trainer.py:84-105): draws `batch` transitions
  * (batch % 64 == 0) with the SAME Philox stream as uavenv_replay_sample (or takes explicit (frame, agent) pairs),
  * gathers them from the ring, forward/backward on the f32 MFMA.  kind 0: max_a Q_target(s'); 1: double-DQN.

@@ -1,0 +1,33 @@
+"""Per-phase timeline of k_dqn_grad from in-kernel s_memtime stamps (needs a UAVENV_PHASE_PROFILE build)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+
+n, B = 16384, 16384
+env = make_city26_env(n)
+ring = DeviceReplayRing(env, 1 << 20)
+ring.reset(seed=1)
+L = FusedDQNLearner({"NetWork": "Qnet2", "w": "100", "hiden_dim": "64", "output": "3"}, "dqn")
+for t in range(30):
+    L.act(ring.current_obs(), 0.1, 1, t, index_out=ring.current_action())
+    ring.step_env(auto_reset=True)
+nb = B // 64
+buf = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
+env.lib.uavenv_dqn_set_debug_buffer(buf.data_ptr())
+rows = []
+for t in range(20):
+    L.learn_from_ring(ring, B, 3, t)
+    torch.cuda.synchronize()
+    rows.append(buf.cpu().numpy().reshape(nb, 8)[:, :6].astype(np.float64))
+env.lib.uavenv_dqn_set_debug_buffer(None)
+d = np.diff(np.stack(rows), axis=2)
+names = ["P0 sample + stage W1,W1t,Xs,Xn", "P1 layer1 x2 (MFMA)", "P4 TD target (64 threads)", "P5 dW2, dH", "P6 dW1 (MFMA) + write"]
+print("k_dqn_grad, batch", B, "- cycles per workgroup (mean / p95 / max)")
+for k, nm in enumerate(names):
+    x = d[:, :, k].ravel()
+    print(f"  {nm:36s} {x.mean():9.0f} {np.percentile(x, 95):9.0f} {x.max():9.0f}")
+tot = d.sum(axis=2).ravel()
+print(f"  {'total':36s} {tot.mean():9.0f} {np.percentile(tot, 95):9.0f} {tot.max():9.0f}")
