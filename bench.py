@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
+    p.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                   help="BASELINE.json configs[] preset: 2 = 16384 envs DQN (the benchmark line); 3 = 65536 envs, "
+                        "DuelingDQN + double-DQN target, f16 observations; 5 = 32768 envs per GPU (262144 over 8)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) | gloo (test: several ranks on one GPU)")
     p.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
     p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
@@ -55,7 +58,12 @@ def parse():
                    help="reset scenarios: planned on the GPU at start-up (csrc/rrt.hip) or the packaged reference resets")
     p.add_argument("--learner", default="fused", choices=["fused", "torch"],
                    help="fused = hand-written HIP kernels (csrc/learner.hip); torch = PyTorch-ROCm ops")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.config == 3:
+        a.envs, a.batch, a.trainer, a.obs_dtype = 65536, 65536, "dueling", "f16"
+    elif a.config == 5:
+        a.envs, a.batch = 32768, 32768
+    return a
 
 
 def cpu_baseline(envs: int, seconds: float):
@@ -242,8 +250,8 @@ def main():
             "learner_samples_per_s": args.steps * args.batch * world_size / dt,
             "env_only_steps_per_s": n_agents / (env_only_ms * 1e-3),
             "config": {"workload": "PathPlan_City 500x500x100, 26 buildings, 1 UAV/env, %d vectorised envs/GPU, %s, "
-                                   "device replay %d transitions/GPU (BASELINE.json configs[1])"
-                                   % (args.envs, args.trainer.upper(), ring.capacity),
+                                   "device replay %d transitions/GPU (BASELINE.json configs[%d])"
+                                   % (args.envs, args.trainer.upper(), ring.capacity, args.config - 1),
                        "envs_per_gpu": args.envs, "learn_batch_per_gpu": args.batch, "obs_dtype": args.obs_dtype,
                        "learner": "fused HIP kernels (f32 MFMA)" if fused else "PyTorch-ROCm ops",
                        "learner_dtype": "f32" if fused or args.obs_dtype == "f32" else "f16 autocast",
