@@ -96,6 +96,7 @@ struct StepArgs {
     PowerParams pw;
     int32_t max_step, K, U, N, n_actions;
     int32_t tile_off;                  // LDS byte offset of the obs tile (TILE kernels)
+    int32_t wave_slot;                 // bytes of per-wavefront LDS (work queue / observation tile share it)
     int32_t obsq_off;                  // LDS byte offset of the per-wave observation work queues (ObsWaveLds[waves])
     int32_t block;                     // workgroup size, passed as an argument: reading blockDim.x costs a vector load
                                        // from the dispatch packet + s_waitcnt vmcnt(0) in front of the staging barrier
@@ -466,15 +467,14 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
 #ifndef UAVENV_KSTEP_WAVES
 #define UAVENV_KSTEP_WAVES 1      // min waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
-template <typename MaskT, bool APF, bool F16, bool TILE>
+template <typename MaskT, bool APF, bool F16>
 __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevState &S = a.st;
     const int N = a.N;
     const int n_round = (N + 63) & ~63;
-    const int stride = gridDim.x * a.block;
-    int i = blockIdx.x * a.block + threadIdx.x;
+    const int i = blockIdx.x * a.block + threadIdx.x;
     UAV_STAMP(0);
 
     // issue the first tile's state loads BEFORE the world is staged: their HBM latency overlaps the LDS fill
@@ -488,10 +488,10 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
     const WorldLds<MaskT> w = stage_world<MaskT>(smem, a);
     UAV_STAMP(1);
 
-    // TILE launches cover N with exactly one tile per thread: a straight-line body (no loop) keeps the compiler from
-    // hoisting ~25 plane addresses out of a loop that runs once (they did not fit the SGPR file and were spilled
-    // through ~100 v_writelane right after the staging barrier: ~2.5 k cycles of a 24 k-cycle wave).
-    while (i < n_round) {
+    // Every launch covers N with exactly one agent per thread: a straight-line body.  (A grid-stride loop made the
+    // compiler hoist ~25 plane addresses out of it; they did not fit the SGPR file and were spilled through ~100
+    // v_writelane right after the staging barrier, and the looped form needed 256 VGPRs instead of 128.)
+    if (i < n_round) {
         const bool active = i < N;
         const int ii = active ? i : N - 1;
         unpack_flags(g);
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         if (masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done)) {
             ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
         } else {
-            step_agent<MaskT, APF, TILE>(a, w, ii, a0, g, r, ret_done, info);
+            step_agent<MaskT, APF, true>(a, w, ii, a0, g, r, ret_done, info);
         }
         UAV_STAMP(3);
         g.o.n_rem = g.n_total - g.sub_idx;
@@ -532,17 +532,8 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         // issued (a wait on a later load would also wait for the stores in flight); wave-cooperative (work queue), so
         // every lane of the wavefront takes part, active or not.
         if (want_obs) {
-#ifdef UAVENV_QUEUE_ALWAYS
-            constexpr bool kQueue = true;
-#else
-            constexpr bool kQueue = TILE;      // measured: the queue wins on single-wave launches, the plain form at large N
-#endif
-            if (kQueue) {
-                ObsWaveLds *L = reinterpret_cast<ObsWaveLds *>(smem + a.obsq_off) + (threadIdx.x >> 6);
-                bits = obs_bits_queued(w, L, g.o.px, g.o.py, g.o.pz, active);
-            } else {
-                bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);
-            }
+            ObsWaveLds *L = reinterpret_cast<ObsWaveLds *>(smem + a.obsq_off + (threadIdx.x >> 6) * a.wave_slot);
+            bits = obs_bits_queued(w, L, g.o.px, g.o.py, g.o.pz, active);
             sc = obs_scalars(g.o, g.head);                                         // :526 heading == cached angle
         }
         if (active) {
@@ -564,16 +555,8 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         }
         if (a.tile_off >= 0 && want_obs) {      // wave-cooperative coalesced tile store (opt-in)
             const int first = i - ((int)threadIdx.x & 63);
-            float *tile = reinterpret_cast<float *>(smem + a.tile_off + (threadIdx.x >> 6) * kTileBytes);
-            store_obs_tile<F16>(a.obs, first, N - first, tile, sc, bits);
-        }
-
-        if (TILE) break;
-        i += stride;
-        if (i < n_round) {
-            const int in = i < N ? i : N - 1;
-            load_agent(S, in, g);
-            ra = load_action_raw(a.actions, a.action_kind, in);
+            uint32_t *tile = reinterpret_cast<uint32_t *>(smem + a.tile_off + (threadIdx.x >> 6) * a.wave_slot);
+            store_obs_ctile<F16>(a.obs, first, N - first, tile, sc, bits);
         }
     }
 }
@@ -729,19 +712,30 @@ static StepArgs base_args(const UavEnv *e)
     return a;
 }
 
-// Launch geometry: one wavefront per workgroup while that still yields fewer than ~8 workgroups per CU
-// (small N is latency-bound: spread agents over all 256 CUs), 256-thread workgroups with a grid-stride
-// loop beyond that so the LDS staging of the world is amortised.
+// Launch geometry.  Every k_step launch is "one agent per thread" (straight-line body, 128 VGPRs):
+//  * N <= 131 072: single-wavefront workgroups, so the wavefronts spread over all 256 CUs;
+//  * beyond that: 256-thread workgroups (the ~10 KB world blob is staged once per 256 agents, not once per 64).
+// Observation rows: up to two wavefronts per CU (N <= 32 768) the launch is latency-bound and each lane stores its
+// own row; above that the wavefront's 64 rows go out through the compact LDS tile (store_obs_ctile), which shares its bytes
+// with the by-then-dead observation work queue: ~16 KB per single-wave workgroup, ~34 KB per 256-thread one, so
+// LDS allows as many wavefronts per CU as the VGPR budget does (16).
+// MEASURED (round 1, us per launch, row-per-lane -> compact tile): 16 384 envs 12.6 -> 14.7 and 32 768: 15.4 -> 16.2
+// (kept row-per-lane); 49 152: 18.2 -> 16.5; 65 536: 21.0 -> 17.0; 131 072: 32.5 -> 22.8; 262 144: 55.1 -> 36.6;
+// 524 288: 117 -> 74; 1 M: 260 -> 174.  The earlier design (grid-stride
+// loop, 256 VGPRs, full 25.9 KB f32 tile: one workgroup per CU) took 65 us at 262 144 and 252 us at 1 M.
+// UAVENV_BLOCK / UAVENV_BLOCK64_MAX / UAVENV_TILE_STORE are A/B knobs.
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static void launch_geometry(int n, int &block, int &grid)
 {
-    if (n <= 131072) {
-        block = 64;
-        grid = (n + 63) / 64;
-    } else {
-        block = 256;
-        grid = (n + 255) / 256;
-        if (grid > 2048) grid = 2048;
-    }
+    static const int thr = env_int("UAVENV_BLOCK64_MAX", 131072);
+    static const int big = env_int("UAVENV_BLOCK", 256);
+    block = n <= thr ? 64 : big;
+    grid = (n + block - 1) / block;
     if (grid < 1) grid = 1;
 }
 
@@ -753,28 +747,23 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     StepArgs a = a_in;
     a.block = block;
     const bool f16 = e->cfg.obs_dtype == UAVENV_OBS_F16, apf = e->cfg.apf_enabled == 1;
-    // single-wave workgroups (small, latency-bound N) stage their 64 observation rows through LDS and store them
-    // coalesced; 256-thread workgroups (large N, throughput-bound) keep LDS for occupancy and store row-per-lane.
-    // MEASURED (round 1): the wave-cooperative tile store pays off when the launch is throughput-bound (256-thread
-    // workgroups, N > 131 072: 1 M envs 318 -> 242 us, +30 %; the row-per-lane form issues 64 separate 16-byte
-    // segments per store instruction) and costs ~2 us when it is latency-bound (single-wave workgroups at 16 384
-    // envs: 12.4 -> 14.3 us).  Default accordingly; UAVENV_TILE_STORE=0/1 forces it off/on for A/B runs.
-    const bool tile = block == 64;                 // the single-wave-workgroup variant (straight-line, inline angles)
-    static const char *tile_env = getenv("UAVENV_TILE_STORE");
-    const bool tile_enabled = tile_env ? atoi(tile_env) != 0 : block == 256;
-    const bool tile_store = tile_enabled;
+    static const int tile_env = env_int("UAVENV_TILE_STORE", -1);
+    const bool tile_store = tile_env >= 0 ? tile_env != 0 : e->N > 32768;
+    const int nw = block / 64;
     a.obsq_off = (e->world_bytes + 15) & ~15;
-    const int obsq_end = a.obsq_off + (block / 64) * (int)sizeof(ObsWaveLds);
-    a.tile_off = tile_store ? (obsq_end + 15) & ~15 : -1;
-    const size_t lds = tile_store ? (size_t)a.tile_off + (size_t)(block / 64) * kTileBytes : (size_t)obsq_end;
-#define UAV_LAUNCH(APF_, F16_)                                                                                   \
-    do {                                                                                                         \
-        if (tile) hipLaunchKernelGGL((k_step<MaskT, APF_, F16_, true>), dim3(grid), dim3(block), lds, s, a);       \
-        else hipLaunchKernelGGL((k_step<MaskT, APF_, F16_, false>), dim3(grid), dim3(block), lds, s, a);           \
-    } while (0)
-    if (apf) { if (f16) UAV_LAUNCH(true, true); else UAV_LAUNCH(true, false); }
-    else     { if (f16) UAV_LAUNCH(false, true); else UAV_LAUNCH(false, false); }
-#undef UAV_LAUNCH
+    int slot = (int)sizeof(ObsWaveLds);            // per-wave LDS slot: the work queue, then (same bytes) the tile
+    if (tile_store && kCTileBytes > slot) slot = kCTileBytes;
+    slot = (slot + 15) & ~15;
+    a.wave_slot = slot;
+    a.tile_off = tile_store ? a.obsq_off : -1;
+    const size_t lds = (size_t)a.obsq_off + (size_t)nw * slot;
+    if (apf) {
+        if (f16) hipLaunchKernelGGL((k_step<MaskT, true, true>), dim3(grid), dim3(block), lds, s, a);
+        else hipLaunchKernelGGL((k_step<MaskT, true, false>), dim3(grid), dim3(block), lds, s, a);
+    } else {
+        if (f16) hipLaunchKernelGGL((k_step<MaskT, false, true>), dim3(grid), dim3(block), lds, s, a);
+        else hipLaunchKernelGGL((k_step<MaskT, false, false>), dim3(grid), dim3(block), lds, s, a);
+    }
 }
 
 extern "C" {

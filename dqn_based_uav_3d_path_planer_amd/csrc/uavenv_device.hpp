@@ -489,40 +489,73 @@ __device__ __forceinline__ void store_obs_row(void *obs_base, int64_t agent, con
     }
 }
 
-// Wave-cooperative, fully coalesced store of a wavefront's 64 observation rows: each lane drops its row into an LDS
-// tile (row stride 101 dwords -> conflict-free column writes), then the wave streams the contiguous 25.6 KB out as
-// 25 x 1 KiB stores.  (A half-row tile that lets two workgroups share a CU was measured slower: 294 vs 242 us at
-// 1 M envs -- the 1 KiB runs matter more than the occupancy.)  The row-per-lane form costs 25 store instructions of 64 separate 16-byte segments each (~64 TA cycles
-// per instruction instead of ~16) -- measured 3.6 k cycles of a 24 k-cycle wave at 16 384 envs.
-constexpr int kTileLd = 101;                      // a full row + 1: odd -> conflict-free column writes
-constexpr int kTileBytes = 64 * kTileLd * 4;      // 25 856 B per wavefront
+// Wave-cooperative, fully coalesced store of a wavefront's 64 observation rows (25.6 KB contiguous = 25 x 1 KiB
+// store instructions).  The row-per-lane form (store_obs_row) issues 25 store instructions of 64 separate 16-byte
+// segments each: ~64 TA cycles per instruction instead of ~16, and partial-line writes at scale (1 M envs: 294 us
+// against 198 us).  A full f32 tile in LDS (64 x 101 dwords = 25.9 KB per wavefront) was the first form of this; it
+// limited a CU to four single-wave workgroups.  The compact form below holds, per row, only what is not a 0/1 flag
+// -- 15 scalars -- plus a column-aligned bit mask of the 80 occupancy flags (23 dwords instead of 101), and the
+// streaming pass rebuilds each lane's four columns from them: 5.9 KB per wavefront, ~30 more VALU per store
+// instruction.
+constexpr int kCTileLd = 23;                      // 3 mask words + 20 scalar slots; odd -> conflict-free column writes
+constexpr int kCTileBytes = 64 * kCTileLd * 4;    // 5 888 B per wavefront
 template <bool F16>
-__device__ __forceinline__ void store_obs_tile(void *obs_base, int64_t first_agent, int n_valid, float *tile,
-                                               const ObsScalars &s, const ObsBits &b)
+__device__ __forceinline__ void store_obs_ctile(void *obs_base, int64_t first_agent, int n_valid, uint32_t *tile,
+                                                const ObsScalars &s, const ObsBits &b)
 {
     const int lane = (int)threadIdx.x & 63;
-    float *row = tile + lane * kTileLd;
+    uint32_t *row = tile + lane * kCTileLd;
+    // bit (col & 31) of word (col >> 5) = the flag of observation column col (stencils 11..85, below-probes 90..94)
+    row[0] = b.s1 << 11;
+    row[1] = (b.s1 >> 21) | (b.s5 << 4) | (b.s10 << 29);
+    row[2] = (b.s10 >> 3) | (b.below << 26);
+    float *sl = reinterpret_cast<float *>(row + 3);   // slot = col for cols 0..10, col - 72 for cols 86..89
 #pragma unroll
-    for (int c = 0; c < 100; ++c) row[c] = obs_col(s, b, c);
+    for (int c = 0; c < 11; ++c) sl[c] = s.f[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sl[14 + c] = s.f[11 + c];
     wave_lds_sync();
-#pragma unroll
-    for (int it = 0; it < 25; ++it) {
-        const int e = it * 256 + lane * 4;            // flat element index inside the 64 x 100 tile
-        const int r = e / 100, c = e - r * 100;
-        if (r < n_valid) {
-            const float *src = tile + r * kTileLd + c;
+    auto emit = [&](int it, bool guard) {
+        const int e = it * 256 + lane * 4;            // flat element index inside the 64 x 100 block of rows
+        const int r = e / 100, c = e - r * 100, cg = c >> 2;
+        // branch-free: every lane reads one mask word and four scalar slots (clamped addresses), then selects
+        const uint32_t *src = tile + r * kCTileLd;
+        const int w = c >> 5;
+        const uint32_t mw = src[w < 3 ? w : 2];
+        const bool edge = (cg == 21) | (cg == 22);
+        const int sb = cg < 3 ? c : edge ? c - 72 : 0;
+        const float s0 = reinterpret_cast<const float *>(src + 3 + sb)[0];
+        const float s1 = reinterpret_cast<const float *>(src + 3 + sb)[1];
+        const float s2 = reinterpret_cast<const float *>(src + 3 + sb)[2];
+        const float s3 = reinterpret_cast<const float *>(src + 3 + sb)[3];
+        const uint32_t nib = w < 3 ? (mw >> (c & 31)) : 0u;
+        const uint32_t snib = cg < 2 ? 15u : cg == 2 ? 7u : cg == 21 ? 12u : cg == 22 ? 3u : 0u;
+        float v[4];
+        v[0] = (snib & 1u) ? s0 : (float)(nib & 1u);
+        v[1] = (snib & 2u) ? s1 : (float)((nib >> 1) & 1u);
+        v[2] = (snib & 4u) ? s2 : (float)((nib >> 2) & 1u);
+        v[3] = (snib & 8u) ? s3 : (float)((nib >> 3) & 1u);
+        if (!guard || r < n_valid) {
             if (!F16) {
                 *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs_base) + first_agent * 100 + e) =
-                    make_float4(src[0], src[1], src[2], src[3]);
+                    make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                __half2 lo = __floats2half2_rn(src[0], src[1]);
-                __half2 hi = __floats2half2_rn(src[2], src[3]);
-                uint2 v;
-                v.x = *reinterpret_cast<uint32_t *>(&lo);
-                v.y = *reinterpret_cast<uint32_t *>(&hi);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(obs_base) + first_agent * 100 + e) = v;
+                __half2 lo = __floats2half2_rn(v[0], v[1]);
+                __half2 hi = __floats2half2_rn(v[2], v[3]);
+                uint2 o;
+                o.x = *reinterpret_cast<uint32_t *>(&lo);
+                o.y = *reinterpret_cast<uint32_t *>(&hi);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(obs_base) + first_agent * 100 + e) = o;
             }
         }
+    };
+    const int nv = __builtin_amdgcn_readfirstlane(n_valid);      // same in every lane; tell the compiler
+    if (nv >= 64) {             // every wavefront but the last takes the unguarded, straight-line form
+#pragma unroll
+        for (int it = 0; it < 25; ++it) emit(it, false);
+    } else {
+#pragma unroll
+        for (int it = 0; it < 25; ++it) emit(it, true);
     }
     wave_lds_sync();
 }
