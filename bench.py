@@ -162,7 +162,10 @@ def main():
     counter = [0]
     step_events = []
 
+    ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "8"))
+
     def one_step(record=False):
+        record = record and counter[0] % ev_every == 0
         if fused:
             learner.act(ring.current_obs(), args.eps, seed, counter[0], index_out=ring.current_action())
         else:
@@ -195,6 +198,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(record=True)
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (the loop is GPU-bound if < dt)
     fence()
     dt = time.perf_counter() - t0
     if world_size > 1:
@@ -228,6 +232,22 @@ def main():
     torch.cuda.synchronize(dev)
     env_only_ms = e0.elapsed_time(e1) / it
 
+    # achievable HBM bandwidth on THIS device, same run: device-to-device copy of 1 GiB, read + write bytes
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_kstep_traffic.json")     # PMC passes cannot run inside this process:
     if os.path.exists(tpath) and args.envs == 16384 and args.obs_dtype == "f32":   # last committed rocprofv3 --pmc result
@@ -247,6 +267,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "learner_updates_per_s": args.steps / dt,
+            "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "learner_samples_per_s": args.steps * args.batch * world_size / dt,
             "env_only_steps_per_s": n_agents / (env_only_ms * 1e-3),
             "config": {"workload": "PathPlan_City 500x500x100, 26 buildings, 1 UAV/env, %d vectorised envs/GPU, %s, "
@@ -263,6 +284,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01_kstep_traffic.json (rocprofv3 --pmc "
                          "FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None, "algorithmic_bytes_per_agent_step": algo,
+                         "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "kernel_ms": k_ms, "kernel_ms_raw_event_pair": k_raw_ms, "empty_event_pair_ms": pair_ms,
                          "agents_per_launch": n_agents,
                          "kernel_ms_env_only_back_to_back": env_only_ms},
