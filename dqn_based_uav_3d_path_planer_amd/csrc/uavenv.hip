@@ -358,19 +358,21 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
     o.px += o.vx;                                                              // :419
     o.py += o.vy;                                                              // :420
     if (g.alias) { o.s0x = o.px; o.s0y = o.py; o.s0z = o.pz; }                 // sub_goals[0] IS position after reset
-    double tri_goal = angle_of<INL>(o.s0x - o.px, o.s0y - o.py);                  // :422
-    g.head = angle_of<INL>(o.vx, o.vy);                                           // :423 (and obs[7], and next :411)
-    double tri_V = g.head;
+    // :422-428  tri_goal = angle(sub0 - pos), tri_V = angle(V) -- or angle(sub0 - old pos) after a collision.  Only
+    // cos|tri_goal - tri_V| is ever used, so the vectors are kept and cos_between() replaces two atan2 chains.
+    const double tgx = o.s0x - o.px, tgy = o.s0y - o.py;                       // :422
+    g.head = angle_of<INL>(o.vx, o.vy);                                        // :423 (and obs[7], and next :411)
+    double tvx = o.vx, tvy = o.vy;
     if (probe(w, o.px, o.py, o.pz)) {                                          // :425-428
         r -= 0.3;
         o.px = ox; o.py = oy; o.pz = oz;
         g.alias = 0;
-        tri_V = angle_of<INL>(o.s0x - o.px, o.s0y - o.py);
+        tvx = o.s0x - o.px; tvy = o.s0y - o.py;
     }
     const double dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);       // :429
     const double g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);            // :430
     r -= 0.13 * fabs(a0);                                                      // :434
-    r += 0.2 * cos(fabs(tri_goal - tri_V));                                    // :435
+    r += 0.2 * cos_between(tgx, tgy, tvx, tvy);                                // :435
     r += 0.4 * (dis_old - dis_new);                                            // :436
     r += 0.4 * (g_old - g_new);                                                // :437
     r -= 0.1;                                                                  // :438
@@ -395,8 +397,7 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
         double fx, fy, fz;
         cal_force(a.apf_b, a.nb, o.px, o.py, o.pz, fx, fy, fz);
         const double force = sqrt(fx * fx + fy * fy + fz * fz);
-        const double tri_force = angle_of<INL>(fx, fy);
-        r += 0.2 * force * cos(fabs(tri_force - tri_V));
+        r += 0.2 * force * cos_between(fx, fy, tvx, tvy);                      // :451-453
     }
 
     const double d_sub = APF ? dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z) : dis_new;   // same operands when !APF
@@ -428,10 +429,8 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
                 const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
                 o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
             }
-            tri_goal = angle_of<INL>(o.s0x - o.px, o.s0y - o.py);                 // :488
             if (o.vx != vx0 || o.vy != vy0) g.head = angle_of<INL>(o.vx, o.vy);   // :489 (Calc_V rescaled again)
-            tri_V = g.head;
-            r += 0.2 * cos(fabs(tri_goal - tri_V));                            // :490
+            r += 0.2 * cos_between(o.s0x - o.px, o.s0y - o.py, o.vx, o.vy);    // :488-490
             r += (double)(max_step - o.step);                                  // :491
             g.score += r; g.total += r;
             ret_done = 1; info = UAVENV_INFO_SUCCESS;                          // returned done; agent NOT done

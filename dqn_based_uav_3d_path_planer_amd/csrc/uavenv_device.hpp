@@ -74,6 +74,20 @@ __device__ __forceinline__ double angle_of(double dx, double dy)
     return INL ? calc_angle_body(dx, dy) : calc_angle(dx, dy);
 }
 
+// cos(|calculate_angle(a) - calculate_angle(b)|) without the two atan2 chains: the cosine of the angle between the two
+// vectors, (a.b) / (|a||b|).  calculate_angle maps the zero vector to angle 0 (atan2(0, 0) = 0), i.e. to the direction
+// (1, 0); the degree/modulo normalisation only shifts angles by multiples of 2 pi, which the cosine ignores.  Agrees
+// with the reference's chain to ~1e-15 (both are a few ulp from the exact value); used ONLY for the reward's heading
+// terms (UAV.py:435, :453, :490) -- the heading that is stored and fed to the next step still goes through calc_angle.
+__device__ __forceinline__ double cos_between(double ax, double ay, double bx, double by)
+{
+    if (ax == 0.0 && ay == 0.0) ax = 1.0;
+    if (bx == 0.0 && by == 0.0) bx = 1.0;
+    const double num = ax * bx + ay * by;
+    const double den = sqrt((ax * ax + ay * ay) * (bx * bx + by * by));
+    return num / den;
+}
+
 // BaseClass/CalMod.py:64-65  Eu_Loc_distance
 __device__ __forceinline__ double dist3(double ax, double ay, double az, double bx, double by, double bz)
 {
