@@ -63,6 +63,8 @@ class simulator:
         self.stat = 1
         self.infos = []
         self.executed_time = 0
+        self.CsvWriter = None
+        self.result_path = None
         self.Init_From_XML(xml_path or os.path.join(os.getcwd(), "config", "PathPlan_City.xml"))
 
     def Init_From_XML(self, XML_path):
@@ -78,6 +80,42 @@ class simulator:
         except Exception as e:      # simulator.py:101-103
             print(e.args)
             return None
+
+    RESULT_HEADER = ["sum_Episode", "Episode", " Score", " Avg.Score", "eps-greedy", "success", "failed", "meet_threaten",
+                     "loss", "step", "avg_trainning_time", "avg_testing_time", "total_time"]
+
+    def Init_Record_Mod(self, result_path=None):
+        """simulator.py:72-80: logs/score_<time>.csv with the reference's 13-column header (opt-in: call it, or pass
+        a path).  One row per episode from record(info)."""
+        import csv
+        import datetime
+        import os
+        if result_path is None:
+            cur = datetime.datetime.now().strftime("%m_%d_%Y(%H_%M_%S)")
+            result_path = os.path.join("logs", "score_%s.csv" % cur)
+        os.makedirs(os.path.dirname(result_path) or ".", exist_ok=True)
+        self.result_path = result_path
+        self._result_file = open(result_path, "a+", newline="")
+        self.CsvWriter = csv.writer(self._result_file)
+        self.CsvWriter.writerow(self.RESULT_HEADER)
+
+    def record(self, info=None):
+        """simulator.py:163-166 plus the four columns its header names but the reference's row leaves out (step,
+        averaged train / test time per agent, wall time) -- the reference's own record_list() writes those."""
+        if info is None or self.CsvWriter is None:
+            return
+        n = max(len(self.env.Agents), 1)
+        tr = sum(u.Train_time for u in self.env.Agents) / n
+        te = sum(u.Testing_time for u in self.env.Agents) / n
+        self.CsvWriter.writerow([info["sum_epoch"], self.epoch, info["score"], info["average_score"], info["eps"],
+                                 info["success"], info["lose"], info["meet_threaten"], info["loss"], info.get("step", 0),
+                                 tr, te, self.executed_time])
+        self._result_file.flush()
+
+    def record_list(self):
+        """simulator.py:151-161.  The reference zeroes the episode columns there and drops its info list; here the row
+        carries the episode's numbers (record()) and `infos` keeps the history."""
+        self.record(self.infos[-1] if self.infos else None)
 
     def epsilon_annealing(self):
         return epsilon_annealing(self.epoch, self.min_eps, self.max_eps_episode)
@@ -98,6 +136,7 @@ class simulator:
                 self.infos.append(info)
                 if self.Max_score < info["average_score"]:
                     self.Max_score = info["average_score"]
+                self.record_list()
 
     def Update_target(self):
         for a in self.env.Agents:

@@ -80,6 +80,12 @@ class PathPlan_City:
         self._state_cache = None
         self._obs = None
         self._episode = 0
+        # UAV.path of env 0 (UAV.py:431) and the path.csv the reference rewrites at every terminal (:461-464,:479-483,
+        # :505-509).  One 16-double read-back of env 0's agents per step; <record_path>0</record_path> turns it off.
+        self.record_path = int(None2Value(param.get("record_path"), 1))
+        self.path_csv = None2Value(param.get("path_csv"), "path.csv")
+        self._paths = [[] for _ in range(self.num_UAV)]
+        self._path_done = [False] * self.num_UAV
         self.Scene_Random_Reset()
 
     # ---- scenario bank (the RRT part of UAV.reset, pre-planned) ------------------------------------------
@@ -126,6 +132,24 @@ class PathPlan_City:
         m[:, j] = 1
         return m.reshape(-1).contiguous()
 
+    def _record_paths(self, stepped):
+        """Append env 0's new positions (UAV.py:431) for the slots in `stepped`; dump path.csv when one terminates."""
+        if not self.record_path:
+            return
+        st = self.backend.get_state(0, self.num_UAV)
+        for j in stepped:
+            if self._path_done[j]:
+                continue                                    # done agents are skipped by run_thread_OffPolicy (:365)
+            self._paths[j].append([float(st[j][0]), float(st[j][1]), float(st[j][2])])
+            if st[j][10] != 0:
+                self._path_done[j] = True
+                try:
+                    import csv
+                    with open(self.path_csv, "w", newline="") as f:
+                        csv.writer(f).writerows(self._paths[j])
+                except OSError as e:
+                    print(e)
+
     def _step_slot(self, j, action):
         """Move UAV_j of every env (BaseEnv.Move_Agent semantics for a batch); other slots are left untouched."""
         dev = self._obs.device
@@ -143,6 +167,7 @@ class PathPlan_City:
         out = self.backend.step(full.reshape(-1).contiguous(), active=self._slot_mask(j), skip_done=False)
         self._obs = out.obs
         self._invalidate()
+        self._record_paths([j])
         sl = slice(j, None, self.num_UAV)
         return (out.reward.cpu().numpy()[sl], out.ret_done.cpu().numpy()[sl], out.info.cpu().numpy()[sl])
 
@@ -156,6 +181,8 @@ class PathPlan_City:
         self._episode += 1
         self._obs = self.backend.reset(self.seed + self._episode)
         self._invalidate()
+        self._paths = [[] for _ in range(self.num_UAV)]                                       # UAV.py:338
+        self._path_done = [False] * self.num_UAV
 
     def Check_uav_Done(self):
         return bool(self._states()[0][:, 10].all())
@@ -234,6 +261,7 @@ class PathPlan_City:
             out = self.backend.step(actions.reshape(-1).contiguous(), skip_done=True)     # done agents wait (:365-366)
             self._obs = out.obs
             self._invalidate()
+            self._record_paths(range(self.num_UAV))
             info = out.info.view(self.num_envs, self.num_UAV)
             valid = out.valid.view(self.num_envs, self.num_UAV).bool()
             for k, nm in enumerate(names):

@@ -46,6 +46,9 @@ class UAV:
         self.task_collect = 0
         self.Train_start = time.time()
         self.infos = []
+        self.CsvWriter = None
+        if int(param.get("record_csv") or 0):
+            self.Init_Record_Mod()
 
     # ---- device-backed state (env 0 scalar view) --------------------------------------------------
     def _row(self, e: int = 0):
@@ -140,7 +143,38 @@ class UAV:
         self.Train_time += time.time() - start
         return re
 
+    @property
+    def path(self):
+        """UAV.py:42,431: the positions env 0's UAV_j has visited since its last reset."""
+        return self.env._paths[self.j]
+
+    RECORD_HEADER = ["sum_Episode", "Episode", " Score", " Avg.Score", "eps-greedy", "success", "failed", "meet_threaten",
+                     "loss", "ALL_UEs_D", "ALL_UEs_F", "energy_cost", "task_collect", "Energy_Efficent", "UE_waiting_time",
+                     "Covered_rate", "task_executed", "executed_rate", "KL", "Train_time", "Testing_time"]
+
+    def Init_Record_Mod(self, directory="logs"):
+        """UAV.py:268-277: logs/<name>_<time>.csv with the reference's 21-column header.  Opt-in here
+        (<record_csv>1</record_csv> in UAV.xml): the reference opens one file per UAV at construction."""
+        import csv
+        import datetime
+        import os
+        os.makedirs(directory, exist_ok=True)
+        cur = datetime.datetime.now().strftime("%m_%d_%Y(%H_%M_%S)")
+        self._record_file = open(os.path.join(directory, "%s_%s.csv" % (self.name, cur)), "a+", newline="")
+        self.CsvWriter = csv.writer(self._record_file)
+        self.CsvWriter.writerow(self.RECORD_HEADER)
+
     def record_list(self):
+        """UAV.py:279-310.  The UE / task / KL columns belong to the data-collection scenarios (out of the PathPlan
+        path): zero here, exactly what the reference writes for a PathPlan run.  Score columns are env 0's, as the
+        scalar accessors are."""
+        if self.CsvWriter is not None:
+            epoch = self.Trainer.epoch if self.Trainer is not None else 0
+            sc = self.score
+            ee = self.task_collect / (self.energy_cost_total + 0.001)
+            self.CsvWriter.writerow([epoch, epoch, sc, sc, 0, 0, 0, 0, 0, 0, 0, self.energy_cost_total, self.task_collect, ee,
+                                     0, 0.0, 0, 0.0, [], self.Train_time, self.Testing_time])
+            self._record_file.flush()
         self.infos = []
 
     def Calc_Fly_Power(self):

@@ -189,3 +189,39 @@ def test_unmodified_reference_simulator_drives_our_plugins(cfg_dir, monkeypatch)
     sim.StartAndTrain()                                       # 10 x 1 episodes through the reference's own loop
     assert sim.epoch == 10 and sim.Max_score > -9999999999
     assert os.path.exists(sim.result_path)                    # the reference wrote its score CSV
+
+
+def test_path_record_and_csv_contracts(cfg_dir):
+    """UAV.path / path.csv (UAV.py:431,461-464), the per-UAV log (UAV.py:268-310) and the simulator's
+    score CSV (simulator.py:72-80,163-166) keep the reference's file names, headers and row shapes."""
+    import csv
+    import re
+    xml = driver.make_config_dir(str(cfg_dir), "DQN", num_envs=3, num_uav=2)
+    uav_xml = cfg_dir / "config" / "UAV.xml"
+    uav_xml.write_text(re.sub(r"</Agent>\s*$", "<record_csv>1</record_csv></Agent>", uav_xml.read_text().rstrip()))
+    sim = driver.simulator(xml)
+    env = sim.env
+    sim.Init_Record_Mod()
+    random.seed(3)
+    torch.manual_seed(3)
+    sim.num_episodes = 10
+    sim.StartAndTrain()
+    # UAV.path: one position per step env 0's UAV actually took, ending where the state says it is
+    for uav in env.Agents:
+        assert 1 <= len(uav.path) <= 150 * 40 and len(uav.path[0]) == 3
+        assert abs(uav.path[-1][0] - uav.position.x) < 1e-12 and abs(uav.path[-1][1] - uav.position.y) < 1e-12
+    rows = list(csv.reader(open("path.csv")))
+    assert rows and len(rows[0]) == 3
+    assert any(len(rows) == len(u.path) and abs(float(rows[-1][0]) - u.path[-1][0]) < 1e-9 for u in env.Agents)
+    # simulator score log
+    rows = list(csv.reader(open(sim.result_path)))
+    assert rows[0] == ["sum_Episode", "Episode", " Score", " Avg.Score", "eps-greedy", "success", "failed", "meet_threaten",
+                       "loss", "step", "avg_trainning_time", "avg_testing_time", "total_time"]
+    assert len(rows) == 11 and [int(r[1]) for r in rows[1:]] == list(range(1, 11)) and all(len(r) == 13 for r in rows[1:])
+    assert abs(float(rows[1][4]) - driver.epsilon_annealing(1, sim.min_eps, sim.max_eps_episode)) < 1e-12
+    # per-UAV log: header + one row every print_loop episodes
+    logs = sorted(f for f in os.listdir("logs") if f.startswith("UAV_"))
+    assert len(logs) == 2
+    rows = list(csv.reader(open(os.path.join("logs", logs[0]))))
+    assert rows[0][:4] == ["sum_Episode", "Episode", " Score", " Avg.Score"] and len(rows[0]) == 21 and rows[0][-1] == "Testing_time"
+    assert len(rows) == 1 + 10 // env.print_loop and all(len(r) == 21 for r in rows[1:])
