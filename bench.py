@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                    help="BASELINE.json configs[] preset: 2 = 16384 envs DQN (the benchmark line); 3 = 65536 envs, "
                         "DuelingDQN + double-DQN target, f16 observations; 5 = 32768 envs per GPU (262144 over 8)")
+    p.add_argument("--sync", default="grad", choices=["grad", "fedavg"],
+                   help="N > 1: all-reduce the gradient bucket every update (default), or average the weights every "
+                        "FL_Loop = 3 updates (the reference's federated mode as all-reduce(avg))")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) | gloo (test: several ranks on one GPU)")
     p.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
     p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
@@ -158,6 +161,7 @@ def main():
     else:
         learner = DQNLearner(net_param, args.trainer, device=dev,
                              amp_dtype=torch.float16 if args.obs_dtype == "f16" else None)
+    learner.sync = args.sync
     seed = 7 + rank
     counter = [0]
     step_events = []
@@ -279,7 +283,8 @@ def main():
                        "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
                                       % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
-                       "epsilon": args.eps, "parallelism": "env-shard x%d + flat-bucket grad all-reduce" % world_size},
+                       "epsilon": args.eps, "parallelism": "env-shard x%d + %s" % (world_size, "flat-bucket grad all-reduce" if args.sync == "grad"
+                                                               else "weight averaging every 3 updates")},
             "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01_kstep_traffic.json (rocprofv3 --pmc "

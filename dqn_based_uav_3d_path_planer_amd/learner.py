@@ -33,6 +33,11 @@ class DQNLearner:
         self.loss_kind = loss                # "mse" (reference) or "huber" (north_star option)
         self.loss = torch.zeros((), device=self.device)
         self._flat = None
+        # multi-rank exchange: "grad" = all-reduce the gradient bucket before every Adam step (the ranks
+        # stay bit-identical); "fedavg" = every rank trains alone and the WEIGHTS are averaged every fl_loop updates
+        # (the reference's federated idea, PathPlan_City.py:590-603 / FL_Loop, as one all-reduce(avg)).
+        self.sync = "grad"
+        self.fl_loop = int(param.get("FL_Loop") or 3)
 
     # -- reference API -------------------------------------------------------------------------
     def hard_update(self):
@@ -81,6 +86,23 @@ class DQNLearner:
             p.grad.copy_(flat[off:off + n].view_as(p))
             off += n
 
+    def federated_average(self):
+        """FedAvg over the ranks: q_local and q_target <- mean over ranks (PathPlan_City.py:590-603 sums the agents'
+        state_dicts and divides by their number; here the agents are the ranks and the sum is one all-reduce).  The
+        Adam moments stay local, as the reference's replace_param leaves each trainer's optimizer untouched."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        with torch.no_grad():
+            ps = list(self.q_local.parameters()) + list(self.q_target.parameters())
+            flat = torch.cat([p.reshape(-1) for p in ps])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= dist.get_world_size()
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.copy_(flat[off:off + n].view_as(p))
+                off += n
+
     def learn(self, batch: dict) -> torch.Tensor:
         """One update on a sampled batch (dict with states/actions/rewards/next_states/dones[/valid])."""
         self.epoch += 1
@@ -93,11 +115,14 @@ class DQNLearner:
                                 batch["dones"], batch.get("valid"))
         self.optim.zero_grad(set_to_none=False)
         loss.backward()
-        self._allreduce_grads()
+        if self.sync == "grad":
+            self._allreduce_grads()
         self.optim.step()
         self.loss = loss.detach()
         if self.epoch % self.update_loop == 0:                                         # DQN_Trainer.py:129-130
             self.hard_update()
+        if self.sync == "fedavg" and self.epoch % self.fl_loop == 0:
+            self.federated_average()
         return self.loss
 
 
@@ -147,6 +172,8 @@ class FusedDQNLearner:
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self._partials = None
         self.force_split = False       # tests: take the multi-GPU (reduce -> all-reduce -> adam) path on one GPU
+        self.sync = "grad"             # or "fedavg": no per-update exchange, weights averaged every fl_loop updates
+        self.fl_loop = int(param.get("FL_Loop") or 3)
 
     def _bind(self, net, flat, hid, w):
         """Move the module's parameters into the flat block (kernel layout) and make them views of it."""
@@ -177,6 +204,15 @@ class FusedDQNLearner:
         self.flat[2:].zero_()
         self.epoch = 0
 
+    def federated_average(self):
+        """FedAvg over the ranks: local and target blocks <- mean over ranks, one all-reduce of 2 x P floats over
+        RCCL (DQNLearner.federated_average has the reference lines)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        w = self.flat[:2]
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        w /= dist.get_world_size()
+
     def act(self, obs: torch.Tensor, eps: float, seed: int, counter: int, index_out: torch.Tensor = None,
             steer_out: torch.Tensor = None, q_out: torch.Tensor = None):
         """Q(s) + epsilon-greedy for all rows of obs [n,100] in one launch."""
@@ -205,11 +241,14 @@ class FusedDQNLearner:
         _lib.check(rc, "uavenv_dqn_grad")
         hard = 1 if self.epoch % self.update_loop == 0 else 0
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if not multi and not self.force_split:      # reduce + Adam (+ hard target copy) in one launch
+        fed = multi and self.sync == "fedavg"
+        if (not multi or fed) and not self.force_split:      # reduce + Adam (+ hard target copy) in one launch
             rc = self.lib.uavenv_dqn_reduce_adam(C.byref(self.net), self._partials.data_ptr(), nblk, self.lr,
                                                  self.betas[0], self.betas[1], self.eps, self.epoch, hard,
                                                  self.loss.data_ptr(), None, s)
             _lib.check(rc, "uavenv_dqn_reduce_adam")
+            if fed and self.epoch % self.fl_loop == 0:
+                self.federated_average()
             return self.loss
         rc = self.lib.uavenv_dqn_reduce(C.byref(self.net), self._partials.data_ptr(), nblk, self.raw.data_ptr(), s)
         _lib.check(rc, "uavenv_dqn_reduce")

@@ -75,3 +75,58 @@ def test_two_ranks_equal_one_process_dqn(tmp_path):
 
 def test_two_ranks_equal_one_process_dueling(tmp_path):
     _run("dueling", "VAnet2", tmp_path)
+
+
+def _fed_worker(rank, world, port, out_dir):
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    g = load_golden("learner_DQN_Trainer.npz")
+    L = DQNLearner(dict(PARAM, FL_Loop="2"), "dqn", device="cpu")
+    L.sync = "fedavg"
+    L.q_local.load_state_dict({k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("l0_")})
+    L.q_target.load_state_dict({k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("t0_")})
+    n = len(g["actions"]) // world
+    sl = slice(rank * n, (rank + 1) * n)
+    batch = dict(states=torch.tensor(g["states"][sl]), next_states=torch.tensor(g["next_states"][sl]),
+                 actions=torch.tensor(g["actions"][sl].astype(np.int32)), rewards=torch.tensor(g["rewards"][sl]),
+                 dones=torch.tensor(g["dones"][sl]))
+    snaps = []
+    for _ in range(4):
+        L.learn(batch)
+        snaps.append({k: v.clone() for k, v in L.q_local.state_dict().items()})
+    torch.save(snaps, os.path.join(out_dir, f"fed{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_federated_averaging_every_fl_loop_updates(tmp_path):
+    """sync="fedavg": ranks train alone (different shards -> different weights after update 1) and hold the same,
+    averaged weights after every FL_Loop-th update; the average is the mean of what each rank would have had."""
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
+    port = _free_port()
+    mp.spawn(_fed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "fed0.pt"), torch.load(tmp_path / "fed1.pt")
+    k = "fc1.weight"
+    assert not torch.equal(a[0][k], b[0][k])                       # update 1: no exchange
+    assert all(torch.equal(a[1][q], b[1][q]) for q in a[1])        # update 2: averaged
+    assert not torch.equal(a[2][k], b[2][k]) and all(torch.equal(a[3][q], b[3][q]) for q in a[3])
+    # the averaged weights equal the mean of two single-process learners run on the two shards for two updates
+    g = load_golden("learner_DQN_Trainer.npz")
+    outs = []
+    for rank in range(2):
+        L = DQNLearner(dict(PARAM), "dqn", device="cpu")
+        L.q_local.load_state_dict({q[3:]: torch.tensor(v) for q, v in g.items() if q.startswith("l0_")})
+        L.q_target.load_state_dict({q[3:]: torch.tensor(v) for q, v in g.items() if q.startswith("t0_")})
+        n = len(g["actions"]) // 2
+        sl = slice(rank * n, (rank + 1) * n)
+        batch = dict(states=torch.tensor(g["states"][sl]), next_states=torch.tensor(g["next_states"][sl]),
+                     actions=torch.tensor(g["actions"][sl].astype(np.int32)), rewards=torch.tensor(g["rewards"][sl]),
+                     dones=torch.tensor(g["dones"][sl]))
+        L.learn(batch)
+        L.learn(batch)
+        outs.append(L.q_local.state_dict())
+    for q in a[1]:
+        assert torch.allclose(a[1][q], (outs[0][q] + outs[1][q]) / 2, rtol=0, atol=1e-7)
