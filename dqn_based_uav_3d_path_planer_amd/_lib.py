@@ -24,6 +24,7 @@ SYMBOLS = (
     "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
+    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
 )
 
 
@@ -48,6 +49,11 @@ class UavReplayRing(C.Structure):
 class UavDqnNet(C.Structure):
     _fields_ = [("local", C.c_void_p), ("target", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("w", C.c_int32), ("hid", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32)]
+
+
+class UavPer(C.Structure):
+    _fields_ = [("prio", C.c_void_p), ("chunk_sum", C.c_void_p), ("chunk_prefix", C.c_void_p),
+                ("capacity", C.c_int64), ("rot", C.c_int64)]
 
 
 class UavEnvError(RuntimeError):
@@ -123,6 +129,19 @@ def load() -> C.CDLL:
     lib.uavenv_dqn_reduce_adam.argtypes = [net, vp, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp]
     lib.uavenv_dqn_act.restype = C.c_int
     lib.uavenv_dqn_act.argtypes = [net, vp, i32, i32, f32, u64, u64, vp, vp, vp, vp]
+    per, f64 = C.POINTER(UavPer), C.c_double
+    lib.uavenv_per_num_chunks.restype = C.c_int
+    lib.uavenv_per_num_chunks.argtypes = [i64]
+    lib.uavenv_per_rotation.restype = C.c_int
+    lib.uavenv_per_rotation.argtypes = [i64]
+    lib.uavenv_per_rebuild.restype = C.c_int
+    lib.uavenv_per_rebuild.argtypes = [per, vp]
+    lib.uavenv_per_sample.restype = C.c_int
+    lib.uavenv_per_sample.argtypes = [per, i32, vp, u64, u64, vp, vp, vp]
+    lib.uavenv_per_set.restype = C.c_int
+    lib.uavenv_per_set.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
+    lib.uavenv_per_fill.restype = C.c_int
+    lib.uavenv_per_fill.argtypes = [per, i64, i64, f64, vp, vp]
     if lib.uavenv_abi_version() != ABI_VERSION:
         raise UavEnvError(f"libuavenv ABI {lib.uavenv_abi_version()} != binding {ABI_VERSION}")
     _LIB = lib

@@ -1,0 +1,226 @@
+// per.hip -- prioritised experience replay on the device (see include/uavenv.h, UavPer).
+//
+// The reference (BaseClass/replay_buffer.py:57-223) keeps a binary sum tree in a flat array and walks it from the
+// root once per sample, one Python loop iteration per level.  On a GPU the tree is the wrong shape: an update would
+// touch log2(c) dependent nodes per leaf, with write conflicts between leaves that share ancestors.  Here the
+// priorities stay a flat f64 array in HBM (one per ring slot) and selection is a two-level prefix search:
+//
+//   k_per_chunk_sum   one workgroup per 1024 in-order leaf positions -> chunk_sum[b]        (reads c x 8 B)
+//   k_per_prefix      exclusive prefix over the chunk sums -> chunk_prefix[n_chunks + 1]    (one workgroup)
+//   k_per_sample      one WAVEFRONT per sample: binary search in chunk_prefix, then the 1024 leaves of that chunk
+//                     are summed 16 per lane, scanned across the 64 lanes, and the owning lane walks its 16
+//   k_per_set         batch_update / push: p[slot] = min(|err| + eps, clip) ** alpha
+//   k_per_fill        the N slots of a freshly written ring frame get the "new transition" priority
+//
+// Selection rule = the tree's: the first in-order leaf whose inclusive cumulative priority reaches v (the descent
+// goes left when v <= left sum, replay_buffer.py:106).  "In-order" matters: with a capacity that is not a power of
+// two the flat tree visits its leaves rotated by rot = 2^floor(log2(2c-1)) - c slots, and position q holds slot
+// (q + rot) % c.  Results equal the reference's for the same draws except where v lands within rounding of a leaf
+// boundary (the tree's inner nodes are history-dependent float sums; these are fresh sums).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uavenv.h"
+#include "uavenv_device.hpp"
+
+using namespace uav;
+
+namespace {
+
+constexpr int kChunk = 1024;
+
+__device__ __forceinline__ int64_t slot_of(const UavPer &p, int64_t q)
+{
+    int64_t s = q + p.rot;
+    return s >= p.capacity ? s - p.capacity : s;
+}
+
+__global__ void __launch_bounds__(256) k_per_chunk_sum(UavPer p)
+{
+    __shared__ double red[256];
+    const int64_t q0 = (int64_t)blockIdx.x * kChunk + (int64_t)threadIdx.x * 4;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t q = q0 + j;
+        if (q < p.capacity) s += p.prio[slot_of(p, q)];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {            // fixed pairing: the sum does not depend on scheduling
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.chunk_sum[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_per_prefix(UavPer p, int n_chunks)
+{
+    __shared__ double part[256];
+    const int per = (n_chunks + 255) / 256;
+    const int b0 = (int)threadIdx.x * per;
+    double s = 0.0;
+    for (int b = b0; b < b0 + per && b < n_chunks; ++b) s += p.chunk_sum[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int t = 0; t < 256; ++t) {
+            const double v = part[t];
+            part[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double run = part[threadIdx.x];
+    for (int b = b0; b < b0 + per && b < n_chunks; ++b) {
+        p.chunk_prefix[b] = run;
+        run += p.chunk_sum[b];
+    }
+    if (b0 < n_chunks && b0 + per >= n_chunks) p.chunk_prefix[n_chunks] = run;     // the total
+}
+
+// One wavefront per sample.
+__global__ void __launch_bounds__(256) k_per_sample(UavPer p, int n_chunks, int batch, const double *__restrict__ draws,
+                                                    uint64_t seed, uint64_t counter, int64_t *__restrict__ out_slot,
+                                                    double *__restrict__ out_prio)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int i = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (i >= batch) return;
+    double v;
+    if (draws) {
+        v = draws[i];
+    } else {      // random.uniform(seg * i, seg * (i + 1)) with seg = int(total) / batch (replay_buffer.py:147,160-162)
+        const double seg = floor(p.chunk_prefix[n_chunks]) / (double)batch;
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)counter, (uint32_t)(counter >> 32), 0x9e7u),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const double a = seg * (double)i, b = seg * (double)(i + 1);
+        v = a + (b - a) * u53(r.x, r.y);
+    }
+    // chunk: the first b with v <= prefix[b + 1]  (wave-uniform binary search)
+    int lo = 0, hi = n_chunks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v <= p.chunk_prefix[mid + 1]) hi = mid; else lo = mid + 1;
+    }
+    const int b = lo;
+    const double r = v - p.chunk_prefix[b];
+    // 16 leaves per lane, then an inclusive scan over the 64 lane sums (fixed order)
+    const int64_t q0 = (int64_t)b * kChunk + (int64_t)lane * 16;
+    double pv[16];
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t q = q0 + j;
+        pv[j] = q < p.capacity ? p.prio[slot_of(p, q)] : 0.0;
+        s += pv[j];
+    }
+    double incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const double excl = incl - s;
+    const unsigned long long hit = __ballot(r <= incl);
+    // rounding can leave r above the chunk's fresh sum: fall back to the last leaf of the chunk (or of the tree)
+    int owner = hit ? __builtin_ctzll(hit) : 63;
+    int64_t last = (int64_t)b * kChunk + kChunk - 1;
+    if (last >= p.capacity) last = p.capacity - 1;
+    if (lane == owner) {
+        int64_t q = last;
+        double pq = 0.0;
+        bool found = false;
+        if (hit) {
+            double run = excl;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                run += pv[j];
+                if (!found && r <= run && q0 + j < p.capacity) { q = q0 + j; pq = pv[j]; found = true; }
+            }
+        }
+        if (!found) { q = last; pq = p.prio[slot_of(p, last)]; }
+        out_slot[i] = slot_of(p, q);
+        if (out_prio) out_prio[i] = pq;
+    }
+}
+
+__global__ void k_per_set(UavPer p, const int64_t *__restrict__ slots, const double *__restrict__ abs_err, int n,
+                          double epsilon, double alpha, double clip)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int64_t s = slots[i];
+    if (s < 0 || s >= p.capacity) return;
+    double e = fabs(abs_err[i]) + epsilon;
+    if (clip > 0.0 && e > clip) e = clip;
+    p.prio[s] = pow(e, alpha);
+}
+
+__global__ void k_per_fill(UavPer p, int64_t first, int64_t count, double value, const uint8_t *__restrict__ valid)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    p.prio[first + i] = (!valid || valid[i]) ? value : 0.0;
+}
+
+bool per_ok(const UavPer *p)
+{
+    return p && p->prio && p->chunk_sum && p->chunk_prefix && p->capacity > 0 && p->rot >= 0 && p->rot < p->capacity;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uavenv_per_num_chunks(int64_t capacity) { return capacity > 0 ? (int)((capacity + kChunk - 1) / kChunk) : 0; }
+
+int uavenv_per_rotation(int64_t capacity)
+{
+    if (capacity <= 0) return 0;
+    int depth = 0;
+    while ((2 * capacity - 1) >> (depth + 1)) ++depth;          // floor(log2(2c - 1))
+    return (int)(((int64_t)1 << depth) - capacity);
+}
+
+int uavenv_per_rebuild(const UavPer *p, void *stream)
+{
+    if (!per_ok(p)) return UAVENV_EINVAL;
+    const int nc = uavenv_per_num_chunks(p->capacity);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_per_chunk_sum, dim3(nc), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(k_per_prefix, dim3(1), dim3(256), 0, s, *p, nc);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_per_sample(const UavPer *p, int32_t batch, const double *draws_dev, uint64_t seed, uint64_t counter,
+                      int64_t *out_slot_dev, double *out_prio_dev, void *stream)
+{
+    if (!per_ok(p) || batch <= 0 || !out_slot_dev) return UAVENV_EINVAL;
+    const int nc = uavenv_per_num_chunks(p->capacity);
+    hipLaunchKernelGGL(k_per_sample, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p, nc, batch, draws_dev,
+                       seed, counter, out_slot_dev, out_prio_dev);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_per_set(const UavPer *p, const int64_t *slots_dev, const double *abs_err_dev, int32_t n, double epsilon,
+                   double alpha, double clip, void *stream)
+{
+    if (!per_ok(p) || !slots_dev || !abs_err_dev || n < 0) return UAVENV_EINVAL;
+    if (n == 0) return UAVENV_OK;
+    hipLaunchKernelGGL(k_per_set, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, slots_dev, abs_err_dev, n,
+                       epsilon, alpha, clip);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_per_fill(const UavPer *p, int64_t first, int64_t count, double priority, const uint8_t *valid_dev, void *stream)
+{
+    if (!per_ok(p) || first < 0 || count < 0 || first + count > p->capacity) return UAVENV_EINVAL;
+    if (count == 0) return UAVENV_OK;
+    hipLaunchKernelGGL(k_per_fill, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, first,
+                       count, priority, valid_dev);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+}  // extern "C"

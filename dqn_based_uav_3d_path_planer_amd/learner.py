@@ -86,6 +86,36 @@ class DQNLearner:
             p.grad.copy_(flat[off:off + n].view_as(p))
             off += n
 
+    def learn_weighted(self, batch: dict, is_weights: torch.Tensor):
+        """One update with importance-sampling weights (prioritised replay): loss = mean_i w_i * per_i, and the
+        |TD error| per sample comes back for ReplayTree.batch_update.  (The reference multiplies the already
+        reduced loss by the weight VECTOR and calls backward on the result -- SAC_Trainer.py:349-350, a RuntimeError
+        in torch; this is the per-sample weighting that line is reaching for.)"""
+        self.epoch += 1
+        states, next_states = batch["states"].float(), batch["next_states"].float()
+        actions = batch["actions"].long().view(-1, 1)
+        rewards, dones = batch["rewards"].view(-1, 1), batch["dones"].view(-1, 1)
+        q_expected = self.q_local(states).gather(1, actions)
+        with torch.no_grad():
+            if self.kind == "dqn":
+                q_next = self.q_target(next_states).max(1)[0].view(-1, 1)
+            else:
+                q_next = self.q_target(next_states).gather(1, self.q_local(next_states).max(1)[1].view(-1, 1))
+            q_targets = rewards + (self.gamma * q_next * (1 - dones))
+        delta = q_expected - q_targets
+        per = torch.nn.functional.smooth_l1_loss(q_expected, q_targets, reduction="none") if self.loss_kind == "huber" \
+            else delta ** 2
+        loss = (per * is_weights.view(-1, 1).to(per.dtype)).mean()
+        self.optim.zero_grad(set_to_none=False)
+        loss.backward()
+        if self.sync == "grad":
+            self._allreduce_grads()
+        self.optim.step()
+        self.loss = loss.detach()
+        if self.epoch % self.update_loop == 0:
+            self.hard_update()
+        return self.loss, delta.detach().abs().view(-1)
+
     def federated_average(self):
         """FedAvg over the ranks: q_local and q_target <- mean over ranks (PathPlan_City.py:590-603 sums the agents'
         state_dicts and divides by their number; here the agents are the ranks and the sum is one all-reduce).  The

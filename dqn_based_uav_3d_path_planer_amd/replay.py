@@ -81,6 +81,16 @@ class DeviceReplayRing:
             self._batch_bufs[batch] = b
         return b
 
+    def gather(self, slots: torch.Tensor) -> dict:
+        """The transitions at data slots frame * N + agent (what a prioritised sampler returns), as a batch dict."""
+        n = self.env.N
+        f = torch.div(slots, n, rounding_mode="floor")
+        nxt = ((f + 1) % self.frames) * n + (slots - f * n)
+        flat = self.obs.view(-1, _lib.OBS_DIM)
+        return dict(states=flat[slots], next_states=flat[nxt], actions=self.action.view(-1)[slots],
+                    rewards=self.reward.view(-1)[slots], dones=self.done.view(-1)[slots].float(),
+                    valid=self.valid.view(-1)[slots].float())
+
     def sample(self, batch: int, seed: int, counter: int) -> dict:
         """ReplayMemory.sample2 (replay_buffer.py:48-51): uniform (frame, agent) draws, gathered on device."""
         if self.filled <= 0:
@@ -93,6 +103,93 @@ class DeviceReplayRing:
                                       self.env._stream())
         _lib.check(rc, "uavenv_replay_sample")
         return b
+
+
+class DevicePER:
+    """ReplayTree (BaseClass/replay_buffer.py:121-223) on the device: one f64 priority per data slot in HBM, selection
+    by the two-level prefix search of csrc/per.hip.  Hyper-parameters and update rules are the reference's:
+    push -> (|error| + epsilon) ** alpha (:143), batch_update -> min(|error| + epsilon, clip) ** alpha (:215-222),
+    beta += beta_inc per sample() (:155), weights (n_entries * p / int(total)) ** -beta / max (:175-178).
+
+    With a replay ring the data slot is frame * N + agent: `on_frame` gives the N transitions k_step has just written
+    the "new transition" priority and clears the frame that became the ring's head (its rows are being reused)."""
+
+    def __init__(self, capacity: int, device="cuda:0", alpha: float = 0.6, beta: float = 0.4, beta_inc: float = 0.001,
+                 epsilon: float = 0.01, clip: float = 1.0, tree_order: bool = True):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.capacity = int(capacity)
+        self.alpha, self.beta, self.beta_inc, self.epsilon, self.clip = alpha, beta, beta_inc, epsilon, clip
+        nc = self.lib.uavenv_per_num_chunks(self.capacity)
+        self.prio = torch.zeros(self.capacity, dtype=torch.float64, device=self.device)
+        self._chunk_sum = torch.zeros(nc, dtype=torch.float64, device=self.device)
+        self._chunk_prefix = torch.zeros(nc + 1, dtype=torch.float64, device=self.device)
+        rot = self.lib.uavenv_per_rotation(self.capacity) if tree_order else 0
+        self._c = _lib.UavPer(self.prio.data_ptr(), self._chunk_sum.data_ptr(), self._chunk_prefix.data_ptr(),
+                              self.capacity, rot)
+        self.n_entries = 0
+        self._dirty = True
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def __len__(self) -> int:
+        return int(self.total())                                                   # ReplayTree.__len__ :133-134
+
+    def total(self) -> float:
+        self._rebuild()
+        return float(self._chunk_prefix[-1].item())
+
+    def _rebuild(self):
+        if self._dirty:
+            _lib.check(self.lib.uavenv_per_rebuild(C.byref(self._c), self._stream()), "uavenv_per_rebuild")
+            self._dirty = False
+
+    def set_priorities(self, prio: torch.Tensor, n_entries: int = None):
+        self.prio.copy_(prio.to(self.device, torch.float64))
+        self.n_entries = self.capacity if n_entries is None else int(n_entries)
+        self._dirty = True
+
+    def fill(self, first: int, count: int, error: float = 0.0, valid: torch.Tensor = None, zero: bool = False):
+        """ReplayTree.push for `count` consecutive slots with the same error (valid[i] == 0 -> priority 0)."""
+        p = 0.0 if zero else (abs(float(error)) + self.epsilon) ** self.alpha
+        rc = self.lib.uavenv_per_fill(C.byref(self._c), int(first), int(count), p,
+                                      None if valid is None else valid.data_ptr(), self._stream())
+        _lib.check(rc, "uavenv_per_fill")
+        self._dirty = True
+
+    def on_frame(self, ring: "DeviceReplayRing"):
+        """Call after ring.step_env(): prioritise the transitions of the frame just completed, retire the new head."""
+        n = ring.env.N
+        t = (ring.head - 1) % ring.frames
+        self.fill(t * n, n, 0.0, valid=ring.valid[t])
+        self.fill(ring.head * n, n, zero=True)
+        self.n_entries = ring.filled * n
+
+    def update(self, slots: torch.Tensor, abs_errors: torch.Tensor):
+        """ReplayTree.batch_update (:215-222)."""
+        slots = slots.to(self.device, torch.int64).contiguous()
+        e = abs_errors.detach().to(self.device, torch.float64).reshape(-1).contiguous()
+        rc = self.lib.uavenv_per_set(C.byref(self._c), slots.data_ptr(), e.data_ptr(), slots.numel(), self.epsilon,
+                                     self.alpha, self.clip, self._stream())
+        _lib.check(rc, "uavenv_per_set")
+        self._dirty = True
+
+    def sample(self, batch: int, seed: int = 0, counter: int = 0, draws: torch.Tensor = None):
+        """ReplayTree.sample (:146-180) -> (slots int64 [batch], is_weights float64 [batch], priorities)."""
+        self._rebuild()
+        self.beta = min(1.0, self.beta + self.beta_inc)
+        slots = torch.empty(batch, dtype=torch.int64, device=self.device)
+        p = torch.empty(batch, dtype=torch.float64, device=self.device)
+        if draws is not None:
+            draws = draws.to(self.device, torch.float64).contiguous()
+        rc = self.lib.uavenv_per_sample(C.byref(self._c), batch, None if draws is None else draws.data_ptr(), int(seed),
+                                        int(counter), slots.data_ptr(), p.data_ptr(), self._stream())
+        _lib.check(rc, "uavenv_per_sample")
+        total_int = torch.floor(self._chunk_prefix[-1])                            # SumTree.total() :117-118
+        w = torch.pow(self.n_entries * (p / total_int), -self.beta)
+        w = w / w.max()
+        return slots, w, p
 
 
 def select_actions(env: VecPathPlanEnv, q: torch.Tensor, eps: float, seed: int, counter: int,

@@ -55,9 +55,12 @@ class SACLearner:
                 p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
 
-    def learn(self, batch: dict, noise=None):
+    def learn(self, batch: dict, noise=None, is_weights=None):
         """One SAC_Trainer.update (continuous branch).  batch: states [B,100], actions [B,2], rewards, next_states,
-        dones.  noise = (eps_next, eps_cur) optionally pins the two rsample() draws."""
+        dones.  noise = (eps_next, eps_cur) optionally pins the two rsample() draws.  is_weights [B] (prioritised
+        replay, IsPriority_Replay == 1): the critic losses become mean_i w_i * err_i^2 and self.abs_errors holds
+        |min(Q1, Q2) - td_target| for ReplayTree.batch_update (SAC_Trainer.py:346-352; the reference's own
+        `is_weights * critic_loss` there is a vector and its backward() raises)."""
         self.epoch += 1
         states, next_states = batch["states"].float(), batch["next_states"].float()
         actions = batch["actions"].float().reshape(len(states), -1)
@@ -65,8 +68,14 @@ class SACLearner:
         e_next, e_cur = noise if noise is not None else (None, None)
         td_target = self.calc_target(rewards, next_states, dones, e_next)
         q1, q2 = self.critic_1(states, actions), self.critic_2(states, actions)
-        critic_1_loss = torch.mean(F.mse_loss(q1, td_target.detach()))
-        critic_2_loss = torch.mean(F.mse_loss(q2, td_target.detach()))
+        if is_weights is None:
+            critic_1_loss = torch.mean(F.mse_loss(q1, td_target.detach()))
+            critic_2_loss = torch.mean(F.mse_loss(q2, td_target.detach()))
+        else:
+            w = is_weights.to(q1.dtype).view(-1, 1)
+            critic_1_loss = torch.mean(w * (q1 - td_target.detach()) ** 2)
+            critic_2_loss = torch.mean(w * (q2 - td_target.detach()) ** 2)
+            self.abs_errors = torch.abs(torch.min(q1, q2) - td_target).detach()[:, 0]      # :351 .squeeze() of [B,2] rows
         for opt, loss, net in ((self.critic_1_optimizer, critic_1_loss, self.critic_1),
                                (self.critic_2_optimizer, critic_2_loss, self.critic_2)):
             opt.zero_grad()

@@ -176,6 +176,37 @@ int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled
 int uavenv_select_actions(const float *q_dev, int32_t n, int32_t n_actions, float eps, uint64_t seed,
                           uint64_t counter, int32_t *index_out_dev, float *steer_out_dev, void *stream);
 
+/* ---- prioritised replay (BaseClass/replay_buffer.py:57-223: SumTree + ReplayTree) on the device -------------------- */
+/* Priorities are a flat f64 array, one per data slot (for the replay ring: slot = frame * N + agent); selection is a
+ * two-level prefix search instead of a tree walk.  chunk_sum / chunk_prefix are scratch the caller allocates:
+ * uavenv_per_num_chunks(capacity) and that + 1 doubles.  rot = uavenv_per_rotation(capacity): the flat-array SumTree
+ * visits its leaves rotated by that many slots when the capacity is not a power of two (0 reproduces plain slot
+ * order). */
+typedef struct UavPer {
+    double *prio;          /* [capacity] */
+    double *chunk_sum;     /* [num_chunks] */
+    double *chunk_prefix;  /* [num_chunks + 1]; the last entry is the total priority */
+    int64_t capacity;
+    int64_t rot;
+} UavPer;
+
+int uavenv_per_num_chunks(int64_t capacity);
+int uavenv_per_rotation(int64_t capacity);
+/* Recompute the chunk sums and their prefix after priorities changed (SumTree.update's propagation, :68-79). */
+int uavenv_per_rebuild(const UavPer *per, void *stream);
+/* ReplayTree.sample (:146-180), selection part: sample i takes v_i = draws_dev[i], or -- draws_dev NULL --
+ * uniform(seg*i, seg*(i+1)) with seg = int(total)/batch from Philox(seed, counter); out_slot_dev[i] = the slot whose
+ * leaf the tree descent (:99-115) reaches, out_prio_dev[i] (nullable) its priority.  Needs a current rebuild. */
+int uavenv_per_sample(const UavPer *per, int32_t batch, const double *draws_dev, uint64_t seed, uint64_t counter,
+                      int64_t *out_slot_dev, double *out_prio_dev, void *stream);
+/* prio[slots[i]] = min(|abs_err[i]| + epsilon, clip) ** alpha   (batch_update :215-222; clip <= 0: no clip = push :143). */
+int uavenv_per_set(const UavPer *per, const int64_t *slots_dev, const double *abs_err_dev, int32_t n, double epsilon,
+                   double alpha, double clip, void *stream);
+/* prio[first .. first+count) = priority where valid_dev[i] != 0 (or everywhere if NULL), 0 elsewhere: the slots of a
+ * ring frame k_step has just written. */
+int uavenv_per_fill(const UavPer *per, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
+                    void *stream);
+
 /* ---- fused DQN-family learner for the reference's Q-MLPs (BaseClass/BaseCNN.py:93-139, w=100, hid=64) ---------- */
 /* Flat f32 parameter blocks in HBM, layout [W1 hid*w][b1 hid][W2 n2*hid][b2 n2] with n2 = n_actions (+1 value row
  * for the dueling VAnet2: rows 0..A-1 = fc_A, row A = fc_V).  m / v are Adam's moments (same layout). */

@@ -1,0 +1,116 @@
+"""Device prioritised replay (csrc/per.hip, replay.DevicePER) against the executed reference's ReplayTree
+(tests/golden/per.npz, made by oracle/gen_golden_per.py) and its CPU restatement (oracle/per_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_selection_and_weights_match_the_reference_on_its_own_draws():
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+    g = load_golden("per.npz")
+    for ci in range(4):
+        pre = f"c{ci}_"
+        cap, batch = int(g[pre + "capacity"]), int(g[pre + "batch"])
+        per = DevicePER(cap)
+        per.set_priorities(torch.tensor(g[pre + "prio"]), n_entries=int(g[pre + "n_entries"]))
+        assert abs(per.total() - float(g[pre + "total"])) <= 1e-12 * float(g[pre + "total"])
+        assert len(per) == int(g[pre + "total_int"])
+        for r in range(3):
+            slots, w, p = per.sample(batch, draws=torch.tensor(g[pre + f"r{r}_draws"]))
+            assert np.array_equal(slots.cpu().numpy(), g[pre + f"r{r}_tree_idx"] - (cap - 1))       # bit-exact indices
+            assert np.allclose(w.cpu().numpy(), g[pre + f"r{r}_weights"], rtol=1e-12, atol=0)
+            assert per.beta == float(g[pre + f"r{r}_beta"])
+
+
+def test_push_and_batch_update_priorities():
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+    g = load_golden("per.npz")
+    pre = "c0_"
+    cap = int(g[pre + "capacity"])
+    per = DevicePER(cap)
+    # push(error): (|e| + eps) ** alpha, no clip  -> same path as update() with clip off
+    per.clip = 0.0
+    per.update(torch.arange(cap), torch.tensor(g[pre + "errors"]))
+    assert np.allclose(per.prio.cpu().numpy(), g[pre + "prio_after_push"], rtol=4e-16, atol=0)
+    per.clip = 1.0
+    per.update(torch.tensor(g[pre + "upd_data"]), torch.tensor(g[pre + "upd_err"]))
+    assert np.allclose(per.prio.cpu().numpy(), g[pre + "prio"], rtol=4e-16, atol=0)
+    per.fill(3, 5, error=0.0)                                   # fresh transitions: 0.01 ** 0.6
+    assert np.allclose(per.prio[3:8].cpu().numpy(), 0.01 ** 0.6, rtol=1e-15)
+    per.fill(3, 5, valid=torch.tensor([1, 0, 1, 0, 0], dtype=torch.uint8, device="cuda"))
+    assert (per.prio[3:8] > 0).cpu().tolist() == [True, False, True, False, False]
+
+
+def test_large_capacity_matches_the_cumsum_restatement_and_the_distribution():
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+    from oracle.per_oracle import sample_by_cumsum
+    rng = np.random.default_rng(5)
+    for cap in (1 << 20, 1000003):
+        prio = rng.uniform(0.0, 1.0, cap) ** 3
+        prio[rng.integers(0, cap, cap // 10)] = 0.0
+        per = DevicePER(cap)
+        per.set_priorities(torch.tensor(prio))
+        total = per.total()
+        assert abs(total - prio.sum()) <= 1e-9 * prio.sum()
+        batch = 4096
+        seg = np.floor(total) / batch
+        draws = seg * (np.arange(batch) + rng.uniform(0, 1, batch))
+        slots, w, p = per.sample(batch, draws=torch.tensor(draws))
+        want = sample_by_cumsum(prio, None, draws)
+        got = slots.cpu().numpy()
+        assert (got != want).sum() <= 2                        # only a draw within rounding of a leaf edge may differ
+        assert np.array_equal(p.cpu().numpy(), prio[got]) and (prio[got] > 0).all()
+        # Philox draws: stratified -> sample i comes from segment i; frequencies follow the priorities
+        slots2, _, _ = per.sample(batch, seed=3, counter=9)
+        s2 = slots2.cpu().numpy()
+        assert (prio[s2] > 0).all() and len(np.unique(s2)) > batch * 0.95
+        slots3, _, _ = per.sample(batch, seed=3, counter=9)
+        assert torch.equal(slots2, slots3)                     # counter-based: reproducible
+    # a heavy slot is drawn in proportion to its priority
+    per = DevicePER(4096)
+    pr = np.full(4096, 0.01)
+    pr[1234] = 40.96 * 3                                       # 3/4 of the mass
+    per.set_priorities(torch.tensor(pr))
+    s, w, _ = per.sample(1024, seed=1, counter=1)
+    frac = float((s == 1234).float().mean())
+    assert 0.70 < frac < 0.80 and float(w.max()) == 1.0
+    assert abs(float(w.min()) - (122.88 / 0.01) ** -per.beta) < 1e-12              # heavy slot: smallest weight
+
+
+def test_ring_integration_new_frames_are_prioritised_and_the_head_is_retired():
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER, DeviceReplayRing
+    n = 512
+    env = make_city26_env(n)
+    ring = DeviceReplayRing(env, 4 * n)
+    ring.reset(seed=3)
+    per = DevicePER(ring.frames * n, tree_order=False)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    L = DQNLearner({"NetWork": "Qnet2", "w": "100", "hiden_dim": "64", "output": "3"}, "dqn", device="cuda:0")
+    for t in range(9):                                          # wraps the 5-frame ring
+        ring.current_action().copy_(torch.randint(0, 3, (n,), generator=gen, device="cuda", dtype=torch.int32))
+        ring.step_env(auto_reset=True)
+        per.on_frame(ring)
+        pf = per.prio.view(ring.frames, n)
+        assert float(pf[ring.head].abs().max()) == 0.0         # the head frame has no action / reward yet
+        assert per.n_entries == ring.filled * n
+        slots, w, _ = per.sample(256, seed=1, counter=t)
+        f = torch.div(slots, n, rounding_mode="floor")
+        assert bool((f != ring.head).all())
+        batch = ring.gather(slots)
+        assert bool((batch["valid"] == 1).all())
+        # next_states of a gathered transition = the observation one frame later of the same agent
+        a = slots - f * n
+        assert torch.equal(batch["next_states"], ring.obs[(f + 1) % ring.frames, a])
+        loss, abs_err = L.learn_weighted(batch, w.float())
+        per.update(slots, abs_err)
+        assert torch.isfinite(loss)
+    # re-prioritised slots carry min(|err| + eps, 1) ** alpha
+    want = torch.clamp(abs_err.double() + 0.01, max=1.0) ** 0.6
+    assert torch.allclose(per.prio[slots], want, rtol=1e-12)
+    env.close()
