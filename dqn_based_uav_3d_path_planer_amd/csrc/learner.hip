@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/uavenv.h"
 #include "uavenv_device.hpp"
@@ -59,14 +60,15 @@ constexpr int kStageIters = (kStageChunks + 255) / 256;  // 7 per thread
 // Phase 1 of staging a 64 x 100 tile: put this thread's 7 global loads in flight (no wait).  Rows come from a
 // per-row pointer table in LDS (gathered replay rows) or are consecutive (weights).
 template <typename T>
-__device__ __forceinline__ void stage_issue(float4 (&v)[kStageIters], const T *const *row_ptr_lds, const T *base_consecutive)
+__device__ __forceinline__ void stage_issue(float4 (&v)[kStageIters], const T *const *row_ptr_lds, const T *base_consecutive,
+                                            int last_row = kTile - 1)
 {
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
         int c = it * 256 + (int)threadIdx.x;
         c = c < kStageChunks ? c : kStageChunks - 1;
         const int row = c / 25, q = c - row * 25;
-        const T *src = row_ptr_lds ? row_ptr_lds[row] : base_consecutive + (size_t)row * kW;
+        const T *src = row_ptr_lds ? row_ptr_lds[row] : base_consecutive + (size_t)(row < last_row ? row : last_row) * kW;
         if (sizeof(T) == 4) {
             v[it] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + 4 * q);
         } else {
@@ -566,21 +568,28 @@ __global__ void __launch_bounds__(256) k_dqn_act(ActArgs g)
     float *b1 = Hs + kTile * kLdh;
     float *W2 = b1 + kHid;
     float *b2 = W2 + kMaxOut * kHid;
-    const ObsT **rows = reinterpret_cast<const ObsT **>(b2 + kMaxOut);
     const int tid = (int)threadIdx.x;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     const NetDev nl = net_view(g.local, n2);
-    if (tid < kTile) {
-        int i = (int)blockIdx.x * kTile + tid;
-        if (i >= g.n) i = g.n - 1;
-        rows[tid] = reinterpret_cast<const ObsT *>(g.obs) + (size_t)i * kW;
-    }
-    for (int k = tid; k < kHid; k += 256) b1[k] = nl.b1[k];
-    for (int k = tid; k < n2 * kHid; k += 256) W2[k] = nl.W2[k];
-    if (tid < n2) b2[tid] = nl.b2[tid];
-    stage_rows<float>(W1, nullptr, nl.W1);
-    __syncthreads();
-    stage_rows<ObsT>(Xs, rows, nullptr);
+    // one memory round trip: the weight tile, the 64 observation rows (consecutive; the last tile clamps to row n-1)
+    // and the small vectors are all in flight before the first LDS write
+    float4 vW[kStageIters], vX[kStageIters];
+    const int first = (int)blockIdx.x * kTile;
+    stage_issue<float>(vW, nullptr, nl.W1);
+    stage_issue<ObsT>(vX, nullptr, reinterpret_cast<const ObsT *>(g.obs) + (size_t)first * kW, g.n - 1 - first);
+    const float pb1 = nl.b1[tid < kHid ? tid : kHid - 1];
+    const int k0 = tid < n2 * kHid ? tid : 0, k1 = tid + 256 < n2 * kHid ? tid + 256 : 0;
+    const int k2 = tid + 512 < n2 * kHid ? tid + 512 : 0, k3 = tid + 768 < n2 * kHid ? tid + 768 : 0;
+    const float pw0 = nl.W2[k0], pw1 = nl.W2[k1], pw2 = nl.W2[k2], pw3 = nl.W2[k3];
+    const float pb2 = nl.b2[tid < n2 ? tid : 0];
+    stage_commit<float>(W1, vW);
+    stage_commit<ObsT>(Xs, vX);
+    if (tid < kHid) b1[tid] = pb1;
+    if (tid < n2 * kHid) W2[tid] = pw0;
+    if (tid + 256 < n2 * kHid) W2[tid + 256] = pw1;
+    if (tid + 512 < n2 * kHid) W2[tid + 512] = pw2;
+    if (tid + 768 < n2 * kHid) W2[tid + 768] = pw3;
+    if (tid < n2) b2[tid] = pb2;
     __syncthreads();
     layer1(Xs, W1, b1, Hs);
     __syncthreads();
