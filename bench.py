@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                    help="BASELINE.json configs[] preset: 2 = 16384 envs DQN (the benchmark line); 3 = 65536 envs, "
                         "DuelingDQN + double-DQN target, f16 observations; 5 = 32768 envs per GPU (262144 over 8)")
+    p.add_argument("--apf", action="store_true", help="diagnostic (env-only): APF on, buildings moving with seeded "
+                   "velocities U(-1,1)^2 (BASELINE configs[3]'s env settings)")
+    p.add_argument("--uav-per-env", type=int, default=1, help="diagnostic (env-only): UAVs per env")
     p.add_argument("--sync", default="grad", choices=["grad", "fedavg"],
                    help="N > 1: all-reduce the gradient bucket every update (default), or average the weights every "
                         "FL_Loop = 3 updates (the reference's federated mode as all-reduce(avg))")
@@ -121,8 +124,17 @@ def main():
 
     obs_dtype = torch.float16 if args.obs_dtype == "f16" else torch.float32
     t_plan = time.perf_counter()
+    extra = {}
+    if args.apf or args.uav_per_env > 1:
+        if not args.env_only:
+            raise SystemExit("--apf / --uav-per-env are env-only diagnostics")
+        extra = dict(apf_enabled=1 if args.apf else 0, uav_per_env=args.uav_per_env)
     env = make_city26_env(args.envs, bank=args.bank, bank_size=max(args.envs, 4096), bank_seed=42 + rank, device=dev,
-                          obs_dtype=obs_dtype, cell_size=args.cell)
+                          obs_dtype=obs_dtype, cell_size=args.cell, **extra)
+    if args.apf:
+        v = np.random.default_rng(42).uniform(-1.0, 1.0, (len(env.buildings), 3))
+        v[:, 2] = 0.0
+        env.set_buildings(env.buildings, velocities=v)
     torch.cuda.synchronize(dev)
     t_plan = time.perf_counter() - t_plan
     ring = DeviceReplayRing(env, args.replay, discrete=True)

@@ -185,24 +185,33 @@ __device__ __noinline__ bool cal_force(const BldApf *__restrict__ b, int nb, dou
     double cum = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
     bool ok = true;
     for (int i = 0; i < nb; ++i) {
-        BldApf B = b[i];
-        if (B.vx == 0.0 && B.vy == 0.0 && B.vz == 0.0) continue;
-        double dis = dist3(x, y, z, B.cx, B.cy, B.cz);
-        double d2e = dis - B.R;
-        if (d2e > 60.0) continue;
-        double q = B.R / (d2e * d2e);
-        double f1 = (q < 1.0) ? q : 1.0;
-        double f1_seta = calc_angle(B.cx - x, B.cy - y);
-        double v_seta = calc_angle(B.vx, B.vy);
-        if (d2e < 0.0) f1 = (-d2e > 2.0) ? -d2e : 2.0;
-        double f1x = -f1 * cos(f1_seta), f1y = -f1 * sin(f1_seta);
-        double q2 = B.vnorm * B.R / (d2e * d2e);
-        double f2 = (q2 < 1.0) ? q2 : 1.0;
-        double f2x = f2 * cos(v_seta), f2y = f2 * sin(v_seta);
+        const BldApf B = b[i];
+        if (B.moving == 0.0) continue;                                          // :180-182 v == 0: no force
+        const double dx = B.cx - x, dy = B.cy - y, dz = B.cz - z;
+        const double h2 = dx * dx + dy * dy;
+        if (h2 + dz * dz > B.far2) continue;                                    // certainly dis - R > 60
+        const double dis = dist3(x, y, z, B.cx, B.cy, B.cz);                    // :183 (same operands as before)
+        const double d2e = dis - B.R;
+        if (d2e > 60.0) continue;                                               // :186-187
+        const double q = B.R / (d2e * d2e);
+        double f1 = (q < 1.0) ? q : 1.0;                                        // :190
+        if (d2e < 0.0) f1 = (-d2e > 2.0) ? -d2e : 2.0;                          // :196-197
+        // :191,:198  direction sub-goal -> centre: (cos, sin) of calculate_angle = the unit vector of (dx, dy); the
+        // zero vector has angle 0.  (The reference goes atan2 -> cos/sin; same direction to ~1e-16.)
+        double cx1 = 1.0, sy1 = 0.0;
+        if (h2 > 0.0) {
+            const double inv = 1.0 / sqrt(h2);
+            cx1 = dx * inv;
+            sy1 = dy * inv;
+        }
+        const double f1x = -f1 * cx1, f1y = -f1 * sy1;
+        const double q2 = B.vnorm * B.R / (d2e * d2e);
+        const double f2 = (q2 < 1.0) ? q2 : 1.0;                                // :200
+        const double f2x = f2 * B.ux, f2y = f2 * B.uy;                          // :201
         cum += (f1 + f2);
         tx = (tx + f1x) + f2x;
         ty = (ty + f1y) + f2y;
-        if (cum > 100.0) { ok = false; break; }
+        if (cum > 100.0) { ok = false; break; }                                 // :205-208
     }
     fx = tx; fy = ty; fz = tz;
     return ok;
@@ -851,7 +860,13 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
         }
         bl[i] = BldLds{cx, cy, t, H};
         double vx = v3 ? v3[3 * i] : 0.0, vy = v3 ? v3[3 * i + 1] : 0.0, vz = v3 ? v3[3 * i + 2] : 0.0;
-        ba[i] = BldApf{cx, cy, cz, R, vx, vy, vz, std::sqrt(vx * vx + vy * vy + vz * vz)};
+        // direction of motion = (cos, sin)(calculate_angle(0, v)) (UAV.py:192,201): a per-building constant
+        const bool moving = !(vx == 0.0 && vy == 0.0 && vz == 0.0);
+        double ang = std::atan2(vy, vx) * (180.0 / M_PI);
+        ang = std::fmod(ang + 360.0, 360.0) / 180.0 * M_PI;
+        const double far = R + 60.0 + 1e-6;
+        ba[i] = BldApf{cx, cy, cz, R, vx, vy, vz, std::sqrt(vx * vx + vy * vy + vz * vz), far * far, std::cos(ang),
+                       std::sin(ang), moving ? 1.0 : 0.0};
     }
     // conservative rasterisation: for halo h the cell rectangle is grown by h (+ margin) on every side and the
     // radius by a margin, so rounding of the cell index (x * inv_cell) or of the distance can never drop a

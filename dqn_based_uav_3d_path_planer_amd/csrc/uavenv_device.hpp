@@ -35,8 +35,11 @@ struct BldAux {
 };
 
 // Cylinder as the APF force needs it (Agents/UAV.py:174-210); global memory, uniform index.
+// far2 = (R + 60 + 1e-6)^2: beyond it `dis - R > 60` holds for sure (1e-6 m guard >> rounding), so the sqrt and
+// everything after it is skipped; ux, uy = (cos, sin) of calculate_angle(0, v): the motion force's direction, a
+// per-building constant the reference recomputes for every (sub-goal, building) pair (:192).
 struct BldApf {
-    double cx, cy, cz, R, vx, vy, vz, vnorm;
+    double cx, cy, cz, R, vx, vy, vz, vnorm, far2, ux, uy, moving;
 };
 
 // The world as a workgroup sees it in LDS: the cylinder table and three candidate grids.
