@@ -139,21 +139,20 @@ struct UavEnv {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
-template <typename MaskT>
-__device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, const StepArgs &a)
+// global -> registers -> LDS by `nthr` threads (this thread is number `tid` of them), no barrier
+__device__ __forceinline__ void stage_copy(unsigned char *smem, const StepArgs &a, int tid, int nthr)
 {
-    // global -> registers -> LDS with up to kInFlight 16-byte loads per lane in flight (a one-load-per-iteration
-    // loop serialises one L2 round trip per KiB and was ~20 % of the kernel at 16 384 envs)
+    // up to kInFlight 16-byte loads per lane in flight (a one-load-per-iteration loop serialises one L2 round trip per
+    // KiB and was ~20 % of the kernel at 16 384 envs)
     constexpr int kInFlight = 12;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.world_blob);
     uint4 *dst = reinterpret_cast<uint4 *>(smem);
     const int n16 = a.world_bytes / 16;
-    const int bsz = a.block;
-    for (int base = 0; base < n16; base += bsz * kInFlight) {
+    for (int base = 0; base < n16; base += nthr * kInFlight) {
         uint4 tmp[kInFlight];
 #pragma unroll
         for (int r = 0; r < kInFlight; ++r) {
-            const int k = base + r * bsz + (int)threadIdx.x;
+            const int k = base + r * nthr + tid;
             tmp[r] = src[k < n16 ? k : n16 - 1];      // unconditional (clamped) so all loads issue back to back
         }
 #pragma unroll
@@ -161,11 +160,15 @@ __device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, cons
             asm volatile("" : "+v"(tmp[r].x), "+v"(tmp[r].y), "+v"(tmp[r].z), "+v"(tmp[r].w));   // its guarded store
 #pragma unroll
         for (int r = 0; r < kInFlight; ++r) {
-            const int k = base + r * bsz + (int)threadIdx.x;
+            const int k = base + r * nthr + tid;
             if (k < n16) dst[k] = tmp[r];
         }
     }
-    __syncthreads();
+}
+
+template <typename MaskT>
+__device__ __forceinline__ WorldLds<MaskT> world_view(unsigned char *smem, const StepArgs &a)
+{
     WorldLds<MaskT> w;
     w.b = reinterpret_cast<const BldLds *>(smem);
     w.aux = reinterpret_cast<const BldAux *>(smem + a.aux_off);
@@ -175,6 +178,14 @@ __device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, cons
     w.W = a.W;
     w.Hbox = a.Hbox;
     return w;
+}
+
+template <typename MaskT>
+__device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, const StepArgs &a)
+{
+    stage_copy(smem, a, (int)threadIdx.x, a.block);
+    __syncthreads();
+    return world_view<MaskT>(smem, a);
 }
 
 // Agents/UAV.py:174-210  cal_force(point): attraction/repulsion + motion force of every MOVING building
@@ -298,66 +309,95 @@ __device__ __forceinline__ const double *list_of(const StepArgs &a, int i, int s
     return scn >= 0 ? a.bank.sub + (size_t)scn * a.K * 3 : a.st.sub + (size_t)i * a.K * 3;
 }
 
-// UAV.reset() from the scenario bank (UAV.py:327-366 with the RRT result pre-planned).  The sub-goal list is
-// NOT copied: the agent just remembers the scenario id (APF mutates sub-goals, so there it is copied).
-template <bool APF>
-__device__ __forceinline__ void reset_agent(const StepArgs &a, int i, Agent &g)
+// UAV.reset() from the scenario bank (UAV.py:327-366 with the RRT result pre-planned), in two halves.
+// reset_candidate needs nothing but (seed, tick, agent index): the Philox draw, the scenario's start / goal / first
+// two sub-goals and the heading's sincos + calc_angle.  apply_reset installs it.  (The cooperative small-N kernel lets
+// a helper wavefront prepare every agent's candidate while the first wavefront runs update_PathPlan.)  The sub-goal
+// list is NOT copied: the agent just remembers the scenario id (APF mutates sub-goals, so there it is copied).
+struct ResetCand {
+    double f[16];     // px py pz gx gy gz s0x s0y s0z s1x s1y s1z vx vy V head
+    int n_total, scn;
+};
+
+__device__ __forceinline__ void reset_candidate(const StepArgs &a, int i, ResetCand &c)
 {
-    ObsIn &o = g.o;
     const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), 0x5eedu),
                                   make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
     const double heading = (kTwoPi)*u53(r.x, r.y);       // random.uniform(0, 2*pi)  (a + (b-a)*random(), a = 0)
     const uint32_t scn = (uint32_t)(((uint64_t)r.z * (uint64_t)a.bank.m) >> 32);
     const double *sg = a.bank.start_goal + (size_t)scn * 6;
     const double *src = a.bank.sub + (size_t)scn * a.K * 3;
-    const int n_total = a.bank.nsub[scn];
-    o.px = sg[0]; o.py = sg[1]; o.pz = sg[2];
-    o.gx = sg[3]; o.gy = sg[4]; o.gz = sg[5];
+    c.scn = (int)scn;
+    c.n_total = a.bank.nsub[scn];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.f[k] = sg[k];
     // bank rows are always K x 3 doubles (zero padded): load unconditionally, no dependent branches
-    o.s0x = src[0]; o.s0y = src[1]; o.s0z = src[2];
-    o.s1x = src[3]; o.s1y = src[4]; o.s1z = src[5];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.f[6 + k] = src[k];
     double sn, cs;
     sincos(heading, &sn, &cs);
-    o.vx = a.max_v * cs;
-    o.vy = a.max_v * sn;
-    o.V = calc_v(o.vx, o.vy, a.max_v);
-    g.head = calc_angle(o.vx, o.vy);
+    double vx = a.max_v * cs, vy = a.max_v * sn;
+    c.f[14] = calc_v(vx, vy, a.max_v);
+    c.f[12] = vx;
+    c.f[13] = vy;
+    c.f[15] = calc_angle(vx, vy);
+}
+
+template <bool APF>
+__device__ __forceinline__ void apply_reset(const StepArgs &a, int i, Agent &g, const ResetCand &c)
+{
+    ObsIn &o = g.o;
+    o.px = c.f[0]; o.py = c.f[1]; o.pz = c.f[2];
+    o.gx = c.f[3]; o.gy = c.f[4]; o.gz = c.f[5];
+    o.s0x = c.f[6]; o.s0y = c.f[7]; o.s0z = c.f[8];
+    o.s1x = c.f[9]; o.s1y = c.f[10]; o.s1z = c.f[11];
+    o.vx = c.f[12]; o.vy = c.f[13]; o.V = c.f[14];
+    g.head = c.f[15];
     o.step = 0;
     g.score = 0.0; g.total = 0.0; g.path_len = 0.0;
     g.done = 0; g.reach = 0; g.epoch = 0;
-    g.n_total = n_total;
+    g.n_total = c.n_total;
     g.sub_idx = 0;
-    g.alias = n_total >= 2 ? 1 : 0;      // path[0] is the start node == the position object (RRT.py:69)
+    g.alias = c.n_total >= 2 ? 1 : 0;      // path[0] is the start node == the position object (RRT.py:69)
     if (APF) {
+        const double *src = a.bank.sub + (size_t)c.scn * a.K * 3;
         double *dst = a.st.sub + (size_t)i * a.K * 3;
-        for (int k = 0; k < n_total * 3; ++k) dst[k] = src[k];
+        for (int k = 0; k < c.n_total * 3; ++k) dst[k] = src[k];
         g.scn = -1;
     } else {
-        g.scn = (int)scn;
+        g.scn = c.scn;
     }
-    o.n_rem = n_total;
+    o.n_rem = c.n_total;
 }
 
-// Agents/UAV.py:397-513  update_PathPlan(action) on the register copy of one agent.
-template <typename MaskT, bool APF, bool INL>
-__device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
-                                           double &r, int &ret_done, int &info)
+template <bool APF>
+__device__ __forceinline__ void reset_agent(const StepArgs &a, int i, Agent &g)
+{
+    ResetCand c;
+    reset_candidate(a, i, c);
+    apply_reset<APF>(a, i, g, c);
+}
+
+// Agents/UAV.py:397-513  update_PathPlan(action), first and second half.
+// Split in two for the cooperative kernel: step_pre needs only the agent's own state and action (no world, no
+// heading angle), step_post everything else.  k_step calls pre, the heading, post back to back (== the one function
+// this used to be).
+struct PreStep {
+    double ox, oy, oz, dis_old, g_old, tgx, tgy;
+    bool moved;                // false: :400-406, no sub-goal left -- nothing moves
+};
+
+__device__ __forceinline__ void step_pre(const StepArgs &a, double a0, Agent &g, PreStep &P)
 {
     ObsIn &o = g.o;
-    const int max_step = a.max_step;
-    r = 0.0; ret_done = 0; info = UAVENV_INFO_NORMAL;
-    if (g.sub_idx >= g.n_total) {                                              // :400-406
-        g.done = 1;
-        r += (double)(max_step - o.step);
-        g.score += r;
-        ret_done = 1; info = UAVENV_INFO_SUCCESS;
-        return;
-    }
+    P.moved = g.sub_idx < g.n_total;
+    P.ox = o.px; P.oy = o.py; P.oz = o.pz;                                     // :409
+    P.dis_old = P.g_old = P.tgx = P.tgy = 0.0;
+    if (!P.moved) return;
     o.step += 1;                                                               // :408
-    const double ox = o.px, oy = o.py, oz = o.pz;                              // :409
     const double seta_old = g.head;                                            // :411 (cached: same V_vector)
-    const double dis_old = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);       // :412
-    const double g_old = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);            // :413
+    P.dis_old = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);                  // :412
+    P.g_old = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);                       // :413
     const double seta_new = seta_old + a0 * a.steer;                           // :414
     double sn, cs;
     sincos(seta_new, &sn, &cs);
@@ -369,15 +409,49 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
     if (g.alias) { o.s0x = o.px; o.s0y = o.py; o.s0z = o.pz; }                 // sub_goals[0] IS position after reset
     // :422-428  tri_goal = angle(sub0 - pos), tri_V = angle(V) -- or angle(sub0 - old pos) after a collision.  Only
     // cos|tri_goal - tri_V| is ever used, so the vectors are kept and cos_between() replaces two atan2 chains.
-    const double tgx = o.s0x - o.px, tgy = o.s0y - o.py;                       // :422
-    g.head = angle_of<INL>(o.vx, o.vy);                                        // :423 (and obs[7], and next :411)
-    double tvx = o.vx, tvy = o.vy;
-    if (probe(w, o.px, o.py, o.pz)) {                                          // :425-428
-        r -= 0.3;
-        o.px = ox; o.py = oy; o.pz = oz;
-        g.alias = 0;
-        tvx = o.s0x - o.px; tvy = o.s0y - o.py;
+    P.tgx = o.s0x - o.px; P.tgy = o.s0y - o.py;                                // :422
+}
+
+// The heading after the move, :423 (and obs[7], and the next step's :411): depends on the OLD heading and the action
+// only, so the cooperative kernel lets another wavefront compute it.
+template <bool INL>
+__device__ __forceinline__ double heading_after(const StepArgs &a, double head_old, double a0)
+{
+    const double seta_new = head_old + a0 * a.steer;
+    double sn, cs;
+    sincos(seta_new, &sn, &cs);
+    double vx = a.max_v * cs, vy = a.max_v * sn;
+    (void)calc_v(vx, vy, a.max_v);
+    return angle_of<INL>(vx, vy);
+}
+
+// `head_set`: true when this function assigned g.head itself (:489, Calc_V rescaled the velocity again)
+template <typename MaskT, bool APF, bool INL>
+__device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
+                                          const PreStep &P, double &r, int &ret_done, int &info, bool &head_set)
+{
+    ObsIn &o = g.o;
+    const int max_step = a.max_step;
+    r = 0.0; ret_done = 0; info = UAVENV_INFO_NORMAL;
+    head_set = false;
+    if (!P.moved) {                                                            // :400-406
+        g.done = 1;
+        r += (double)(max_step - o.step);
+        g.score += r;
+        ret_done = 1; info = UAVENV_INFO_SUCCESS;
+        return;
     }
+    const double ox = P.ox, oy = P.oy, oz = P.oz, dis_old = P.dis_old, g_old = P.g_old, tgx = P.tgx, tgy = P.tgy;
+    // :425-428 as selects, not a branch.  (hipcc 7.2 was seen to merge the divergent `if (collided) { pos = old; }` with
+    // a stale copy of the new position feeding the distances below -- in one kernel, not in the other, same source.
+    // Selects leave it nothing to merge.)
+    const bool hit = probe(w, o.px, o.py, o.pz);
+    r = hit ? r - 0.3 : r;
+    o.px = hit ? ox : o.px;
+    o.py = hit ? oy : o.py;
+    o.pz = hit ? oz : o.pz;
+    g.alias = hit ? 0 : g.alias;
+    const double tvx = hit ? o.s0x - o.px : o.vx, tvy = hit ? o.s0y - o.py : o.vy;
     const double dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);       // :429
     const double g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);            // :430
     r -= 0.13 * fabs(a0);                                                      // :434
@@ -438,7 +512,7 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
                 const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
                 o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
             }
-            if (o.vx != vx0 || o.vy != vy0) g.head = angle_of<INL>(o.vx, o.vy);   // :489 (Calc_V rescaled again)
+            if (o.vx != vx0 || o.vy != vy0) { g.head = angle_of<INL>(o.vx, o.vy); head_set = true; }   // :489
             r += 0.2 * cos_between(o.s0x - o.px, o.s0y - o.py, o.vx, o.vy);    // :488-490
             r += (double)(max_step - o.step);                                  // :491
             g.score += r; g.total += r;
@@ -455,6 +529,18 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
     } else {                                                                   // :510-513
         g.score += r; g.total += r;
     }
+}
+
+// Agents/UAV.py:397-513  update_PathPlan(action) on the register copy of one agent.
+template <typename MaskT, bool APF, bool INL>
+__device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
+                                           double &r, int &ret_done, int &info)
+{
+    PreStep P;
+    step_pre(a, a0, g, P);
+    if (P.moved) g.head = angle_of<INL>(g.o.vx, g.o.vy);                       // :423
+    bool head_set;
+    step_post<MaskT, APF, INL>(a, w, ii, a0, g, P, r, ret_done, info, head_set);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -567,6 +653,178 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
             store_obs_ctile<F16>(a.obs, first, N - first, tile, sc, bits);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same step for SMALL launches (<= 2 wavefronts' worth of agents per CU): four wavefronts per 64 agents.
+// With one wavefront per CU the launch is as long as its slowest wavefront's serial chain (staging -> f64 step math ->
+// reset -> observation -> 50+ stores) and three of the CU's four SIMDs idle.  Here wavefront 0 is the agent (lane ==
+// agent, exactly the code above), and the other three take the work that does not depend on its serial chain:
+//   while wave 0 runs update_PathPlan:  wave 1 prepares EVERY agent's reset candidate (Philox, bank rows, heading)
+//   after the positions are final:      waves 0 / 1 / 2 each build one occupancy stencil, wave 3 the below-probes
+//   store phase:                        waves 1-3 stream the 64 observation rows out of the compact tile (coalesced
+//                                       1 KiB runs) while wave 0 writes the state planes and the step outputs.
+// Three workgroup barriers; every value is computed by the same device functions on the same operands as in k_step.
+struct CoopLds {
+    double cand[16][64];
+    int32_t cand_n[64], cand_scn[64];
+    double pos[64][4];                 // position after step + reset (x, y, z, pad)
+    double head[64];                   // heading after the move, from wave 2
+    uint32_t acc[4][64];               // per-wave stencil accumulators (atomicOr targets)
+    uint32_t queue[4][kObsQueueCap];
+    uint32_t tile[64 * kCTileLd];
+};
+
+template <typename MaskT, bool APF, bool F16>
+__global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const DevState &S = a.st;
+    const int N = a.N;
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    const int first = (int)blockIdx.x * 64;
+    const int i = first + lane;
+    const bool active = i < N;
+    const int ii = active ? i : N - 1;
+    CoopLds *C = reinterpret_cast<CoopLds *>(smem + a.obsq_off);
+    const bool want_obs = a.obs && !(a.flags & UAVENV_STEP_NO_OBS);
+    const bool auto_reset = (a.flags & UAVENV_STEP_AUTO_RESET) != 0;
+    UAV_STAMP(0);
+
+    Agent g;
+    RawAction ra = {0u, 0u};
+    double head_old = 0.0;
+    if (wv == 0) {                       // the state loads fly while the other three wavefronts stage the world blob
+        load_agent(S, ii, g);
+        ra = load_action_raw(a.actions, a.action_kind, ii);
+    } else if (wv == 2) {                // wave 2 computes the heading after the move (:423): old heading + action only
+        head_old = S.F(F_HEAD)[ii];
+        ra = load_action_raw(a.actions, a.action_kind, ii);
+    }
+    uint32_t *trow = C->tile + lane * kCTileLd;
+    if (wv == 3) { trow[0] = 0u; trow[1] = 0u; trow[2] = 0u; }               // mask words: OR targets of the four waves
+    double r = 0.0, a0 = 0.0;
+    int ret_done = 0, info = UAVENV_INFO_NORMAL, valid = 1, agent_done = 0;
+    double energy = 0.0;
+    bool did_reset = false, skip = false, head_set = false;
+    PreStep pre;
+    pre.moved = false;
+    if (wv != 0) {
+        stage_copy(smem, a, (int)threadIdx.x - 64, 192);
+    } else {                             // first half of update_PathPlan: needs the agent's own state only
+        unpack_flags(g);
+        a0 = decode_action(ra, a.action_kind, a.n_actions);
+        const bool masked = a.active && a.active[ii] == 0;
+        skip = masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done);
+        if (!skip) step_pre(a, a0, g, pre);
+    }
+    __syncthreads();                                                         // world staged
+    const WorldLds<MaskT> w = world_view<MaskT>(smem, a);
+    UAV_STAMP(1);
+
+    if (wv == 1 && auto_reset) {
+        ResetCand c;
+        reset_candidate(a, ii, c);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) C->cand[k][lane] = c.f[k];
+        C->cand_n[lane] = c.n_total;
+        C->cand_scn[lane] = c.scn;
+    }
+    if (wv == 2) C->head[lane] = heading_after<true>(a, head_old, decode_action(ra, a.action_kind, a.n_actions));
+    if (wv == 0) {
+        if (skip) {
+            ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
+        } else {
+            step_post<MaskT, APF, true>(a, w, ii, a0, g, pre, r, ret_done, info, head_set);
+        }
+    }
+    UAV_STAMP(2);
+    __syncthreads();                                                         // candidates ready, step done
+    UAV_STAMP(3);
+    if (wv == 0) {
+        if (!skip && pre.moved && !head_set) g.head = C->head[lane];         // :423, computed by wave 2
+        g.o.n_rem = g.n_total - g.sub_idx;
+        agent_done = g.done;
+        energy = a.energy64 ? fly_power(a.pw, g.o.V, ii % a.U) : 0.0;
+        // ---- auto reset: the env restarts when ALL of its U agents are done (PathPlan_City.py:252-259,416-417)
+        if (auto_reset) {
+            const unsigned long long dm = __ballot(active && g.done);
+            const int g0 = (lane / a.U) * a.U;
+            const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
+            if (active && ((dm & gm) == gm)) {
+                ResetCand c;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) c.f[k] = C->cand[k][lane];
+                c.n_total = C->cand_n[lane];
+                c.scn = C->cand_scn[lane];
+                apply_reset<APF>(a, ii, g, c);
+                did_reset = true;
+            }
+        }
+        C->pos[lane][0] = g.o.px;
+        C->pos[lane][1] = g.o.py;
+        C->pos[lane][2] = g.o.pz;
+    }
+    __syncthreads();                                                         // positions final
+    UAV_STAMP(4);
+    if (want_obs) {
+        const double px = C->pos[lane][0], py = C->pos[lane][1], pz = C->pos[lane][2];
+        if (wv == 0) ctile_write_scalars(trow, obs_scalars(g.o, g.head));    // :526 heading == cached angle
+        // wave 0: 1 m stencil (+ the scalars above); wave 1: 5 m stencil; waves 2 and 3 share the 10 m stencil (the
+        // one with the most candidate cylinders: even / odd candidates), wave 3 adds the below-probes
+        ObsBits part = {0u, 0u, 0u, 0u};
+        const MaskT all = (MaskT)~(MaskT)0, even = (MaskT)0x5555555555555555ull;
+        if (wv == 0) {
+            part.s1 = obs_stencil_queued<MaskT>(w, C->queue[0], C->acc[0], &C->pos[0][0], 0, px, py, pz, active, all);
+        } else if (wv == 1) {
+            part.s5 = obs_stencil_queued<MaskT>(w, C->queue[1], C->acc[1], &C->pos[0][0], 1, px, py, pz, active, all);
+        } else if (wv == 2) {
+            part.s10 = obs_stencil_queued<MaskT>(w, C->queue[2], C->acc[2], &C->pos[0][0], 2, px, py, pz, active, even);
+        } else {
+            part.s10 = obs_stencil_queued<MaskT>(w, C->queue[3], C->acc[3], &C->pos[0][0], 2, px, py, pz, active,
+                                                 (MaskT)~even);
+            part.below = obs_below_bits(w, px, py, pz);
+        }
+        uint32_t m0, m1, m2;
+        ctile_mask_words(part, m0, m1, m2);
+        if (m0) atomicOr(&trow[0], m0);
+        if (m1) atomicOr(&trow[1], m1);
+        if (m2) atomicOr(&trow[2], m2);
+    }
+    UAV_STAMP(5);
+    __syncthreads();                                                         // tile complete
+    UAV_STAMP(6);
+    if (wv == 0) {
+        if (active) {
+            // ---- outputs of the transition
+            if (a.reward64) a.reward64[i] = r;
+            if (a.reward32) a.reward32[i] = (float)r;
+            if (a.ret_done) a.ret_done[i] = (uint8_t)ret_done;
+            if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
+            if (a.info) a.info[i] = (uint8_t)info;
+            if (a.valid) a.valid[i] = (uint8_t)valid;
+            if (a.energy64) a.energy64[i] = energy;
+            // ---- state write-back
+            if (valid || did_reset) store_agent(S, i, g);
+        }
+    }
+    if (want_obs) {
+        // 25 coalesced store instructions: 8 each for waves 1..3 (fixed trip count: unrolled, so the LDS reads of one
+        // instruction overlap the selects of the previous), the odd one for wave 0 after its own stores
+        const int nv = N - first;
+        const int lo = wv == 0 ? 24 : (wv - 1) * 8;
+        if (nv >= 64) {                     // workgroup-uniform: all but the last workgroup take the unguarded form
+            if (wv == 0) {
+                ctile_emit<F16>(a.obs, first, nv, C->tile, 24, false);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ctile_emit<F16>(a.obs, first, nv, C->tile, lo + j, false);
+            }
+        } else {
+            for (int j = 0; j < (wv == 0 ? 1 : 8); ++j) ctile_emit<F16>(a.obs, first, nv, C->tile, lo + j, true);
+        }
+    }
+    UAV_STAMP(7);
 }
 
 // state_PathPlan only
@@ -765,6 +1023,23 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     a.wave_slot = slot;
     a.tile_off = tile_store ? a.obsq_off : -1;
     const size_t lds = (size_t)a.obsq_off + (size_t)nw * slot;
+    // <= 32 768 agents: the cooperative four-wavefronts-per-64-agents kernel (see k_step_coop)
+    static const int coop_env = env_int("UAVENV_COOP", -1);
+    const bool coop = coop_env >= 0 ? coop_env != 0 : e->N <= 32768;
+    if (coop) {
+        a.block = 256;
+        a.obsq_off = (e->world_bytes + 15) & ~15;
+        const size_t clds = (size_t)a.obsq_off + sizeof(CoopLds);
+        const int cgrid = (e->N + 63) / 64;
+        if (apf) {
+            if (f16) hipLaunchKernelGGL((k_step_coop<MaskT, true, true>), dim3(cgrid), dim3(256), clds, s, a);
+            else hipLaunchKernelGGL((k_step_coop<MaskT, true, false>), dim3(cgrid), dim3(256), clds, s, a);
+        } else {
+            if (f16) hipLaunchKernelGGL((k_step_coop<MaskT, false, true>), dim3(cgrid), dim3(256), clds, s, a);
+            else hipLaunchKernelGGL((k_step_coop<MaskT, false, false>), dim3(cgrid), dim3(256), clds, s, a);
+        }
+        return;
+    }
     if (apf) {
         if (f16) hipLaunchKernelGGL((k_step<MaskT, true, true>), dim3(grid), dim3(block), lds, s, a);
         else hipLaunchKernelGGL((k_step<MaskT, true, false>), dim3(grid), dim3(block), lds, s, a);

@@ -435,6 +435,120 @@ __device__ __forceinline__ ObsBits obs_bits_queued(const WorldLds<MaskT> &w, Obs
     return o;
 }
 
+// ---- one stencil per wavefront (the cooperative small-N kernel) ---------------------------------------------------
+// Stencil k (spacing kSp[k]) of state_PathPlan for the 64 agents of a workgroup, by ONE wavefront: the same
+// classify -> queue -> dense 25-point tests as obs_bits_queued, but over the stencil's own halo grid g[k] (fewer
+// candidates than the widest grid) and with a single test per candidate.  pos = LDS [64][4] doubles (x, y, z, pad),
+// acc = LDS [64] words this function zeroes and ORs into.  Same exact tests on the same operands => the same bits.
+template <typename MaskT>
+__device__ __forceinline__ void stencil_queue_drain(const WorldLds<MaskT> &w, const uint32_t *queue, uint32_t *acc,
+                                                    const double *pos, double sp, int count)
+{
+    const int lane = (int)threadIdx.x & 63;
+    wave_lds_sync();
+    for (int base = 0; base < count; base += 64) {
+        const int it = base + lane;
+        if (it < count) {
+            const uint32_t item = queue[it];
+            const int owner = (int)(item & 63u), b = (int)(item >> 6);
+            const double px = pos[owner * 4], py = pos[owner * 4 + 1];
+            const BldLds B = w.b[b];
+            double dx2[5], dy2[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double dx = (px + sp * (double)(i - 2)) - B.cx, dy = (py + sp * (double)(i - 2)) - B.cy;
+                dx2[i] = dx * dx;
+                dy2[i] = dy * dy;
+            }
+            uint32_t bk = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bk |= ((dx2[i] + dy2[j]) < B.thr) ? (1u << (5 * i + j)) : 0u;
+            if (bk) atomicOr(&acc[owner], bk);
+        }
+    }
+    wave_lds_sync();
+}
+
+// `subset` selects which candidate cylinders this wavefront handles (all ones: every candidate); two wavefronts with
+// complementary subsets split one stencil between them and OR their results.
+template <typename MaskT>
+__device__ __forceinline__ uint32_t obs_stencil_queued(const WorldLds<MaskT> &w, uint32_t *queue, uint32_t *acc,
+                                                       const double *pos, int k, double px, double py, double pz,
+                                                       bool active, MaskT subset)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const double sp = k == 0 ? 1.0 : (k == 1 ? 5.0 : 10.0);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const double xi = px + sp * (double)(i - 2), yi = py + sp * (double)(i - 2);
+        mine |= ((xi < 0.0) | (xi > w.W)) ? (0x1Fu << (5 * i)) : 0u;
+        mine |= ((yi < 0.0) | (yi > w.W)) ? (0x108421u << i) : 0u;
+    }
+    if ((pz < 0.0) | (pz > w.Hbox)) mine = 0x1FFFFFFu;
+    acc[lane] = 0u;
+    MaskT m = active ? (MaskT)(w.g[k][cell_of(w, px, py)] & subset) : (MaskT)0;
+    int count = 0;                                   // wave-uniform
+    while (__ballot(m != 0) != 0ull) {
+        if (count > kObsQueueCap - 64) {
+            stencil_queue_drain(w, queue, acc, pos, sp, count);
+            count = 0;
+        }
+        const bool have = m != 0;
+        const int b = have ? ctz_mask(m) : 0;
+        if (have) m &= (MaskT)(m - 1);
+        bool full = false;
+        if (have) {
+            const BldLds B = w.b[b];
+            const double rej2 = w.aux[b].rej2[k], acc2 = w.aux[b].acc2[k];
+            const double dcx = px - B.cx, dcy = py - B.cy;
+            const double dc2 = dcx * dcx + dcy * dcy;
+            if (!(pz > B.H)) {
+                if (dc2 < acc2) mine = 0x1FFFFFFu;                  // stencil entirely inside the disc
+                else if (dc2 < rej2) full = true;                   // can touch: needs the 25 exact tests
+            }
+        }
+        const unsigned long long bm = __ballot(full);
+        if (bm) {
+            const int at = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (full) queue[at] = (uint32_t)lane | ((uint32_t)b << 6);
+            count += __builtin_popcountll(bm);
+        }
+    }
+    stencil_queue_drain(w, queue, acc, pos, sp, count);
+    return mine | acc[lane];
+}
+
+// UAV.py:562-566: Threaten_rate(px, py, pz - k), k = 1..5 (all 1 while the UAV is on the ground: z - k < 0)
+template <typename MaskT>
+__device__ __forceinline__ uint32_t obs_below_bits(const WorldLds<MaskT> &w, double px, double py, double pz)
+{
+    uint32_t bl = 0;
+    const bool xy_out = (px < 0.0) | (px > w.W) | (py < 0.0) | (py > w.W);
+#pragma unroll
+    for (int k = 1; k <= 5; ++k) {
+        const double z = pz - (double)k;
+        bl |= (xy_out | (z < 0.0) | (z > w.Hbox)) ? (1u << (k - 1)) : 0u;
+    }
+    if (bl != 0x1Fu) {                                   // only when the UAV flies above ground level
+        MaskT m = w.g[0][cell_of(w, px, py)];
+        while (m) {
+            const int b = ctz_mask(m);
+            m &= (MaskT)(m - 1);
+            const BldLds B = w.b[b];
+            const double dcx = px - B.cx, dcy = py - B.cy;
+            if (dcx * dcx + dcy * dcy < B.thr) {
+#pragma unroll
+                for (int k = 1; k <= 5; ++k) bl |= !((pz - (double)k) > B.H) ? (1u << (k - 1)) : 0u;
+            }
+        }
+    }
+    return bl;
+}
+
 // The 20 scalar features of state_PathPlan (UAV.py:518-531, 557-560), as float.
 struct ObsScalars {
     float f[20];   // 0..10 -> cols 0..10 ; 11..14 -> cols 86..89
@@ -516,63 +630,79 @@ __device__ __forceinline__ void store_obs_row(void *obs_base, int64_t agent, con
 // instruction.
 constexpr int kCTileLd = 23;                      // 3 mask words + 20 scalar slots; odd -> conflict-free column writes
 constexpr int kCTileBytes = 64 * kCTileLd * 4;    // 5 888 B per wavefront
+// mask words of a compact-tile row from the four bit fields (bit (col & 31) of word (col >> 5) = column col's flag)
+__device__ __forceinline__ void ctile_mask_words(const ObsBits &b, uint32_t &m0, uint32_t &m1, uint32_t &m2)
+{
+    m0 = b.s1 << 11;
+    m1 = (b.s1 >> 21) | (b.s5 << 4) | (b.s10 << 29);
+    m2 = (b.s10 >> 3) | (b.below << 26);
+}
+
+__device__ __forceinline__ void ctile_write_scalars(uint32_t *row, const ObsScalars &s)
+{
+    float *sl = reinterpret_cast<float *>(row + 3);   // slot = col for cols 0..10, col - 72 for cols 86..89
+#pragma unroll
+    for (int c = 0; c < 11; ++c) sl[c] = s.f[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sl[14 + c] = s.f[11 + c];
+}
+
+// store instruction `it` (0..24) of the 64-row block: lane handles flat elements it*256 + lane*4 .. +3
+template <bool F16>
+__device__ __forceinline__ void ctile_emit(void *obs_base, int64_t first_agent, int n_valid, const uint32_t *tile, int it,
+                                           bool guard)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int e = it * 256 + lane * 4;            // flat element index inside the 64 x 100 block of rows
+    const int r = e / 100, c = e - r * 100, cg = c >> 2;
+    // branch-free: every lane reads one mask word and four scalar slots (clamped addresses), then selects
+    const uint32_t *src = tile + r * kCTileLd;
+    const int w = c >> 5;
+    const uint32_t mw = src[w < 3 ? w : 2];
+    const bool edge = (cg == 21) | (cg == 22);
+    const int sb = cg < 3 ? c : edge ? c - 72 : 0;
+    const float s0 = reinterpret_cast<const float *>(src + 3 + sb)[0];
+    const float s1 = reinterpret_cast<const float *>(src + 3 + sb)[1];
+    const float s2 = reinterpret_cast<const float *>(src + 3 + sb)[2];
+    const float s3 = reinterpret_cast<const float *>(src + 3 + sb)[3];
+    const uint32_t nib = w < 3 ? (mw >> (c & 31)) : 0u;
+    const uint32_t snib = cg < 2 ? 15u : cg == 2 ? 7u : cg == 21 ? 12u : cg == 22 ? 3u : 0u;
+    float v[4];
+    v[0] = (snib & 1u) ? s0 : (float)(nib & 1u);
+    v[1] = (snib & 2u) ? s1 : (float)((nib >> 1) & 1u);
+    v[2] = (snib & 4u) ? s2 : (float)((nib >> 2) & 1u);
+    v[3] = (snib & 8u) ? s3 : (float)((nib >> 3) & 1u);
+    if (!guard || r < n_valid) {
+        if (!F16) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs_base) + first_agent * 100 + e) =
+                make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            __half2 lo = __floats2half2_rn(v[0], v[1]);
+            __half2 hi = __floats2half2_rn(v[2], v[3]);
+            uint2 o;
+            o.x = *reinterpret_cast<uint32_t *>(&lo);
+            o.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(obs_base) + first_agent * 100 + e) = o;
+        }
+    }
+}
+
 template <bool F16>
 __device__ __forceinline__ void store_obs_ctile(void *obs_base, int64_t first_agent, int n_valid, uint32_t *tile,
                                                 const ObsScalars &s, const ObsBits &b)
 {
     const int lane = (int)threadIdx.x & 63;
     uint32_t *row = tile + lane * kCTileLd;
-    // bit (col & 31) of word (col >> 5) = the flag of observation column col (stencils 11..85, below-probes 90..94)
-    row[0] = b.s1 << 11;
-    row[1] = (b.s1 >> 21) | (b.s5 << 4) | (b.s10 << 29);
-    row[2] = (b.s10 >> 3) | (b.below << 26);
-    float *sl = reinterpret_cast<float *>(row + 3);   // slot = col for cols 0..10, col - 72 for cols 86..89
-#pragma unroll
-    for (int c = 0; c < 11; ++c) sl[c] = s.f[c];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sl[14 + c] = s.f[11 + c];
+    ctile_mask_words(b, row[0], row[1], row[2]);
+    ctile_write_scalars(row, s);
     wave_lds_sync();
-    auto emit = [&](int it, bool guard) {
-        const int e = it * 256 + lane * 4;            // flat element index inside the 64 x 100 block of rows
-        const int r = e / 100, c = e - r * 100, cg = c >> 2;
-        // branch-free: every lane reads one mask word and four scalar slots (clamped addresses), then selects
-        const uint32_t *src = tile + r * kCTileLd;
-        const int w = c >> 5;
-        const uint32_t mw = src[w < 3 ? w : 2];
-        const bool edge = (cg == 21) | (cg == 22);
-        const int sb = cg < 3 ? c : edge ? c - 72 : 0;
-        const float s0 = reinterpret_cast<const float *>(src + 3 + sb)[0];
-        const float s1 = reinterpret_cast<const float *>(src + 3 + sb)[1];
-        const float s2 = reinterpret_cast<const float *>(src + 3 + sb)[2];
-        const float s3 = reinterpret_cast<const float *>(src + 3 + sb)[3];
-        const uint32_t nib = w < 3 ? (mw >> (c & 31)) : 0u;
-        const uint32_t snib = cg < 2 ? 15u : cg == 2 ? 7u : cg == 21 ? 12u : cg == 22 ? 3u : 0u;
-        float v[4];
-        v[0] = (snib & 1u) ? s0 : (float)(nib & 1u);
-        v[1] = (snib & 2u) ? s1 : (float)((nib >> 1) & 1u);
-        v[2] = (snib & 4u) ? s2 : (float)((nib >> 2) & 1u);
-        v[3] = (snib & 8u) ? s3 : (float)((nib >> 3) & 1u);
-        if (!guard || r < n_valid) {
-            if (!F16) {
-                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs_base) + first_agent * 100 + e) =
-                    make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                __half2 lo = __floats2half2_rn(v[0], v[1]);
-                __half2 hi = __floats2half2_rn(v[2], v[3]);
-                uint2 o;
-                o.x = *reinterpret_cast<uint32_t *>(&lo);
-                o.y = *reinterpret_cast<uint32_t *>(&hi);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(obs_base) + first_agent * 100 + e) = o;
-            }
-        }
-    };
     const int nv = __builtin_amdgcn_readfirstlane(n_valid);      // same in every lane; tell the compiler
     if (nv >= 64) {             // every wavefront but the last takes the unguarded, straight-line form
 #pragma unroll
-        for (int it = 0; it < 25; ++it) emit(it, false);
+        for (int it = 0; it < 25; ++it) ctile_emit<F16>(obs_base, first_agent, n_valid, tile, it, false);
     } else {
 #pragma unroll
-        for (int it = 0; it < 25; ++it) emit(it, true);
+        for (int it = 0; it < 25; ++it) ctile_emit<F16>(obs_base, first_agent, n_valid, tile, it, true);
     }
     wave_lds_sync();
 }
