@@ -108,6 +108,7 @@ struct StepArgs {
     float *reward32;
     uint8_t *ret_done, *agent_done, *info, *valid;
     double *energy64;
+    const uint2 *emit_lut;             // [25][64] packed (row, mask word, shift, scalar base, scalar nibble) of ctile_emit
     const uint8_t *active;             // nullable per-agent mask: 0 -> the agent is left untouched (valid = 0)
     unsigned long long *dbg;           // diagnostics: per-wave phase timestamps (s_memtime), 8 slots per wave
     uint32_t flags;
@@ -127,6 +128,7 @@ struct UavEnv {
     int world_bytes = 0, aux_off = 0, grid_off = 0, grid_stride = 0, nb = 0, gn = 0, mask_bytes = 8;
     double cell = 10.0;
     BldApf *apf_b = nullptr;
+    uint2 *emit_lut = nullptr;
     bool have_world = false;
     // bank
     double *bank_sg = nullptr, *bank_sub = nullptr;
@@ -319,7 +321,7 @@ struct ResetCand {
     int n_total, scn;
 };
 
-__device__ __forceinline__ void reset_candidate(const StepArgs &a, int i, ResetCand &c)
+__device__ __forceinline__ double reset_candidate_issue(const StepArgs &a, int i, ResetCand &c)
 {
     const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), 0x5eedu),
                                   make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
@@ -334,6 +336,11 @@ __device__ __forceinline__ void reset_candidate(const StepArgs &a, int i, ResetC
     // bank rows are always K x 3 doubles (zero padded): load unconditionally, no dependent branches
 #pragma unroll
     for (int k = 0; k < 6; ++k) c.f[6 + k] = src[k];
+    return heading;
+}
+
+__device__ __forceinline__ void reset_candidate_finish(const StepArgs &a, double heading, ResetCand &c)
+{
     double sn, cs;
     sincos(heading, &sn, &cs);
     double vx = a.max_v * cs, vy = a.max_v * sn;
@@ -341,6 +348,12 @@ __device__ __forceinline__ void reset_candidate(const StepArgs &a, int i, ResetC
     c.f[12] = vx;
     c.f[13] = vy;
     c.f[15] = calc_angle(vx, vy);
+}
+
+__device__ __forceinline__ void reset_candidate(const StepArgs &a, int i, ResetCand &c)
+{
+    const double heading = reset_candidate_issue(a, i, c);
+    reset_candidate_finish(a, heading, c);
 }
 
 template <bool APF>
@@ -425,10 +438,13 @@ __device__ __forceinline__ double heading_after(const StepArgs &a, double head_o
     return angle_of<INL>(vx, vy);
 }
 
-// `head_set`: true when this function assigned g.head itself (:489, Calc_V rescaled the velocity again)
-template <typename MaskT, bool APF, bool INL>
+// `head_set`: true when this function assigned g.head itself (:489, Calc_V rescaled the velocity again).
+// DEFER (cooperative kernel, APF off): after a pop the new look-ahead sub-goal is NOT fetched here -- nothing in this
+// function reads it -- but `need_s1` is raised and the caller installs it from where a helper wavefront put it.
+template <typename MaskT, bool APF, bool INL, bool DEFER = false>
 __device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
-                                          const PreStep &P, double &r, int &ret_done, int &info, bool &head_set)
+                                          const PreStep &P, double &r, int &ret_done, int &info, bool &head_set,
+                                          bool *need_s1 = nullptr)
 {
     ObsIn &o = g.o;
     const int max_step = a.max_step;
@@ -509,8 +525,12 @@ __device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<Mask
             o.V = calc_v(o.vx, o.vy, a.max_v);
             o.s0x = o.s1x; o.s0y = o.s1y; o.s0z = o.s1z;
             if (g.sub_idx + 1 < g.n_total) {
-                const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
-                o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
+                if (DEFER && !APF) {
+                    *need_s1 = true;
+                } else {
+                    const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
+                    o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
+                }
             }
             if (o.vx != vx0 || o.vy != vy0) { g.head = angle_of<INL>(o.vx, o.vy); head_set = true; }   // :489
             r += 0.2 * cos_between(o.s0x - o.px, o.s0y - o.py, o.vx, o.vy);    // :488-490
@@ -670,6 +690,7 @@ struct CoopLds {
     int32_t cand_n[64], cand_scn[64];
     double pos[64][4];                 // position after step + reset (x, y, z, pad)
     double head[64];                   // heading after the move, from wave 2
+    double ahead[64][3];               // sub-goal (sub_idx + 2) of every agent, from wave 3: what a pop moves into s1
     uint32_t acc[4][64];               // per-wave stencil accumulators (atomicOr targets)
     uint32_t queue[4][kObsQueueCap];
     uint32_t tile[64 * kCTileLd];
@@ -701,6 +722,23 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         head_old = S.F(F_HEAD)[ii];
         ra = load_action_raw(a.actions, a.action_kind, ii);
     }
+    // wave 1: every agent's reset candidate.  Philox and the bank rows need nothing but the agent index: their round
+    // trip runs under the world staging.
+    ResetCand cand;
+    double cand_heading = 0.0;
+    if (wv == 1 && auto_reset) cand_heading = reset_candidate_issue(a, ii, cand);
+    // wave 3: the sub-goal two places ahead of every agent -- what a pop moves into the look-ahead slot (APF rewrites
+    // the list inside the step and reads it there)
+    int ah_sub = 0, ah_scn = -1;
+    if (wv == 3 && !APF) { ah_sub = S.I(I_SUBIDX)[ii]; ah_scn = S.I(I_SCN)[ii]; }
+    // waves 1-3: their rows of the copy-out table (depends on (instruction, lane) only)
+    uint2 lut[8];
+    if (wv != 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lut[j] = a.emit_lut[((wv - 1) * 8 + j) * 64 + lane];
+    } else {
+        lut[0] = a.emit_lut[24 * 64 + lane];
+    }
     uint32_t *trow = C->tile + lane * kCTileLd;
     if (wv == 3) { trow[0] = 0u; trow[1] = 0u; trow[2] = 0u; }               // mask words: OR targets of the four waves
     double r = 0.0, a0 = 0.0;
@@ -709,7 +747,8 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     bool did_reset = false, skip = false, head_set = false;
     PreStep pre;
     pre.moved = false;
-    if (wv != 0) {
+    bool need_s1 = false;
+    if (wv != 0) {                       // the world blob comes in through waves 1-3
         stage_copy(smem, a, (int)threadIdx.x - 64, 192);
     } else {                             // first half of update_PathPlan: needs the agent's own state only
         unpack_flags(g);
@@ -723,19 +762,24 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     UAV_STAMP(1);
 
     if (wv == 1 && auto_reset) {
-        ResetCand c;
-        reset_candidate(a, ii, c);
+        reset_candidate_finish(a, cand_heading, cand);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) C->cand[k][lane] = c.f[k];
-        C->cand_n[lane] = c.n_total;
-        C->cand_scn[lane] = c.scn;
+        for (int k = 0; k < 16; ++k) C->cand[k][lane] = cand.f[k];
+        C->cand_n[lane] = cand.n_total;
+        C->cand_scn[lane] = cand.scn;
     }
     if (wv == 2) C->head[lane] = heading_after<true>(a, head_old, decode_action(ra, a.action_kind, a.n_actions));
+    if (wv == 3 && !APF) {
+        int q = ah_sub + 2;
+        q = q < a.K ? q : a.K - 1;
+        const double *nx = list_of(a, ii, ah_scn) + (size_t)(q < 0 ? 0 : q) * 3;
+        C->ahead[lane][0] = nx[0]; C->ahead[lane][1] = nx[1]; C->ahead[lane][2] = nx[2];
+    }
     if (wv == 0) {
         if (skip) {
             ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
         } else {
-            step_post<MaskT, APF, true>(a, w, ii, a0, g, pre, r, ret_done, info, head_set);
+            step_post<MaskT, APF, true, true>(a, w, ii, a0, g, pre, r, ret_done, info, head_set, &need_s1);
         }
     }
     UAV_STAMP(2);
@@ -743,6 +787,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     UAV_STAMP(3);
     if (wv == 0) {
         if (!skip && pre.moved && !head_set) g.head = C->head[lane];         // :423, computed by wave 2
+        if (need_s1) { g.o.s1x = C->ahead[lane][0]; g.o.s1y = C->ahead[lane][1]; g.o.s1z = C->ahead[lane][2]; }
         g.o.n_rem = g.n_total - g.sub_idx;
         agent_done = g.done;
         energy = a.energy64 ? fly_power(a.pw, g.o.V, ii % a.U) : 0.0;
@@ -815,13 +860,18 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         const int lo = wv == 0 ? 24 : (wv - 1) * 8;
         if (nv >= 64) {                     // workgroup-uniform: all but the last workgroup take the unguarded form
             if (wv == 0) {
-                ctile_emit<F16>(a.obs, first, nv, C->tile, 24, false);
+                ctile_emit_lut<F16>(a.obs, first, nv, C->tile, 24, lut[0], false);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ctile_emit<F16>(a.obs, first, nv, C->tile, lo + j, false);
+                for (int j = 0; j < 8; ++j) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, lo + j, lut[j], false);
             }
         } else {
-            for (int j = 0; j < (wv == 0 ? 1 : 8); ++j) ctile_emit<F16>(a.obs, first, nv, C->tile, lo + j, true);
+            if (wv == 0) {
+                ctile_emit_lut<F16>(a.obs, first, nv, C->tile, 24, lut[0], true);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, lo + j, lut[j], true);
+            }
         }
     }
     UAV_STAMP(7);
@@ -959,6 +1009,7 @@ static StepArgs base_args(const UavEnv *e)
     a.W = e->cfg.width;
     a.Hbox = e->cfg.h;
     a.apf_b = e->apf_b;
+    a.emit_lut = e->emit_lut;
     a.max_v = e->cfg.max_v;
     a.steer = e->cfg.steering_angle;
     a.pw = PowerParams{e->cfg.power[0], e->cfg.power[1], e->cfg.power[2], e->cfg.power[3],
@@ -981,8 +1032,7 @@ static StepArgs base_args(const UavEnv *e)
 // Launch geometry.  Every k_step launch is "one agent per thread" (straight-line body, 128 VGPRs):
 //  * N <= 131 072: single-wavefront workgroups, so the wavefronts spread over all 256 CUs;
 //  * beyond that: 256-thread workgroups (the ~10 KB world blob is staged once per 256 agents, not once per 64).
-// Observation rows: up to two wavefronts per CU (N <= 32 768) the launch is latency-bound and each lane stores its
-// own row; above that the wavefront's 64 rows go out through the compact LDS tile (store_obs_ctile), which shares its bytes
+// Observation rows: small launches (N <= 49 152) go to k_step_coop; above that the wavefront's 64 rows go out through the compact LDS tile (store_obs_ctile), which shares its bytes
 // with the by-then-dead observation work queue: ~16 KB per single-wave workgroup, ~34 KB per 256-thread one, so
 // LDS allows as many wavefronts per CU as the VGPR budget does (16).
 // MEASURED (round 1, us per launch, row-per-lane -> compact tile): 16 384 envs 12.6 -> 14.7 and 32 768: 15.4 -> 16.2
@@ -1023,9 +1073,11 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     a.wave_slot = slot;
     a.tile_off = tile_store ? a.obsq_off : -1;
     const size_t lds = (size_t)a.obsq_off + (size_t)nw * slot;
-    // <= 32 768 agents: the cooperative four-wavefronts-per-64-agents kernel (see k_step_coop)
+    // <= 49 152 agents (three wavefronts' worth of agents per CU): the cooperative four-wavefronts-per-64-agents kernel
+    // (see k_step_coop).  MEASURED (us per launch, k_step -> k_step_coop): 4 096 envs 10.6 -> 7.8; 16 384: 11.7 -> 8.8;
+    // 32 768: 14.6 -> 11.6; 49 152: 16.1 -> 14.1; 65 536: 16.6 -> 19.5 (k_step kept from there on).
     static const int coop_env = env_int("UAVENV_COOP", -1);
-    const bool coop = coop_env >= 0 ? coop_env != 0 : e->N <= 32768;
+    const bool coop = coop_env >= 0 ? coop_env != 0 : e->N <= 49152;
     if (coop) {
         a.block = 256;
         a.obsq_off = (e->world_bytes + 15) & ~15;
@@ -1092,6 +1144,17 @@ int uavenv_create(const UavEnvConfig *cfg, UavEnv **out)
     p = (unsigned char *)(((uintptr_t)p + 63) & ~(uintptr_t)63);
     e->st.i32 = (int32_t *)p; p += npad * 4 * kNumI32;
     (void)hipMemset(e->st.I(I_SCN), 0xff, npad * 4);   // scn = -1: private (empty) list
+    {
+        std::vector<uint2> lut(25 * 64);
+        for (int it = 0; it < 25; ++it)
+            for (int l = 0; l < 64; ++l) lut[(size_t)it * 64 + l] = ctile_emit_lut_entry(it, l);
+        if (hipMalloc((void **)&e->emit_lut, lut.size() * sizeof(uint2)) != hipSuccess ||
+            hipMemcpy(e->emit_lut, lut.data(), lut.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(e->slab);
+            delete e;
+            return fail(UAVENV_ENOMEM, "emit table");
+        }
+    }
     *out = e;
     return UAVENV_OK;
 }
@@ -1103,6 +1166,7 @@ int uavenv_destroy(UavEnv *e)
     (void)hipFree(e->slab);
     (void)hipFree(e->world_blob);
     (void)hipFree(e->apf_b);
+    (void)hipFree(e->emit_lut);
     (void)hipFree(e->bank_sg);
     (void)hipFree(e->bank_sub);
     (void)hipFree(e->bank_nsub);

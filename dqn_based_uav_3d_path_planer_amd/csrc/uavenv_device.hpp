@@ -687,6 +687,57 @@ __device__ __forceinline__ void ctile_emit(void *obs_base, int64_t first_agent, 
     }
 }
 
+// The same store instruction with everything that depends only on (it, lane) -- the row, the mask word and shift, the
+// scalar slot base and which of the four columns are scalars -- read from two precomputed words (host side:
+// ctile_emit_lut_entry; LDS byte offsets included): ~25 VALU per instruction instead of ~60.  Columns 96..99 take mask word 2 shifted by 31
+// (bit 31 of that word is never set), so they need no special case.
+__host__ __device__ inline uint2 ctile_emit_lut_entry(int it, int lane)
+{
+    const int e = it * 256 + lane * 4;
+    const int r = e / 100, c = e - r * 100, cg = c >> 2;
+    const int w = c >> 5;
+    const uint32_t wi = w < 3 ? (uint32_t)w : 2u, sh = w < 3 ? (uint32_t)(c & 31) : 31u;
+    const bool edge = (cg == 21) | (cg == 22);
+    const uint32_t sb = (uint32_t)(cg < 3 ? c : edge ? c - 72 : 0);
+    const uint32_t snib = cg < 2 ? 15u : cg == 2 ? 7u : cg == 21 ? 12u : cg == 22 ? 3u : 0u;
+    uint2 L;
+    L.x = (uint32_t)(r * kCTileLd + (int)wi) * 4u | (sh << 16) | (snib << 24);       // mask word byte offset, shift, nibble
+    L.y = (uint32_t)(r * kCTileLd + 3 + (int)sb) * 4u | ((uint32_t)r << 16);          // scalar slots byte offset, row
+    return L;
+}
+
+template <bool F16>
+__device__ __forceinline__ void ctile_emit_lut(void *obs_base, int64_t first_agent, int n_valid, const uint32_t *tile,
+                                               int it, uint2 L, bool guard)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int e = it * 256 + lane * 4;
+    const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile);
+    const uint32_t mw = *reinterpret_cast<const uint32_t *>(tb + (L.x & 0xFFFFu));
+    const float *ss = reinterpret_cast<const float *>(tb + (L.y & 0xFFFFu));
+    float s0 = ss[0], s1 = ss[1], s2 = ss[2], s3 = ss[3];
+    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));       // all four LDS reads unconditional: hipcc otherwise
+    const uint32_t nib = mw >> ((L.x >> 16) & 31u);                   // wraps some in a branch on their select bit
+    float v[4];
+    v[0] = (L.x & (1u << 24)) ? s0 : (float)(nib & 1u);
+    v[1] = (L.x & (1u << 25)) ? s1 : (float)((nib >> 1) & 1u);
+    v[2] = (L.x & (1u << 26)) ? s2 : (float)((nib >> 2) & 1u);
+    v[3] = (L.x & (1u << 27)) ? s3 : (float)((nib >> 3) & 1u);
+    if (!guard || (int)(L.y >> 16) < n_valid) {
+        if (!F16) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs_base) + first_agent * 100 + e) =
+                make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            __half2 lo = __floats2half2_rn(v[0], v[1]);
+            __half2 hi = __floats2half2_rn(v[2], v[3]);
+            uint2 o;
+            o.x = *reinterpret_cast<uint32_t *>(&lo);
+            o.y = *reinterpret_cast<uint32_t *>(&hi);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(obs_base) + first_agent * 100 + e) = o;
+        }
+    }
+}
+
 template <bool F16>
 __device__ __forceinline__ void store_obs_ctile(void *obs_base, int64_t first_agent, int n_valid, uint32_t *tile,
                                                 const ObsScalars &s, const ObsBits &b)
