@@ -321,21 +321,31 @@ struct ResetCand {
     int n_total, scn;
 };
 
-__device__ __forceinline__ double reset_candidate_issue(const StepArgs &a, int i, ResetCand &c)
+// the draw: scenario index + heading (random.uniform(0, 2*pi) = a + (b-a)*random(), a = 0)
+__device__ __forceinline__ double reset_candidate_draw(const StepArgs &a, int i, ResetCand &c)
 {
     const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), 0x5eedu),
                                   make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
-    const double heading = (kTwoPi)*u53(r.x, r.y);       // random.uniform(0, 2*pi)  (a + (b-a)*random(), a = 0)
-    const uint32_t scn = (uint32_t)(((uint64_t)r.z * (uint64_t)a.bank.m) >> 32);
-    const double *sg = a.bank.start_goal + (size_t)scn * 6;
-    const double *src = a.bank.sub + (size_t)scn * a.K * 3;
-    c.scn = (int)scn;
-    c.n_total = a.bank.nsub[scn];
+    c.scn = (int)(uint32_t)(((uint64_t)r.z * (uint64_t)a.bank.m) >> 32);
+    return (kTwoPi)*u53(r.x, r.y);
+}
+
+// the scenario's bank rows: start, goal, first two sub-goals (always K x 3 doubles, zero padded: no dependent branches)
+__device__ __forceinline__ void reset_candidate_fetch(const StepArgs &a, ResetCand &c)
+{
+    const double *sg = a.bank.start_goal + (size_t)c.scn * 6;
+    const double *src = a.bank.sub + (size_t)c.scn * a.K * 3;
+    c.n_total = a.bank.nsub[c.scn];
 #pragma unroll
     for (int k = 0; k < 6; ++k) c.f[k] = sg[k];
-    // bank rows are always K x 3 doubles (zero padded): load unconditionally, no dependent branches
 #pragma unroll
     for (int k = 0; k < 6; ++k) c.f[6 + k] = src[k];
+}
+
+__device__ __forceinline__ double reset_candidate_issue(const StepArgs &a, int i, ResetCand &c)
+{
+    const double heading = reset_candidate_draw(a, i, c);
+    reset_candidate_fetch(a, c);
     return heading;
 }
 
@@ -439,12 +449,9 @@ __device__ __forceinline__ double heading_after(const StepArgs &a, double head_o
 }
 
 // `head_set`: true when this function assigned g.head itself (:489, Calc_V rescaled the velocity again).
-// DEFER (cooperative kernel, APF off): after a pop the new look-ahead sub-goal is NOT fetched here -- nothing in this
-// function reads it -- but `need_s1` is raised and the caller installs it from where a helper wavefront put it.
-template <typename MaskT, bool APF, bool INL, bool DEFER = false>
+template <typename MaskT, bool APF, bool INL>
 __device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
-                                          const PreStep &P, double &r, int &ret_done, int &info, bool &head_set,
-                                          bool *need_s1 = nullptr)
+                                          const PreStep &P, double &r, int &ret_done, int &info, bool &head_set)
 {
     ObsIn &o = g.o;
     const int max_step = a.max_step;
@@ -525,12 +532,8 @@ __device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<Mask
             o.V = calc_v(o.vx, o.vy, a.max_v);
             o.s0x = o.s1x; o.s0y = o.s1y; o.s0z = o.s1z;
             if (g.sub_idx + 1 < g.n_total) {
-                if (DEFER && !APF) {
-                    *need_s1 = true;
-                } else {
-                    const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
-                    o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
-                }
+                const double *nx = list_of(a, ii, g.scn) + (size_t)(g.sub_idx + 1) * 3;
+                o.s1x = nx[0]; o.s1y = nx[1]; o.s1z = nx[2];
             }
             if (o.vx != vx0 || o.vy != vy0) { g.head = angle_of<INL>(o.vx, o.vy); head_set = true; }   // :489
             r += 0.2 * cos_between(o.s0x - o.px, o.s0y - o.py, o.vx, o.vy);    // :488-490
@@ -690,7 +693,6 @@ struct CoopLds {
     int32_t cand_n[64], cand_scn[64];
     double pos[64][4];                 // position after step + reset (x, y, z, pad)
     double head[64];                   // heading after the move, from wave 2
-    double ahead[64][3];               // sub-goal (sub_idx + 2) of every agent, from wave 3: what a pop moves into s1
     uint32_t acc[4][64];               // per-wave stencil accumulators (atomicOr targets)
     uint32_t queue[4][kObsQueueCap];
     uint32_t tile[64 * kCTileLd];
@@ -724,13 +726,22 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     }
     // wave 1: every agent's reset candidate.  Philox and the bank rows need nothing but the agent index: their round
     // trip runs under the world staging.
+    // Only for agents that CAN be done after this step (already done, on their last sub-goal, out of steps, or within
+    // reach of the goal): fetching bank rows for everyone tripled the launch's HBM reads.  Wave 0 falls back to
+    // reset_agent for an agent without a candidate (cannot happen with this predicate; kept for safety).
     ResetCand cand;
     double cand_heading = 0.0;
-    if (wv == 1 && auto_reset) cand_heading = reset_candidate_issue(a, ii, cand);
-    // wave 3: the sub-goal two places ahead of every agent -- what a pop moves into the look-ahead slot (APF rewrites
-    // the list inside the step and reads it there)
-    int ah_sub = 0, ah_scn = -1;
-    if (wv == 3 && !APF) { ah_sub = S.I(I_SUBIDX)[ii]; ah_scn = S.I(I_SCN)[ii]; }
+    bool cand_want = false;
+    if (wv == 1 && auto_reset) {
+        const int c_flags = S.I(I_FLAGS)[ii], c_sub = S.I(I_SUBIDX)[ii], c_n = S.I(I_NTOTAL)[ii], c_step = S.I(I_STEP)[ii];
+        const double dx = S.F(F_GX)[ii] - S.F(F_PX)[ii], dy = S.F(F_GY)[ii] - S.F(F_PY)[ii],
+                     dz = S.F(F_GZ)[ii] - S.F(F_PZ)[ii];
+        cand_heading = reset_candidate_draw(a, ii, cand);                    // under the loads' round trip
+        const double reach = 7.0 + a.max_v + 1.0;                            // :496 d_goal < 7 after a move of <= max_v
+        cand_want = (c_flags & kFlagDone) || c_sub >= c_n - 1 || c_step + 1 >= a.max_step ||
+                    dx * dx + dy * dy + dz * dz < reach * reach;
+        if (cand_want) reset_candidate_fetch(a, cand);
+    }
     // waves 1-3: their rows of the copy-out table (depends on (instruction, lane) only)
     uint2 lut[8];
     if (wv != 0) {
@@ -747,10 +758,9 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     bool did_reset = false, skip = false, head_set = false;
     PreStep pre;
     pre.moved = false;
-    bool need_s1 = false;
-    if (wv != 0) {                       // the world blob comes in through waves 1-3
-        stage_copy(smem, a, (int)threadIdx.x - 64, 192);
-    } else {                             // first half of update_PathPlan: needs the agent's own state only
+    if (wv >= 2) {                       // the world blob comes in through waves 2 and 3 (wave 1's loads depend on
+        stage_copy(smem, a, (int)threadIdx.x - 128, 128);                    // its state loads: it would hold the barrier)
+    } else if (wv == 0) {                             // first half of update_PathPlan: needs the agent's own state only
         unpack_flags(g);
         a0 = decode_action(ra, a.action_kind, a.n_actions);
         const bool masked = a.active && a.active[ii] == 0;
@@ -762,24 +772,22 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     UAV_STAMP(1);
 
     if (wv == 1 && auto_reset) {
-        reset_candidate_finish(a, cand_heading, cand);
+        if (cand_want) {
+            reset_candidate_finish(a, cand_heading, cand);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) C->cand[k][lane] = cand.f[k];
-        C->cand_n[lane] = cand.n_total;
-        C->cand_scn[lane] = cand.scn;
+            for (int k = 0; k < 16; ++k) C->cand[k][lane] = cand.f[k];
+            C->cand_n[lane] = cand.n_total;
+            C->cand_scn[lane] = cand.scn;
+        } else {
+            C->cand_scn[lane] = -1;                                          // no candidate prepared
+        }
     }
     if (wv == 2) C->head[lane] = heading_after<true>(a, head_old, decode_action(ra, a.action_kind, a.n_actions));
-    if (wv == 3 && !APF) {
-        int q = ah_sub + 2;
-        q = q < a.K ? q : a.K - 1;
-        const double *nx = list_of(a, ii, ah_scn) + (size_t)(q < 0 ? 0 : q) * 3;
-        C->ahead[lane][0] = nx[0]; C->ahead[lane][1] = nx[1]; C->ahead[lane][2] = nx[2];
-    }
     if (wv == 0) {
         if (skip) {
             ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
         } else {
-            step_post<MaskT, APF, true, true>(a, w, ii, a0, g, pre, r, ret_done, info, head_set, &need_s1);
+            step_post<MaskT, APF, true>(a, w, ii, a0, g, pre, r, ret_done, info, head_set);
         }
     }
     UAV_STAMP(2);
@@ -787,7 +795,6 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     UAV_STAMP(3);
     if (wv == 0) {
         if (!skip && pre.moved && !head_set) g.head = C->head[lane];         // :423, computed by wave 2
-        if (need_s1) { g.o.s1x = C->ahead[lane][0]; g.o.s1y = C->ahead[lane][1]; g.o.s1z = C->ahead[lane][2]; }
         g.o.n_rem = g.n_total - g.sub_idx;
         agent_done = g.done;
         energy = a.energy64 ? fly_power(a.pw, g.o.V, ii % a.U) : 0.0;
@@ -798,11 +805,15 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
             if (active && ((dm & gm) == gm)) {
                 ResetCand c;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) c.f[k] = C->cand[k][lane];
-                c.n_total = C->cand_n[lane];
                 c.scn = C->cand_scn[lane];
-                apply_reset<APF>(a, ii, g, c);
+                if (c.scn >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) c.f[k] = C->cand[k][lane];
+                    c.n_total = C->cand_n[lane];
+                    apply_reset<APF>(a, ii, g, c);
+                } else {
+                    reset_agent<APF>(a, ii, g);
+                }
                 did_reset = true;
             }
         }
