@@ -140,27 +140,6 @@ __device__ __forceinline__ void layer1(const float *X, const float *W1, const fl
     }
 }
 
-// layer 2 for one sample: out[n2] = W2 h + b2, then Q (dueling: V + A - mean A, BaseCNN.py:131-138)
-__device__ __forceinline__ void layer2(const float *h, const float *W2, const float *b2, int n_actions, int dueling,
-                                       float *q /*[n_actions]*/)
-{
-    const int n2 = n_actions + (dueling ? 1 : 0);
-    float out[kMaxOut];
-    for (int a = 0; a < n2; ++a) {
-        float s = 0.0f;
-        for (int j = 0; j < kHid; ++j) s = fmaf(h[j], W2[a * kHid + j], s);
-        out[a] = s + b2[a];
-    }
-    if (dueling) {
-        float mean = 0.0f;
-        for (int a = 0; a < n_actions; ++a) mean += out[a];
-        mean /= (float)n_actions;
-        for (int a = 0; a < n_actions; ++a) q[a] = out[n_actions] + out[a] - mean;
-    } else {
-        for (int a = 0; a < n_actions; ++a) q[a] = out[a];
-    }
-}
-
 // Layer 2 for a whole 64-sample tile with ALL threads of the workgroup: one (sample, output) dot product per thread
 // (consecutive threads -> consecutive samples -> conflict-free H reads; W2 row broadcast), four accumulators so the
 // LDS latency overlaps.  out2[s][a] = W2[a] . H[s] + b2[a].  (A thread-per-sample loop over all outputs ran on 64

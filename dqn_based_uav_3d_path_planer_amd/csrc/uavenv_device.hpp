@@ -191,51 +191,6 @@ struct ObsIn {
     int step, n_rem;   // n_rem = len(sub_goals)
 };
 
-// 5x5 occupancy stencil at `sp` metres (UAV.py:533-555): bit 5*i+j <- Threaten_rate(px+(i-2)sp, py+(j-2)sp, pz).
-// One candidate mask (grid with halo 2*sp) serves all 25 points; per candidate the 25 exact tests share the
-// 5 dx^2 and 5 dy^2 terms and run branch-free.
-template <typename MaskT>
-__device__ __forceinline__ uint32_t stencil_bits(const WorldLds<MaskT> &w, int k, int cell, double px, double py,
-                                                 double pz, double sp)
-{
-    double x[5], y[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        x[i] = px + sp * (double)(i - 2);
-        y[i] = py + sp * (double)(i - 2);
-    }
-    uint32_t bits = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        bits |= ((x[i] < 0.0) | (x[i] > w.W)) ? (0x1Fu << (5 * i)) : 0u;        // whole row i out of the box
-        bits |= ((y[i] < 0.0) | (y[i] > w.W)) ? (0x108421u << i) : 0u;          // whole column j=i out of the box
-    }
-    if ((pz < 0.0) | (pz > w.Hbox)) bits = 0x1FFFFFFu;
-    MaskT m = w.g[k][cell];
-    while (m) {
-        const int b = ctz_mask(m);
-        m &= (MaskT)(m - 1);
-        const BldLds B = w.b[b];
-        const double dcx = px - B.cx, dcy = py - B.cy;
-        const double dc2 = dcx * dcx + dcy * dcy;
-        const double rej2 = w.aux[b].rej2[k], acc2 = w.aux[b].acc2[k];
-        if ((dc2 >= rej2) | (pz > B.H)) continue;          // cannot touch this stencil / UAV above the roof
-        if (dc2 < acc2) { bits = 0x1FFFFFFu; continue; }   // stencil entirely inside the disc
-        double dx2[5], dy2[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const double dx = x[i] - B.cx, dy = y[i] - B.cy;
-            dx2[i] = dx * dx;
-            dy2[i] = dy * dy;
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int j = 0; j < 5; ++j) bits |= ((dx2[i] + dy2[j]) < B.thr) ? (1u << (5 * i + j)) : 0u;
-    }
-    return bits;
-}
-
 struct ObsBits {
     uint32_t s1, s5, s10, below;
 };
