@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         if (a.flags & UAVENV_STEP_AUTO_RESET) {
             const unsigned long long dm = __ballot(active && g.done);
             const int lane = threadIdx.x & 63;
-            const int g0 = (lane / a.U) * a.U;
+            const int g0 = lane & ~(a.U - 1);          // U is a power of two (uavenv_create)
             const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
             if (active && ((dm & gm) == gm)) {
                 reset_agent<APF>(a, ii, g);
@@ -683,18 +683,25 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
 // With one wavefront per CU the launch is as long as its slowest wavefront's serial chain (staging -> f64 step math ->
 // reset -> observation -> 50+ stores) and three of the CU's four SIMDs idle.  Here wavefront 0 is the agent (lane ==
 // agent, exactly the code above), and the other three take the work that does not depend on its serial chain:
-//   while wave 0 runs update_PathPlan:  wave 1 prepares EVERY agent's reset candidate (Philox, bank rows, heading)
-//   after the positions are final:      waves 0 / 1 / 2 each build one occupancy stencil, wave 3 the below-probes
-//   store phase:                        waves 1-3 stream the 64 observation rows out of the compact tile (coalesced
-//                                       1 KiB runs) while wave 0 writes the state planes and the step outputs.
-// Three workgroup barriers; every value is computed by the same device functions on the same operands as in k_step.
+//   while wave 0 waits for its state and runs update_PathPlan:  waves 2-3 stage the world blob, wave 1 prepares the
+//       reset candidate of every agent that can finish this step (Philox, bank rows, heading), wave 2 the heading
+//       after the move (calc_angle of the new velocity: old heading + action only)
+//   barrier; every wave derives the reset decision and the final positions itself (stepped position, done flags and
+//       candidates are all in LDS), so nobody waits for wave 0's reset bookkeeping:
+//       waves 1-3: the cylinder part of the three occupancy stencils, every third candidate cylinder of each agent
+//                  (+ the out-of-box bits of one stencil each)
+//       wave 0:    installs resets, writes the state planes and step outputs, the below-probes and the 15 scalars
+//       each ORs its bits into the compact tile
+//   barrier; all four stream the 64 observation rows out of the tile (coalesced 1 KiB runs).
+// Two workgroup barriers after the staging one; every value is computed by the same device functions on the same
+// operands as in k_step.
 struct CoopLds {
     double cand[16][64];
     int32_t cand_n[64], cand_scn[64];
-    double pos[64][4];                 // position after step + reset (x, y, z, pad)
+    double pos[64][4];                 // position after update_PathPlan (x, y, z, pad); after a fallback reset: final
     double head[64];                   // heading after the move, from wave 2
-    uint32_t acc[4][64];               // per-wave stencil accumulators (atomicOr targets)
-    uint32_t queue[4][kObsQueueCap];
+    int32_t done[64];                  // agent done after update_PathPlan (what the reset decision looks at)
+    ObsWaveLds q[3];                   // work queues of waves 1..3
     uint32_t tile[64 * kCTileLd];
 };
 
@@ -743,12 +750,12 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         if (cand_want) reset_candidate_fetch(a, cand);
     }
     // waves 1-3: their rows of the copy-out table (depends on (instruction, lane) only)
-    uint2 lut[8];
-    if (wv != 0) {
+    uint2 lut[7];
+    {
+        const int lo = wv == 0 ? 0 : 7 + (wv - 1) * 6;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lut[j] = a.emit_lut[((wv - 1) * 8 + j) * 64 + lane];
-    } else {
-        lut[0] = a.emit_lut[24 * 64 + lane];
+        for (int j = 0; j < 6; ++j) lut[j] = a.emit_lut[(lo + j) * 64 + lane];
+        lut[6] = a.emit_lut[6 * 64 + lane];          // wave 0's seventh
     }
     uint32_t *trow = C->tile + lane * kCTileLd;
     if (wv == 3) { trow[0] = 0u; trow[1] = 0u; trow[2] = 0u; }               // mask words: OR targets of the four waves
@@ -790,66 +797,53 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             step_post<MaskT, APF, true>(a, w, ii, a0, g, pre, r, ret_done, info, head_set);
         }
     }
+    if (wv == 0) {                       // what the other waves need to place every agent: where it is, whether it is done
+        C->pos[lane][0] = g.o.px;
+        C->pos[lane][1] = g.o.py;
+        C->pos[lane][2] = g.o.pz;
+        C->done[lane] = g.done;
+    }
     UAV_STAMP(2);
     __syncthreads();                                                         // candidates ready, step done
     UAV_STAMP(3);
+    // ---- auto reset: the env restarts when ALL of its U agents are done (PathPlan_City.py:252-259,416-417).  Every
+    // wave takes the decision from the same LDS data.
+    bool will_reset = false;
+    if (auto_reset) {
+        const unsigned long long dm = __ballot(active && C->done[lane] != 0);
+        const int g0 = lane & ~(a.U - 1);          // U is a power of two (uavenv_create)
+        const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
+        will_reset = active && ((dm & gm) == gm);
+    }
+    // an agent that resets without a prepared candidate (the predicate above makes that impossible; kept for safety):
+    // wave 0 plans it the slow way and publishes the position behind one more barrier.  Workgroup-uniform.
+    const bool fallback = __ballot(will_reset && C->cand_scn[lane] < 0) != 0ull;
     if (wv == 0) {
         if (!skip && pre.moved && !head_set) g.head = C->head[lane];         // :423, computed by wave 2
         g.o.n_rem = g.n_total - g.sub_idx;
         agent_done = g.done;
         energy = a.energy64 ? fly_power(a.pw, g.o.V, ii % a.U) : 0.0;
-        // ---- auto reset: the env restarts when ALL of its U agents are done (PathPlan_City.py:252-259,416-417)
-        if (auto_reset) {
-            const unsigned long long dm = __ballot(active && g.done);
-            const int g0 = (lane / a.U) * a.U;
-            const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
-            if (active && ((dm & gm) == gm)) {
-                ResetCand c;
-                c.scn = C->cand_scn[lane];
-                if (c.scn >= 0) {
+        if (will_reset) {
+            ResetCand c;
+            c.scn = C->cand_scn[lane];
+            if (c.scn >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) c.f[k] = C->cand[k][lane];
-                    c.n_total = C->cand_n[lane];
-                    apply_reset<APF>(a, ii, g, c);
-                } else {
-                    reset_agent<APF>(a, ii, g);
-                }
-                did_reset = true;
+                for (int k = 0; k < 16; ++k) c.f[k] = C->cand[k][lane];
+                c.n_total = C->cand_n[lane];
+                apply_reset<APF>(a, ii, g, c);
+            } else {
+                reset_agent<APF>(a, ii, g);
             }
+            did_reset = true;
         }
-        C->pos[lane][0] = g.o.px;
-        C->pos[lane][1] = g.o.py;
-        C->pos[lane][2] = g.o.pz;
+        if (fallback) {
+            C->pos[lane][0] = g.o.px;
+            C->pos[lane][1] = g.o.py;
+            C->pos[lane][2] = g.o.pz;
+        }
     }
-    __syncthreads();                                                         // positions final
+    if (fallback) __syncthreads();
     UAV_STAMP(4);
-    if (want_obs) {
-        const double px = C->pos[lane][0], py = C->pos[lane][1], pz = C->pos[lane][2];
-        if (wv == 0) ctile_write_scalars(trow, obs_scalars(g.o, g.head));    // :526 heading == cached angle
-        // wave 0: 1 m stencil (+ the scalars above); wave 1: 5 m stencil; waves 2 and 3 share the 10 m stencil (the
-        // one with the most candidate cylinders: even / odd candidates), wave 3 adds the below-probes
-        ObsBits part = {0u, 0u, 0u, 0u};
-        const MaskT all = (MaskT)~(MaskT)0, even = (MaskT)0x5555555555555555ull;
-        if (wv == 0) {
-            part.s1 = obs_stencil_queued<MaskT>(w, C->queue[0], C->acc[0], &C->pos[0][0], 0, px, py, pz, active, all);
-        } else if (wv == 1) {
-            part.s5 = obs_stencil_queued<MaskT>(w, C->queue[1], C->acc[1], &C->pos[0][0], 1, px, py, pz, active, all);
-        } else if (wv == 2) {
-            part.s10 = obs_stencil_queued<MaskT>(w, C->queue[2], C->acc[2], &C->pos[0][0], 2, px, py, pz, active, even);
-        } else {
-            part.s10 = obs_stencil_queued<MaskT>(w, C->queue[3], C->acc[3], &C->pos[0][0], 2, px, py, pz, active,
-                                                 (MaskT)~even);
-            part.below = obs_below_bits(w, px, py, pz);
-        }
-        uint32_t m0, m1, m2;
-        ctile_mask_words(part, m0, m1, m2);
-        if (m0) atomicOr(&trow[0], m0);
-        if (m1) atomicOr(&trow[1], m1);
-        if (m2) atomicOr(&trow[2], m2);
-    }
-    UAV_STAMP(5);
-    __syncthreads();                                                         // tile complete
-    UAV_STAMP(6);
     if (wv == 0) {
         if (active) {
             // ---- outputs of the transition
@@ -863,26 +857,49 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);
         }
+        if (want_obs) {                  // the cylinder-free part of state_PathPlan
+            ctile_write_scalars(trow, obs_scalars(g.o, g.head));             // :526 heading == cached angle
+            ObsBits part = {0u, 0u, 0u, 0u};
+            part.below = obs_below_bits(w, g.o.px, g.o.py, g.o.pz);
+            uint32_t m0, m1, m2;
+            ctile_mask_words(part, m0, m1, m2);
+            if (m0) atomicOr(&trow[0], m0);
+            if (m1) atomicOr(&trow[1], m1);
+            if (m2) atomicOr(&trow[2], m2);
+        }
+    } else if (want_obs) {               // the cylinders: every third candidate of each agent, from its (wave - 1)-th
+        const bool from_cand = will_reset && !fallback;
+        const double px = from_cand ? C->cand[0][lane] : C->pos[lane][0];
+        const double py = from_cand ? C->cand[1][lane] : C->pos[lane][1];
+        const double pz = from_cand ? C->cand[2][lane] : C->pos[lane][2];
+        ObsBits part = obs_cand_queued<MaskT>(w, &C->q[wv - 1], px, py, pz, active, wv - 1);
+        // + the out-of-box part of one stencil each
+        const uint32_t box = obs_box_bits(w.W, w.Hbox, wv == 1 ? 1.0 : (wv == 2 ? 5.0 : 10.0), px, py, pz);
+        if (wv == 1) part.s1 |= box;
+        else if (wv == 2) part.s5 |= box;
+        else part.s10 |= box;
+        uint32_t m0, m1, m2;
+        ctile_mask_words(part, m0, m1, m2);
+        if (m0) atomicOr(&trow[0], m0);
+        if (m1) atomicOr(&trow[1], m1);
+        if (m2) atomicOr(&trow[2], m2);
     }
+    UAV_STAMP(5);
+    __syncthreads();                                                         // tile complete
+    UAV_STAMP(6);
     if (want_obs) {
-        // 25 coalesced store instructions: 8 each for waves 1..3 (fixed trip count: unrolled, so the LDS reads of one
-        // instruction overlap the selects of the previous), the odd one for wave 0 after its own stores
+        // 25 coalesced store instructions: 7 for wave 0, 6 each for waves 1..3 (fixed trip counts: unrolled, so the
+        // LDS reads of one instruction overlap the selects of the previous)
         const int nv = N - first;
-        const int lo = wv == 0 ? 24 : (wv - 1) * 8;
+        const int lo = wv == 0 ? 0 : 7 + (wv - 1) * 6;
         if (nv >= 64) {                     // workgroup-uniform: all but the last workgroup take the unguarded form
-            if (wv == 0) {
-                ctile_emit_lut<F16>(a.obs, first, nv, C->tile, 24, lut[0], false);
-            } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, lo + j, lut[j], false);
-            }
+            for (int j = 0; j < 6; ++j) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, lo + j, lut[j], false);
+            if (wv == 0) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, 6, lut[6], false);
         } else {
-            if (wv == 0) {
-                ctile_emit_lut<F16>(a.obs, first, nv, C->tile, 24, lut[0], true);
-            } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, lo + j, lut[j], true);
-            }
+            for (int j = 0; j < 6; ++j) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, lo + j, lut[j], true);
+            if (wv == 0) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, 6, lut[6], true);
         }
     }
     UAV_STAMP(7);
@@ -1085,8 +1102,8 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     a.tile_off = tile_store ? a.obsq_off : -1;
     const size_t lds = (size_t)a.obsq_off + (size_t)nw * slot;
     // <= 49 152 agents (three wavefronts' worth of agents per CU): the cooperative four-wavefronts-per-64-agents kernel
-    // (see k_step_coop).  MEASURED (us per launch, k_step -> k_step_coop): 4 096 envs 10.6 -> 7.8; 16 384: 11.7 -> 8.8;
-    // 32 768: 14.6 -> 11.6; 49 152: 16.1 -> 14.1; 65 536: 16.6 -> 19.5 (k_step kept from there on).
+    // (see k_step_coop).  MEASURED (us per launch, k_step -> k_step_coop): 4 096 envs 10.6 -> 7.8; 16 384: 11.7 -> 8.7;
+    // 32 768: 14.6 -> 10.1; 49 152: 16.1 -> 12.3; 65 536: 16.6 -> 19.5 (k_step kept from there on).
     static const int coop_env = env_int("UAVENV_COOP", -1);
     const bool coop = coop_env >= 0 ? coop_env != 0 : e->N <= 49152;
     if (coop) {

@@ -390,6 +390,80 @@ __device__ __forceinline__ ObsBits obs_bits_queued(const WorldLds<MaskT> &w, Obs
     return o;
 }
 
+// ---- the cooperative small-N kernel's split of the same work --------------------------------------------------------
+// obs_box_bits: the out-of-box part of ONE stencil (every probe of a row / column that leaves [0, W], or of a UAV
+// outside [0, H], is 1), no cylinders.  obs_cand_queued: the cylinder part of the three stencils for every third
+// candidate cylinder of each agent, starting with its `phase`-th -- three wavefronts (phase 0, 1, 2) cover all of them
+// with a third of the classify iterations and a third of the queue each, balanced agent by agent.  OR of all parts ==
+// obs_bits().
+__device__ __forceinline__ uint32_t obs_box_bits(double W, double Hbox, double sp, double px, double py, double pz)
+{
+    uint32_t bk = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const double xi = px + sp * (double)(i - 2), yi = py + sp * (double)(i - 2);
+        bk |= ((xi < 0.0) | (xi > W)) ? (0x1Fu << (5 * i)) : 0u;
+        bk |= ((yi < 0.0) | (yi > W)) ? (0x108421u << i) : 0u;
+    }
+    return ((pz < 0.0) | (pz > Hbox)) ? 0x1FFFFFFu : bk;
+}
+
+template <typename MaskT>
+__device__ __forceinline__ ObsBits obs_cand_queued(const WorldLds<MaskT> &w, ObsWaveLds *L, double px, double py,
+                                                   double pz, bool active, int phase)
+{
+    const int lane = (int)threadIdx.x & 63;
+    uint32_t bits[3] = {0u, 0u, 0u};
+    L->pxy[lane][0] = px;
+    L->pxy[lane][1] = py;
+    L->bits[lane][0] = 0u; L->bits[lane][1] = 0u; L->bits[lane][2] = 0u;
+    MaskT m = active ? w.g[2][cell_of(w, px, py)] : (MaskT)0;
+    for (int q = 0; q < phase; ++q) m &= (MaskT)(m - 1);          // skip the candidates the earlier phases start with
+    int count = 0;                                   // wave-uniform
+    while (__ballot(m != 0) != 0ull) {
+        if (count > kObsQueueCap - 192) {            // room for one more iteration's worst case (64 lanes x 3)
+            obs_queue_drain(w, L, count);
+            count = 0;
+        }
+        const bool have = m != 0;
+        const int b = have ? ctz_mask(m) : 0;
+        m &= (MaskT)(m - 1);                         // this candidate, and the two the other phases take
+        m &= (MaskT)(m - 1);
+        m &= (MaskT)(m - 1);
+        bool full[3] = {false, false, false};
+        if (have) {
+            const BldLds B = w.b[b];
+            const BldAux X = w.aux[b];
+            const double dcx = px - B.cx, dcy = py - B.cy;
+            const double dc2 = dcx * dcx + dcy * dcy;
+            if (!(pz > B.H)) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (dc2 < X.acc2[k]) bits[k] = 0x1FFFFFFu;          // stencil entirely inside the disc
+                    else if (dc2 < X.rej2[k]) full[k] = true;           // can touch: needs the 25 exact tests
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long bm = __ballot(full[k]);
+            if (bm) {
+                const int at = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                if (full[k]) L->queue[at] = (uint32_t)lane | ((uint32_t)b << 6) | ((uint32_t)k << 12);
+                count += __builtin_popcountll(bm);
+            }
+        }
+    }
+    obs_queue_drain(w, L, count);
+    ObsBits o;
+    o.s1 = bits[0] | L->bits[lane][0];
+    o.s5 = bits[1] | L->bits[lane][1];
+    o.s10 = bits[2] | L->bits[lane][2];
+    o.below = 0u;
+    return o;
+}
+
 // ---- one stencil per wavefront (the cooperative small-N kernel) ---------------------------------------------------
 // Stencil k (spacing kSp[k]) of state_PathPlan for the 64 agents of a workgroup, by ONE wavefront: the same
 // classify -> queue -> dense 25-point tests as obs_bits_queued, but over the stencil's own halo grid g[k] (fewer
