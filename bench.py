@@ -95,9 +95,32 @@ def cpu_baseline(envs: int, seconds: float):
         steps += n
         # finished agents keep stepping from their terminal state (empty-list guard): same per-step cost class
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{steps} agent-steps ({n} envs, update_PathPlan + state_PathPlan, random steering, "
-                      f"no learner) in {dt:.1f} s; C port of the reference's Python env path, OpenMP"}
+    out = {"value": steps / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+           "sample": f"{steps} agent-steps ({n} envs, update_PathPlan + state_PathPlan, random steering, "
+                     f"no learner) in {dt:.1f} s; C port of the reference's Python env path, OpenMP"}
+    out["learner"] = cpu_learner_baseline()
+    return out
+
+
+def cpu_learner_baseline(batch: int = 16384, seconds: float = 4.0):
+    """The learner half of the metric on the host: DQN_Trainer.learn_off_policy's arithmetic (learner.DQNLearner =
+    the same PyTorch ops as the reference, Trainer/DQN_Trainer.py:101-139) on CPU torch, batch as on the GPU."""
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
+    torch.manual_seed(0)
+    L = DQNLearner({"NetWork": "Qnet2", "w": "100", "hiden_dim": "64", "output": "3"}, "dqn", device="cpu")
+    g = torch.Generator().manual_seed(0)
+    b = dict(states=torch.rand((batch, 100), generator=g), next_states=torch.rand((batch, 100), generator=g),
+             actions=torch.randint(0, 3, (batch,), generator=g), rewards=torch.rand(batch, generator=g),
+             dones=(torch.rand(batch, generator=g) < 0.05).float())
+    L.learn(b)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        L.learn(b)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "learner updates/s", "batch": batch, "threads": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n} updates of {batch} resident samples in {dt:.1f} s, PyTorch CPU"}
 
 
 def main():
