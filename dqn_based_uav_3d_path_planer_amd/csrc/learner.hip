@@ -350,41 +350,74 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
             dvals[a] = dv;
             dout[tid * kMaxOut + a] = dv;
         }
-        // db2, the loss sum and the valid count ride along with the dW2 reduction below: two extra dout columns and a
-        // ones column in Hs (its pad column 64) turn them into three more dot products over the 64 samples
+        // the loss sum and the valid count ride along as two extra dout columns: P5 sums every column over the samples
         dout[tid * kMaxOut + n2] = per * v;
         dout[tid * kMaxOut + n2 + 1] = v;
-        Hs[tid * kLdh + kHid] = 1.0f;
     }
     __syncthreads();
 
     L_STAMP(3);
-    // ---- P5: layer-2 gradients (needs the forward Hs), then dH in place
+    // ---- P5: layer-2 gradients and dH on the matrix cores (both are small dense products over the 64 samples; as
+    // thread-per-output VALU loops they cost ~10 k cycles of LDS round trips):
+    //   waves 0, 1:  dW2[a][j] = sum_s dout[s][a] * Hs[s][j]   (A[m = a][k = s], B[k = s][n = j]; M padded 16 -> 32)
+    //   waves 2, 3:  dH[s][j]  = sum_a dout[s][a] * W2[a][j]   (A[m = s][k = a], B[k = a][n = j]; K = 16, a >= n2 masked)
+    //   db2 / loss sum / valid count = column sums of dout (16 threads of wave 3 afterwards).
+    // dH stays in registers until every wave has finished reading the forward Hs, then goes in place under the ReLU mask.
+    // (f32 MFMA runs at 64 FLOP/cycle/SIMD -- no faster than the VALU: what this buys is instruction count and LDS
+    // round trips, 10 k -> 6.5 k cycles.  Layer 2 and the column sums were tried the same way and were slower.)
     float *out = g.partials + (size_t)blockIdx.x * (g.P + 2);
     const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
-    for (int k = tid; k < n2 * (kHid + 1) + 2; k += 256) {
-        int a, j;
-        if (k < n2 * (kHid + 1)) { a = k / (kHid + 1); j = k - a * (kHid + 1); }
-        else { a = n2 + (k - n2 * (kHid + 1)); j = kHid; }          // loss sum, valid count
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    floatx16 dh0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dh1 = dh0;
+    {
+        const int wv = tid >> 6, l = tid & 63, lm = l & 31, h = l >> 5;
+        if (wv < 2) {
+            const int n0 = wv * 32;
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+            for (int k0 = 0; k0 < kTile; k0 += 2) {
+                const int smp = k0 + h;
+                const float av = dout[smp * kMaxOut + (lm & (kMaxOut - 1))];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lm < kMaxOut ? av : 0.0f, Hs[smp * kLdh + n0 + lm], acc, 0, 0, 0);
+            }
 #pragma unroll
-        for (int smp = 0; smp < kTile; smp += 4) {
-            s0 = fmaf(dout[smp * kMaxOut + a], Hs[smp * kLdh + j], s0);
-            s1 = fmaf(dout[(smp + 1) * kMaxOut + a], Hs[(smp + 1) * kLdh + j], s1);
-            s2 = fmaf(dout[(smp + 2) * kMaxOut + a], Hs[(smp + 2) * kLdh + j], s2);
-            s3 = fmaf(dout[(smp + 3) * kMaxOut + a], Hs[(smp + 3) * kLdh + j], s3);
+            for (int reg = 0; reg < 8; ++reg) {                   // rows m < 16 live in registers 0..7
+                const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (m < n2) out[oW2 + m * kHid + n0 + lm] = acc[reg];
+            }
+        } else {
+            const int m0 = (wv - 2) * 32;
+#pragma unroll
+            for (int k0 = 0; k0 < kMaxOut; k0 += 2) {
+                const int kk = k0 + h;
+                const float dv = dout[(m0 + lm) * kMaxOut + kk];
+                const bool use = kk < n2;                         // columns n2, n2+1 carry the loss / count, not a gradient;
+                const float av = use ? dv : 0.0f;                 // W2 rows >= n2 are not staged (0 x garbage could be NaN)
+                const float b0 = W2[(use ? kk : 0) * kHid + lm], b1 = W2[(use ? kk : 0) * kHid + 32 + lm];
+                dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, use ? b0 : 0.0f, dh0, 0, 0, 0);
+                dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, use ? b1 : 0.0f, dh1, 0, 0, 0);
+            }
         }
-        const float t = (s0 + s1) + (s2 + s3);
-        if (a >= n2) out[g.P + (a - n2)] = t;
-        else if (j == kHid) out[ob2 + a] = t;
-        else out[oW2 + a * kHid + j] = t;
+        if (tid >= 192 && tid < 192 + n2 + 2) {                   // db2[a], loss sum, valid count: column sums of dout
+            const int a = tid - 192;
+            float sa = 0.0f;
+            for (int smp = 0; smp < kTile; ++smp) sa += dout[smp * kMaxOut + a];
+            if (a < n2) out[ob2 + a] = sa;
+            else out[g.P + (a - n2)] = sa;
+        }
     }
     __syncthreads();
-    for (int k = tid; k < kTile * kHid; k += 256) {
-        const int smp = k / kHid, j = k - smp * kHid;
-        float s = 0.0f;
-        for (int a = 0; a < n2; ++a) s = fmaf(dout[smp * kMaxOut + a], W2[a * kHid + j], s);
-        Hs[smp * kLdh + j] = Hs[smp * kLdh + j] > 0.0f ? s : 0.0f;        // ReLU mask
+    {
+        const int wv = tid >> 6, l = tid & 63, lm = l & 31, h = l >> 5;
+        if (wv >= 2) {
+            const int m0 = (wv - 2) * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int smp = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float *p0 = Hs + smp * kLdh + lm, *p1 = p0 + 32;
+                *p0 = *p0 > 0.0f ? dh0[reg] : 0.0f;               // ReLU mask
+                *p1 = *p1 > 0.0f ? dh1[reg] : 0.0f;
+            }
+        }
     }
     __syncthreads();
 
