@@ -91,6 +91,7 @@ struct StepArgs {
     int32_t nb, gn;
     double inv_cell, W, Hbox;
     const BldApf *apf_b;
+    const uint64_t *apf_grid;          // [gn][gn] masks of the MOVING cylinders whose 60 m force range can reach the cell
     // agent params
     double max_v, steer;
     PowerParams pw;
@@ -128,6 +129,7 @@ struct UavEnv {
     int world_bytes = 0, aux_off = 0, grid_off = 0, grid_stride = 0, nb = 0, gn = 0, mask_bytes = 8;
     double cell = 10.0;
     BldApf *apf_b = nullptr;
+    uint64_t *apf_grid = nullptr;
     uint2 *emit_lut = nullptr;
     bool have_world = false;
     // bank
@@ -192,41 +194,63 @@ __device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, cons
 
 // Agents/UAV.py:174-210  cal_force(point): attraction/repulsion + motion force of every MOVING building
 // within 60 m of its rim.  Returns false where the reference would call Cal_SubTask_Dynamic() (raises).
-__device__ __noinline__ bool cal_force(const BldApf *__restrict__ b, int nb, double x, double y, double z, double &fx,
-                                       double &fy, double &fz)
+// One (point, moving cylinder) pair of cal_force.  Returns false when the accumulated force passed 100 (:205-208).
+__device__ __forceinline__ bool cal_force_pair(const BldApf &B, double x, double y, double z, double &cum, double &tx,
+                                               double &ty)
 {
-    double cum = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
-    bool ok = true;
-    for (int i = 0; i < nb; ++i) {
-        const BldApf B = b[i];
-        if (B.moving == 0.0) continue;                                          // :180-182 v == 0: no force
-        const double dx = B.cx - x, dy = B.cy - y, dz = B.cz - z;
-        const double h2 = dx * dx + dy * dy;
-        if (h2 + dz * dz > B.far2) continue;                                    // certainly dis - R > 60
-        const double dis = dist3(x, y, z, B.cx, B.cy, B.cz);                    // :183 (same operands as before)
-        const double d2e = dis - B.R;
-        if (d2e > 60.0) continue;                                               // :186-187
-        const double q = B.R / (d2e * d2e);
-        double f1 = (q < 1.0) ? q : 1.0;                                        // :190
-        if (d2e < 0.0) f1 = (-d2e > 2.0) ? -d2e : 2.0;                          // :196-197
-        // :191,:198  direction sub-goal -> centre: (cos, sin) of calculate_angle = the unit vector of (dx, dy); the
-        // zero vector has angle 0.  (The reference goes atan2 -> cos/sin; same direction to ~1e-16.)
-        double cx1 = 1.0, sy1 = 0.0;
-        if (h2 > 0.0) {
-            const double inv = 1.0 / sqrt(h2);
-            cx1 = dx * inv;
-            sy1 = dy * inv;
-        }
-        const double f1x = -f1 * cx1, f1y = -f1 * sy1;
-        const double q2 = B.vnorm * B.R / (d2e * d2e);
-        const double f2 = (q2 < 1.0) ? q2 : 1.0;                                // :200
-        const double f2x = f2 * B.ux, f2y = f2 * B.uy;                          // :201
-        cum += (f1 + f2);
-        tx = (tx + f1x) + f2x;
-        ty = (ty + f1y) + f2y;
-        if (cum > 100.0) { ok = false; break; }                                 // :205-208
+    const double dx = B.cx - x, dy = B.cy - y, dz = B.cz - z;
+    const double h2 = dx * dx + dy * dy;
+    if (h2 + dz * dz > B.far2) return true;                                 // certainly dis - R > 60
+    const double dis = dist3(x, y, z, B.cx, B.cy, B.cz);                    // :183 (same operands as before)
+    const double d2e = dis - B.R;
+    if (d2e > 60.0) return true;                                            // :186-187
+    const double q = B.R / (d2e * d2e);
+    double f1 = (q < 1.0) ? q : 1.0;                                        // :190
+    if (d2e < 0.0) f1 = (-d2e > 2.0) ? -d2e : 2.0;                          // :196-197
+    // :191,:198  direction sub-goal -> centre: (cos, sin) of calculate_angle = the unit vector of (dx, dy); the
+    // zero vector has angle 0.  (The reference goes atan2 -> cos/sin; same direction to ~1e-16.)
+    double cx1 = 1.0, sy1 = 0.0;
+    if (h2 > 0.0) {
+        const double inv = 1.0 / sqrt(h2);
+        cx1 = dx * inv;
+        sy1 = dy * inv;
     }
-    fx = tx; fy = ty; fz = tz;
+    const double f1x = -f1 * cx1, f1y = -f1 * sy1;
+    const double q2 = B.vnorm * B.R / (d2e * d2e);
+    const double f2 = (q2 < 1.0) ? q2 : 1.0;                                // :200
+    const double f2x = f2 * B.ux, f2y = f2 * B.uy;                          // :201
+    cum += (f1 + f2);
+    tx = (tx + f1x) + f2x;
+    ty = (ty + f1y) + f2y;
+    return !(cum > 100.0);
+}
+
+// Inside the box only the cylinders listed for the point's cell are visited (ascending index = the reference's loop
+// order with the out-of-range ones, which contribute nothing, left out); outside it, all of them.
+__device__ __noinline__ bool cal_force(const BldApf *__restrict__ b, int nb, const uint64_t *__restrict__ grid, int gn,
+                                       double inv_cell, double W, double x, double y, double z, double &fx, double &fy,
+                                       double &fz)
+{
+    double cum = 0.0, tx = 0.0, ty = 0.0;
+    bool ok = true;
+    if (grid && x >= 0.0 && x <= W && y >= 0.0 && y <= W) {
+        int ix = (int)(x * inv_cell), iy = (int)(y * inv_cell);
+        ix = ix > gn - 1 ? gn - 1 : ix;
+        iy = iy > gn - 1 ? gn - 1 : iy;
+        uint64_t m = grid[iy * gn + ix];
+        while (m) {
+            const int i = __builtin_ctzll(m);
+            m &= m - 1;
+            if (!cal_force_pair(b[i], x, y, z, cum, tx, ty)) { ok = false; break; }
+        }
+    } else {
+        for (int i = 0; i < nb; ++i) {
+            const BldApf B = b[i];
+            if (B.moving == 0.0) continue;                                      // :180-182 v == 0: no force
+            if (!cal_force_pair(B, x, y, z, cum, tx, ty)) { ok = false; break; }
+        }
+    }
+    fx = tx; fy = ty; fz = 0.0;
     return ok;
 }
 
@@ -492,7 +516,7 @@ __device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<Mask
         for (int k = g.sub_idx; k < g.n_total; ++k) {                          // Adjust_subgoal :156-166
             double fx, fy, fz;
             const double sx = lst[k * 3], sy = lst[k * 3 + 1], sz = lst[k * 3 + 2];
-            cal_force(a.apf_b, a.nb, sx, sy, sz, fx, fy, fz);
+            cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, sx, sy, sz, fx, fy, fz);
             lst[k * 3] = sx + fx; lst[k * 3 + 1] = sy + fy; lst[k * 3 + 2] = sz + fz;
         }
         g.alias = 0;
@@ -501,7 +525,7 @@ __device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<Mask
             o.s1x = lst[g.sub_idx * 3 + 3]; o.s1y = lst[g.sub_idx * 3 + 4]; o.s1z = lst[g.sub_idx * 3 + 5];
         }
         double fx, fy, fz;
-        cal_force(a.apf_b, a.nb, o.px, o.py, o.pz, fx, fy, fz);
+        cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, o.px, o.py, o.pz, fx, fy, fz);
         const double force = sqrt(fx * fx + fy * fy + fz * fz);
         r += 0.2 * force * cos_between(fx, fy, tvx, tvy);                      // :451-453
     }
@@ -1037,6 +1061,7 @@ static StepArgs base_args(const UavEnv *e)
     a.W = e->cfg.width;
     a.Hbox = e->cfg.h;
     a.apf_b = e->apf_b;
+    a.apf_grid = e->apf_grid;
     a.emit_lut = e->emit_lut;
     a.max_v = e->cfg.max_v;
     a.steer = e->cfg.steering_angle;
@@ -1194,6 +1219,7 @@ int uavenv_destroy(UavEnv *e)
     (void)hipFree(e->slab);
     (void)hipFree(e->world_blob);
     (void)hipFree(e->apf_b);
+    (void)hipFree(e->apf_grid);
     (void)hipFree(e->emit_lut);
     (void)hipFree(e->bank_sg);
     (void)hipFree(e->bank_sub);
@@ -1284,6 +1310,27 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
     HIP_TRY(hipMemcpy(e->world_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&e->apf_b, ba.size() * sizeof(BldApf)));
     HIP_TRY(hipMemcpy(e->apf_b, ba.data(), ba.size() * sizeof(BldApf), hipMemcpyHostToDevice));
+    {   // APF broad phase: per cell, the moving cylinders whose force range (60 m beyond the rim) can reach the cell.
+        // Same conservative rasterisation as the collision grids (2-D distance <= 3-D distance, 1e-6-scale margins).
+        std::vector<uint64_t> ag((size_t)gn * gn, 0);
+        for (int iy = 0; iy < gn; ++iy)
+            for (int ix = 0; ix < gn; ++ix) {
+                const double x0 = ix * cell - margin, x1 = (ix + 1) * cell + margin;
+                const double y0 = iy * cell - margin, y1 = (iy + 1) * cell + margin;
+                uint64_t m = 0;
+                for (int i = 0; i < nb; ++i) {
+                    if (ba[i].moving == 0.0) continue;
+                    const double qx = ba[i].cx < x0 ? x0 : (ba[i].cx > x1 ? x1 : ba[i].cx);
+                    const double qy = ba[i].cy < y0 ? y0 : (ba[i].cy > y1 ? y1 : ba[i].cy);
+                    if (std::hypot(qx - ba[i].cx, qy - ba[i].cy) < ba[i].R + 60.0 + 1e-6 + margin) m |= (1ull << i);
+                }
+                ag[(size_t)iy * gn + ix] = m;
+            }
+        (void)hipFree(e->apf_grid);
+        e->apf_grid = nullptr;
+        HIP_TRY(hipMalloc((void **)&e->apf_grid, ag.size() * 8));
+        HIP_TRY(hipMemcpy(e->apf_grid, ag.data(), ag.size() * 8, hipMemcpyHostToDevice));
+    }
     e->world_bytes = (int)blob.size();
     e->aux_off = bld_only;
     e->grid_off = bld_bytes;
