@@ -1,5 +1,7 @@
-"""Per-phase timeline of k_step from in-kernel s_memtime stamps (diagnostic).  python scripts/phase_profile.py [envs]"""
+"""Per-phase timeline of k_step (the one-wavefront-per-64-agents kernel) from in-kernel s_memtime stamps (diagnostic,
+-DUAVENV_PHASE_PROFILE build).  python scripts/phase_profile.py [envs]   (phase_profile_coop.py for k_step_coop)"""
 import sys, os
+os.environ.setdefault("UAVENV_COOP", "0")      # small launches would otherwise take the cooperative kernel
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
