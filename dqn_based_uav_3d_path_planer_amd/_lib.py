@@ -15,7 +15,7 @@ INFO_NORMAL, INFO_SUCCESS, INFO_LOSE, INFO_SKIPPED = 0, 1, 2, 3
 INFO_NAMES = ("normal", "success", "lose", "skipped")
 ACT_STEER_F32, ACT_STEER_F64, ACT_INDEX_I32 = 0, 1, 2
 OBS_F32, OBS_F16 = 0, 1
-STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS = 1, 2, 4
+STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE = 1, 2, 4, 8
 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = (

@@ -1130,7 +1130,7 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     // (see k_step_coop).  MEASURED (us per launch, k_step -> k_step_coop): 4 096 envs 10.6 -> 7.8; 16 384: 11.7 -> 8.7;
     // 32 768: 14.6 -> 10.1; 49 152: 16.1 -> 12.3; 65 536: 16.6 -> 19.5 (k_step kept from there on).
     static const int coop_env = env_int("UAVENV_COOP", -1);
-    const bool coop = coop_env >= 0 ? coop_env != 0 : e->N <= 49152;
+    const bool coop = !(a.flags & UAVENV_STEP_ONE_WAVE) && (coop_env >= 0 ? coop_env != 0 : e->N <= 49152);
     if (coop) {
         a.block = 256;
         a.obsq_off = (e->world_bytes + 15) & ~15;

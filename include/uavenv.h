@@ -59,6 +59,7 @@ extern "C" {
                                        launch (replaces PathPlan_City.py:416-417 Scene_Random_Reset per episode) */
 #define UAVENV_STEP_SKIP_DONE 2u    /* agents with done==1 do not move (PathPlan_City.py:365-366) */
 #define UAVENV_STEP_NO_OBS 4u       /* do not compute/write the observation */
+#define UAVENV_STEP_ONE_WAVE 8u     /* diagnostics: small launches also take the one-wavefront-per-64-agents kernel (same results) */
 
 typedef struct UavEnv UavEnv;       /* opaque; owns the per-agent state in HBM */
 
