@@ -9,8 +9,13 @@ Workload at --gpus 1: BASELINE.json configs[1] -- 16 384 vectorised envs, DQN, d
 Multi-GPU is weak scaling: every rank owns its own 16 384-env shard + ring; the only exchange is the ~26 KB
 gradient bucket per update.
 
+A bench "step" (--steps K) is PASSES_PER_STEP = 128 such passes, enqueued back to back by csrc/loop.hip (one C call per
+bench step, four kernel launches per pass): one pass lasts ~40 us, so that the timed region stays >= 50 ms whatever K
+the driver picks (20 steps = 2 560 passes).  `ms_per_step` is per bench step, `ms_per_pass` per pass.
+
 Prints ONE JSON line (rank 0).  `value` = whole-job env-steps/s of the full loop (inputs resident in HBM);
-`roofline` is for the dominant kernel k_step; `cpu_baseline` times the CPU oracle port on the host cores.
+`roofline` is for the env kernel k_step (HBM-bound by design), `roofline_learner` for k_dqn_grad (the largest share of
+the pass, MFMA); `cpu_baseline` times the CPU oracle port on the host cores (1 core and all cores).
 """
 from __future__ import annotations
 
@@ -30,13 +35,30 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_AGENT_STEP = 604        # 137 B read + 467 B written, obs f32
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+MFMA_F16_PEAK_TF = 2500.0              # MI355X_MICROARCH.md: bf16/f16 MFMA, dense
+PASSES_PER_STEP = 128                  # hot-path passes per bench step (see module docstring)
+
+
+def learner_flops_per_sample(trainer: str, n_actions: int = 3) -> float:
+    """Algorithmic FLOPs of one learn_off_policy() per sampled transition for the 100-64-A MLP (2 per multiply-add):
+    forward of q_local(s) and q_target(s') (+ q_local(s') for the double-DQN target, + the value head for VAnet2),
+    backward of q_local(s): dW1 (64 x 100), dW2 and dH (64 x n2 each).  DQN: 39.9 kFLOP; Dueling + DDQN: 54.1 kFLOP."""
+    n2 = n_actions + (1 if trainer == "dueling" else 0)
+    fwd = 2 * (100 * 64 + 64 * n2)
+    n_fwd = 2 if trainer == "dqn" else 3
+    bwd = 2 * (64 * 100) + 2 * (64 * n2) * 2
+    return float(n_fwd * fwd + bwd)
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=40, help="bench steps of PASSES_PER_STEP passes each")
+    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--passes-per-step", type=int, default=PASSES_PER_STEP)
+    p.add_argument("--host-loop", default="c", choices=["c", "python"],
+                   help="c = csrc/loop.hip enqueues the passes (default at 1 GPU); python = four ctypes calls per pass")
     p.add_argument("--envs", type=int, default=16384, help="envs per GPU (BASELINE configs[1]: 16384)")
     p.add_argument("--batch", type=int, default=16384, help="learner batch per GPU per update")
     p.add_argument("--replay", type=int, default=1 << 20, help="replay capacity in transitions per GPU")
@@ -44,7 +66,7 @@ def parse():
     p.add_argument("--obs-dtype", default="f32", choices=["f32", "f16"])
     p.add_argument("--eps", type=float, default=0.1)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
     p.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
@@ -73,31 +95,41 @@ def parse():
 
 
 def cpu_baseline(envs: int, seconds: float):
-    """The oracle port (oracle/uav_oracle.c, -O3 build) stepping the same workload on all host cores."""
+    """The oracle port (oracle/uav_oracle.c, -O3 build) on the host cores: the SAME env count as the GPU run, all steps
+    inside C (orc_rollout_many: each OpenMP thread owns a block of agents and runs its steps without coming back to
+    Python), auto-reset from the same packaged scenario bank.  Timed twice: one core, then every core."""
     from dqn_based_uav_3d_path_planer_amd.data import load_city26
     from oracle import pyoracle as po
     c = load_city26()
     world = po.OracleWorld(c["buildings"], c["len"], c["width"], c["h"], fast=True)
     params = dict(max_v=float(c["max_v"]), steering_angle=float(c["steering_angle"]), max_step=int(c["max_step"]),
                   apf_enabled=0)
-    n = min(envs, 4096)
+    n = envs
     batch = po.OracleBatch(world, params, n)
     head = np.random.default_rng(0).uniform(0, 2 * np.pi, len(c["start_goal"]))
     batch.load_scenarios(c["start_goal"][:, :3], c["start_goal"][:, 3:], head, c["sub_goals"], c["n_sub"])
-    rng = np.random.default_rng(1)
-    cores = po.lib(fast=True).orc_max_threads()
-    batch.step(rng.uniform(-1, 1, n))          # warm-up (thread pool, page faults)
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < seconds:
-        a = rng.uniform(-1, 1, n)
-        batch.step(a, want_obs=True, nthreads=cores)
-        steps += n
-        # finished agents keep stepping from their terminal state (empty-list guard): same per-step cost class
-    dt = time.perf_counter() - t0
-    out = {"value": steps / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
-           "sample": f"{steps} agent-steps ({n} envs, update_PathPlan + state_PathPlan, random steering, "
-                     f"no learner) in {dt:.1f} s; C port of the reference's Python env path, OpenMP"}
+    cores = int(po.lib(fast=True).orc_max_threads())
+    bank = (c["start_goal"], c["sub_goals"], c["n_sub"])
+
+    def timed(threads, budget_s):
+        batch.rollout(1, *bank, seed=1, nthreads=threads)            # warm-up: thread pool, page faults
+        t0 = time.perf_counter()
+        done, _ = batch.rollout(2, *bank, seed=2, nthreads=threads)
+        rate = done / (time.perf_counter() - t0)
+        k = max(2, min(4000, int(budget_s * rate / n)))
+        t0 = time.perf_counter()
+        done, _ = batch.rollout(k, *bank, seed=3, nthreads=threads)
+        dt = time.perf_counter() - t0
+        return done / dt, done, dt
+
+    one, done1, dt1 = timed(1, 0.25 * seconds)
+    allc, done, dt = timed(cores, 0.75 * seconds)
+    out = {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "one_core_value": one,
+           "sample": f"{done} agent-steps ({n} envs x {done // n} steps inside one C call, update_PathPlan + "
+                     f"state_PathPlan, random steering, auto-reset from the packaged bank, no learner) in {dt:.1f} s on "
+                     f"{cores} threads; 1 thread: {done1} agent-steps in {dt1:.1f} s; C port of the reference's Python env "
+                     f"path (oracle/uav_oracle.c, -O3, OpenMP static blocks)"}
     out["learner"] = cpu_learner_baseline()
     return out
 
@@ -121,6 +153,20 @@ def cpu_learner_baseline(batch: int = 16384, seconds: float = 4.0):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "learner updates/s", "batch": batch, "threads": torch.get_num_threads(),
             "kind": "port", "sample": f"{n} updates of {batch} resident samples in {dt:.1f} s, PyTorch CPU"}
+
+
+def committed_profile(args) -> dict:
+    """The rocprofv3 figures of THIS command line as last committed under profiles/ (kernel-trace averages, PMC
+    traffic, MFMA busy): scripts/summarize_profile.py writes profiles/summary.json keyed by workload."""
+    path = os.path.join(ROOT, "profiles", "summary.json")
+    key = "envs%d_batch%d_%s_%s" % (args.envs, args.batch, args.trainer, args.obs_dtype)
+    try:
+        d = json.load(open(path)).get(key, {})
+        if d:
+            d["source"] = "profiles/summary.json[%s] <- %s" % (key, d.get("files", "rocprofv3"))
+        return d
+    except Exception:
+        return {}
 
 
 def main():
@@ -167,7 +213,7 @@ def main():
         ring.extra_flags = _l.STEP_NO_OBS
     if args.env_only:      # diagnostic mode (not the benchmark contract): k_step alone, random actions, steady state
         gen = torch.Generator(device=dev).manual_seed(0)
-        for _ in range(max(args.warmup, 260)):        # run past the first resets so episodes are desynchronised
+        for _ in range(max(args.warmup * 16, 260)):   # run past the first resets so episodes are desynchronised
             ring.current_action().copy_(torch.randint(0, 3, (env.N,), generator=gen, device=dev, dtype=torch.int32))
             ring.step_env(auto_reset=True)
         for f in range(ring.frames):
@@ -175,11 +221,12 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         e0.record()
-        for _ in range(args.steps):
+        iters = args.steps * args.passes_per_step
+        for _ in range(iters):
             ring.step_env(auto_reset=True)
         e1.record()
         torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / args.steps
+        ms = e0.elapsed_time(e1) / iters
         algo = ALGO_BYTES_PER_AGENT_STEP if args.obs_dtype == "f32" else 404
         gbs = algo * env.N / (ms * 1e-3) / 1e9
         print(json.dumps({"mode": "env-only", "envs": env.N, "k_step_ms_back_to_back": ms,
@@ -198,12 +245,17 @@ def main():
                              amp_dtype=torch.float16 if args.obs_dtype == "f16" else None)
     learner.sync = args.sync
     seed = 7 + rank
+    pps = args.passes_per_step
+    use_c = fused and world_size == 1 and args.host_loop == "c"
     counter = [0]
-    step_events = []
-
+    py_events = []
     ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "8"))
+    hot = None
+    if use_c:
+        from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+        hot = HotLoop(ring, learner, args.batch, seed, eps=args.eps, time_every=ev_every)
 
-    def one_step(record=False):
+    def one_pass(record=False):
         record = record and counter[0] % ev_every == 0
         if fused:
             learner.act(ring.current_obs(), args.eps, seed, counter[0], index_out=ring.current_action())
@@ -215,7 +267,7 @@ def main():
             e0.record()
             ring.step_env(auto_reset=True)
             e1.record()
-            step_events.append((e0, e1))
+            py_events.append((e0, e1))
         else:
             ring.step_env(auto_reset=True)
         if fused:
@@ -224,15 +276,25 @@ def main():
             learner.learn(ring.sample(args.batch, seed, counter[0]))
         counter[0] += 1
 
+    def one_step(record=False):
+        """One bench step = pps passes of act -> env step (+ replay write) -> learner update."""
+        if hot is not None:
+            hot.run(pps)
+        else:
+            for _ in range(pps):
+                one_pass(record)
+
     def fence():
         torch.cuda.synchronize(dev)
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # untimed: a few frames of experience + warm-up of every kernel / allocator path
-    for _ in range(max(args.warmup, 2)):
+    # untimed: experience in the ring + warm-up of every kernel / allocator path
+    for _ in range(max(args.warmup, 1)):
         one_step()
+    if hot is not None:
+        hot.step_times_ms()                   # drop the warm-up's event pairs
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -244,26 +306,17 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    n_pass = args.steps * pps
 
-    # dominant kernel: k_step.  (a) HIP events around each launch inside the timed region, on the launch stream,
-    # minus 0.4 x the cost of an EMPTY event pair on the same stream: without that correction the event figure sits
-    # 20-30 % above rocprofv3's kernel-trace average for a ~10 us kernel.
-    empty = []
-    for _ in range(50):
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record()
-        a1.record()
-        empty.append((a0, a1))
-    torch.cuda.synchronize(dev)
-    pair_ms = float(np.median([a.elapsed_time(b) for a, b in empty]))
-    k_raw_ms = float(np.mean([a.elapsed_time(b) for a, b in step_events])) if step_events else float("nan")
-    # an empty pair costs two marker packets back to back; a pair around a kernel carries part of that inside the
-    # interval.  Calibrated against rocprofv3 --kernel-trace of the same command on four boxes (raw, empty pair,
-    # rocprofv3 average, in us): (15.54, 5.54, 12.76) (14.76, 4.76, 12.95) (12.34, 7.22, 9.28) (12.23, 7.50, 9.57)
-    # -> (raw - rocprofv3) / pair = 0.50, 0.38, 0.42, 0.36: 0.4 of an empty pair is subtracted (within 4 % of
-    # rocprofv3 on all four).
-    k_ms = k_raw_ms - 0.4 * pair_ms
-    # (b) env-only: back-to-back k_step launches between two events (adds ~1.5 us boundary per launch)
+    # ---- k_step, three ways (no correction terms):
+    # (a) HIP event pairs around the launch inside the timed loop, on the launch stream (every ev_every-th pass).  A
+    #     pair brackets the kernel PLUS the two marker packets: for a ~9 us kernel it reads 2-3 us above rocprofv3.
+    if hot is not None:
+        pair = hot.step_times_ms(1 << 16)
+        k_pair_ms = float(np.mean(pair)) if len(pair) else float("nan")
+    else:
+        k_pair_ms = float(np.mean([a.elapsed_time(b) for a, b in py_events])) if py_events else float("nan")
+    # (b) back-to-back k_step launches between ONE event pair (each launch includes its ~1.5 us dispatch boundary)
     it = args.env_only_iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
@@ -272,7 +325,35 @@ def main():
         ring.step_env(auto_reset=True)
     e1.record()
     torch.cuda.synchronize(dev)
-    env_only_ms = e0.elapsed_time(e1) / it
+    k_b2b_ms = e0.elapsed_time(e1) / it
+    # (c) the rocprofv3 --kernel-trace average of this same command, from the committed profile (cannot be taken in-process)
+    prof = committed_profile(args)
+    k_prof_ms = prof.get("k_step_ms")
+    k_ms = max(k_b2b_ms, k_prof_ms or 0.0)    # the roofline fraction is quoted on the LARGER of (b) and (c)
+
+    # ---- k_dqn_grad back to back (fused learner): same ring, same batch, fresh draws per launch
+    g_b2b_ms = None
+    if fused:
+        import ctypes as C
+        from dqn_based_uav_3d_path_planer_amd import _lib
+        nblk = args.batch // 64
+        part = torch.empty((nblk, learner.P + 2), dtype=torch.float32, device=dev)
+        kind = 0 if args.trainer == "dqn" else 1
+        s_ = torch.cuda.current_stream(dev).cuda_stream
+
+        def grad(cn):
+            _lib.check(learner.lib.uavenv_dqn_grad(C.byref(ring._c), ring.head, ring.filled, args.batch, seed, cn, None,
+                                                   C.byref(learner.net), kind, learner.gamma, 0, part.data_ptr(), s_),
+                       "uavenv_dqn_grad")
+        for cn in range(5):
+            grad(cn)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for cn in range(it):
+            grad(100 + cn)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        g_b2b_ms = e0.elapsed_time(e1) / it
 
     # achievable HBM bandwidth on THIS device, same run: device-to-device copy of 1 GiB, read + write bytes
     copy_gbs = None
@@ -290,34 +371,32 @@ def main():
         copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_kstep_traffic.json")     # PMC passes cannot run inside this process:
-    if os.path.exists(tpath) and args.envs == 16384 and args.obs_dtype == "f32":   # last committed rocprofv3 --pmc result
-        try:
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
     if rank == 0:
         n_agents = env.N
-        total_env_steps = args.steps * n_agents * world_size
-        value = total_env_steps / dt
+        value = n_pass * n_agents * world_size / dt
         algo = ALGO_BYTES_PER_AGENT_STEP if args.obs_dtype == "f32" else 404
         achieved = algo * n_agents / (k_ms * 1e-3) / 1e9
+        traffic = prof.get("k_step_traffic_bytes_per_launch")
+        ldt = "f16" if (fused and args.obs_dtype == "f16") else "f32"
         out = {
             "metric": "env-steps/sec + learner updates/sec, PathPlan_City DQN",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "learner_updates_per_s": args.steps / dt,
-            "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
-            "learner_samples_per_s": args.steps * args.batch * world_size / dt,
-            "env_only_steps_per_s": n_agents / (env_only_ms * 1e-3),
+            "passes_per_step": pps, "ms_per_pass": dt / n_pass * 1e3, "timed_region_ms": dt * 1e3,
+            "learner_updates_per_s": n_pass / dt,
+            "host_enqueue_ms_per_pass": 1e3 * t_enq / n_pass,
+            "learner_samples_per_s": n_pass * args.batch * world_size / dt,
+            "env_only_steps_per_s": n_agents / (k_b2b_ms * 1e-3),
             "config": {"workload": "PathPlan_City 500x500x100, 26 buildings, 1 UAV/env, %d vectorised envs/GPU, %s, "
                                    "device replay %d transitions/GPU (BASELINE.json configs[%d])"
                                    % (args.envs, args.trainer.upper(), ring.capacity, args.config - 1),
+                       "step_definition": "1 bench step = %d passes of (act -> env step + replay write -> sample + "
+                                          "learner update) over the whole env batch" % pps,
                        "envs_per_gpu": args.envs, "learn_batch_per_gpu": args.batch, "obs_dtype": args.obs_dtype,
-                       "learner": "fused HIP kernels (f32 MFMA)" if fused else "PyTorch-ROCm ops",
-                       "learner_dtype": "f32" if fused or args.obs_dtype == "f32" else "f16 autocast",
+                       "host_loop": "csrc/loop.hip (C, 4 launches per pass)" if use_c else "python (ctypes per launch)",
+                       "learner": "fused HIP kernels (%s MFMA)" % ldt if fused else "PyTorch-ROCm ops",
+                       "learner_dtype": ldt if fused else ("f32" if args.obs_dtype == "f32" else "f16 autocast"),
                        "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
                                       % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
@@ -325,16 +404,36 @@ def main():
                                                                else "weight averaging every 3 updates")},
             "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r01_kstep_traffic.json (rocprofv3 --pmc "
-                         "FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None, "algorithmic_bytes_per_agent_step": algo,
+                         "traffic": traffic,
+                         "traffic_source": prof.get("source") if traffic else None,
+                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": n_agents,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                         "kernel_ms": k_ms, "kernel_ms_raw_event_pair": k_raw_ms, "empty_event_pair_ms": pair_ms,
-                         "agents_per_launch": n_agents,
-                         "kernel_ms_env_only_back_to_back": env_only_ms},
+                         "kernel_ms": k_ms,
+                         "kernel_ms_definition": "max(back-to-back launches between one HIP event pair in this run, "
+                                                 "rocprofv3 --kernel-trace average of the committed profile of this command)",
+                         "kernel_ms_back_to_back": k_b2b_ms, "kernel_ms_rocprofv3_committed": k_prof_ms,
+                         "kernel_ms_event_pair_in_loop": k_pair_ms},
         }
+        if g_b2b_ms is not None:
+            fl = learner_flops_per_sample(args.trainer)
+            g_prof_ms = prof.get("k_dqn_grad_ms")
+            g_ms = max(g_b2b_ms, g_prof_ms or 0.0)
+            peak = MFMA_F16_PEAK_TF if ldt == "f16" else MFMA_F32_PEAK_TF
+            tf = fl * args.batch / (g_ms * 1e-3) / 1e12
+            row = 813 if args.obs_dtype == "f32" else 413
+            out["roofline_learner"] = {
+                "bound": "mfma", "kernel": "k_dqn_grad (sample + gather + forward/backward of the 100-64-A MLPs)",
+                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "flops_per_sample": fl, "samples_per_launch": args.batch,
+                "kernel_ms": g_ms, "kernel_ms_back_to_back": g_b2b_ms, "kernel_ms_rocprofv3_committed": g_prof_ms,
+                "hbm_GBs": row * args.batch / (g_ms * 1e-3) / 1e9, "algorithmic_bytes_per_sample": row,
+                "mfma_busy_frac_pmc": prof.get("k_dqn_grad_mfma_busy_frac"),
+                "traffic": prof.get("k_dqn_grad_traffic_bytes_per_launch")}
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(args.envs, args.cpu_seconds)
         print(json.dumps(out))
+    if hot is not None:
+        hot.close()
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libuavenv.so")
-SOURCES = ["uavenv.hip", "replay.hip", "learner.hip", "rrt.hip", "per.hip"]
+SOURCES = ["uavenv.hip", "replay.hip", "learner.hip", "rrt.hip", "per.hip", "loop.hip"]
 HEADERS = ["uavenv_device.hpp", os.path.join("..", "..", "include", "uavenv.h")]
 # -ffp-contract=off: the reward / collision arithmetic must round like the reference's
 # separate multiplies and adds (no FMA fusion); see csrc/uavenv_device.hpp.
@@ -36,16 +36,34 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile under an exclusive file lock into a temporary name, then rename: `torchrun bench.py --gpus N` starts N
+    ranks that may all find the library stale; one builds, the others wait on the lock and find it fresh."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():       # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     extra = ["-DUAVENV_PHASE_PROFILE"] if os.environ.get("UAVENV_PHASE_PROFILE") else []   # diagnostics build
     extra += os.environ.get("UAVENV_EXTRA_FLAGS", "").split()                              # A/B experiments
-    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+    cmd = [_hipcc()] + FLAGS + extra + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)                          # atomic: a concurrent CDLL never maps a half-written file
     return LIB_PATH
 
 

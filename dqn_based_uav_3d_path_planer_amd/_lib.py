@@ -8,7 +8,7 @@ from . import _build
 
 OBS_DIM = 100
 MAX_BUILDINGS = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV = 0, -22, -12, -5, -19
 INFO_NORMAL, INFO_SUCCESS, INFO_LOSE, INFO_SKIPPED = 0, 1, 2, 3
@@ -22,8 +22,9 @@ SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
-    "uavenv_replay_sample", "uavenv_select_actions",
+    "uavenv_replay_sample", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
+    "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
 )
 
@@ -54,6 +55,21 @@ class UavDqnNet(C.Structure):
 class UavPer(C.Structure):
     _fields_ = [("prio", C.c_void_p), ("chunk_sum", C.c_void_p), ("chunk_prefix", C.c_void_p),
                 ("capacity", C.c_int64), ("rot", C.c_int64)]
+
+
+class UavLoopConfig(C.Structure):
+    _fields_ = [("env", C.c_void_p), ("ring", UavReplayRing), ("net", UavDqnNet),
+                ("head", C.c_int32), ("filled", C.c_int32), ("batch", C.c_int32), ("kind", C.c_int32),
+                ("huber", C.c_int32), ("update_loop", C.c_int32), ("epoch", C.c_int32), ("learn_start", C.c_int32),
+                ("seed", C.c_uint64), ("counter", C.c_uint64),
+                ("eps", C.c_float), ("gamma", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("adam_eps", C.c_float), ("step_flags", C.c_uint32), ("partials_dev", C.c_void_p),
+                ("loss_dev", C.c_void_p), ("time_every", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class UavLoopCursor(C.Structure):
+    _fields_ = [("head", C.c_int32), ("filled", C.c_int32), ("epoch", C.c_int32), ("reserved0", C.c_int32),
+                ("counter", C.c_uint64)]
 
 
 class UavEnvError(RuntimeError):
@@ -112,6 +128,20 @@ def load() -> C.CDLL:
     lib.uavenv_threaten_rate_allpairs.argtypes = [vp, vp, vp, i64, vp]
     lib.uavenv_replay_sample.restype = C.c_int
     lib.uavenv_replay_sample.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp]
+    lib.uavenv_replay_draw.restype = C.c_int
+    lib.uavenv_replay_draw.argtypes = [i32, i32, i32, i32, i32, u64, u64, vp, vp]
+    lib.uavenv_loop_create.restype = C.c_int
+    lib.uavenv_loop_create.argtypes = [C.POINTER(UavLoopConfig), C.POINTER(vp)]
+    lib.uavenv_loop_destroy.restype = C.c_int
+    lib.uavenv_loop_destroy.argtypes = [vp]
+    lib.uavenv_loop_set_eps.restype = C.c_int
+    lib.uavenv_loop_set_eps.argtypes = [vp, f32]
+    lib.uavenv_loop_run.restype = C.c_int
+    lib.uavenv_loop_run.argtypes = [vp, i32, vp]
+    lib.uavenv_loop_get.restype = C.c_int
+    lib.uavenv_loop_get.argtypes = [vp, C.POINTER(UavLoopCursor)]
+    lib.uavenv_loop_step_times.restype = C.c_int
+    lib.uavenv_loop_step_times.argtypes = [vp, vp, i32, C.POINTER(i32)]
     lib.uavenv_select_actions.restype = C.c_int
     lib.uavenv_select_actions.argtypes = [vp, i32, i32, f32, u64, u64, vp, vp, vp]
     net = C.POINTER(UavDqnNet)

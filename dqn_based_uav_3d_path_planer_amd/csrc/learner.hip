@@ -229,12 +229,8 @@ __global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
             f = g.explicit_idx[2 * s];
             agent = g.explicit_idx[2 * s + 1];
         } else {
-            const uint4 r = philox4x32_10(make_uint4((uint32_t)s, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0x5a3bu),
-                                          make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
-            const int back = 1 + (int)(((uint64_t)r.x * (uint64_t)g.filled) >> 32);
-            f = g.head - back;
-            if (f < 0) f += g.ring.frames;
-            agent = (int)(((uint64_t)r.y * (uint64_t)g.ring.n_agents) >> 32);
+            const ReplayPerm perm = replay_perm(g.seed, g.counter, (uint32_t)g.filled * (uint32_t)g.ring.n_agents);
+            replay_slot_to_frame(replay_perm_apply(perm, (uint32_t)s), g.head, g.ring.frames, g.ring.n_agents, f, agent);
         }
         int fn = f + 1;
         if (fn >= g.ring.frames) fn = 0;

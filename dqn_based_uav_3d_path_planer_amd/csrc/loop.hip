@@ -1,0 +1,152 @@
+// loop.hip -- the off-policy loop of PathPlan_City.run_thread_OffPolicy (Envs/PathPlan_City.py:364-385), all envs of
+// the shard at once, enqueued from C: act -> step (+ replay write) -> learn, K times per call.
+//
+// Why this exists: driven from Python through four ctypes calls per step the host needed ~33 us to enqueue a step
+// whose kernels take ~45 us; any kernel improvement beyond that made the loop host-bound.  From C the same four
+// launches cost the HIP runtime's ~3 us each and nothing else.  Every launch goes through the library's own extern "C"
+// entry points (same validation, same kernels), so a loop of K steps is bit-identical to K rounds of
+// uavenv_dqn_act / uavenv_step / uavenv_dqn_grad / uavenv_dqn_reduce_adam issued by the caller.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <new>
+#include <vector>
+
+#include "../../include/uavenv.h"
+
+struct UavLoop {
+    UavLoopConfig c;
+    int32_t head, filled, epoch;
+    uint64_t counter;
+    size_t obs_row_bytes;
+    std::vector<hipEvent_t> ev;      // pairs (start, stop), recorded so far
+    std::vector<hipEvent_t> pool;    // idle events
+};
+
+extern "C" {
+
+int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
+{
+    if (!cfg || !out || !cfg->env || !cfg->ring.obs || !cfg->ring.action || !cfg->ring.reward || !cfg->ring.done ||
+        !cfg->net.local)
+        return UAVENV_EINVAL;
+    if (!cfg->ring.action_is_index || cfg->ring.frames < 3 || cfg->ring.n_agents != uavenv_num_agents(cfg->env))
+        return UAVENV_EINVAL;
+    if (cfg->head < 0 || cfg->head >= cfg->ring.frames || cfg->filled < 0 || cfg->filled > cfg->ring.frames - 1)
+        return UAVENV_EINVAL;
+    if (cfg->batch < 0 || cfg->batch % 64 != 0 || (cfg->batch > 0 && (!cfg->partials_dev || !cfg->net.target ||
+                                                                        !cfg->net.m || !cfg->net.v)))
+        return UAVENV_EINVAL;
+    if (cfg->update_loop <= 0 || cfg->epoch < 0) return UAVENV_EINVAL;
+    UavLoop *l = new (std::nothrow) UavLoop();
+    if (!l) return UAVENV_ENOMEM;
+    l->c = *cfg;
+    l->head = cfg->head;
+    l->filled = cfg->filled;
+    l->epoch = cfg->epoch;
+    l->counter = cfg->counter;
+    l->obs_row_bytes = (size_t)cfg->ring.n_agents * UAVENV_OBS_DIM * (cfg->ring.obs_dtype == UAVENV_OBS_F16 ? 2 : 4);
+    *out = l;
+    return UAVENV_OK;
+}
+
+int uavenv_loop_destroy(UavLoop *l)
+{
+    if (!l) return UAVENV_OK;
+    for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : l->pool) (void)hipEventDestroy(e);
+    delete l;
+    return UAVENV_OK;
+}
+
+int uavenv_loop_set_eps(UavLoop *l, float eps)
+{
+    if (!l) return UAVENV_EINVAL;
+    l->c.eps = eps;
+    return UAVENV_OK;
+}
+
+int uavenv_loop_get(const UavLoop *l, UavLoopCursor *out)
+{
+    if (!l || !out) return UAVENV_EINVAL;
+    out->head = l->head;
+    out->filled = l->filled;
+    out->epoch = l->epoch;
+    out->reserved0 = 0;
+    out->counter = l->counter;
+    return UAVENV_OK;
+}
+
+static hipEvent_t take_event(UavLoop *l)
+{
+    hipEvent_t e = nullptr;
+    if (!l->pool.empty()) {
+        e = l->pool.back();
+        l->pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+    }
+    return e;
+}
+
+int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
+{
+    if (!l || n_steps < 0) return UAVENV_EINVAL;
+    const UavLoopConfig &c = l->c;
+    const UavReplayRing &R = c.ring;
+    const size_t n = (size_t)R.n_agents;
+    hipStream_t s = (hipStream_t)stream;
+    for (int k = 0; k < n_steps; ++k) {
+        const int t = l->head, nxt = t + 1 == R.frames ? 0 : t + 1;
+        unsigned char *obs_t = (unsigned char *)R.obs + (size_t)t * l->obs_row_bytes;
+        unsigned char *obs_n = (unsigned char *)R.obs + (size_t)nxt * l->obs_row_bytes;
+        int32_t *act_t = (int32_t *)R.action + (size_t)t * n;
+        int rc = uavenv_dqn_act(&c.net, obs_t, R.obs_dtype, R.n_agents, c.eps, c.seed, l->counter, act_t, nullptr, nullptr, s);
+        if (rc != UAVENV_OK) return rc;
+        const bool timed = c.time_every > 0 && (l->counter % (uint64_t)c.time_every) == 0;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) {
+            e0 = take_event(l);
+            e1 = take_event(l);
+            if (e0 && e1) (void)hipEventRecord(e0, s);
+        }
+        rc = uavenv_step(c.env, act_t, UAVENV_ACT_INDEX_I32, obs_n, nullptr, R.reward + (size_t)t * n, R.done + (size_t)t * n,
+                         nullptr, nullptr, R.valid ? R.valid + (size_t)t * n : nullptr, nullptr, nullptr, c.step_flags, s);
+        if (timed && e0 && e1) {
+            (void)hipEventRecord(e1, s);
+            l->ev.push_back(e0);
+            l->ev.push_back(e1);
+        }
+        if (rc != UAVENV_OK) return rc;
+        l->head = nxt;
+        if (l->filled < R.frames - 1) l->filled += 1;
+        if (c.batch > 0 && (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch)) {
+            rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
+                                 c.huber, c.partials_dev, s);
+            if (rc != UAVENV_OK) return rc;
+            l->epoch += 1;
+            rc = uavenv_dqn_reduce_adam(&c.net, c.partials_dev, c.batch / 64, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch,
+                                        l->epoch % c.update_loop == 0 ? 1 : 0, c.loss_dev, nullptr, s);
+            if (rc != UAVENV_OK) return rc;
+        }
+        l->counter += 1;
+    }
+    return UAVENV_OK;
+}
+
+int uavenv_loop_step_times(UavLoop *l, float *ms_out, int32_t max_n, int32_t *n_out)
+{
+    if (!l || !n_out || (max_n > 0 && !ms_out)) return UAVENV_EINVAL;
+    int n = 0;
+    for (size_t i = 0; i + 1 < l->ev.size(); i += 2) {
+        if (hipEventSynchronize(l->ev[i + 1]) != hipSuccess) return UAVENV_EHIP;
+        float ms = 0.0f;
+        if (n < max_n && hipEventElapsedTime(&ms, l->ev[i], l->ev[i + 1]) == hipSuccess) ms_out[n++] = ms;
+        l->pool.push_back(l->ev[i]);
+        l->pool.push_back(l->ev[i + 1]);
+    }
+    l->ev.clear();
+    *n_out = n;
+    return UAVENV_OK;
+}
+
+}  // extern "C"

@@ -28,16 +28,13 @@ __global__ void k_sample_gather(UavReplayRing ring, int head, int filled, int ba
     constexpr int ROW_UNITS = 25;                        // 25 x 16 B (f32) or 25 x 8 B (f16)
     const int row_bytes = ROW_UNITS * UNIT;
     const int64_t total = (int64_t)batch * (2 * ROW_UNITS);
+    const ReplayPerm perm = replay_perm(seed, counter, (uint32_t)filled * (uint32_t)ring.n_agents);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int s = (int)(t / (2 * ROW_UNITS));
         const int q = (int)(t - (int64_t)s * (2 * ROW_UNITS));
-        // every thread of a sample re-derives the same draw from the counter-based generator
-        const uint4 r = philox4x32_10(make_uint4((uint32_t)s, (uint32_t)counter, (uint32_t)(counter >> 32), 0x5a3bu),
-                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-        const int back = 1 + (int)(((uint64_t)r.x * (uint64_t)filled) >> 32);        // 1..filled frames behind head
-        int f = head - back;
-        if (f < 0) f += ring.frames;
-        const int agent = (int)(((uint64_t)r.y * (uint64_t)ring.n_agents) >> 32);
+        // every thread of a sample re-derives the same draw (SIMD lanes: no extra instructions per wavefront)
+        int f, agent;
+        replay_slot_to_frame(replay_perm_apply(perm, (uint32_t)s), head, ring.frames, ring.n_agents, f, agent);
         int fn = f + 1;
         if (fn >= ring.frames) fn = 0;
         const bool is_next = q >= ROW_UNITS;
@@ -54,6 +51,19 @@ __global__ void k_sample_gather(UavReplayRing ring, int head, int filled, int ba
             done_b[s] = (float)ring.done[k];
             if (valid_b) valid_b[s] = ring.valid ? (float)ring.valid[k] : 1.0f;
         }
+    }
+}
+
+// the draws alone: (frame, agent) of samples 0 .. batch-1 (tests, prioritised replay bookkeeping)
+__global__ void k_replay_draw(int frames, int n_agents, int head, int filled, int batch, uint64_t seed, uint64_t counter,
+                              int32_t *__restrict__ out)
+{
+    const ReplayPerm perm = replay_perm(seed, counter, (uint32_t)filled * (uint32_t)n_agents);
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < batch; s += gridDim.x * blockDim.x) {
+        int f, agent;
+        replay_slot_to_frame(replay_perm_apply(perm, (uint32_t)s), head, frames, n_agents, f, agent);
+        out[2 * s] = f;
+        out[2 * s + 1] = agent;
     }
 }
 
@@ -94,7 +104,7 @@ int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled
         !reward_b || !done_b)
         return UAVENV_EINVAL;
     if (ring->frames < 2 || ring->n_agents <= 0 || batch <= 0 || filled <= 0 || filled > ring->frames - 1 ||
-        head < 0 || head >= ring->frames)
+        head < 0 || head >= ring->frames || (uint64_t)filled * (uint64_t)ring->n_agents >= (1ull << 32))
         return UAVENV_EINVAL;
     const int64_t total = (int64_t)batch * 50;
     const int block = 256;
@@ -109,6 +119,20 @@ int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled
         hipLaunchKernelGGL((k_sample_gather<8>), dim3(grid), dim3(block), 0, s, *ring, head, filled, batch, seed, counter,
                            (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
                            done_b, valid_b);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_replay_draw(int32_t frames, int32_t n_agents, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                       uint64_t counter, int32_t *frame_agent_out, void *stream)
+{
+    if (!frame_agent_out || frames < 2 || n_agents <= 0 || batch <= 0 || filled <= 0 || filled > frames - 1 || head < 0 ||
+        head >= frames || (uint64_t)filled * (uint64_t)n_agents >= (1ull << 32))
+        return UAVENV_EINVAL;
+    const int block = 256;
+    int grid = (batch + block - 1) / block;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_replay_draw, dim3(grid), dim3(block), 0, (hipStream_t)stream, frames, n_agents, head, filled, batch,
+                       seed, counter, frame_agent_out);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

@@ -807,4 +807,61 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+// ReplayMemory.sample2 = random.sample(self.memory, batch_size) (BaseClass/replay_buffer.py:48-51): `batch` DISTINCT
+// stored transitions, every subset equally likely.  On the device: sample s of update (seed, counter) is P(s), where P
+// is a keyed pseudo-random permutation of the D = filled * n_agents stored transitions -- a balanced Feistel network
+// over 2*hb >= log2(D) bits (6 rounds, murmur3-finaliser round function, round keys from Philox(seed, counter)),
+// cycle-walked back into [0, D) (the network permutes [0, 4^hb) with 4^hb < 4 D, so < 4 passes are expected).
+// Distinct s < D give distinct transitions; s >= D wraps (the reference raises there).  oracle/philox.py restates it.
+struct ReplayPerm {
+    uint32_t k[6];
+    uint32_t D, hb;
+};
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ ReplayPerm replay_perm(uint64_t seed, uint64_t counter, uint32_t D)
+{
+    ReplayPerm p;
+    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint4 a = philox4x32_10(make_uint4(0u, (uint32_t)counter, (uint32_t)(counter >> 32), 0x5a3bu), key);
+    const uint4 b = philox4x32_10(make_uint4(1u, (uint32_t)counter, (uint32_t)(counter >> 32), 0x5a3bu), key);
+    p.k[0] = a.x; p.k[1] = a.y; p.k[2] = a.z; p.k[3] = a.w; p.k[4] = b.x; p.k[5] = b.y;
+    p.D = D;
+    const uint32_t bits = D > 1u ? 32u - (uint32_t)__builtin_clz(D - 1u) : 1u;     // ceil(log2 D), >= 1
+    p.hb = (bits + 1u) >> 1;
+    return p;
+}
+
+__device__ __forceinline__ uint32_t replay_perm_apply(const ReplayPerm &p, uint32_t s)
+{
+    if (p.D <= 1u) return 0u;
+    uint32_t x = s < p.D ? s : s % p.D;
+    const uint32_t hb = p.hb, mask = (1u << hb) - 1u;
+    do {
+        uint32_t L = x >> hb, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const uint32_t t = L ^ (fmix32(R ^ p.k[r]) >> (32u - hb));
+            L = R;
+            R = t;
+        }
+        x = (L << hb) | R;
+    } while (x >= p.D);
+    return x;
+}
+
+// transition slot -> (frame, agent): slot / n_agents + 1 frames behind the ring head
+__device__ __forceinline__ void replay_slot_to_frame(uint32_t slot, int head, int frames, int n_agents, int &f, int &agent)
+{
+    const uint32_t back = slot / (uint32_t)n_agents;
+    agent = (int)(slot - back * (uint32_t)n_agents);
+    f = head - 1 - (int)back;
+    if (f < 0) f += frames;
+}
+
 }  // namespace uav

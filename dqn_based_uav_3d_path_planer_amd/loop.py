@@ -1,0 +1,85 @@
+"""HotLoop -- PathPlan_City.run_thread_OffPolicy (Envs/PathPlan_City.py:364-385) for a whole env shard, enqueued by
+csrc/loop.hip: act -> step (+ replay write) -> learn, K steps per call, four launches per step issued from C.
+
+The ring cursor and the learner's update count live in the C object while a HotLoop exists; `run` writes them back to
+the DeviceReplayRing / FusedDQNLearner it was built from, so the two stay usable between calls."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .learner import FusedDQNLearner
+from .replay import DeviceReplayRing
+
+
+class HotLoop:
+    def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
+                 counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
+                 time_every: int = 0):
+        if not ring.discrete:
+            raise ValueError("HotLoop drives the discrete (DQN-family) path")
+        if batch % 64:
+            raise ValueError("batch must be a multiple of 64")
+        self.lib = _lib.load()
+        self.ring, self.learner = ring, learner
+        env = ring.env
+        if skip_done is None:
+            skip_done = env.uav_per_env > 1
+        nblk = max(batch // 64, 1)
+        self._partials = torch.empty((nblk, learner.P + 2), dtype=torch.float32, device=env.device)
+        cfg = _lib.UavLoopConfig()
+        cfg.env = env._h
+        cfg.ring = ring._c
+        cfg.net = learner.net
+        cfg.head, cfg.filled = ring.head, ring.filled
+        cfg.batch = int(batch)
+        cfg.kind = 0 if learner.kind == "dqn" else 1
+        cfg.huber = learner.huber
+        cfg.update_loop = learner.update_loop
+        cfg.epoch = learner.epoch
+        cfg.learn_start = int(learn_start)
+        cfg.seed, cfg.counter = int(seed), int(counter)
+        cfg.eps, cfg.gamma, cfg.lr = float(eps), learner.gamma, learner.lr
+        cfg.beta1, cfg.beta2, cfg.adam_eps = learner.betas[0], learner.betas[1], learner.eps
+        cfg.step_flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | \
+            ring.extra_flags
+        cfg.partials_dev = self._partials.data_ptr()
+        cfg.loss_dev = learner.loss.data_ptr()
+        cfg.time_every = int(time_every)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.uavenv_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_loop_create")
+        self.counter = int(counter)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.uavenv_loop_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_eps(self, eps: float):
+        _lib.check(self.lib.uavenv_loop_set_eps(self._h, float(eps)), "uavenv_loop_set_eps")
+
+    def run(self, n_steps: int):
+        """Enqueue n_steps of act -> step -> learn on the current torch stream (asynchronous)."""
+        s = torch.cuda.current_stream(self.ring.env.device).cuda_stream
+        _lib.check(self.lib.uavenv_loop_run(self._h, int(n_steps), s), "uavenv_loop_run")
+        cur = _lib.UavLoopCursor()
+        _lib.check(self.lib.uavenv_loop_get(self._h, C.byref(cur)), "uavenv_loop_get")
+        self.ring.head, self.ring.filled = cur.head, cur.filled
+        self.learner.epoch = cur.epoch
+        self.counter = int(cur.counter)
+
+    def step_times_ms(self, max_n: int = 4096) -> np.ndarray:
+        """Durations of the event-bracketed step kernels since the last call (synchronises on them)."""
+        buf = np.zeros(max_n, dtype=np.float32)
+        n = C.c_int32(0)
+        _lib.check(self.lib.uavenv_loop_step_times(self._h, buf.ctypes.data, max_n, C.byref(n)), "uavenv_loop_step_times")
+        return buf[:n.value].copy()

@@ -56,8 +56,13 @@ class DeviceReplayRing:
         """The slot the policy writes its action for the current frame into."""
         return self.action[self.head]
 
-    def step_env(self, auto_reset: bool = True, skip_done: bool = False):
-        """Apply action[head] with the fused kernel; the transition lands in the ring in the same launch."""
+    def step_env(self, auto_reset: bool = True, skip_done: bool = None):
+        """Apply action[head] with the fused kernel; the transition lands in the ring in the same launch.
+        skip_done defaults to True when an env holds several UAVs: an env only auto-resets once ALL its agents are
+        done, and the reference never steps a finished agent while it waits (PathPlan_City.py:365-366) -- its rows
+        land in the ring with valid = 0."""
+        if skip_done is None:
+            skip_done = self.env.uav_per_env > 1
         t, nxt = self.head, (self.head + 1) % self.frames
         n = self.env.N
         flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | self.extra_flags

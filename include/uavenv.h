@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 1
+#define UAVENV_ABI_VERSION 2
 #define UAVENV_OBS_DIM 100          /* Agents/UAV.py:517  state_map = zeros(1,1,1,100) */
 #define UAVENV_MAX_BUILDINGS 64     /* broad-phase masks are 64-bit */
 
@@ -164,13 +164,20 @@ typedef struct UavReplayRing {
     int32_t action_is_index;
 } UavReplayRing;
 
-/* ReplayMemory.sample2 (replay_buffer.py:48-51) on device: draw `batch` (frame, agent) pairs uniformly (with
- * replacement, Philox(seed, counter)) from the `filled` frames preceding `head` and gather them into
+/* ReplayMemory.sample2 = random.sample(memory, batch) (replay_buffer.py:48-51) on device: `batch` DISTINCT stored
+ * transitions (frame, agent) out of the `filled` frames preceding `head` -- the first `batch` images of a keyed
+ * pseudo-random permutation of the filled * n_agents transitions (Feistel network keyed by Philox(seed, counter);
+ * batch > filled * n_agents wraps around, where the reference raises) -- gathered into
  * contiguous batch buffers: obs_b/next_obs_b batch x 100 (ring dtype), action_b batch (ring type),
  * reward_b batch f32, done_b batch f32 (0/1), valid_b batch f32 (0/1). */
 int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
                          uint64_t counter, void *obs_b, void *next_obs_b, void *action_b, float *reward_b,
                          float *done_b, float *valid_b, void *stream);
+
+/* The draws alone: frame_agent_out_dev[2*s], [2*s+1] = (frame, agent) of sample s, s < batch -- exactly the
+ * transitions uavenv_replay_sample / uavenv_dqn_grad use for the same (seed, counter, head, filled). */
+int uavenv_replay_draw(int32_t frames, int32_t n_agents, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                       uint64_t counter, int32_t *frame_agent_out_dev, void *stream);
 
 /* epsilon-greedy over Q-values (Trainer/DuelingDQN_Trainer.py:86-97): q_dev N x A f32 (row-major).
  * Writes the chosen index (int32, nullable) and its steering value (f32, nullable). */
@@ -243,6 +250,50 @@ int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials_dev, int3
 /* Q(s) for n envs + epsilon-greedy in one launch (DuelingDQN_Trainer.py:86-97); q_out_dev nullable [n][A]. */
 int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype, int32_t n, float eps, uint64_t seed,
                    uint64_t counter, int32_t *index_out_dev, float *steer_out_dev, float *q_out_dev, void *stream);
+
+/* ---- the whole off-policy loop, enqueued from C ------------------------------------------------------------------ */
+/* PathPlan_City.run_thread_OffPolicy (Envs/PathPlan_City.py:364-385) for every env of the shard at once, K times:
+ *     act     Q(s) + epsilon-greedy            -> ring.action[head]          (Choose_Action2, :346,370)
+ *     step    update_PathPlan + state_PathPlan -> ring frame head / head+1   (Move_Agent + Push_Replay, :371-379)
+ *     learn   learn_off_policy(): sample, TD target, loss, Adam, hard copy   (:380-383; skipped while the ring holds
+ *             fewer than `learn_start` transitions or when batch == 0)
+ * One call enqueues all 4 K launches on the stream; the host does nothing per step but four kernel launches from
+ * C (no interpreter, no per-step allocation).  The cursor (head, filled, counter, epoch) lives in the UavLoop and is
+ * advanced by uavenv_loop_run; read it back with uavenv_loop_get. */
+typedef struct UavLoop UavLoop;
+typedef struct UavLoopConfig {
+    UavEnv *env;
+    UavReplayRing ring;          /* action_is_index must be 1 */
+    UavDqnNet net;
+    int32_t head, filled;        /* initial ring cursor */
+    int32_t batch;               /* learner batch (multiple of 64); 0 = rollout only */
+    int32_t kind;                /* 0 max_a Q_target(s'), 1 double-DQN */
+    int32_t huber;
+    int32_t update_loop;         /* hard target copy every update_loop updates */
+    int32_t epoch;               /* learner updates done so far (Adam's step count) */
+    int32_t learn_start;         /* transitions the ring must hold before the first update (>= batch) */
+    uint64_t seed, counter;      /* Philox key / first step's counter (one counter value per step) */
+    float eps, gamma, lr, beta1, beta2, adam_eps;
+    uint32_t step_flags;         /* UAVENV_STEP_* for every step */
+    float *partials_dev;         /* [batch / 64][num_params + 2] scratch */
+    float *loss_dev;             /* device scalar: mean loss of the last update */
+    int32_t time_every;          /* > 0: bracket the step kernel of every time_every-th step with HIP events */
+    int32_t reserved0;
+} UavLoopConfig;
+typedef struct UavLoopCursor {
+    int32_t head, filled, epoch, reserved0;
+    uint64_t counter;
+} UavLoopCursor;
+
+int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out);
+int uavenv_loop_destroy(UavLoop *loop);
+int uavenv_loop_set_eps(UavLoop *loop, float eps);
+/* Enqueue n_steps iterations on `stream`; never synchronises. */
+int uavenv_loop_run(UavLoop *loop, int32_t n_steps, void *stream);
+int uavenv_loop_get(const UavLoop *loop, UavLoopCursor *out);
+/* Synchronises the recorded events; writes up to max_n step-kernel durations (ms) and returns their number in *n_out;
+ * clears the record. */
+int uavenv_loop_step_times(UavLoop *loop, float *ms_out, int32_t max_n, int32_t *n_out);
 
 #ifdef __cplusplus
 }

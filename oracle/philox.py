@@ -1,0 +1,100 @@
+"""TEST INFRASTRUCTURE (oracle): independent numpy restatement of the counter-based random streams the device uses.
+
+* philox4x32_10: Salmon, Moraes, Dror, Shaw, "Parallel Random Numbers: As Easy as 1, 2, 3" (SC'11), the
+  Philox-4x32 bijection with 10 rounds, multipliers 0xD2511F53 / 0xCD9E8D57, Weyl key increments 0x9E3779B9 /
+  0xBB67AE85.  Pinned against the Random123 known-answer vectors in tests/test_oracle_philox.py.
+* replay_draws: which stored transitions `uavenv_replay_sample` / `uavenv_dqn_grad` must pick for update
+  (seed, counter): ReplayMemory.sample2 = random.sample(memory, batch) (BaseClass/replay_buffer.py:48-51) draws
+  DISTINCT transitions; the device realises that as the first `batch` images of a keyed pseudo-random permutation
+  of the D = filled * n_agents stored transitions (6-round balanced Feistel network over 2*hb bits, cycle-walked
+  into [0, D); csrc/uavenv_device.hpp: replay_perm / replay_perm_apply).
+* act_draws: the epsilon-greedy stream of uavenv_dqn_act / uavenv_select_actions (DuelingDQN_Trainer.py:86-97).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+U32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(ctr, key):
+    """ctr: (..., 4) uint32-valued, key: (2,) or (..., 2) -> (..., 4) uint32.  Vectorised over the leading axes."""
+    c = np.asarray(ctr, dtype=np.uint64) & U32
+    k = np.broadcast_to(np.asarray(key, dtype=np.uint64) & U32, c.shape[:-1] + (2,)).copy()
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = k[..., 0], k[..., 1]
+    for _ in range(10):
+        p0 = M0 * c0                      # 32 x 32 -> 64 bit products (fit in uint64)
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & U32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & U32
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & U32, lo1, (hi0 ^ c3 ^ k1) & U32, lo0
+        k0 = (k0 + np.uint64(W0)) & U32
+        k1 = (k1 + np.uint64(W1)) & U32
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def _key(seed: int):
+    return np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+
+
+def fmix32(h):
+    """MurmurHash3's 32-bit finaliser (Appleby, public domain) on uint64-held 32-bit values."""
+    h = np.asarray(h, dtype=np.uint64) & U32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & U32
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & U32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def replay_slots(batch: int, seed: int, counter: int, filled: int, n_agents: int) -> np.ndarray:
+    """Transition slot (0 = newest frame's agent 0 ... D-1) of samples 0..batch-1."""
+    D = filled * n_agents
+    if D <= 1:
+        return np.zeros(batch, dtype=np.int64)
+    lo, hi = counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF
+    a = philox4x32_10(np.array([0, lo, hi, 0x5A3B]), _key(seed))
+    b = philox4x32_10(np.array([1, lo, hi, 0x5A3B]), _key(seed))
+    keys = [np.uint64(v) for v in (a[0], a[1], a[2], a[3], b[0], b[1])]
+    bits = max(1, int(D - 1).bit_length())
+    hb = (bits + 1) // 2
+    mask = np.uint64((1 << hb) - 1)
+    sh = np.uint64(32 - hb)
+    x = (np.arange(batch, dtype=np.uint64) % np.uint64(D))
+    todo = np.ones(batch, dtype=bool)
+    while todo.any():
+        v = x[todo]
+        L, R = v >> np.uint64(hb), v & mask
+        for r in range(6):
+            t = L ^ (fmix32(R ^ keys[r]) >> sh)
+            L, R = R, t
+        v = (L << np.uint64(hb)) | R
+        x[todo] = v
+        todo[todo] = v >= np.uint64(D)
+    return x.astype(np.int64)
+
+
+def replay_draws(batch: int, seed: int, counter: int, head: int, filled: int, frames: int, n_agents: int):
+    """-> (frame [batch], agent [batch]) of the transitions update (seed, counter) must use."""
+    slot = replay_slots(batch, seed, counter, filled, n_agents)
+    back = slot // n_agents
+    agent = slot - back * n_agents
+    f = (head - 1 - back) % frames
+    return f.astype(np.int64), agent.astype(np.int64)
+
+
+def act_draws(n: int, seed: int, counter: int, n_actions: int):
+    """-> (u [n] float32 in [0,1), random_action [n]) of the epsilon-greedy stream: greedy iff u > eps."""
+    lo, hi = counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF
+    ctr = np.stack([np.arange(n, dtype=np.uint64), np.full(n, lo, np.uint64), np.full(n, hi, np.uint64),
+                    np.full(n, 0xAC7, np.uint64)], axis=-1)
+    r = philox4x32_10(ctr, _key(seed)).astype(np.uint64)
+    u = ((r[:, 0] >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+    rnd = ((r[:, 1] * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int64)
+    return u, rnd

@@ -90,6 +90,9 @@ def _load(name: str) -> C.CDLL:
     lib.orc_step_many.restype = None
     lib.orc_step_many.argtypes = [C.POINTER(World), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_rollout_many.restype = C.c_int64
+    lib.orc_rollout_many.argtypes = [C.POINTER(World), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_sizeof_uav.restype = C.c_int
     lib.orc_max_threads.restype = C.c_int
     assert lib.orc_sizeof_uav() == C.sizeof(Uav), (lib.orc_sizeof_uav(), C.sizeof(Uav))
@@ -259,6 +262,21 @@ class OracleBatch:
             u.n_sub = int(n_sub[s])
             C.memmove(C.addressof(u.sub), np.ascontiguousarray(sub_goals[s], dtype=np.float64).ctypes.data,
                       int(n_sub[s]) * 24)
+
+    def rollout(self, n_steps: int, bank_start_goal, bank_sub, bank_nsub, seed: int = 0, want_obs=True, nthreads=0):
+        """orc_rollout_many: n_steps of update + state for every agent inside C (auto-reset from the bank).
+        -> (agent-steps executed, sum of rewards)."""
+        sg = np.ascontiguousarray(bank_start_goal, dtype=np.float64).reshape(-1, 6)
+        sub = np.ascontiguousarray(bank_sub, dtype=np.float64)
+        ns = np.ascontiguousarray(bank_nsub, dtype=np.int32)
+        if want_obs and getattr(self, "_obs", None) is None:
+            self._obs = np.zeros((self.n, OBS_DIM))
+        rsum = C.c_double(0.0)
+        done = self.lib.orc_rollout_many(C.byref(self.world.w), C.addressof(self.arr), self.n, int(n_steps),
+                                         sg.ctypes.data, sub.ctypes.data, ns.ctypes.data, len(sg), sub.shape[1],
+                                         int(seed), self._obs.ctypes.data if want_obs else None, C.byref(rsum),
+                                         int(nthreads))
+        return int(done), float(rsum.value)
 
     def step(self, a0: np.ndarray, want_obs=True, nthreads=0):
         n = self.n

@@ -532,6 +532,62 @@ void orc_step_many(const orc_world *w, orc_uav *u, int64_t n, const double *a0,
     }
 }
 
+/* The timed CPU baseline (bench.py cpu_baseline): n_steps rounds of update_PathPlan + state_PathPlan for n
+ * independent agents, entirely inside C -- each OpenMP thread owns a contiguous block of agents and runs all its
+ * steps without returning to the caller (no fork/join, no interpreter per step).  Steering actions come from a
+ * per-agent 64-bit LCG (uniform in [-1, 1): what the random policy of the GPU run does); an agent whose episode ended
+ * (Check_uav_Done, PathPlan_City.py:252-259) restarts from scenario `bank` row (agent + episode count) mod m with the
+ * next LCG draw as heading -- the CPU twin of the GPU loop's auto-reset from the same scenario bank (UAV.reset with
+ * the RRT result pre-planned, UAV.py:327-366).  obs: n * 100 doubles (each agent's row is overwritten every step).
+ * Returns the number of agent-steps executed. */
+int64_t orc_rollout_many(const orc_world *w, orc_uav *u, int64_t n, int32_t n_steps, const double *bank_start_goal,
+                         const double *bank_sub, const int32_t *bank_nsub, int32_t bank_m, int32_t bank_k,
+                         uint64_t seed, double *obs, double *reward_sum, int nthreads)
+{
+    int64_t total = 0;
+    double rsum = 0.0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static) reduction(+ : total, rsum)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        orc_uav *a = &u[i];
+        uint64_t x = seed * 0x9E3779B97F4A7C15ull + (uint64_t)i * 0xD1342543DE82EF95ull + 1ull;
+        int64_t episodes = 0;
+        for (int32_t t = 0; t < n_steps; ++t) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            const double a0 = (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+            double r;
+            int32_t d, info;
+            orc_update_pathplan(w, a, a0, &r, &d, &info);
+            rsum += r;
+            if (a->done && bank_m > 0) {
+                ++episodes;
+                const int64_t sc = (i + episodes * 7919) % bank_m;
+                const double *sg = bank_start_goal + 6 * sc;
+                x = x * 6364136223846793005ull + 1442695040888963407ull;
+                const double seta = (double)(x >> 11) * (2.0 * ORC_PI / 9007199254740992.0);
+                a->step = 0; a->score = 0; a->done = 0;
+                a->v_dir = seta;
+                a->vx = a->max_v * cos(seta); a->vy = a->max_v * sin(seta); a->vz = 0;
+                a->V = orc_calc_v(a);
+                a->px = sg[0]; a->py = sg[1]; a->pz = sg[2];
+                a->gx = sg[3]; a->gy = sg[4]; a->gz = sg[5];
+                int32_t ns = bank_nsub[sc];
+                if (ns > ORC_KMAX) ns = ORC_KMAX;
+                memcpy(&a->sub[0][0], bank_sub + (size_t)sc * (size_t)bank_k * 3, (size_t)ns * 3 * sizeof(double));
+                a->n_sub = ns;
+                a->sub0_alias = ns >= 2 ? 1 : 0;
+                a->total_score = 0; a->path_len = 0; a->reach_goal = 0;
+            }
+            if (obs) orc_state_pathplan(w, a, obs + (size_t)ORC_OBS_DIM * (size_t)i);
+        }
+        total += n_steps;
+    }
+    if (reward_sum) *reward_sum = rsum;
+    return total;
+}
+
 int orc_sizeof_uav(void) { return (int)sizeof(orc_uav); }
 
 int orc_max_threads(void)

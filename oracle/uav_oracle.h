@@ -110,6 +110,10 @@ void orc_reset(const orc_world *w, orc_uav *u, orc_rng *r, double sub_granularit
 void orc_step_many(const orc_world *w, orc_uav *u, int64_t n, const double *a0,
                    double *reward, int32_t *ret_done, int32_t *info, double *obs /* n*100 or NULL */,
                    int nthreads);
+/* n_steps of update + state per agent inside C, auto-reset from a scenario bank (see uav_oracle.c); returns agent-steps */
+int64_t orc_rollout_many(const orc_world *w, orc_uav *u, int64_t n, int32_t n_steps, const double *bank_start_goal,
+                         const double *bank_sub, const int32_t *bank_nsub, int32_t bank_m, int32_t bank_k,
+                         uint64_t seed, double *obs, double *reward_sum, int nthreads);
 int orc_sizeof_uav(void);
 int orc_max_threads(void);
 

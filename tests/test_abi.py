@@ -38,6 +38,29 @@ def test_config_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.UavReplayRing) == 5 * 8 + 4 * 4
 
 
+def test_every_struct_layout_matches_the_header_as_gcc_sees_it(tmp_path):
+    """sizeof / offsetof of every struct in include/uavenv.h, printed by a C program gcc builds against the header,
+    must equal the ctypes mirror in _lib.py."""
+    import subprocess
+    structs = {"UavEnvConfig": _lib.UavEnvConfig, "UavReplayRing": _lib.UavReplayRing, "UavDqnNet": _lib.UavDqnNet,
+               "UavPer": _lib.UavPer, "UavLoopConfig": _lib.UavLoopConfig, "UavLoopCursor": _lib.UavLoopCursor}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "uavenv.h"', 'int main(void){']
+    for name, ct in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, ct in structs.items():
+        assert int(got[name]) == ctypes.sizeof(ct), name
+        for fname, _ in ct._fields_:
+            assert int(got[f"{name}.{fname}"]) == getattr(ct, fname).offset, (name, fname)
+
+
 def test_fails_loudly_without_a_gpu():
     import torch
     if torch.cuda.is_available():

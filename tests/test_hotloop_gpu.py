@@ -1,0 +1,74 @@
+"""csrc/loop.hip: K steps enqueued from C == the same K steps driven call by call from Python (same kernels, same
+Philox counters): ring contents, weights, Adam moments, cursor -- bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PARAM = {"w": "100", "hiden_dim": "64", "output": "3", "LEARNING_RATE": "0.001", "gamma": "0.99", "Update_loop": "3"}
+
+
+@pytest.mark.parametrize("kind,net,dtype", [("dqn", "Qnet2", torch.float32), ("dueling", "VAnet2", torch.float16)])
+def test_c_loop_equals_python_loop(kind, net, dtype):
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    n, batch, steps = 1024, 1024, 23
+
+    def build():
+        env = make_city26_env(n, obs_dtype=dtype)
+        ring = DeviceReplayRing(env, 8 * n, discrete=True)       # 9 frames: 23 steps wrap the ring twice
+        ring.reset(seed=12)
+        torch.manual_seed(1)
+        return env, ring, FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
+
+    env_a, ring_a, La = build()
+    for c in range(steps):
+        La.act(ring_a.current_obs(), 0.2, 9, c, index_out=ring_a.current_action())
+        ring_a.step_env(auto_reset=True)
+        La.learn_from_ring(ring_a, batch, 9, c)
+    env_b, ring_b, Lb = build()
+    assert torch.equal(La.flat[0] * 0 + Lb.flat[0], Lb.flat[0])
+    loop = HotLoop(ring_b, Lb, batch, seed=9, eps=0.2, time_every=4)
+    loop.run(10)
+    loop.run(steps - 10)
+    torch.cuda.synchronize()
+    assert (ring_b.head, ring_b.filled, Lb.epoch, loop.counter) == (ring_a.head, ring_a.filled, La.epoch, steps)
+    for name in ("obs", "action", "reward", "done", "valid"):
+        assert torch.equal(getattr(ring_a, name), getattr(ring_b, name)), name
+    assert torch.equal(La.flat, Lb.flat)
+    assert float(La.loss) == float(Lb.loss)
+    ms = loop.step_times_ms()
+    assert len(ms) == 6 and (ms > 0).all() and (ms < 5).all()           # steps 0, 4, 8, ... were bracketed
+    assert len(loop.step_times_ms()) == 0
+    loop.close()
+    env_a.close()
+    env_b.close()
+
+
+def test_rollout_only_and_learn_start():
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    env = make_city26_env(512)
+    ring = DeviceReplayRing(env, 16 * 512, discrete=True)
+    ring.reset(seed=1)
+    L = FusedDQNLearner(dict(PARAM, NetWork="Qnet2"), "dqn", device="cuda:0")
+    w0 = L.flat[0].clone()
+    loop = HotLoop(ring, L, 1024, seed=3, learn_start=5 * 512)
+    loop.run(4)                                   # 4 x 512 transitions < learn_start: no update yet
+    torch.cuda.synchronize()
+    assert L.epoch == 0 and torch.equal(L.flat[0], w0)
+    loop.run(3)                                   # updates at filled = 5, 6, 7
+    torch.cuda.synchronize()
+    assert L.epoch == 3 and not torch.equal(L.flat[0], w0)
+    loop.close()
+    roll = HotLoop(ring, L, 0, seed=3)            # batch 0: rollout only
+    w1 = L.flat[0].clone()
+    roll.run(5)
+    torch.cuda.synchronize()
+    assert L.epoch == 3 and torch.equal(L.flat[0], w1) and ring.filled == 12
+    roll.close()
+    env.close()

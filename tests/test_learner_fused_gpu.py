@@ -115,3 +115,137 @@ def test_fused_act_matches_torch_forward():
         assert (counts - 1 / 3).abs().max().item() < 0.03
         F.act(obs.half(), 0.0, 3, 0, index_out=idx, q_out=q)   # f16 observations
         assert (q - F.q_local(obs.half().float())).abs().max().item() <= 2e-5
+
+
+class HandRingF16(HandRing):
+    """The same hand-made batch stored as f16 observations (BASELINE configs[2]'s ring dtype)."""
+
+    def __init__(self, states, next_states, actions, rewards, dones):
+        from dqn_based_uav_3d_path_planer_amd import _lib
+        super().__init__(states, next_states, actions, rewards, dones)
+        self.obs = self.obs.half().contiguous()
+        self._c = _lib.UavReplayRing(self.obs.data_ptr(), self.action.data_ptr(), self.reward.data_ptr(),
+                                     self.done.data_ptr(), self.valid.data_ptr(), 2, len(actions), _lib.OBS_F16, 1)
+
+
+@pytest.mark.parametrize("ref_name,kind,net", CASES)
+def test_fused_f16_ring_updates_match_reference(ref_name, kind, net):
+    """k_dqn_grad<__half> (the kernel behind BASELINE configs[2]): the executed-reference goldens through an f16 ring.
+    (a) against the PyTorch learner fed the SAME f16-rounded observations: only summation order differs -> the f32
+        bars (2e-5 relative on losses, 5e-6 on weights);
+    (b) against the executed reference itself (f32 observations): the difference is the observations' f16 rounding
+        (2^-11 relative per input); bars: 3e-3 relative on losses, 2e-4 absolute on weights after 7 Adam steps of
+        lr 1e-3 (Adam normalises the gradient, so a sign-stable gradient moves a weight by <= lr per step whatever
+        its magnitude: input rounding can only show up where a gradient component is near zero)."""
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
+    g = load_golden(f"learner_{ref_name}.npz")
+    L = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
+    T = DQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
+    for netobj, pref in ((L.q_local, "l0_"), (L.q_target, "t0_"), (T.q_local, "l0_"), (T.q_target, "t0_")):
+        _load(netobj, g, pref)
+    ring = HandRingF16(g["states"], g["next_states"], g["actions"], g["rewards"], g["dones"])
+    batch = dict(states=ring.obs[0].float(), next_states=ring.obs[1].float(),
+                 actions=torch.tensor(g["actions"].astype(np.int32), device="cuda"),
+                 rewards=torch.tensor(g["rewards"], device="cuda"), dones=torch.tensor(g["dones"], device="cuda"))
+    lf, lt = [], []
+    for _ in range(len(g["losses"])):
+        lf.append(float(L.learn_from_ring(ring, 64, 0, 0, explicit_idx=ring.idx)))
+        lt.append(float(T.learn(batch)))
+    assert np.allclose(lf, lt, rtol=2e-5, atol=0), (lf, lt)
+    assert np.allclose(lf, g["losses"], rtol=3e-3, atol=0), (lf, g["losses"])
+    for (k, a), (_, b) in zip(T.q_local.state_dict().items(), L.q_local.state_dict().items()):
+        assert (a - b).abs().max().item() <= 5e-6, k
+    for pref, netobj in (("l1_", L.q_local), ("t1_", L.q_target)):
+        for k, v in netobj.state_dict().items():
+            assert np.abs(v.cpu().numpy() - g[pref + k]).max() <= 2e-4, (pref, k)
+
+
+@pytest.mark.parametrize("kind,net,dtype", [("dqn", "Qnet2", torch.float32), ("dueling", "VAnet2", torch.float16)])
+def test_fused_huber_and_f16_ring_match_torch_learner_on_a_real_ring(kind, net, dtype):
+    """The north_star's Huber option (learner.hip's smooth-L1 branch) and the f16 ring at B = 4 096, against the
+    PyTorch-ROCm learner on the identical sampled batch."""
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    n = 2048
+    env = make_city26_env(n, obs_dtype=dtype)
+    ring = DeviceReplayRing(env, 6 * n, discrete=True)
+    ring.reset(seed=4)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(5):
+        ring.current_action().copy_(torch.randint(0, 3, (n,), generator=gen, device="cuda", dtype=torch.int32))
+        ring.step_env(auto_reset=True)
+    torch.manual_seed(0)
+    T = DQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0", loss="huber")
+    F = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0", loss="huber")
+    F.q_local.load_state_dict(T.q_local.state_dict())
+    F.q_target.load_state_dict(T.q_target.state_dict())
+    saw_linear = False
+    for it in range(4):
+        batch = ring.sample(4096, seed=11, counter=it)
+        with torch.no_grad():        # the batch must exercise BOTH Huber branches (rewards reach ~200: |delta| > 1)
+            d = T.q_local(batch["states"].float()).gather(1, batch["actions"].long().view(-1, 1)).view(-1) - batch["rewards"]
+            saw_linear |= bool((d.abs() > 1.5).any()) and bool((d.abs() < 0.5).any())
+        lt = float(T.learn(batch))
+        lf = float(F.learn_from_ring(ring, 4096, seed=11, counter=it))
+        assert abs(lt - lf) <= 2e-5 * abs(lt), (it, lt, lf)
+    assert saw_linear
+    for (k, a), (_, b) in zip(T.q_local.state_dict().items(), F.q_local.state_dict().items()):
+        assert (a - b).abs().max().item() <= 2e-5, k
+    env.close()
+
+
+def _two_rank_worker(rank, world, port, kind, net, out_dir):
+    import os
+    import torch.distributed as dist
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    n = 1024
+    env = make_city26_env(n)
+    ring = DeviceReplayRing(env, 4 * n, discrete=True)
+    ring.reset(seed=4)                                  # every rank builds the SAME ring
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(3):
+        ring.current_action().copy_(torch.randint(0, 3, (n,), generator=gen, device="cuda", dtype=torch.int32))
+        ring.step_env(auto_reset=True)
+    torch.manual_seed(0)                                # same initial weights everywhere
+    L = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
+    g = torch.Generator().manual_seed(7)
+    idx = torch.stack([torch.randint(0, 3, (512,), generator=g), torch.randint(0, n, (512,), generator=g)], 1).int()
+    per = 512 // world
+    mine = idx[rank * per:(rank + 1) * per].contiguous().cuda()
+    losses = [float(L.learn_from_ring(ring, per, 0, it, explicit_idx=mine)) for it in range(4)]
+    torch.cuda.synchronize()
+    torch.save({"flat": L.flat.cpu(), "losses": losses}, os.path.join(out_dir, f"w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    env.close()
+
+
+@pytest.mark.parametrize("kind,net", [("dqn", "Qnet2"), ("dueling", "VAnet2")])
+def test_fused_learner_two_ranks_equal_one_process(kind, net, tmp_path):
+    """The N > 1 branch of FusedDQNLearner.learn_from_ring (k_dqn_reduce -> all_reduce(sum) of the raw bucket ->
+    k_dqn_adam, learner.py) with two ranks sharing this GPU over gloo: each takes half of a 512-transition list; the
+    result must be the update ONE process applies to the whole list (mean over the valid samples of all ranks)."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, kind, net, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(1, port, kind, net, str(tmp_path)), nprocs=1, join=True)
+    r0, r1 = torch.load(os.path.join(tmp_path, "w2_r0.pt")), torch.load(os.path.join(tmp_path, "w2_r1.pt"))
+    one = torch.load(os.path.join(tmp_path, "w1_r0.pt"))
+    assert torch.equal(r0["flat"], r1["flat"])                         # ranks stay in lock-step, bit for bit
+    assert r0["losses"] == r1["losses"]
+    assert (r0["flat"][:2] - one["flat"][:2]).abs().max().item() <= 2e-6
+    assert np.allclose(r0["losses"], one["losses"], rtol=1e-5)

@@ -81,3 +81,25 @@ def test_sac_trainer_plugin_surface(tmp_path):
     tr.save()
     assert {"model", "optimizer", "epoch"} == set(torch.load(tmp_path / "actor_SAC_UAV_0.pth"))
     assert (tmp_path / "critic_1_SAC_UAV_0.pth").exists() and (tmp_path / "critic_2_SAC_UAV_0.pth").exists()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_sac_updates_match_reference_on_the_gpu():
+    """The same executed-reference goldens with SACLearner on the MI355X (PyTorch-ROCm kernels, hipBLASLt GEMMs):
+    injected rsample() noise pins the two N(0,1) draws, so everything is deterministic up to f32 summation order.
+    Bars: 5e-5 relative on the actor loss, 1e-5 on weights after the golden's updates (CPU bars: 2e-5 / 2e-6)."""
+    from dqn_based_uav_3d_path_planer_amd.sac import SACLearner
+    g = load_golden("learner_SAC_Trainer.npz")
+    L = SACLearner(PARAM, device="cuda:0")
+    _load(L, g, "0")
+    batch = {k: torch.tensor(g[k]).cuda() for k in ("states", "actions", "rewards", "next_states", "dones")}
+    for k in range(len(g["losses"])):
+        n = torch.tensor(g["noise"][k]).cuda()
+        loss = float(L.learn(batch, noise=(n[0], n[1])))
+        assert abs(loss - g["losses"][k]) <= 5e-5 * max(1.0, abs(g["losses"][k])), k
+        assert abs(float(L.log_alpha) - g["log_alpha"][k]) <= 1e-5
+    assert L.epoch == int(g["epoch"])
+    _check(L, g, 1e-5)
