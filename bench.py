@@ -114,19 +114,32 @@ def cpu_baseline(envs: int, seconds: float):
     def timed(threads, budget_s):
         batch.rollout(1, *bank, seed=1, nthreads=threads)            # warm-up: thread pool, page faults
         t0 = time.perf_counter()
-        done, _ = batch.rollout(2, *bank, seed=2, nthreads=threads)
-        rate = done / (time.perf_counter() - t0)
-        k = max(2, min(4000, int(budget_s * rate / n)))
-        t0 = time.perf_counter()
-        done, _ = batch.rollout(k, *bank, seed=3, nthreads=threads)
-        dt = time.perf_counter() - t0
-        return done / dt, done, dt
+        done, k, seed = 0, 2, 2
+        while True:                                                  # chunks sized from the rate seen so far
+            d, _ = batch.rollout(k, *bank, seed=seed, nthreads=threads)
+            done += d
+            seed += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s:
+                break
+            k = max(2, min(2000, int(0.5 * (budget_s - el) * (done / el) / n) + 1))
+        return done / el, done, el
 
     one, done1, dt1 = timed(1, 0.25 * seconds)
     allc, done, dt = timed(cores, 0.75 * seconds)
+    quota = None
+    try:                                                             # the container's CPU quota, if it has one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception:
+            pass
     out = {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "one_core_value": one,
-           "sample": f"{done} agent-steps ({n} envs x {done // n} steps inside one C call, update_PathPlan + "
+           "one_core_value": one, "cgroup_cpu_quota_cores": quota,
+           "sample": f"{done} agent-steps ({n} envs x {done // n} steps, every step inside C, update_PathPlan + "
                      f"state_PathPlan, random steering, auto-reset from the packaged bank, no learner) in {dt:.1f} s on "
                      f"{cores} threads; 1 thread: {done1} agent-steps in {dt1:.1f} s; C port of the reference's Python env "
                      f"path (oracle/uav_oracle.c, -O3, OpenMP static blocks)"}
@@ -348,8 +361,7 @@ def main():
     if fused:
         import ctypes as C
         from dqn_based_uav_3d_path_planer_amd import _lib
-        nblk = args.batch // 64
-        part = torch.empty((nblk, learner.P + 2), dtype=torch.float32, device=dev)
+        part = learner.new_partials(args.batch)
         kind = 0 if args.trainer == "dqn" else 1
         s_ = torch.cuda.current_stream(dev).cuda_stream
 

@@ -23,7 +23,7 @@ SYMBOLS = (
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_replay_draw", "uavenv_select_actions",
-    "uavenv_dqn_num_params", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
+    "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
 )
@@ -147,6 +147,10 @@ def load() -> C.CDLL:
     net = C.POINTER(UavDqnNet)
     lib.uavenv_dqn_num_params.restype = C.c_int
     lib.uavenv_dqn_num_params.argtypes = [net]
+    lib.uavenv_dqn_partial_stride.restype = C.c_int
+    lib.uavenv_dqn_partial_stride.argtypes = [net]
+    lib.uavenv_dqn_partial_rows.restype = C.c_int
+    lib.uavenv_dqn_partial_rows.argtypes = [i32]
     lib.uavenv_dqn_set_debug_buffer.restype = C.c_int
     lib.uavenv_dqn_set_debug_buffer.argtypes = [vp]
     lib.uavenv_dqn_grad.restype = C.c_int

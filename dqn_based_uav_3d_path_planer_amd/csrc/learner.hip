@@ -4,16 +4,17 @@
 // TD target -> MSE -> backward -> Adam -> hard target copy  (Trainer/DQN_Trainer.py:85-136,
 // DDQN_Trainer.py:72-117, DuelingDQN_Trainer.py:99-190, nets BaseClass/BaseCNN.py:93-139) by three kernels:
 //
-//   k_dqn_grad   one workgroup per 64 sampled transitions: draws the samples (same Philox stream as
-//                uavenv_replay_sample), gathers the two 400 B rows straight from the replay ring into LDS,
-//                runs the three 64x64x100 layer-1 products and the 64x100x64 weight-gradient product on the
-//                f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 FMA chains, 157 TF class), everything else
-//                (layer 2 with A <= 15 outputs, TD target, ReLU masks, bias/W2 gradients) on the VALU, and
-//                writes ONE partial-gradient row per workgroup -- no atomics, deterministic.
+//   k_dqn_grad   one workgroup per 64 sampled transitions (persistent over tiles when the batch has more than 512):
+//                draws the samples (same permutation as uavenv_replay_sample), gathers the two 400 B rows straight
+//                from the replay ring into LDS; each of the four wavefronts then runs the forward passes, the TD
+//                target and dL/dH of ITS 16 samples without leaving its registers (v_mfma_f32_16x16x4_f32 on
+//                H^T = W1 X^T: lane = sample, registers = hidden units), the weight-gradient products run on the
+//                same MFMA over all 64 samples, and ONE partial-gradient row is written per workgroup -- no
+//                atomics, deterministic.  f32 MFMA = exact f32 FMA chains (the reference's precision).
 //   k_dqn_reduce sums the partial rows -> raw[P+2] = gradient sums, loss sum, valid count (this flat vector is
 //                what multi-GPU all-reduces over RCCL: the mean is then over the valid samples of ALL ranks).
 //   k_dqn_adam   normalises by the valid count, torch.optim.Adam step (+ hard target copy every Update_loop).
-//   k_dqn_act    Q(s) for all N envs + epsilon-greedy in one launch (same MFMA forward).
+//   k_dqn_act    Q(s) for all N envs + epsilon-greedy in one launch (same wave-strip MFMA forward).
 //
 // The generic PyTorch-ROCm learner (learner.py) remains for other shapes and as the numerical cross-check.
 #include <hip/hip_runtime.h>
@@ -31,12 +32,7 @@ namespace {
 constexpr int kW = 100;        // input width   (config/Trainer.xml <w>)
 constexpr int kHid = 64;       // hidden width  (<hiden_dim>)
 constexpr int kTile = 64;      // samples per workgroup
-constexpr int kLdx = 101;      // LDS leading dim of the 64 x 100 tiles: odd -> the 32 rows a wave reads hit 32 banks
-constexpr int kLdh = 65;
 constexpr int kMaxOut = 16;    // layer-2 outputs: A (+1 for the dueling value head)
-constexpr int kXTile = kTile * kLdx + 32;   // + pad: the dW1 product reads 28 columns past the last row
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct NetDev {
     const float *W1, *b1, *W2, *b2;
@@ -52,138 +48,21 @@ __device__ __forceinline__ NetDev net_view(const float *flat, int n2)
     return n;
 }
 
-// 64 rows x 100 floats -> LDS tile [64][kLdx].  Rows are given by a per-row base pointer (gathered from the ring)
-// or are consecutive (weights).  16-byte global loads, all issued before the LDS writes.
+// a 64 x 100 f32 matrix as 16-byte chunks (staging of the fc1 weights)
 constexpr int kStageChunks = kTile * 25;                 // 25 chunks of 4 elements per row
 constexpr int kStageIters = (kStageChunks + 255) / 256;  // 7 per thread
-
-// Phase 1 of staging a 64 x 100 tile: put this thread's 7 global loads in flight (no wait).  Rows come from a
-// per-row pointer table in LDS (gathered replay rows) or are consecutive (weights).
-template <typename T>
-__device__ __forceinline__ void stage_issue(float4 (&v)[kStageIters], const T *const *row_ptr_lds, const T *base_consecutive,
-                                            int last_row = kTile - 1)
-{
-#pragma unroll
-    for (int it = 0; it < kStageIters; ++it) {
-        int c = it * 256 + (int)threadIdx.x;
-        c = c < kStageChunks ? c : kStageChunks - 1;
-        const int row = c / 25, q = c - row * 25;
-        const T *src = row_ptr_lds ? row_ptr_lds[row] : base_consecutive + (size_t)(row < last_row ? row : last_row) * kW;
-        if (sizeof(T) == 4) {
-            v[it] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + 4 * q);
-        } else {
-            const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(src) + 4 * q);
-            v[it] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f);   // decoded at commit
-        }
-    }
-}
-
-// Phase 2: LDS writes (the first use of v[] is where the compiler waits for the loads).
-template <typename T>
-__device__ __forceinline__ void stage_commit(float *dst, float4 (&v)[kStageIters])
-{
-#pragma unroll
-    for (int it = 0; it < kStageIters; ++it)
-        asm volatile("" : "+v"(v[it].x), "+v"(v[it].y), "+v"(v[it].z), "+v"(v[it].w));
-#pragma unroll
-    for (int it = 0; it < kStageIters; ++it) {
-        const int c = it * 256 + (int)threadIdx.x;
-        if (c < kStageChunks) {
-            const int row = c / 25, q = c - row * 25;
-            float4 w = v[it];
-            if (sizeof(T) != 4) {
-                const uint32_t rx = __float_as_uint(v[it].x), ry = __float_as_uint(v[it].y);
-                const __half2 lo = *reinterpret_cast<const __half2 *>(&rx);
-                const __half2 hi = *reinterpret_cast<const __half2 *>(&ry);
-                w = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
-            }
-            float *d = dst + row * kLdx + 4 * q;
-            d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-        }
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void stage_rows(float *dst, const T *const *row_ptr_lds, const T *base_consecutive)
-{
-    float4 v[kStageIters];
-    stage_issue<T>(v, row_ptr_lds, base_consecutive);
-    stage_commit<T>(dst, v);
-}
-
-// One wave: acc(32x32) += A(32 x K) * B(K x 32) with  A[i][k] = a[(i)*lda + k],  B[k][j] = b[(j)*ldb + k]
-// (both operands stored "row = output index, contiguous k"): lane l feeds A[l&31][k + (l>>5)], B[k + (l>>5)][l&31].
-__device__ __forceinline__ floatx16 mfma_rows(const float *a, int lda, const float *b, int ldb, int K)
-{
-    const int l = (int)threadIdx.x & 63;
-    const float *ap = a + (l & 31) * lda + (l >> 5);
-    const float *bp = b + (l & 31) * ldb + (l >> 5);
-    floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 10
-    for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
-    return acc;
-}
-
-// H[64][kLdh] = relu(X[64][kLdx] * W1^T + b1): wave w owns the 32x32 quadrant (w>>1, w&1).
-__device__ __forceinline__ void layer1(const float *X, const float *W1, const float *b1, float *H)
-{
-    const int wv = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
-    const int r0 = (wv >> 1) * 32, c0 = (wv & 1) * 32;
-    const floatx16 acc = mfma_rows(X + r0 * kLdx, kLdx, W1 + c0 * kLdx, kLdx, kW);
-    const int col = c0 + (l & 31);
-    const float bias = b1[col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
-        const float v = acc[reg] + bias;
-        H[row * kLdh + col] = v > 0.0f ? v : 0.0f;
-    }
-}
-
-// Layer 2 for a whole 64-sample tile with ALL threads of the workgroup: one (sample, output) dot product per thread
-// (consecutive threads -> consecutive samples -> conflict-free H reads; W2 row broadcast), four accumulators so the
-// LDS latency overlaps.  out2[s][a] = W2[a] . H[s] + b2[a].  (A thread-per-sample loop over all outputs ran on 64
-// lanes only and cost 11 k cycles per tile.)
-__device__ __forceinline__ void layer2_block(const float *H, const float *W2, const float *b2, int n2, float *out2)
-{
-    for (int item = (int)threadIdx.x; item < kTile * n2; item += 256) {
-        const int smp = item & (kTile - 1), a = item >> 6;
-        const float *h = H + smp * kLdh, *wr = W2 + a * kHid;
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kHid; j += 4) {
-            s0 = fmaf(h[j], wr[j], s0);
-            s1 = fmaf(h[j + 1], wr[j + 1], s1);
-            s2 = fmaf(h[j + 2], wr[j + 2], s2);
-            s3 = fmaf(h[j + 3], wr[j + 3], s3);
-        }
-        out2[smp * kMaxOut + a] = ((s0 + s1) + (s2 + s3)) + b2[a];
-    }
-}
-
-// Q from the layer-2 outputs of one sample (dueling: V + A - mean A, BaseCNN.py:131-138)
-__device__ __forceinline__ void q_from_out(const float *o, int n_actions, int dueling, float *q)
-{
-    if (dueling) {
-        float mean = 0.0f;
-        for (int a = 0; a < n_actions; ++a) mean += o[a];
-        mean /= (float)n_actions;
-        for (int a = 0; a < n_actions; ++a) q[a] = o[n_actions] + o[a] - mean;
-    } else {
-        for (int a = 0; a < n_actions; ++a) q[a] = o[a];
-    }
-}
 
 struct GradArgs {
     UavReplayRing ring;
     int head, filled, batch;
     uint64_t seed, counter;
-    const int32_t *explicit_idx;     // nullable: batch x (frame, agent) overriding the Philox draws
+    ReplayPerm perm;                 // the update's sample permutation (round keys derived on the host)
+    const int32_t *explicit_idx;     // nullable: batch x (frame, agent) overriding the draws
     const float *local, *target;     // flat parameter blocks
     int n_actions, dueling, kind;    // kind 0: max_a Q_target(s')   1: Q_target(s', argmax_a Q_local(s'))
     float gamma;
     int huber;
-    float *partials;                 // [gridDim.x][P + 2]
+    float *partials;                 // [gridDim.x][stride]: parameter layout, then loss sum and valid count
     int P;
     unsigned long long *dbg;         // diagnostics build: 8 s_memtime stamps per workgroup
 };
@@ -194,270 +73,531 @@ struct GradArgs {
 #define L_STAMP(slot) do { } while (0)
 #endif
 
-template <typename ObsT>
-__global__ void __launch_bounds__(256) k_dqn_grad(GradArgs g)
+
+// =====================================================================================================================
+// k_dqn_grad, wave-strip formulation.
+//
+// Layer 1 is computed transposed, H^T[j][s] = sum_k W1[j][k] X[s][k], on v_mfma_f32_16x16x4_f32: the C/D fragment puts
+// sample s = lane & 15 in the lane and hidden units j = 16 t + 4 (lane >> 4) + r (t = tile 0..3, r = register 0..3) in
+// its registers.  A wavefront owning 16 samples therefore holds, per lane, one sample's share of the hidden layer,
+// and layer 2 (n2 <= 16 outputs), the dueling combine, the TD target, dL/dout and dL/dH are per-lane register
+// arithmetic plus two cross-lane adds -- no LDS round trip, no workgroup barrier between the phases (the previous
+// formulation spent 2/3 of its 44 k cycles on those).  K is padded to 104: column 100 of the X tile is 1 and column
+// 100 of the W1 tile is b1, so the MFMA adds the bias and the weight-gradient product yields db1 as its column 100.
+// K index of MFMA step i in lane group g = 26 g + 2 i (+1): each lane reads its operands as 13 aligned float2 per row.
+// =====================================================================================================================
+constexpr int kK = 104;                     // padded K of the layer-1 products
+constexpr int kLd = 108;                    // LDS row stride (floats) of the X / W1 tiles: 16-byte rows; row * 108 mod 64 walks
+                                            // the multiples of 4, so the 32 lanes of a ds_read_b64 phase hit 64 distinct banks
+constexpr int kLh = 68;                     // LDS row stride of the hidden tiles: rows 4 apart are 16 banks apart
+constexpr int kTileF = kTile * kLd;         // floats per X / W1 tile
+constexpr int kStripF = 16 * kLd;           // floats per 16-row strip of a tile
+constexpr int kXIters = 7;                  // 16 rows x 25 chunks = 400 chunks per strip = 7 per lane
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c)
 {
-    extern __shared__ __align__(16) float lds[];
-    float *Xs = lds;                       // states       [64][101]
-    float *Xn = Xs + kXTile;               // next states
-    float *W1 = Xn + kXTile;               // local fc1
-    float *W1t = W1 + kXTile;              // target fc1
-    float *Hs = W1t + kXTile;              // relu(fc1(s)) -> later dH
-    float *Ht = Hs + kTile * kLdh;         // scratch hidden (local(s') then target(s'))
-    float *small = Ht + kTile * kLdh;
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// fc1 weights (64 x 100 f32, rows consecutive in HBM): 1 600 16-byte chunks, 7 per thread, all in flight
+// (floatx4 = a plain vector value: HIP's float4 is a struct, and arrays of it copied whole become memcpys through
+// scratch memory instead of registers)
+__device__ __forceinline__ void w_issue(floatx4 (&v)[kStageIters], const float *W)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        int c = it * 256 + (int)threadIdx.x;
+        c = c < kStageChunks ? c : kStageChunks - 1;
+        v[it] = *reinterpret_cast<const floatx4 *>(W + 4 * c);         // parameter blocks are 16-byte aligned (checked by the host)
+    }
+}
+
+__device__ __forceinline__ void w_commit(float *dst, floatx4 (&v)[kStageIters], float bias)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int c = it * 256 + (int)threadIdx.x;
+        if (c < kStageChunks) {
+            const int row = c / 25, q = c - row * 25;
+            *reinterpret_cast<floatx4 *>(dst + row * kLd + 4 * q) = v[it];
+        }
+    }
+    if (threadIdx.x < kHid)                                     // column 100 = b1, 101..103 = 0
+        *reinterpret_cast<floatx4 *>(dst + (int)threadIdx.x * kLd + kW) = floatx4{bias, 0.0f, 0.0f, 0.0f};
+}
+
+// The 16 gathered observation rows of this wavefront's strip: lane l & 15 holds the ring row index of sample l & 15.
+template <typename T>
+__device__ __forceinline__ void x_issue(floatx4 (&v)[kXIters], const T *obs, uint32_t my_row)
+{
+    const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < kXIters; ++it) {
+        int c = it * 64 + lane;
+        c = c < 400 ? c : 399;
+        const int row = c / 25, q = c - row * 25;
+        const uint32_t ring_row = (uint32_t)__shfl((int)my_row, row, 64);
+        const T *src = obs + (size_t)ring_row * kW + 4 * q;
+        if (sizeof(T) == 4) {
+            v[it] = *reinterpret_cast<const floatx4 *>(src);
+        } else {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(src);
+            v[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};       // decoded at commit
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void x_commit(float *strip, floatx4 (&v)[kXIters])
+{
+    const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < kXIters; ++it) {
+        const int c = it * 64 + lane;
+        if (c < 400) {
+            const int row = c / 25, q = c - row * 25;
+            floatx4 w = v[it];
+            if (sizeof(T) != 4) {
+                const uint32_t rx = __float_as_uint(v[it][0]), ry = __float_as_uint(v[it][1]);
+                const __half2 lo = *reinterpret_cast<const __half2 *>(&rx);
+                const __half2 hi = *reinterpret_cast<const __half2 *>(&ry);
+                w = floatx4{__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi)};
+            }
+            *reinterpret_cast<floatx4 *>(strip + row * kLd + 4 * q) = w;
+        }
+    }
+    if (lane < 16) *reinterpret_cast<floatx4 *>(strip + lane * kLd + kW) = floatx4{1.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// acc[t][r] = b1[j] + sum_k W1[j][k] X[s][k],  j = 16 t + 4 g + r,  s = this lane's sample (strip row lane & 15).
+// One wavefront per SIMD: nothing else hides the LDS latency, so the operands of step i + 1 are requested before the
+// eight MFMAs of step i issue (256 cycles of cover), and the scheduler is fenced so that it keeps that order and never
+// puts two MFMAs on the same accumulator back to back (40-cycle dependent latency against a 32-cycle issue interval).
+__device__ __forceinline__ void fwd_strip(const float *W, const float *strip, floatx4 (&acc)[4])
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float *xp = strip + r * kLd + 26 * g;
+    const float *wp = W + r * kLd + 26 * g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    float2 b = *reinterpret_cast<const float2 *>(xp);
+    float2 a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float2 *>(wp + t * 16 * kLd);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        float2 bn = b, an[4] = {a[0], a[1], a[2], a[3]};
+        if (i + 1 < 13) {
+            bn = *reinterpret_cast<const float2 *>(xp + 2 * (i + 1));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) an[t] = *reinterpret_cast<const float2 *>(wp + t * 16 * kLd + 2 * (i + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t].x, b.x, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t].y, b.y, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        b = bn;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = an[t];
+    }
+}
+
+// sum over the 16 lanes of a DPP row (the 16 samples of a strip), result in every lane of the row
+__device__ __forceinline__ float row_sum16(float v)
+{
+#define UAV_ROW_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xf, 0xf, false))
+    v += UAV_ROW_ROR(v, 8);
+    v += UAV_ROW_ROR(v, 4);
+    v += UAV_ROW_ROR(v, 2);
+    v += UAV_ROW_ROR(v, 1);
+#undef UAV_ROW_ROR
+    return v;
+}
+
+// Sum over the four lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48), result in all of them, on the VALU: gfx950's
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second; with both operands equal the two
+// results are the two halves of the sum.  (Inline asm: hipcc 7.2 maps both results of the builtin to one register.
+// ds_bpermute, which __shfl_xor compiles to, costs an LDS round trip per step -- ~1 k cycles per layer-2 evaluation.)
+__device__ __forceinline__ float group_sum4(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// This lane's share of fc2 (+ bias): rows a < n2, hidden units 16 t + 4 g .. + 3.
+template <int NMAX>
+struct W2Frag {
+    floatx4 w[NMAX][4];
+    float b[NMAX];
+};
+
+template <int NMAX>
+__device__ __forceinline__ void w2_load(W2Frag<NMAX> &F, const float *W2, const float *b2, int n2)
+{
+    const int g = ((int)threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int a = 0; a < NMAX; ++a) {
+        F.b[a] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) F.w[a][t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (a < n2) {
+            F.b[a] = b2[a];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) F.w[a][t] = *reinterpret_cast<const floatx4 *>(W2 + a * kHid + 16 * t + 4 * g);
+        }
+    }
+}
+
+// layer 2 + (dueling) Q for this lane's sample from its registers: q[a], a < n_actions.  acc holds pre-activations.
+template <int NMAX>
+__device__ __forceinline__ void q_strip(const floatx4 (&acc)[4], const W2Frag<NMAX> &F, int n2, int n_actions, int dueling,
+                                        float (&q)[NMAX])
+{
+    floatx4 h[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = acc[t][r] > 0.0f ? acc[t][r] : 0.0f;
+    float o[NMAX];
+#pragma unroll
+    for (int a = 0; a < NMAX; ++a) {
+        o[a] = 0.0f;
+        if (a < n2) {
+            float st[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const floatx4 wv = F.w[a][t];
+                st[t] = fmaf(h[t][3], wv[3], fmaf(h[t][2], wv[2], fmaf(h[t][1], wv[1], h[t][0] * wv[0])));
+            }
+            o[a] = group_sum4((st[0] + st[1]) + (st[2] + st[3])) + F.b[a];
+        }
+    }
+    if (dueling) {                                            // Q = V + A - mean(A)   (BaseCNN.py:131-138)
+        float mean = 0.0f, val = 0.0f;
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a) {
+            if (a < n_actions) mean += o[a];
+            if (a == n_actions) val = o[a];
+        }
+        mean /= (float)n_actions;
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a) q[a] = val + o[a] - mean;
+    } else {
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a) q[a] = o[a];
+    }
+}
+
+struct Grad2Args {
+    GradArgs g;
+    int n_tiles, stride;             // tiles of 64 samples in the batch; floats per partial row (multiple of 4)
+};
+
+struct GradLds {
+    float *W1l, *W1t, *Xs, *Xn, *dHs, *douts, *W2l, *W2t, *b2l, *b2t, *red;
+};
+
+template <int NMAX>
+struct GradAcc {
+    floatx4 acc1[7], acc2;           // dW1^T tiles (k columns 16 u + 4 gq + rr, hidden unit 16 wv + r), dW2^T tile
+    float csum[NMAX + 2];            // column sums of dout (db2), loss sum, valid count -- of this wave's strips
+};
+
+// One tile of 64 transitions.  FIRST: also stages the weights (their loads fly together with the observation rows).
+template <typename ObsT, int NMAX, bool FIRST>
+__device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, int tile, bool more, GradAcc<NMAX> &A)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
-    float *b1 = small;                     // [64]
-    float *b1t = b1 + kHid;                // [64]
-    float *W2 = b1t + kHid;                // [16][64]
-    float *W2t = W2 + kMaxOut * kHid;      // [16][64]
-    float *b2 = W2t + kMaxOut * kHid;      // [16]
-    float *b2t = b2 + kMaxOut;             // [16]
-    float *dout = b2t + kMaxOut;           // [64][16]  dL/d(layer-2 output) per sample
-    float *red = dout + kTile * kMaxOut;   // [64] per-sample loss, [64] per-sample weight
-    const ObsT **rows_s = reinterpret_cast<const ObsT **>(red + 2 * kTile);   // [64] row pointers
-    const ObsT **rows_n = rows_s + kTile;
-    int *aux = reinterpret_cast<int *>(rows_n + kTile);                       // [64] action, [64] argmax, [64] slot
-    const int tid = (int)threadIdx.x;
-    const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
+    const ObsT *obs = reinterpret_cast<const ObsT *>(g.ring.obs);
+    float *xs_strip = L.Xs + wv * kStripF, *xn_strip = L.Xn + wv * kStripF;
+    // every global load in flight before the first LDS write.  The weights go first: they do not depend on the draw,
+    // whose Feistel rounds (a serial chain of ~100 integer operations) then run under their round trip.
+    floatx4 vXs[kXIters], vXn[kXIters], vWl[kStageIters], vWt[kStageIters];
+    float pb1 = 0.0f, pb1t = 0.0f, pw[4] = {0, 0, 0, 0}, pt[4] = {0, 0, 0, 0}, pb2 = 0.0f, pb2t = 0.0f;
+    if (FIRST) w_issue(vWl, g.local);
+    // ---- the 16 transitions of this wavefront's strip (lanes l, l + 16, l + 32, l + 48 hold the same sample)
+    const int smp = tile * kTile + wv * 16 + r;
+    int f, agent;
+    if (g.explicit_idx) {
+        f = g.explicit_idx[2 * smp];
+        agent = g.explicit_idx[2 * smp + 1];
+    } else {
+        replay_slot_to_frame(replay_perm_apply(g.perm, (uint32_t)smp), g.head, g.ring.frames, g.ring.n_agents, f, agent);
+    }
+    int fn = f + 1;
+    if (fn >= g.ring.frames) fn = 0;
+    const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    x_issue<ObsT>(vXs, obs, row_s);
+    x_issue<ObsT>(vXn, obs, row_n);
+    if (FIRST) {
+        const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
+        w_issue(vWt, g.target);
+        const int kb = tid < kHid ? tid : kHid - 1;
+        pb1 = nl.b1[kb]; pb1t = nt.b1[kb];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k < n2 * kHid ? tid + 256 * k : 0;
+            pw[k] = nl.W2[idx]; pt[k] = nt.W2[idx];
+        }
+        const int kq = tid < n2 ? tid : 0;
+        pb2 = nl.b2[kq]; pb2t = nt.b2[kq];
+    }
+    // this sample's scalar fields (needed at the TD target: fetched now, long arrived by then)
+    const int p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
+    const float p_rew = g.ring.reward[row_s];
+    const float p_done = (float)g.ring.done[row_s];
+    const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+
+    if (FIRST) w_commit(L.W1l, vWl, pb1);
+    x_commit<ObsT>(xs_strip, vXs);
+    wave_lds_sync();
+    if (FIRST) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < n2 * kHid) { L.W2l[tid + 256 * k] = pw[k]; L.W2t[tid + 256 * k] = pt[k]; }
+        if (tid < n2) { L.b2l[tid] = pb2; L.b2t[tid] = pb2t; }
+        __syncthreads();                      // local weights staged (the target fc1 and the s' rows are still in flight)
+    }
+    L_STAMP(1);
+    // ---- forward of q_local on s: the pre-activations stay in registers for the backward pass
+    floatx4 hl[4];
+    fwd_strip(L.W1l, xs_strip, hl);
+    L_STAMP(6);
+    // fc2 of q_local in registers: layer 2 of s (and s'), and dL/dH below.  (The general variant, up to 14 outputs,
+    // cannot afford to keep 238 registers alive across the forward passes and re-reads LDS each time.)
+    constexpr bool kKeepW2 = NMAX <= 4;
+    W2Frag<NMAX> Fl;
+    w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+    float ql[NMAX];
+    q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+    x_commit<ObsT>(xn_strip, vXn);
+    if (FIRST) {
+        w_commit(L.W1t, vWt, pb1t);
+        __syncthreads();                      // target weights staged
+    }
+    wave_lds_sync();
+    L_STAMP(2);
+    int best = 0;
+    floatx4 ht[4];
+    if (g.kind == 1) {                        // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
+        fwd_strip(L.W1l, xn_strip, ht);
+        float qn_l[NMAX];
+        if (!kKeepW2) w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+        q_strip<NMAX>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
+        float bq = qn_l[0];
+#pragma unroll
+        for (int a = 1; a < NMAX; ++a)
+            if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }           // torch.max: first maximum
+    }
+    fwd_strip(L.W1t, xn_strip, ht);
+    L_STAMP(7);
+    float qt[NMAX];
+    {
+        W2Frag<NMAX> Ft;
+        w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
+        q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+    }
+    L_STAMP(3);
+    // ---- TD target, loss, dL/dout of this lane's sample (Trainer/DQN_Trainer.py:107-119)
+    float qn = qt[0], qa = ql[0];
+#pragma unroll
+    for (int a = 1; a < NMAX; ++a) {
+        if (g.kind == 1) { if (a == best) qn = qt[a]; }
+        else if (a < g.n_actions && qt[a] > qn) qn = qt[a];
+        if (a == p_act) qa = ql[a];
+    }
+    const float y = p_rew + (g.gamma * qn * (1.0f - p_done));
+    const float delta = qa - y;
+    float per, dq;
+    if (g.huber) {
+        const float ad = fabsf(delta);
+        per = ad < 1.0f ? 0.5f * delta * delta : ad - 0.5f;
+        dq = ad < 1.0f ? delta : (delta > 0.0f ? 1.0f : -1.0f);
+    } else {
+        per = delta * delta;                          // MSELoss (BaseTrainer.py:40)
+        dq = 2.0f * delta;
+    }
+    dq *= p_valid;
+    float dv[NMAX + 2];
+    const float inv_a = 1.0f / (float)g.n_actions;
+#pragma unroll
+    for (int a = 0; a < NMAX; ++a) {
+        float d = 0.0f;
+        if (g.dueling) {                              // Q = V + A - mean(A)
+            if (a < g.n_actions) d = dq * ((a == p_act ? 1.0f : 0.0f) - inv_a);
+            else if (a == g.n_actions) d = dq;
+        } else if (a == p_act) {
+            d = dq;
+        }
+        dv[a] = d;
+    }
+    dv[NMAX] = per * p_valid;                         // loss and valid count ride along as two more columns
+    dv[NMAX + 1] = p_valid;
+    // column sums over the strip's 16 samples (db2, loss sum, valid count): four DPP row rotations each
+#pragma unroll
+    for (int a = 0; a < NMAX + 2; ++a) {
+        if (a < n2 || a >= NMAX) {
+            A.csum[a] += row_sum16(dv[a]);
+        }
+    }
+    // ---- dL/dH = relu'(h) * W2^T dout, and the forward H, into LDS for the weight-gradient products
+    float *hrow = xn_strip + r * kLh;                 // H of sample r of this strip (its s' rows are dead now)
+    float *drow = L.dHs + (wv * 16 + r) * kLh;
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        floatx4 dh = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a) {
+            if (a < n2) {
+                const floatx4 wv4 = kKeepW2 ? Fl.w[a][t]
+                                            : *reinterpret_cast<const floatx4 *>(L.W2l + a * kHid + 16 * t + 4 * gq);
+                dh[0] = fmaf(dv[a], wv4[0], dh[0]); dh[1] = fmaf(dv[a], wv4[1], dh[1]);
+                dh[2] = fmaf(dv[a], wv4[2], dh[2]); dh[3] = fmaf(dv[a], wv4[3], dh[3]);
+            }
+        }
+        floatx4 hh;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            hh[rr] = hl[t][rr] > 0.0f ? hl[t][rr] : 0.0f;
+            dh[rr] = hl[t][rr] > 0.0f ? dh[rr] : 0.0f;
+        }
+        *reinterpret_cast<floatx4 *>(hrow + 16 * t + 4 * gq) = hh;
+        *reinterpret_cast<floatx4 *>(drow + 16 * t + 4 * gq) = dh;
+    }
+    {   // douts[s][4 gq .. 4 gq + 3]
+        floatx4 d4 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a)
+            if ((a >> 2) == gq) d4[a & 3] = dv[a];
+        *reinterpret_cast<floatx4 *>(L.douts + (wv * 16 + r) * kMaxOut + 4 * gq) = d4;
+    }
+    __syncthreads();                                  // H, dH, dout of all 64 samples visible
+    L_STAMP(4);
+    // ---- weight gradients over the 64 samples (K index of MFMA step kk in lane group g: sample (kk & 3) + 16 (kk >> 2) + 4 g)
+    //   dW1^T[k][j] += sum_s X[s][k] dH[s][j]   (7 tiles of 16 k-columns, hidden units 16 wv .. 16 wv + 15)
+    //   dW2^T[j][a] += sum_s H[s][j] dout[s][a]
+    {
+        const float *xa = L.Xs + 4 * gq * kLd + r;
+        const float *db = L.dHs + 4 * gq * kLh + 16 * wv + r;
+        const float *ha = L.Xn + 4 * gq * kLh + 16 * wv + r;              // + strip * kStripF + (kk & 3) * kLh
+        const float *ob = L.douts + 4 * gq * kMaxOut + r;
+        // operands of step kk + 1 are requested before the eight MFMAs of step kk (same reasoning as fwd_strip)
+        float bdh = db[0], ah = ha[0], bo = ob[0], ax[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) ax[u] = xa[16 * u];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float bdh_n = bdh, ah_n = ah, bo_n = bo, ax_n[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) ax_n[u] = ax[u];
+            if (kk + 1 < 16) {
+                const int k1 = kk + 1, s1 = (k1 & 3) + 16 * (k1 >> 2);
+                bdh_n = db[s1 * kLh];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) ax_n[u] = xa[s1 * kLd + 16 * u];
+                ah_n = ha[(k1 >> 2) * kStripF + (k1 & 3) * kLh];
+                bo_n = ob[s1 * kMaxOut];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 7; ++u) A.acc1[u] = mfma16(ax[u], bdh, A.acc1[u]);
+            A.acc2 = mfma16(ah, bo, A.acc2);
+            __builtin_amdgcn_sched_barrier(0);
+            bdh = bdh_n; ah = ah_n; bo = bo_n;
+#pragma unroll
+            for (int u = 0; u < 7; ++u) ax[u] = ax_n[u];
+        }
+    }
+    if (more) __syncthreads();                        // the next tile overwrites Xs / Xn / dHs / douts
+}
+
+template <typename ObsT, int NMAX>
+__global__ void __launch_bounds__(256) k_dqn_grad(Grad2Args ga)
+{
+    const GradArgs &g = ga.g;
+    extern __shared__ __align__(16) float lds[];
+    GradLds L;
+    L.W1l = lds;                            // [64][108] local fc1 (+ b1 in column 100)
+    L.W1t = L.W1l + kTileF;                 // target fc1
+    L.Xs = L.W1t + kTileF;                  // states        (strip w = rows 16 w ..)
+    L.Xn = L.Xs + kTileF;                   // next states; after the forward passes strip w's first 16 x 68 floats hold H of its samples
+    L.dHs = L.Xn + kTileF;                  // [64][68] dL/dH
+    L.douts = L.dHs + kTile * kLh;          // [64][16] dL/d(layer-2 output)
+    L.W2l = L.douts + kTile * kMaxOut;      // [16][64]
+    L.W2t = L.W2l + kMaxOut * kHid;
+    L.b2l = L.W2t + kMaxOut * kHid;         // [16]
+    L.b2t = L.b2l + kMaxOut;
+    L.red = L.b2t + kMaxOut;                // [4][18] per-wave column sums
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    GradAcc<NMAX> A;
+    A.acc2 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 7; ++u) A.acc1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = 0.0f;
 
     L_STAMP(0);
-    // ---- P0: draw / look up the 64 transitions of this tile, then stage everything
-    if (tid < kTile) {
-        const int s = (int)blockIdx.x * kTile + tid;
-        int f, agent;
-        if (g.explicit_idx) {
-            f = g.explicit_idx[2 * s];
-            agent = g.explicit_idx[2 * s + 1];
-        } else {
-            const ReplayPerm perm = replay_perm(g.seed, g.counter, (uint32_t)g.filled * (uint32_t)g.ring.n_agents);
-            replay_slot_to_frame(replay_perm_apply(perm, (uint32_t)s), g.head, g.ring.frames, g.ring.n_agents, f, agent);
-        }
-        int fn = f + 1;
-        if (fn >= g.ring.frames) fn = 0;
-        const ObsT *obs = reinterpret_cast<const ObsT *>(g.ring.obs);
-        rows_s[tid] = obs + ((size_t)f * g.ring.n_agents + agent) * kW;
-        rows_n[tid] = obs + ((size_t)fn * g.ring.n_agents + agent) * kW;
-        aux[2 * kTile + tid] = f * g.ring.n_agents + agent;
-    }
-    __syncthreads();      // row pointers visible
-    // every global load of the tile in flight at once: 4 x 7 wide loads + the small vectors, ONE memory round trip
-    float4 vW1[kStageIters], vW1t[kStageIters], vXs[kStageIters], vXn[kStageIters];
-    stage_issue<float>(vW1, nullptr, nl.W1);
-    stage_issue<float>(vW1t, nullptr, nt.W1);
-    stage_issue<ObsT>(vXs, rows_s, nullptr);
-    stage_issue<ObsT>(vXn, rows_n, nullptr);
-    const int kb = tid < kHid ? tid : kHid - 1;
-    const float pb1 = nl.b1[kb], pb1t = nt.b1[kb];
-    const int k0 = tid < n2 * kHid ? tid : 0, k1 = tid + 256 < n2 * kHid ? tid + 256 : 0;
-    const int k2 = tid + 512 < n2 * kHid ? tid + 512 : 0, k3 = tid + 768 < n2 * kHid ? tid + 768 : 0;
-    const float pw0 = nl.W2[k0], pw1 = nl.W2[k1], pw2 = nl.W2[k2], pw3 = nl.W2[k3];
-    const float pt0 = nt.W2[k0], pt1 = nt.W2[k1], pt2 = nt.W2[k2], pt3 = nt.W2[k3];
-    const int kq = tid < n2 ? tid : 0;
-    const float pb2 = nl.b2[kq], pb2t = nt.b2[kq];
-    // this sample's scalar fields (needed only in P4: fetched now so their latency is long gone by then)
-    int p_act = 0;
-    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f;
-    if (tid < kTile) {
-        const int slot = aux[2 * kTile + tid];
-        p_act = g.ring.action_is_index ? reinterpret_cast<const int32_t *>(g.ring.action)[slot] : 0;
-        p_rew = g.ring.reward[slot];
-        p_done = (float)g.ring.done[slot];
-        p_valid = g.ring.valid ? (float)g.ring.valid[slot] : 1.0f;
-    }
-    stage_commit<float>(W1, vW1);
-    stage_commit<float>(W1t, vW1t);
-    stage_commit<ObsT>(Xs, vXs);
-    stage_commit<ObsT>(Xn, vXn);
-    if (tid < kHid) { b1[tid] = pb1; b1t[tid] = pb1t; }
-    if (tid < n2 * kHid) { W2[tid] = pw0; W2t[tid] = pt0; }
-    if (tid + 256 < n2 * kHid) { W2[tid + 256] = pw1; W2t[tid + 256] = pt1; }
-    if (tid + 512 < n2 * kHid) { W2[tid + 512] = pw2; W2t[tid + 512] = pt2; }
-    if (tid + 768 < n2 * kHid) { W2[tid + 768] = pw3; W2t[tid + 768] = pt3; }
-    if (tid < n2) { b2[tid] = pb2; b2t[tid] = pb2t; }
-    if (tid < 32) {       // zero the pad the dW1 product over-reads
-        Xs[kTile * kLdx + tid] = 0.0f;
-        Xn[kTile * kLdx + tid] = 0.0f;
-    }
-    if (tid < kTile) Xs[tid * kLdx + kW] = 1.0f;     // ones column: the dW1 product then yields db1 as its column 100
-    __syncthreads();
-
-    L_STAMP(1);
-    // ---- P1: hidden layers on the matrix cores
-    layer1(Xs, W1, b1, Hs);
-    if (g.kind == 1) layer1(Xn, W1, b1, Ht);         // local net on s' (double-DQN action choice)
-    __syncthreads();
-    if (g.kind == 1) {
-        layer2_block(Ht, W2, b2, n2, dout);           // dout is free until P4: scratch for Q_local(s')
-        __syncthreads();
-        if (tid < kTile) {
-            float q[kMaxOut];
-            q_from_out(dout + tid * kMaxOut, g.n_actions, g.dueling, q);
-            int best = 0;
-            for (int a = 1; a < g.n_actions; ++a) if (q[a] > q[best]) best = a;     // torch.max: first maximum
-            aux[kTile + tid] = best;
-        }
-        __syncthreads();
-    }
-    layer1(Xn, W1t, b1t, Ht);                        // target net on s'
-    __syncthreads();
-    float *outl = Xn, *outt = Xn + kTile * kMaxOut;  // Xn (and W1t) are dead from here on: 2 x [64][16] scratch
-    layer2_block(Hs, W2, b2, n2, outl);
-    layer2_block(Ht, W2t, b2t, n2, outt);
-    __syncthreads();
-
-    L_STAMP(2);
-    // ---- P4: TD target, loss, dL/dout per sample (Trainer/DQN_Trainer.py:107-119)
-    if (tid < kTile) {
-        const int act = p_act;
-        const float r = p_rew, d = p_done, v = p_valid;
-        float ql[kMaxOut], qt[kMaxOut];
-        q_from_out(outl + tid * kMaxOut, g.n_actions, g.dueling, ql);
-        q_from_out(outt + tid * kMaxOut, g.n_actions, g.dueling, qt);
-        float qn;
-        if (g.kind == 1) {
-            qn = qt[aux[kTile + tid]];
-        } else {
-            qn = qt[0];
-            for (int a = 1; a < g.n_actions; ++a) qn = qt[a] > qn ? qt[a] : qn;
-        }
-        const float y = r + (g.gamma * qn * (1.0f - d));
-        const float delta = ql[act] - y;
-        float per, dq;
-        if (g.huber) {
-            const float ad = fabsf(delta);
-            per = ad < 1.0f ? 0.5f * delta * delta : ad - 0.5f;
-            dq = ad < 1.0f ? delta : (delta > 0.0f ? 1.0f : -1.0f);
-        } else {
-            per = delta * delta;                      // MSELoss (BaseTrainer.py:40)
-            dq = 2.0f * delta;
-        }
-        dq *= v;
-        float dvals[kMaxOut];                         // compile-time indexed only (stays in registers)
-        const float inv_a = 1.0f / (float)g.n_actions;
-#pragma unroll
-        for (int a = 0; a < kMaxOut; ++a) {
-            float dv = 0.0f;
-            if (g.dueling) {                          // Q = V + A - mean(A)
-                if (a < g.n_actions) dv = dq * ((a == act ? 1.0f : 0.0f) - inv_a);
-                else if (a == g.n_actions) dv = dq;
-            } else if (a == act) {
-                dv = dq;
-            }
-            dvals[a] = dv;
-            dout[tid * kMaxOut + a] = dv;
-        }
-        // the loss sum and the valid count ride along as two extra dout columns: P5 sums every column over the samples
-        dout[tid * kMaxOut + n2] = per * v;
-        dout[tid * kMaxOut + n2 + 1] = v;
-    }
-    __syncthreads();
-
-    L_STAMP(3);
-    // ---- P5: layer-2 gradients and dH on the matrix cores (both are small dense products over the 64 samples; as
-    // thread-per-output VALU loops they cost ~10 k cycles of LDS round trips):
-    //   waves 0, 1:  dW2[a][j] = sum_s dout[s][a] * Hs[s][j]   (A[m = a][k = s], B[k = s][n = j]; M padded 16 -> 32)
-    //   waves 2, 3:  dH[s][j]  = sum_a dout[s][a] * W2[a][j]   (A[m = s][k = a], B[k = a][n = j]; K = 16, a >= n2 masked)
-    //   db2 / loss sum / valid count = column sums of dout (16 threads of wave 3 afterwards).
-    // dH stays in registers until every wave has finished reading the forward Hs, then goes in place under the ReLU mask.
-    // (f32 MFMA runs at 64 FLOP/cycle/SIMD -- no faster than the VALU: what this buys is instruction count and LDS
-    // round trips, 10 k -> 6.5 k cycles.  Layer 2 and the column sums were tried the same way and were slower.)
-    float *out = g.partials + (size_t)blockIdx.x * (g.P + 2);
-    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
-    floatx16 dh0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dh1 = dh0;
-    {
-        const int wv = tid >> 6, l = tid & 63, lm = l & 31, h = l >> 5;
-        if (wv < 2) {
-            const int n0 = wv * 32;
-            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 8
-            for (int k0 = 0; k0 < kTile; k0 += 2) {
-                const int smp = k0 + h;
-                const float av = dout[smp * kMaxOut + (lm & (kMaxOut - 1))];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lm < kMaxOut ? av : 0.0f, Hs[smp * kLdh + n0 + lm], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 8; ++reg) {                   // rows m < 16 live in registers 0..7
-                const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (m < n2) out[oW2 + m * kHid + n0 + lm] = acc[reg];
-            }
-        } else {
-            const int m0 = (wv - 2) * 32;
-#pragma unroll
-            for (int k0 = 0; k0 < kMaxOut; k0 += 2) {
-                const int kk = k0 + h;
-                const float dv = dout[(m0 + lm) * kMaxOut + kk];
-                const bool use = kk < n2;                         // columns n2, n2+1 carry the loss / count, not a gradient;
-                const float av = use ? dv : 0.0f;                 // W2 rows >= n2 are not staged (0 x garbage could be NaN)
-                const float b0 = W2[(use ? kk : 0) * kHid + lm], b1 = W2[(use ? kk : 0) * kHid + 32 + lm];
-                dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, use ? b0 : 0.0f, dh0, 0, 0, 0);
-                dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, use ? b1 : 0.0f, dh1, 0, 0, 0);
-            }
-        }
-        if (tid >= 192 && tid < 192 + n2 + 2) {                   // db2[a], loss sum, valid count: column sums of dout
-            const int a = tid - 192;
-            float sa = 0.0f;
-            for (int smp = 0; smp < kTile; ++smp) sa += dout[smp * kMaxOut + a];
-            if (a < n2) out[ob2 + a] = sa;
-            else out[g.P + (a - n2)] = sa;
-        }
-    }
-    __syncthreads();
-    {
-        const int wv = tid >> 6, l = tid & 63, lm = l & 31, h = l >> 5;
-        if (wv >= 2) {
-            const int m0 = (wv - 2) * 32;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int smp = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                float *p0 = Hs + smp * kLdh + lm, *p1 = p0 + 32;
-                *p0 = *p0 > 0.0f ? dh0[reg] : 0.0f;               // ReLU mask
-                *p1 = *p1 > 0.0f ? dh1[reg] : 0.0f;
-            }
-        }
-    }
-    __syncthreads();
-
-    L_STAMP(4);
-    // ---- P6: dW1[j][k] = sum_s dH[s][j] X[s][k] on the matrix cores; db1[j] = sum_s dH[s][j]
-    {
-        const int wv = tid >> 6, l = tid & 63;
-        const int m0 = (wv & 1) * 32;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int n0 = ((wv >> 1) * 2 + t) * 32;
-            // A[m = j][kk = s] = dH[s][j]  (address s*kLdh + j);  B[kk = s][n = k] = Xs[s][k]
-            const float *ap = Hs + (l >> 5) * kLdh + m0 + (l & 31);
-            const float *bp = Xs + (l >> 5) * kLdx + n0 + (l & 31);
-            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 8
-            for (int kk = 0; kk < kTile; kk += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * kLdh], bp[kk * kLdx], acc, 0, 0, 0);
-            const int n = n0 + (l & 31);
-            if (n <= kW) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int m = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5);
-                    if (n < kW) out[m * kW + n] = acc[reg];
-                    else out[kHid * kW + m] = acc[reg];          // column 100 = X's ones column -> db1[m]
-                }
-            }
-        }
-    }
+    const int step = (int)gridDim.x;
+    int tile = (int)blockIdx.x;                       // the grid never exceeds the number of tiles
+    grad_tile<ObsT, NMAX, true>(g, L, tile, tile + step < ga.n_tiles, A);
+    for (tile += step; tile < ga.n_tiles; tile += step)
+        grad_tile<ObsT, NMAX, false>(g, L, tile, tile + step < ga.n_tiles, A);
     L_STAMP(5);
+    // ---- the partial-gradient row of this workgroup
+    float *out = g.partials + (size_t)blockIdx.x * ga.stride;
+    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
+    {
+        const int j = 16 * wv + r;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            *reinterpret_cast<floatx4 *>(out + j * kW + 16 * u + 4 * gq) = A.acc1[u];
+        if (gq == 0) *reinterpret_cast<floatx4 *>(out + j * kW + 96) = A.acc1[6];
+        else if (gq == 1) out[kHid * kW + j] = A.acc1[6][0];            // column 100 = X's ones column -> db1[j]
+        if (r < n2) *reinterpret_cast<floatx4 *>(out + oW2 + r * kHid + 16 * wv + 4 * gq) = A.acc2;
+    }
+    // column sums: every lane of a wave holds the wave's sums; add the four waves through LDS
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) L.red[wv * (kMaxOut + 2) + a] = A.csum[a];
+    }
+    __syncthreads();
+    if (tid < NMAX + 2) {
+        const float s = (L.red[tid] + L.red[(kMaxOut + 2) + tid]) + (L.red[2 * (kMaxOut + 2) + tid] + L.red[3 * (kMaxOut + 2) + tid]);
+        if (tid < n2) out[ob2 + tid] = s;
+        else if (tid == NMAX) out[g.P] = s;
+        else if (tid == NMAX + 1) out[g.P + 1] = s;
+    }
 }
+
+constexpr int kMaxGradGrid = 256;           // one workgroup per CU (140 KB of LDS each)
+constexpr size_t kGrad2Lds = (size_t)(4 * kTileF + kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut +
+                                      4 * (kMaxOut + 2)) * 4;
 
 // raw[p] = sum_b partial[b][p] for p in [0, P+2): gradient sums, loss sum, valid count.  32 columns x 8 row-groups
 // per workgroup so that each lane keeps nblk/8 independent, coalesced loads in flight (a one-thread-per-column loop
 // over 256 partial rows was latency-bound at 63 us).
-__global__ void __launch_bounds__(256) k_dqn_reduce(const float *__restrict__ partials, int nblk, int P,
+__global__ void __launch_bounds__(256) k_dqn_reduce(const float *__restrict__ partials, int nblk, int P, int stride,
                                                     float *__restrict__ raw)
 {
     __shared__ float red[8][33];
-    const int stride = P + 2;
     const int px = (int)threadIdx.x & 31, gy = (int)threadIdx.x >> 5;
     const int p = (int)blockIdx.x * 32 + px;
     float s = 0.0f;
-    if (p < stride) {
+    if (p < P + 2) {
         int b = gy;
         for (; b + 24 < nblk; b += 32) {
             const float v0 = partials[(size_t)b * stride + p], v1 = partials[(size_t)(b + 8) * stride + p];
@@ -468,7 +608,7 @@ __global__ void __launch_bounds__(256) k_dqn_reduce(const float *__restrict__ pa
     }
     red[gy][px] = s;
     __syncthreads();
-    if (gy == 0 && p < stride) {
+    if (gy == 0 && p < P + 2) {
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][px];
@@ -500,7 +640,7 @@ __global__ void k_dqn_adam(float *__restrict__ local, float *__restrict__ target
 
 // Single-GPU fast path: k_dqn_reduce + k_dqn_adam in one launch (each workgroup owns 32 parameters end to end; the
 // valid count is re-derived per workgroup from the nblk count cells, 1 load per thread).
-__global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict__ partials, int nblk, int P,
+__global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict__ partials, int nblk, int P, int stride,
                                                          float *__restrict__ local, float *__restrict__ target,
                                                          float *__restrict__ m, float *__restrict__ v, float lr,
                                                          float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
@@ -509,7 +649,6 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
     __shared__ float red[8][33];
     __shared__ float cnt_part[4];
     __shared__ float s_inv;
-    const int stride = P + 2;
     const int tid = (int)threadIdx.x;
     float c = 0.0f;
     for (int b = tid; b < nblk; b += 256) c += partials[(size_t)b * stride + P + 1];
@@ -518,7 +657,7 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
     const int px = tid & 31, gy = tid >> 5;
     const int p = (int)blockIdx.x * 32 + px;
     float s = 0.0f;
-    if (p < stride) {
+    if (p < P + 2) {
         int b = gy;
         for (; b + 24 < nblk; b += 32) {
             const float v0 = partials[(size_t)b * stride + p], v1 = partials[(size_t)(b + 8) * stride + p];
@@ -534,7 +673,7 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
         s_inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
     }
     __syncthreads();
-    if (gy == 0 && p < stride) {
+    if (gy == 0 && p < P + 2) {
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][px];
@@ -565,71 +704,89 @@ struct ActArgs {
     float *q_out;          // nullable [n][A]
 };
 
-// Q(s) + epsilon-greedy for a tile of 64 envs (Trainer/DuelingDQN_Trainer.py:86-97)
-template <typename ObsT>
+// Q(s) + epsilon-greedy for a tile of 64 envs (Trainer/DuelingDQN_Trainer.py:86-97), same wave-strip forward as
+// k_dqn_grad: wavefront w owns rows 16 w .. 16 w + 15 of the tile (consecutive observation rows: one 6.4 KB run).
+template <typename ObsT, int NMAX>
 __global__ void __launch_bounds__(256) k_dqn_act(ActArgs g)
 {
     extern __shared__ __align__(16) float lds[];
-    float *Xs = lds;
-    float *W1 = Xs + kXTile;
-    float *Hs = W1 + kXTile;
-    float *b1 = Hs + kTile * kLdh;
-    float *W2 = b1 + kHid;
-    float *b2 = W2 + kMaxOut * kHid;
-    const int tid = (int)threadIdx.x;
+    float *W1 = lds;                        // [64][108] fc1 (+ b1 in column 100)
+    float *Xs = W1 + kTileF;                // [64][108]
+    float *W2 = Xs + kTileF;                // [16][64]
+    float *b2 = W2 + kMaxOut * kHid;        // [16]
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     const NetDev nl = net_view(g.local, n2);
-    // one memory round trip: the weight tile, the 64 observation rows (consecutive; the last tile clamps to row n-1)
-    // and the small vectors are all in flight before the first LDS write
-    float4 vW[kStageIters], vX[kStageIters];
-    const int first = (int)blockIdx.x * kTile;
-    stage_issue<float>(vW, nullptr, nl.W1);
-    stage_issue<ObsT>(vX, nullptr, reinterpret_cast<const ObsT *>(g.obs) + (size_t)first * kW, g.n - 1 - first);
+    const int first = (int)blockIdx.x * kTile + wv * 16;              // first row of this wavefront's strip
+    float *strip = Xs + wv * kStripF;
+    // one memory round trip: observation strip, fc1, the small vectors
+    floatx4 vX[kXIters], vW[kStageIters];
+    {
+        const ObsT *obs = reinterpret_cast<const ObsT *>(g.obs);
+#pragma unroll
+        for (int it = 0; it < kXIters; ++it) {
+            int c = it * 64 + lane;
+            c = c < 400 ? c : 399;
+            const int row = c / 25, q = c - row * 25;
+            int i = first + row;
+            i = i < g.n ? i : g.n - 1;                                 // ragged last tile: clamp (results discarded)
+            const ObsT *src = obs + (size_t)i * kW + 4 * q;
+            if (sizeof(ObsT) == 4) {
+                vX[it] = *reinterpret_cast<const floatx4 *>(src);
+            } else {
+                const uint2 raw = *reinterpret_cast<const uint2 *>(src);
+                vX[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};
+            }
+        }
+    }
+    w_issue(vW, g.local);
+    // the epsilon-greedy draw of this lane's env: a serial chain, computed under the loads' round trip
+    const int i = first + r;
+    const uint4 rn = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
+                                   make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
     const float pb1 = nl.b1[tid < kHid ? tid : kHid - 1];
-    const int k0 = tid < n2 * kHid ? tid : 0, k1 = tid + 256 < n2 * kHid ? tid + 256 : 0;
-    const int k2 = tid + 512 < n2 * kHid ? tid + 512 : 0, k3 = tid + 768 < n2 * kHid ? tid + 768 : 0;
-    const float pw0 = nl.W2[k0], pw1 = nl.W2[k1], pw2 = nl.W2[k2], pw3 = nl.W2[k3];
+    float pw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pw[k] = nl.W2[tid + 256 * k < n2 * kHid ? tid + 256 * k : 0];
     const float pb2 = nl.b2[tid < n2 ? tid : 0];
-    stage_commit<float>(W1, vW);
-    stage_commit<ObsT>(Xs, vX);
-    if (tid < kHid) b1[tid] = pb1;
-    if (tid < n2 * kHid) W2[tid] = pw0;
-    if (tid + 256 < n2 * kHid) W2[tid + 256] = pw1;
-    if (tid + 512 < n2 * kHid) W2[tid + 512] = pw2;
-    if (tid + 768 < n2 * kHid) W2[tid + 768] = pw3;
+    x_commit<ObsT>(strip, vX);
+    w_commit(W1, vW, pb1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (tid + 256 * k < n2 * kHid) W2[tid + 256 * k] = pw[k];
     if (tid < n2) b2[tid] = pb2;
     __syncthreads();
-    layer1(Xs, W1, b1, Hs);
-    __syncthreads();
-    float *out2 = Xs;                                 // the staged observations are dead after layer 1
-    layer2_block(Hs, W2, b2, n2, out2);
-    __syncthreads();
-    if (tid < kTile) {
-        const int i = (int)blockIdx.x * kTile + tid;
-        if (i < g.n) {
-            float q[kMaxOut];
-            q_from_out(out2 + tid * kMaxOut, g.n_actions, g.dueling, q);
-            if (g.q_out)
-                for (int a = 0; a < g.n_actions; ++a) g.q_out[(size_t)i * g.n_actions + a] = q[a];
-            const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
-                                          make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
-            const float sample = (float)(r.x >> 8) * (1.0f / 16777216.0f);
-            int a;
-            if (sample > g.eps) {
-                a = 0;
-                for (int k = 1; k < g.n_actions; ++k) if (q[k] > q[a]) a = k;
-            } else {
-                a = (int)(((uint64_t)r.y * (uint64_t)g.n_actions) >> 32);
-            }
-            if (g.index_out) g.index_out[i] = a;
-            if (g.steer_out) g.steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(g.n_actions - 1));
+    floatx4 h[4];
+    fwd_strip(W1, strip, h);
+    float q[NMAX];
+    {
+        W2Frag<NMAX> F;
+        w2_load<NMAX>(F, W2, b2, n2);
+        q_strip<NMAX>(h, F, n2, g.n_actions, g.dueling, q);
+    }
+    if (lane < 16 && i < g.n) {
+        if (g.q_out) {
+#pragma unroll
+            for (int a = 0; a < NMAX; ++a)
+                if (a < g.n_actions) g.q_out[(size_t)i * g.n_actions + a] = q[a];
         }
+        const float sample = (float)(rn.x >> 8) * (1.0f / 16777216.0f);
+        int a;
+        if (sample > g.eps) {
+            a = 0;
+            float bq = q[0];
+#pragma unroll
+            for (int k = 1; k < NMAX; ++k)
+                if (k < g.n_actions && q[k] > bq) { bq = q[k]; a = k; }
+        } else {
+            a = (int)(((uint64_t)rn.y * (uint64_t)g.n_actions) >> 32);
+        }
+        if (g.index_out) g.index_out[i] = a;
+        if (g.steer_out) g.steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(g.n_actions - 1));
     }
 }
 
-constexpr size_t kGradLds = (size_t)(4 * kXTile + 2 * kTile * kLdh + 2 * kHid + 2 * kMaxOut * kHid + 2 * kMaxOut +
-                                     kTile * kMaxOut + 2 * kTile) * 4 + 2 * kTile * 8 + 3 * kTile * 4;
-constexpr size_t kActLds = (size_t)(2 * kXTile + kTile * kLdh + kHid + kMaxOut * kHid + kMaxOut) * 4 + kTile * 8;
+constexpr size_t kAct2Lds = (size_t)(2 * kTileF + kMaxOut * kHid + kMaxOut) * 4;
 
 unsigned long long *g_learner_dbg = nullptr;
 
@@ -638,6 +795,35 @@ bool net_ok(const UavDqnNet *n)
     return n && n->local && n->w == kW && n->hid == kHid && n->n_actions >= 2 &&
            n->n_actions + (n->dueling ? 1 : 0) + 2 <= kMaxOut;     // + 2 spare dout columns (loss sum, valid count)
 }
+
+template <typename ObsT, int NMAX>
+static int launch_act(const ActArgs &g, int grid, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_act<ObsT, NMAX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAct2Lds) != hipSuccess)
+            return UAVENV_EHIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_dqn_act<ObsT, NMAX>), dim3(grid), dim3(256), kAct2Lds, s, g);
+    return UAVENV_OK;
+}
+
+template <typename ObsT, int NMAX>
+static int launch_grad(const Grad2Args &ga, int grid, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad<ObsT, NMAX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGrad2Lds) != hipSuccess)
+            return UAVENV_EHIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_dqn_grad<ObsT, NMAX>), dim3(grid), dim3(256), kGrad2Lds, s, ga);
+    return UAVENV_OK;
+}
+
 
 }  // namespace
 
@@ -656,6 +842,19 @@ int uavenv_dqn_num_params(const UavDqnNet *net)
     return net->hid * net->w + net->hid + n2 * net->hid + n2;
 }
 
+int uavenv_dqn_partial_stride(const UavDqnNet *net)
+{
+    if (!net_ok(net)) return UAVENV_EINVAL;
+    return (uavenv_dqn_num_params(net) + 2 + 3) & ~3;         // rows start 16-byte aligned: the kernel stores float4
+}
+
+int uavenv_dqn_partial_rows(int32_t batch)
+{
+    if (batch <= 0 || batch % kTile != 0) return UAVENV_EINVAL;
+    const int tiles = batch / kTile;
+    return tiles < kMaxGradGrid ? tiles : kMaxGradGrid;       // more tiles than that: persistent workgroups loop over them
+}
+
 int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
                     uint64_t counter, const int32_t *explicit_idx, const UavDqnNet *net, int32_t kind, float gamma,
                     int32_t huber, float *partials, void *stream)
@@ -664,39 +863,33 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
         return UAVENV_EINVAL;
     if (batch <= 0 || batch % kTile != 0 || ring->frames < 2 || head < 0 || head >= ring->frames) return UAVENV_EINVAL;
     if (!explicit_idx && (filled <= 0 || filled > ring->frames - 1)) return UAVENV_EINVAL;
+    if ((uint64_t)ring->frames * (uint64_t)ring->n_agents >= (1ull << 32)) return UAVENV_EINVAL;
     if (!ring->action_is_index) return UAVENV_EINVAL;
-    GradArgs g;
+    if ((((uintptr_t)partials | (uintptr_t)net->local | (uintptr_t)net->target) & 15u) != 0) return UAVENV_EINVAL;
+    Grad2Args ga;
+    GradArgs &g = ga.g;
     g.ring = *ring;
     g.head = head; g.filled = filled; g.batch = batch;
     g.seed = seed; g.counter = counter;
     g.explicit_idx = explicit_idx;
+    g.perm = replay_perm(seed, counter, explicit_idx ? 1u : (uint32_t)filled * (uint32_t)ring->n_agents);
     g.local = net->local; g.target = net->target;
     g.n_actions = net->n_actions; g.dueling = net->dueling; g.kind = kind;
     g.gamma = gamma; g.huber = huber;
     g.partials = partials;
     g.P = uavenv_dqn_num_params(net);
     g.dbg = g_learner_dbg;
-    const int grid = batch / kTile;
+    ga.n_tiles = batch / kTile;
+    ga.stride = uavenv_dqn_partial_stride(net);
+    const int grid = uavenv_dqn_partial_rows(batch);
     hipStream_t s = (hipStream_t)stream;
-    if (ring->obs_dtype == UAVENV_OBS_F32) {
-        static bool attr32 = false;
-        if (!attr32) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad<float>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradLds) != hipSuccess)
-                return UAVENV_EHIP;
-            attr32 = true;
-        }
-        hipLaunchKernelGGL((k_dqn_grad<float>), dim3(grid), dim3(256), kGradLds, s, g);
-    } else {
-        static bool attr16 = false;
-        if (!attr16) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad<__half>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradLds) != hipSuccess)
-                return UAVENV_EHIP;
-            attr16 = true;
-        }
-        hipLaunchKernelGGL((k_dqn_grad<__half>), dim3(grid), dim3(256), kGradLds, s, g);
-    }
+    const bool small = net->n_actions + (net->dueling ? 1 : 0) <= 4;
+    int rc;
+    if (ring->obs_dtype == UAVENV_OBS_F32)
+        rc = small ? launch_grad<float, 4>(ga, grid, s) : launch_grad<float, kMaxOut - 2>(ga, grid, s);
+    else
+        rc = small ? launch_grad<__half, 4>(ga, grid, s) : launch_grad<__half, kMaxOut - 2>(ga, grid, s);
+    if (rc != UAVENV_OK) return rc;
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 
@@ -705,7 +898,7 @@ int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials, int32_t n_par
     if (!net_ok(net) || !partials || !raw_out || n_partials <= 0) return UAVENV_EINVAL;
     const int P = uavenv_dqn_num_params(net);
     hipLaunchKernelGGL(k_dqn_reduce, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials, P,
-                       raw_out);
+                       uavenv_dqn_partial_stride(net), raw_out);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 
@@ -731,7 +924,7 @@ int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials, int32_t 
     const float bc1 = 1.0f - powf(beta1, (float)step_t);
     const float bc2 = 1.0f - powf(beta2, (float)step_t);
     hipLaunchKernelGGL(k_dqn_reduce_adam, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
-                       P, net->local, net->target, net->m, net->v, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update,
+                       P, uavenv_dqn_partial_stride(net), net->local, net->target, net->m, net->v, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update,
                        loss_out, raw_out);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
@@ -740,23 +933,18 @@ int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype,
                    uint64_t counter, int32_t *index_out, float *steer_out, float *q_out, void *stream)
 {
     if (!net_ok(net) || !obs_dev || n <= 0) return UAVENV_EINVAL;
+    if ((((uintptr_t)net->local | (uintptr_t)obs_dev) & 15u) != 0) return UAVENV_EINVAL;
     ActArgs g;
     g.obs = obs_dev; g.n = n; g.n_actions = net->n_actions; g.dueling = net->dueling;
     g.local = net->local; g.eps = eps; g.seed = seed; g.counter = counter;
     g.index_out = index_out; g.steer_out = steer_out; g.q_out = q_out;
     const int grid = (n + kTile - 1) / kTile;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_act<float>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_act<__half>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kActLds) != hipSuccess)
-            return UAVENV_EHIP;
-        attr = true;
-    }
-    if (obs_dtype == UAVENV_OBS_F32) hipLaunchKernelGGL((k_dqn_act<float>), dim3(grid), dim3(256), kActLds, s, g);
-    else hipLaunchKernelGGL((k_dqn_act<__half>), dim3(grid), dim3(256), kActLds, s, g);
+    const bool small = net->n_actions + (net->dueling ? 1 : 0) <= 4;
+    int rc;
+    if (obs_dtype == UAVENV_OBS_F32) rc = small ? launch_act<float, 4>(g, grid, s) : launch_act<float, kMaxOut - 2>(g, grid, s);
+    else rc = small ? launch_act<__half, 4>(g, grid, s) : launch_act<__half, kMaxOut - 2>(g, grid, s);
+    if (rc != UAVENV_OK) return rc;
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

@@ -124,7 +124,7 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                                  c.huber, c.partials_dev, s);
             if (rc != UAVENV_OK) return rc;
             l->epoch += 1;
-            rc = uavenv_dqn_reduce_adam(&c.net, c.partials_dev, c.batch / 64, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch,
+            rc = uavenv_dqn_reduce_adam(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch,
                                         l->epoch % c.update_loop == 0 ? 1 : 0, c.loss_dev, nullptr, s);
             if (rc != UAVENV_OK) return rc;
         }

@@ -20,7 +20,7 @@ namespace {
 // One 16-byte chunk per thread: chunk q of sample s, q in [0, 2*CH) = obs row then next_obs row.
 // CH = 25 (f32 rows, 400 B) or 13 (f16 rows, 200 B = 12.5 chunks -> handled as 8-byte units, CH8 = 25).
 template <int UNIT /*bytes per copy unit*/>
-__global__ void k_sample_gather(UavReplayRing ring, int head, int filled, int batch, uint64_t seed, uint64_t counter,
+__global__ void k_sample_gather(UavReplayRing ring, int head, int batch, ReplayPerm perm,
                                 unsigned char *__restrict__ obs_b, unsigned char *__restrict__ next_b,
                                 unsigned char *__restrict__ act_b, float *__restrict__ rew_b,
                                 float *__restrict__ done_b, float *__restrict__ valid_b)
@@ -28,7 +28,6 @@ __global__ void k_sample_gather(UavReplayRing ring, int head, int filled, int ba
     constexpr int ROW_UNITS = 25;                        // 25 x 16 B (f32) or 25 x 8 B (f16)
     const int row_bytes = ROW_UNITS * UNIT;
     const int64_t total = (int64_t)batch * (2 * ROW_UNITS);
-    const ReplayPerm perm = replay_perm(seed, counter, (uint32_t)filled * (uint32_t)ring.n_agents);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int s = (int)(t / (2 * ROW_UNITS));
         const int q = (int)(t - (int64_t)s * (2 * ROW_UNITS));
@@ -55,10 +54,8 @@ __global__ void k_sample_gather(UavReplayRing ring, int head, int filled, int ba
 }
 
 // the draws alone: (frame, agent) of samples 0 .. batch-1 (tests, prioritised replay bookkeeping)
-__global__ void k_replay_draw(int frames, int n_agents, int head, int filled, int batch, uint64_t seed, uint64_t counter,
-                              int32_t *__restrict__ out)
+__global__ void k_replay_draw(int frames, int n_agents, int head, int batch, ReplayPerm perm, int32_t *__restrict__ out)
 {
-    const ReplayPerm perm = replay_perm(seed, counter, (uint32_t)filled * (uint32_t)n_agents);
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < batch; s += gridDim.x * blockDim.x) {
         int f, agent;
         replay_slot_to_frame(replay_perm_apply(perm, (uint32_t)s), head, frames, n_agents, f, agent);
@@ -111,12 +108,13 @@ int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled
     int64_t g = (total + block - 1) / block;
     const int grid = (int)(g > 4096 ? 4096 : g);
     hipStream_t s = (hipStream_t)stream;
+    const ReplayPerm perm = replay_perm(seed, counter, (uint32_t)filled * (uint32_t)ring->n_agents);
     if (ring->obs_dtype == UAVENV_OBS_F32)
-        hipLaunchKernelGGL((k_sample_gather<16>), dim3(grid), dim3(block), 0, s, *ring, head, filled, batch, seed, counter,
+        hipLaunchKernelGGL((k_sample_gather<16>), dim3(grid), dim3(block), 0, s, *ring, head, batch, perm,
                            (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
                            done_b, valid_b);
     else
-        hipLaunchKernelGGL((k_sample_gather<8>), dim3(grid), dim3(block), 0, s, *ring, head, filled, batch, seed, counter,
+        hipLaunchKernelGGL((k_sample_gather<8>), dim3(grid), dim3(block), 0, s, *ring, head, batch, perm,
                            (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
                            done_b, valid_b);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
@@ -131,8 +129,8 @@ int uavenv_replay_draw(int32_t frames, int32_t n_agents, int32_t head, int32_t f
     const int block = 256;
     int grid = (batch + block - 1) / block;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_replay_draw, dim3(grid), dim3(block), 0, (hipStream_t)stream, frames, n_agents, head, filled, batch,
-                       seed, counter, frame_agent_out);
+    hipLaunchKernelGGL(k_replay_draw, dim3(grid), dim3(block), 0, (hipStream_t)stream, frames, n_agents, head, batch,
+                       replay_perm(seed, counter, (uint32_t)filled * (uint32_t)n_agents), frame_agent_out);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

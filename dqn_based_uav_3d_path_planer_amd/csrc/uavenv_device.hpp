@@ -788,12 +788,13 @@ __device__ __forceinline__ void store_obs_ctile(void *obs_base, int64_t first_ag
 }
 
 // Philox4x32-10 (counter-based; one independent stream per (seed, agent, tick)).
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+__host__ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
         k.x += 0x9E3779B9u;
         k.y += 0xBB67AE85u;
@@ -824,7 +825,9 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
     return h;
 }
 
-__device__ __forceinline__ ReplayPerm replay_perm(uint64_t seed, uint64_t counter, uint32_t D)
+// (host-callable: the round keys are the same for every sample of an update, so the launch code derives them once and
+// passes them as kernel arguments -- two Philox chains less on every wavefront's critical path)
+__host__ __device__ __forceinline__ ReplayPerm replay_perm(uint64_t seed, uint64_t counter, uint32_t D)
 {
     ReplayPerm p;
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
@@ -832,7 +835,8 @@ __device__ __forceinline__ ReplayPerm replay_perm(uint64_t seed, uint64_t counte
     const uint4 b = philox4x32_10(make_uint4(1u, (uint32_t)counter, (uint32_t)(counter >> 32), 0x5a3bu), key);
     p.k[0] = a.x; p.k[1] = a.y; p.k[2] = a.z; p.k[3] = a.w; p.k[4] = b.x; p.k[5] = b.y;
     p.D = D;
-    const uint32_t bits = D > 1u ? 32u - (uint32_t)__builtin_clz(D - 1u) : 1u;     // ceil(log2 D), >= 1
+    uint32_t bits = 1u;                                                            // ceil(log2 D), >= 1
+    while (bits < 32u && (1ull << bits) < (uint64_t)D) ++bits;
     p.hb = (bits + 1u) >> 1;
     return p;
 }

@@ -190,7 +190,9 @@ class FusedDQNLearner:
         self.epoch = 0
         n2 = self.n_actions + (1 if self.dueling else 0)
         self.P = hid * w + hid + n2 * hid + n2
-        self.flat = torch.zeros((4, self.P), dtype=torch.float32, device=self.device)   # local, target, m, v
+        # local, target, m, v: rows padded to a multiple of 4 floats so that every block starts 16-byte aligned
+        self._flat_pad = torch.zeros((4, (self.P + 3) & ~3), dtype=torch.float32, device=self.device)
+        self.flat = self._flat_pad[:, :self.P]
         self._bind(self.q_local, self.flat[0], hid, w)
         self._bind(self.q_target, self.flat[1], hid, w)
         self.net = _lib.UavDqnNet(self.flat[0].data_ptr(), self.flat[1].data_ptr(), self.flat[2].data_ptr(),
@@ -227,6 +229,14 @@ class FusedDQNLearner:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def new_partials(self, batch: int) -> torch.Tensor:
+        """Scratch for uavenv_dqn_grad: partial_rows(batch) x partial_stride(net) floats."""
+        rows = self.lib.uavenv_dqn_partial_rows(int(batch))
+        stride = self.lib.uavenv_dqn_partial_stride(self._C.byref(self.net))
+        if rows <= 0 or stride <= 0:
+            raise ValueError("fused learner needs batch % 64 == 0")
+        return torch.empty((rows, stride), dtype=torch.float32, device=self.device)
+
     def hard_update(self):
         self.flat[1].copy_(self.flat[0])
 
@@ -239,7 +249,7 @@ class FusedDQNLearner:
         RCCL (DQNLearner.federated_average has the reference lines)."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        w = self.flat[:2]
+        w = self._flat_pad[:2]             # contiguous (the pad column rides along)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         w /= dist.get_world_size()
 
@@ -259,9 +269,9 @@ class FusedDQNLearner:
         C, _lib = self._C, self._lib_mod
         if batch % 64:
             raise ValueError("fused learner needs batch % 64 == 0")
-        nblk = batch // 64
+        nblk = self.lib.uavenv_dqn_partial_rows(batch)
         if self._partials is None or self._partials.shape[0] != nblk:
-            self._partials = torch.empty((nblk, self.P + 2), dtype=torch.float32, device=self.device)
+            self._partials = self.new_partials(batch)
         self.epoch += 1
         s = self._stream()
         kind = 0 if self.kind == "dqn" else 1

@@ -28,8 +28,7 @@ class HotLoop:
         env = ring.env
         if skip_done is None:
             skip_done = env.uav_per_env > 1
-        nblk = max(batch // 64, 1)
-        self._partials = torch.empty((nblk, learner.P + 2), dtype=torch.float32, device=env.device)
+        self._partials = learner.new_partials(max(batch, 64))
         cfg = _lib.UavLoopConfig()
         cfg.env = env._h
         cfg.ring = ring._c

@@ -216,8 +216,8 @@ int uavenv_per_fill(const UavPer *per, int64_t first, int64_t count, double prio
                     void *stream);
 
 /* ---- fused DQN-family learner for the reference's Q-MLPs (BaseClass/BaseCNN.py:93-139, w=100, hid=64) ---------- */
-/* Flat f32 parameter blocks in HBM, layout [W1 hid*w][b1 hid][W2 n2*hid][b2 n2] with n2 = n_actions (+1 value row
- * for the dueling VAnet2: rows 0..A-1 = fc_A, row A = fc_V).  m / v are Adam's moments (same layout). */
+/* Flat f32 parameter blocks in HBM (16-byte aligned), layout [W1 hid*w][b1 hid][W2 n2*hid][b2 n2] with n2 = n_actions
+ * (+1 value row for the dueling VAnet2: rows 0..A-1 = fc_A, row A = fc_V).  m / v are Adam's moments (same layout). */
 typedef struct UavDqnNet {
     float *local;     /* q_local  */
     float *target;    /* q_target */
@@ -228,14 +228,18 @@ typedef struct UavDqnNet {
 int uavenv_dqn_num_params(const UavDqnNet *net);
 /* Diagnostics (UAVENV_PHASE_PROFILE builds): 8 s_memtime stamps per workgroup of uavenv_dqn_grad; NULL disables. */
 int uavenv_dqn_set_debug_buffer(unsigned long long *dev_buf);
+/* Partial-gradient scratch: uavenv_dqn_partial_rows(batch) rows of uavenv_dqn_partial_stride(net) floats (16-byte
+ * aligned base); row layout = the parameter layout, then loss sum and valid count at [num_params], [num_params + 1]. */
+int uavenv_dqn_partial_stride(const UavDqnNet *net);
+int uavenv_dqn_partial_rows(int32_t batch);
 /* One learn_off_policy() gradient (Trainer/DQN_Trainer.py:93-121, DDQN_Trainer.py:84-105): draws `batch` transitions
- * (batch % 64 == 0) with the SAME Philox stream as uavenv_replay_sample (or takes explicit (frame, agent) pairs),
+ * (batch % 64 == 0) with the SAME permutation as uavenv_replay_sample (or takes explicit (frame, agent) pairs),
  * gathers them from the ring, forward/backward on the f32 MFMA.  kind 0: max_a Q_target(s'); 1: double-DQN.
- * Writes batch/64 partial rows of (num_params + 2) floats (gradient sums, loss sum, valid count). */
+ * Writes the partial rows described above (gradient sums, loss sum, valid count). */
 int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
                     uint64_t counter, const int32_t *explicit_idx_dev, const UavDqnNet *net, int32_t kind, float gamma,
                     int32_t huber, float *partials_dev, void *stream);
-/* Sum the partial rows -> raw_out_dev[num_params + 2] = gradient sums, loss sum, valid-sample count.  This flat vector
+/* n_partials = uavenv_dqn_partial_rows(batch).  Sum the partial rows -> raw_out_dev[num_params + 2] = gradient sums, loss sum, valid-sample count.  This flat vector
  * is the RCCL all-reduce(sum) payload for multi-GPU (the mean is then over the valid samples of all ranks). */
 int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, float *raw_out_dev,
                       void *stream);
@@ -275,7 +279,7 @@ typedef struct UavLoopConfig {
     uint64_t seed, counter;      /* Philox key / first step's counter (one counter value per step) */
     float eps, gamma, lr, beta1, beta2, adam_eps;
     uint32_t step_flags;         /* UAVENV_STEP_* for every step */
-    float *partials_dev;         /* [batch / 64][num_params + 2] scratch */
+    float *partials_dev;         /* uavenv_dqn_partial_rows(batch) x uavenv_dqn_partial_stride(net) floats of scratch */
     float *loss_dev;             /* device scalar: mean loss of the last update */
     int32_t time_every;          /* > 0: bracket the step kernel of every time_every-th step with HIP events */
     int32_t reserved0;

@@ -21,10 +21,13 @@ rows = []
 for t in range(20):
     L.learn_from_ring(ring, B, 3, t)
     torch.cuda.synchronize()
-    rows.append(buf.cpu().numpy().reshape(nb, 8)[:, :6].astype(np.float64))
+    rows.append(buf.cpu().numpy().reshape(nb, 8).astype(np.float64))
 env.lib.uavenv_dqn_set_debug_buffer(None)
-d = np.diff(np.stack(rows), axis=2)
-names = ["P0 sample + stage W1,W1t,Xs,Xn", "P1 layer1 x2 (MFMA)", "P4 TD target (64 threads)", "P5 dW2, dH", "P6 dW1 (MFMA) + write"]
+R = np.stack(rows)
+print("fwd_strip local (MFMA only):", (R[:, :, 6] - R[:, :, 1]).mean(), " fwd_strip target (MFMA only):", (R[:, :, 7] - R[:, :, 2]).mean())
+d = np.diff(R[:, :, :6], axis=2)
+names = ["draw, issue loads, commit s rows + local fc1", "forward q_local(s) + commit s' rows, target fc1",
+         "forward q_target(s') [+ q_local(s')]", "TD target, dL/dH, H / dH / dout -> LDS", "dW1^T, dW2^T products (MFMA)"]
 print("k_dqn_grad, batch", B, "- cycles per workgroup (mean / p95 / max)")
 for k, nm in enumerate(names):
     x = d[:, :, k].ravel()

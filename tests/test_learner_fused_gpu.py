@@ -251,3 +251,43 @@ def test_fused_learner_two_ranks_equal_one_process(kind, net, tmp_path):
     assert r0["losses"] == r1["losses"]
     assert (r0["flat"][:2] - one["flat"][:2]).abs().max().item() <= 2e-6
     assert np.allclose(r0["losses"], one["losses"], rtol=1e-5)
+
+
+def test_fused_learner_and_act_with_nine_actions():
+    """The general (up to 14 layer-2 outputs) kernel variants: A = 9 discrete steering values, dueling (n2 = 10) and
+    plain (n2 = 9), against the PyTorch-ROCm learner / forward on a real ring."""
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    n = 1024
+    env = make_city26_env(n, n_actions=9)
+    ring = DeviceReplayRing(env, 5 * n, discrete=True)
+    ring.reset(seed=4)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(4):
+        ring.current_action().copy_(torch.randint(0, 9, (n,), generator=gen, device="cuda", dtype=torch.int32))
+        ring.step_env(auto_reset=True)
+    for kind, net in (("ddqn", "Qnet2"), ("dueling", "VAnet2")):
+        param = dict(PARAM, NetWork=net, output="9")
+        torch.manual_seed(0)
+        T = DQNLearner(param, kind, device="cuda:0")
+        F = FusedDQNLearner(param, kind, device="cuda:0")
+        F.q_local.load_state_dict(T.q_local.state_dict())
+        F.q_target.load_state_dict(T.q_target.state_dict())
+        q = torch.empty(n, 9, device="cuda")
+        idx = torch.empty(n, dtype=torch.int32, device="cuda")
+        F.act(ring.current_obs(), 0.0, 3, 0, index_out=idx, q_out=q)
+        with torch.no_grad():
+            ref = T.q_local(ring.current_obs().float())
+        assert (q - ref).abs().max().item() <= 2e-5
+        top = ref.topk(2, dim=1).values
+        clear = (top[:, 0] - top[:, 1]) > 1e-4
+        assert torch.equal(idx[clear].long(), ref.argmax(1)[clear])
+        for it in range(3):
+            batch = ring.sample(2048, seed=5, counter=it)
+            lt = float(T.learn(batch))
+            lf = float(F.learn_from_ring(ring, 2048, seed=5, counter=it))
+            assert abs(lt - lf) <= 2e-5 * abs(lt), (kind, it, lt, lf)
+        for (k, a), (_, b) in zip(T.q_local.state_dict().items(), F.q_local.state_dict().items()):
+            assert (a - b).abs().max().item() <= 2e-5, (kind, k)
+    env.close()

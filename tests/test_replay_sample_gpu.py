@@ -67,7 +67,7 @@ def test_draw_entry_point_matches_oracle_and_is_uniform():
     per_frame = hits.reshape(filled, n).sum(1)
     assert abs(per_frame.mean() - 8 * batch / filled) < 1e-9
     assert per_frame.std() < 4 * np.sqrt(8 * batch / filled)
-    assert hits.max() <= 3
+    assert hits.max() <= 5                  # 131 072 draws into 1 M slots: Poisson(1/8), P(>= 6 somewhere) ~ 1e-6
 
 
 def test_fused_learner_draws_the_same_transitions_as_sample():
