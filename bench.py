@@ -63,7 +63,9 @@ def parse():
     p.add_argument("--batch", type=int, default=16384, help="learner batch per GPU per update")
     p.add_argument("--replay", type=int, default=1 << 20, help="replay capacity in transitions per GPU")
     p.add_argument("--trainer", default="dqn", choices=["dqn", "ddqn", "dueling"])
-    p.add_argument("--obs-dtype", default="f32", choices=["f32", "f16"])
+    p.add_argument("--obs-dtype", default="packed", choices=["packed", "f32", "f16"],
+                   help="replay / observation storage: packed = 15 f32 scalars + 80 flag bits per row (80 B, lossless image "
+                        "of the f32 row: include/uavenv.h UAVENV_OBS_PACKED); f32 / f16 = rows of 100 elements")
     p.add_argument("--eps", type=float, default=0.1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -204,7 +206,7 @@ def main():
     from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
     from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing, select_actions
 
-    obs_dtype = torch.float16 if args.obs_dtype == "f16" else torch.float32
+    obs_dtype = "packed" if args.obs_dtype == "packed" else (torch.float16 if args.obs_dtype == "f16" else torch.float32)
     t_plan = time.perf_counter()
     extra = {}
     if args.apf or args.uav_per_env > 1:
@@ -240,7 +242,7 @@ def main():
         e1.record()
         torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / iters
-        algo = ALGO_BYTES_PER_AGENT_STEP if args.obs_dtype == "f32" else 404
+        algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
         gbs = algo * env.N / (ms * 1e-3) / 1e9
         print(json.dumps({"mode": "env-only", "envs": env.N, "k_step_ms_back_to_back": ms,
                           "env_steps_per_s": env.N / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS,
@@ -273,7 +275,7 @@ def main():
         if fused:
             learner.act(ring.current_obs(), args.eps, seed, counter[0], index_out=ring.current_action())
         else:
-            q = learner.q_values(ring.current_obs())
+            q = learner.q_values(env.unpack(ring.current_obs()))
             select_actions(env, q, args.eps, seed, counter[0], index_out=ring.current_action())
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -398,7 +400,10 @@ def main():
     if rank == 0:
         n_agents = env.N
         value = n_pass * n_agents * world_size / dt
-        algo = ALGO_BYTES_PER_AGENT_STEP if args.obs_dtype == "f32" else 404
+        # algorithmic bytes are the SURVEY 8(d) figure for the observation the row stands for (f32: 604 B, f16: 404 B);
+        # packed rows are a lossless image of the f32 row, so they are priced as f32 and simply move fewer bytes
+        algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
+        stored = algo - (200 if args.obs_dtype == "f16" else 400) + ring.obs.shape[-1] * ring.obs.element_size()
         achieved = algo * n_agents / (k_ms * 1e-3) / 1e9
         traffic = prof.get("k_step_traffic_bytes_per_launch")
         ldt = "f16" if (fused and args.obs_dtype == "f16") else "f32"
@@ -431,7 +436,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_source": prof.get("source") if traffic else None,
-                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": n_agents,
+                         "algorithmic_bytes_per_agent_step": algo, "stored_bytes_per_agent_step": stored,
+                         "agents_per_launch": n_agents,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "kernel_ms": k_ms,
                          "kernel_ms_definition": "max(back-to-back launches between one HIP event pair in this run, "
@@ -445,7 +451,7 @@ def main():
             g_ms = max(g_b2b_ms, g_prof_ms or 0.0)
             peak = MFMA_F16_PEAK_TF if ldt == "f16" else MFMA_F32_PEAK_TF
             tf = fl * args.batch / (g_ms * 1e-3) / 1e12
-            row = 813 if args.obs_dtype == "f32" else 413
+            row = 413 if args.obs_dtype == "f16" else 813
             out["roofline_learner"] = {
                 "bound": "mfma", "kernel": "k_dqn_grad (sample + gather + forward/backward of the 100-64-A MLPs)",
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,

@@ -14,7 +14,8 @@ OK, EINVAL, ENOMEM, EHIP, ENODEV = 0, -22, -12, -5, -19
 INFO_NORMAL, INFO_SUCCESS, INFO_LOSE, INFO_SKIPPED = 0, 1, 2, 3
 INFO_NAMES = ("normal", "success", "lose", "skipped")
 ACT_STEER_F32, ACT_STEER_F64, ACT_INDEX_I32 = 0, 1, 2
-OBS_F32, OBS_F16 = 0, 1
+OBS_F32, OBS_F16, OBS_PACKED = 0, 1, 2
+PACKED_DWORDS = 20
 STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE = 1, 2, 4, 8
 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -22,7 +23,7 @@ SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
-    "uavenv_replay_sample", "uavenv_replay_draw", "uavenv_select_actions",
+    "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
@@ -128,6 +129,8 @@ def load() -> C.CDLL:
     lib.uavenv_threaten_rate_allpairs.argtypes = [vp, vp, vp, i64, vp]
     lib.uavenv_replay_sample.restype = C.c_int
     lib.uavenv_replay_sample.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp]
+    lib.uavenv_obs_unpack.restype = C.c_int
+    lib.uavenv_obs_unpack.argtypes = [vp, i64, vp, i32, vp]
     lib.uavenv_replay_draw.restype = C.c_int
     lib.uavenv_replay_draw.argtypes = [i32, i32, i32, i32, i32, u64, u64, vp, vp]
     lib.uavenv_loop_create.restype = C.c_int

@@ -128,7 +128,20 @@ __device__ __forceinline__ void w_commit(float *dst, floatx4 (&v)[kStageIters], 
         *reinterpret_cast<floatx4 *>(dst + (int)threadIdx.x * kLd + kW) = floatx4{bias, 0.0f, 0.0f, 0.0f};
 }
 
-// The 16 gathered observation rows of this wavefront's strip: lane l & 15 holds the ring row index of sample l & 15.
+// one 16-byte piece (four columns) of a ring row of floats or halfs
+template <typename T>
+__device__ __forceinline__ floatx4 x_load(const T *obs, uint32_t ring_row, int q)
+{
+    if (sizeof(T) == 4) {
+        return *reinterpret_cast<const floatx4 *>(reinterpret_cast<const float *>(obs) + (size_t)ring_row * kW + 4 * q);
+    } else {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(obs) + (size_t)ring_row * kW + 4 * q);
+        return floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};            // decoded at commit
+    }
+}
+
+// The 16 gathered observation rows of this wavefront's strip (f32 / f16 rings; packed rings never build this tile, see
+// below): lane l & 15 holds the ring row index of sample l & 15; 400 chunks of four columns, 7 per lane.
 template <typename T>
 __device__ __forceinline__ void x_issue(floatx4 (&v)[kXIters], const T *obs, uint32_t my_row)
 {
@@ -139,13 +152,7 @@ __device__ __forceinline__ void x_issue(floatx4 (&v)[kXIters], const T *obs, uin
         c = c < 400 ? c : 399;
         const int row = c / 25, q = c - row * 25;
         const uint32_t ring_row = (uint32_t)__shfl((int)my_row, row, 64);
-        const T *src = obs + (size_t)ring_row * kW + 4 * q;
-        if (sizeof(T) == 4) {
-            v[it] = *reinterpret_cast<const floatx4 *>(src);
-        } else {
-            const uint2 raw = *reinterpret_cast<const uint2 *>(src);
-            v[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};       // decoded at commit
-        }
+        v[it] = x_load<T>(obs, ring_row, q);
     }
 }
 
@@ -313,6 +320,91 @@ struct GradAcc {
     float csum[NMAX + 2];            // column sums of dout (db2), loss sum, valid count -- of this wave's strips
 };
 
+// TD target, loss, dL/dout of this lane's sample, the strip's column sums, dL/dH and the forward H into LDS -- everything
+// between the forward passes and the weight-gradient products; common to the f32-tile and the packed-row kernels.
+template <int NMAX>
+__device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l, const floatx4 (&hl)[4], const W2Frag<NMAX> &Fl,
+                                            const float (&ql)[NMAX], const float (&qt)[NMAX], int best, int p_act, float p_rew,
+                                            float p_done, float p_valid, GradAcc<NMAX> &A, float *hrow, float *drow,
+                                            float *dout_row)
+{
+    constexpr bool kKeepW2 = NMAX <= 4;
+    const int gq = ((int)threadIdx.x & 63) >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    // ---- TD target, loss, dL/dout of this lane's sample (Trainer/DQN_Trainer.py:107-119)
+    float qn = qt[0], qa = ql[0];
+#pragma unroll
+    for (int a = 1; a < NMAX; ++a) {
+        if (g.kind == 1) { if (a == best) qn = qt[a]; }
+        else if (a < g.n_actions && qt[a] > qn) qn = qt[a];
+        if (a == p_act) qa = ql[a];
+    }
+    const float y = p_rew + (g.gamma * qn * (1.0f - p_done));
+    const float delta = qa - y;
+    float per, dq;
+    if (g.huber) {
+        const float ad = fabsf(delta);
+        per = ad < 1.0f ? 0.5f * delta * delta : ad - 0.5f;
+        dq = ad < 1.0f ? delta : (delta > 0.0f ? 1.0f : -1.0f);
+    } else {
+        per = delta * delta;                          // MSELoss (BaseTrainer.py:40)
+        dq = 2.0f * delta;
+    }
+    dq *= p_valid;
+    float dv[NMAX + 2];
+    const float inv_a = 1.0f / (float)g.n_actions;
+#pragma unroll
+    for (int a = 0; a < NMAX; ++a) {
+        float d = 0.0f;
+        if (g.dueling) {                              // Q = V + A - mean(A)
+            if (a < g.n_actions) d = dq * ((a == p_act ? 1.0f : 0.0f) - inv_a);
+            else if (a == g.n_actions) d = dq;
+        } else if (a == p_act) {
+            d = dq;
+        }
+        dv[a] = d;
+    }
+    dv[NMAX] = per * p_valid;                         // loss and valid count ride along as two more columns
+    dv[NMAX + 1] = p_valid;
+    // column sums over the strip's 16 samples (db2, loss sum, valid count): four DPP row rotations each
+#pragma unroll
+    for (int a = 0; a < NMAX + 2; ++a) {
+        if (a < n2 || a >= NMAX) {
+            A.csum[a] += row_sum16(dv[a]);
+        }
+    }
+    // ---- dL/dH = relu'(h) * W2^T dout, and the forward H, into LDS for the weight-gradient products
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        floatx4 dh = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a) {
+            if (a < n2) {
+                const floatx4 wv4 = kKeepW2 ? Fl.w[a][t]
+                                            : *reinterpret_cast<const floatx4 *>(W2l + a * kHid + 16 * t + 4 * gq);
+                dh[0] = fmaf(dv[a], wv4[0], dh[0]); dh[1] = fmaf(dv[a], wv4[1], dh[1]);
+                dh[2] = fmaf(dv[a], wv4[2], dh[2]); dh[3] = fmaf(dv[a], wv4[3], dh[3]);
+            }
+        }
+        floatx4 hh;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            hh[rr] = hl[t][rr] > 0.0f ? hl[t][rr] : 0.0f;
+            dh[rr] = hl[t][rr] > 0.0f ? dh[rr] : 0.0f;
+        }
+        *reinterpret_cast<floatx4 *>(hrow + 16 * t + 4 * gq) = hh;
+        *reinterpret_cast<floatx4 *>(drow + 16 * t + 4 * gq) = dh;
+    }
+    {   // douts[s][4 gq .. 4 gq + 3]
+        floatx4 d4 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a)
+            if ((a >> 2) == gq) d4[a & 3] = dv[a];
+        *reinterpret_cast<floatx4 *>(dout_row + 4 * gq) = d4;
+    }
+}
+
 // One tile of 64 transitions.  FIRST: also stages the weights (their loads fly together with the observation rows).
 template <typename ObsT, int NMAX, bool FIRST>
 __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, int tile, bool more, GradAcc<NMAX> &A)
@@ -325,25 +417,11 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
     // whose Feistel rounds (a serial chain of ~100 integer operations) then run under their round trip.
     floatx4 vXs[kXIters], vXn[kXIters], vWl[kStageIters], vWt[kStageIters];
     float pb1 = 0.0f, pb1t = 0.0f, pw[4] = {0, 0, 0, 0}, pt[4] = {0, 0, 0, 0}, pb2 = 0.0f, pb2t = 0.0f;
-    if (FIRST) w_issue(vWl, g.local);
-    // ---- the 16 transitions of this wavefront's strip (lanes l, l + 16, l + 32, l + 48 hold the same sample)
-    const int smp = tile * kTile + wv * 16 + r;
-    int f, agent;
-    if (g.explicit_idx) {
-        f = g.explicit_idx[2 * smp];
-        agent = g.explicit_idx[2 * smp + 1];
-    } else {
-        replay_slot_to_frame(replay_perm_apply(g.perm, (uint32_t)smp), g.head, g.ring.frames, g.ring.n_agents, f, agent);
-    }
-    int fn = f + 1;
-    if (fn >= g.ring.frames) fn = 0;
-    const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
-    const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
-    x_issue<ObsT>(vXs, obs, row_s);
-    x_issue<ObsT>(vXn, obs, row_n);
     if (FIRST) {
+        // (the small vectors right behind the local fc1: vmcnt retires in order, so anything issued after the s' rows
+        // and the target fc1 would make the first LDS commit wait for ALL of the tile's loads)
+        w_issue(vWl, g.local);
         const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
-        w_issue(vWt, g.target);
         const int kb = tid < kHid ? tid : kHid - 1;
         pb1 = nl.b1[kb]; pb1t = nt.b1[kb];
 #pragma unroll
@@ -354,11 +432,28 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
         const int kq = tid < n2 ? tid : 0;
         pb2 = nl.b2[kq]; pb2t = nt.b2[kq];
     }
-    // this sample's scalar fields (needed at the TD target: fetched now, long arrived by then)
+    // ---- the 16 transitions of this wavefront's strip (lanes l, l + 16, l + 32, l + 48 hold the same sample)
+    const int smp = tile * kTile + wv * 16 + r;
+    int f, agent;
+    if (g.explicit_idx) {
+        f = g.explicit_idx[2 * smp];
+        agent = g.explicit_idx[2 * smp + 1];
+    } else {
+        replay_slot_to_frame(g.perm, replay_perm_apply(g.perm, (uint32_t)smp), g.head, g.ring.frames, f, agent);
+    }
+    int fn = f + 1;
+    if (fn >= g.ring.frames) fn = 0;
+    const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    x_issue<ObsT>(vXs, obs, row_s);
+    // this sample's scalar fields (needed at the TD target; behind the s rows, ahead of everything the first commit
+    // does not wait for)
     const int p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
     const float p_rew = g.ring.reward[row_s];
     const float p_done = (float)g.ring.done[row_s];
     const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    x_issue<ObsT>(vXn, obs, row_n);
+    if (FIRST) w_issue(vWt, g.target);
 
     if (FIRST) w_commit(L.W1l, vWl, pb1);
     x_commit<ObsT>(xs_strip, vXs);
@@ -410,80 +505,9 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
         q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
     }
     L_STAMP(3);
-    // ---- TD target, loss, dL/dout of this lane's sample (Trainer/DQN_Trainer.py:107-119)
-    float qn = qt[0], qa = ql[0];
-#pragma unroll
-    for (int a = 1; a < NMAX; ++a) {
-        if (g.kind == 1) { if (a == best) qn = qt[a]; }
-        else if (a < g.n_actions && qt[a] > qn) qn = qt[a];
-        if (a == p_act) qa = ql[a];
-    }
-    const float y = p_rew + (g.gamma * qn * (1.0f - p_done));
-    const float delta = qa - y;
-    float per, dq;
-    if (g.huber) {
-        const float ad = fabsf(delta);
-        per = ad < 1.0f ? 0.5f * delta * delta : ad - 0.5f;
-        dq = ad < 1.0f ? delta : (delta > 0.0f ? 1.0f : -1.0f);
-    } else {
-        per = delta * delta;                          // MSELoss (BaseTrainer.py:40)
-        dq = 2.0f * delta;
-    }
-    dq *= p_valid;
-    float dv[NMAX + 2];
-    const float inv_a = 1.0f / (float)g.n_actions;
-#pragma unroll
-    for (int a = 0; a < NMAX; ++a) {
-        float d = 0.0f;
-        if (g.dueling) {                              // Q = V + A - mean(A)
-            if (a < g.n_actions) d = dq * ((a == p_act ? 1.0f : 0.0f) - inv_a);
-            else if (a == g.n_actions) d = dq;
-        } else if (a == p_act) {
-            d = dq;
-        }
-        dv[a] = d;
-    }
-    dv[NMAX] = per * p_valid;                         // loss and valid count ride along as two more columns
-    dv[NMAX + 1] = p_valid;
-    // column sums over the strip's 16 samples (db2, loss sum, valid count): four DPP row rotations each
-#pragma unroll
-    for (int a = 0; a < NMAX + 2; ++a) {
-        if (a < n2 || a >= NMAX) {
-            A.csum[a] += row_sum16(dv[a]);
-        }
-    }
-    // ---- dL/dH = relu'(h) * W2^T dout, and the forward H, into LDS for the weight-gradient products
-    float *hrow = xn_strip + r * kLh;                 // H of sample r of this strip (its s' rows are dead now)
-    float *drow = L.dHs + (wv * 16 + r) * kLh;
-    wave_lds_sync();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        floatx4 dh = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int a = 0; a < NMAX; ++a) {
-            if (a < n2) {
-                const floatx4 wv4 = kKeepW2 ? Fl.w[a][t]
-                                            : *reinterpret_cast<const floatx4 *>(L.W2l + a * kHid + 16 * t + 4 * gq);
-                dh[0] = fmaf(dv[a], wv4[0], dh[0]); dh[1] = fmaf(dv[a], wv4[1], dh[1]);
-                dh[2] = fmaf(dv[a], wv4[2], dh[2]); dh[3] = fmaf(dv[a], wv4[3], dh[3]);
-            }
-        }
-        floatx4 hh;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            hh[rr] = hl[t][rr] > 0.0f ? hl[t][rr] : 0.0f;
-            dh[rr] = hl[t][rr] > 0.0f ? dh[rr] : 0.0f;
-        }
-        *reinterpret_cast<floatx4 *>(hrow + 16 * t + 4 * gq) = hh;
-        *reinterpret_cast<floatx4 *>(drow + 16 * t + 4 * gq) = dh;
-    }
-    {   // douts[s][4 gq .. 4 gq + 3]
-        floatx4 d4 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int a = 0; a < NMAX; ++a)
-            if ((a >> 2) == gq) d4[a & 3] = dv[a];
-        *reinterpret_cast<floatx4 *>(L.douts + (wv * 16 + r) * kMaxOut + 4 * gq) = d4;
-    }
+    // H of sample r of this strip goes where its s' rows were (dead now)
+    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qt, best, p_act, p_rew, p_done, p_valid, A, xn_strip + r * kLh,
+                      L.dHs + (wv * 16 + r) * kLh, L.douts + (wv * 16 + r) * kMaxOut);
     __syncthreads();                                  // H, dH, dout of all 64 samples visible
     L_STAMP(4);
     // ---- weight gradients over the 64 samples (K index of MFMA step kk in lane group g: sample (kk & 3) + 16 (kk >> 2) + 4 g)
@@ -524,6 +548,339 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
     if (more) __syncthreads();                        // the next tile overwrites Xs / Xn / dHs / douts
 }
 
+// the partial-gradient row of this workgroup: dW1 | db1 | dW2 | db2 | loss sum | valid count
+template <int NMAX>
+__device__ __forceinline__ void grad_write_partials(const GradArgs &g, int stride, float *red, const GradAcc<NMAX> &A)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    // ---- the partial-gradient row of this workgroup
+    float *out = g.partials + (size_t)blockIdx.x * stride;
+    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
+    {
+        const int j = 16 * wv + r;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            *reinterpret_cast<floatx4 *>(out + j * kW + 16 * u + 4 * gq) = A.acc1[u];
+        if (gq == 0) *reinterpret_cast<floatx4 *>(out + j * kW + 96) = A.acc1[6];
+        else if (gq == 1) out[kHid * kW + j] = A.acc1[6][0];            // column 100 = X's ones column -> db1[j]
+        if (r < n2) *reinterpret_cast<floatx4 *>(out + oW2 + r * kHid + 16 * wv + 4 * gq) = A.acc2;
+    }
+    // column sums: every lane of a wave holds the wave's sums; add the four waves through LDS
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) red[wv * (kMaxOut + 2) + a] = A.csum[a];
+    }
+    __syncthreads();
+    if (tid < NMAX + 2) {
+        const float s = (red[tid] + red[(kMaxOut + 2) + tid]) + (red[2 * (kMaxOut + 2) + tid] + red[3 * (kMaxOut + 2) + tid]);
+        if (tid < n2) out[ob2 + tid] = s;
+        else if (tid == NMAX) out[g.P] = s;
+        else if (tid == NMAX + 1) out[g.P + 1] = s;
+    }
+}
+
+// =====================================================================================================================
+// Packed rings (UAVENV_OBS_PACKED): the kernels consume the 80-byte rows in place.
+//
+// Expanding packed rows into f32 tiles in LDS costs more VALU + LDS time on a one-wave-per-SIMD kernel than the gather it
+// saves.  Instead every lane loads the packed row of ITS sample into registers (five 16-byte loads, no cross-lane
+// traffic) and produces the B operand of each forward MFMA step -- two consecutive columns of its sample's row -- with
+// a handful of VALU instructions that issue in the shadow of the MFMAs: a flag column is one bit-field extract of the
+// 26-bit slice of the flag words belonging to the lane group's column range, a scalar column is a select.  For the
+// weight-gradient product, where the observations are the A operand over all 64 samples, the packed rows of s are kept
+// in LDS (5 KB instead of 27 KB) and each lane extracts its column from them.  No f32 observation tile exists.
+// =====================================================================================================================
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+
+struct PRow {                        // one packed observation row in registers
+    uint32_t m0, m1, m2;
+    float sc[11];                    // columns 0..10
+    float sg[4];                     // columns 86..89
+};
+
+__device__ __forceinline__ void prow_load(PRow &R, const uint32_t *p)       // p: 16-byte aligned packed row in HBM
+{
+    const uintx4 a = reinterpret_cast<const uintx4 *>(p)[0], b = reinterpret_cast<const uintx4 *>(p)[1];
+    const uintx4 c = reinterpret_cast<const uintx4 *>(p)[2], d = reinterpret_cast<const uintx4 *>(p)[3];
+    const uintx4 e = reinterpret_cast<const uintx4 *>(p)[4];
+    R.m0 = a[0]; R.m1 = a[1]; R.m2 = a[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { R.sc[k] = __uint_as_float(b[k]); R.sc[4 + k] = __uint_as_float(c[k]); }
+    R.sc[8] = __uint_as_float(d[0]); R.sc[9] = __uint_as_float(d[1]); R.sc[10] = __uint_as_float(d[2]);
+    R.sg[0] = __uint_as_float(d[3]);
+    R.sg[1] = __uint_as_float(e[0]); R.sg[2] = __uint_as_float(e[1]); R.sg[3] = __uint_as_float(e[2]);
+}
+
+__device__ __forceinline__ void prow_store_lds(uint32_t *dst, const PRow &R)
+{
+    reinterpret_cast<uintx4 *>(dst)[0] = uintx4{R.m0, R.m1, R.m2, 0u};
+    reinterpret_cast<uintx4 *>(dst)[1] = uintx4{__float_as_uint(R.sc[0]), __float_as_uint(R.sc[1]), __float_as_uint(R.sc[2]), __float_as_uint(R.sc[3])};
+    reinterpret_cast<uintx4 *>(dst)[2] = uintx4{__float_as_uint(R.sc[4]), __float_as_uint(R.sc[5]), __float_as_uint(R.sc[6]), __float_as_uint(R.sc[7])};
+    reinterpret_cast<uintx4 *>(dst)[3] = uintx4{__float_as_uint(R.sc[8]), __float_as_uint(R.sc[9]), __float_as_uint(R.sc[10]), __float_as_uint(R.sg[0])};
+    reinterpret_cast<uintx4 *>(dst)[4] = uintx4{__float_as_uint(R.sg[1]), __float_as_uint(R.sg[2]), __float_as_uint(R.sg[3]), 0u};
+}
+
+// the flag bits of columns [26 g, 26 g + 26) of a row, column 26 g at bit 0 (scalar and constant columns read 0)
+__device__ __forceinline__ uint32_t prow_slice(const PRow &R, int g)
+{
+    const uint32_t lo = g < 2 ? R.m0 : (g == 2 ? R.m1 : R.m2);
+    const uint32_t hi = g < 2 ? R.m1 : (g == 2 ? R.m2 : 0u);
+    const uint32_t sh = g == 0 ? 0u : g == 1 ? 26u : g == 2 ? 20u : 14u;
+    return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> sh);
+}
+
+// columns 26 g + 2 i and 26 g + 2 i + 1 of the row (column 100 = the ones column, 101..103 = 0); i is a constant after unrolling
+__device__ __forceinline__ float2 prow_pair(const PRow &R, uint32_t slice, bool g0, bool g3, int i)
+{
+    float x0 = (float)((slice >> (2 * i)) & 1u), x1 = (float)((slice >> (2 * i + 1)) & 1u);
+    if (i <= 4) { x0 = g0 ? R.sc[i <= 4 ? 2 * i : 0] : x0; x1 = g0 ? R.sc[i <= 4 ? 2 * i + 1 : 0] : x1; }   // columns 0..9
+    if (i == 5) x0 = g0 ? R.sc[10] : x0;                                                                     // column 10
+    if (i == 4) { x0 = g3 ? R.sg[0] : x0; x1 = g3 ? R.sg[1] : x1; }                                          // 86, 87
+    if (i == 5) { x0 = g3 ? R.sg[2] : x0; x1 = g3 ? R.sg[3] : x1; }                                          // 88, 89
+    if (i == 11) x0 = g3 ? 1.0f : x0;                                                                        // 100
+    return make_float2(x0, x1);
+}
+
+// fwd_strip with the B operand generated from the lane's packed row
+__device__ __forceinline__ void fwd_strip_packed(const float *W, const PRow &R, floatx4 (&acc)[4])
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const float *wp = W + r * kLd + 26 * g;
+    const uint32_t slice = prow_slice(R, g);
+    const bool g0 = g == 0, g3 = g == 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    float2 b = prow_pair(R, slice, g0, g3, 0);
+    float2 a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float2 *>(wp + t * 16 * kLd);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        float2 bn = b, an[4] = {a[0], a[1], a[2], a[3]};
+        if (i + 1 < 13) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) an[t] = *reinterpret_cast<const float2 *>(wp + t * 16 * kLd + 2 * (i + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t].x, b.x, acc[t]);
+        if (i + 1 < 13) bn = prow_pair(R, slice, g0, g3, i + 1);       // ~8 VALU: issue in the shadow of the MFMAs around them
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t].y, b.y, acc[t]);
+        // order inside this region: MFMA, then two VALU, ... (an MFMA occupies the matrix pipe for 32 cycles; the VALU pipe is free)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        b = bn;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = an[t];
+    }
+}
+
+struct GradLdsP {
+    float *W1l, *W1t, *Hs, *dHs, *douts, *W2l, *W2t, *b2l, *b2t, *red;
+    uint32_t *Ps;                    // [64][20] packed rows of s (+ 4 dwords of pad)
+};
+
+template <int NMAX, bool FIRST>
+__device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLdsP &L, int tile, bool more, GradAcc<NMAX> &A)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    const uint32_t *obs = reinterpret_cast<const uint32_t *>(g.ring.obs);
+    floatx4 vWl[kStageIters], vWt[kStageIters];
+    float pb1 = 0.0f, pb1t = 0.0f, pw[4] = {0, 0, 0, 0}, pt[4] = {0, 0, 0, 0}, pb2 = 0.0f, pb2t = 0.0f;
+    if (FIRST) {
+        w_issue(vWl, g.local);
+        const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
+        const int kb = tid < kHid ? tid : kHid - 1;
+        pb1 = nl.b1[kb]; pb1t = nt.b1[kb];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k < n2 * kHid ? tid + 256 * k : 0;
+            pw[k] = nl.W2[idx]; pt[k] = nt.W2[idx];
+        }
+        const int kq = tid < n2 ? tid : 0;
+        pb2 = nl.b2[kq]; pb2t = nt.b2[kq];
+    }
+    // ---- this lane's transition (lanes l, l + 16, l + 32, l + 48 hold the same sample) and its two packed rows
+    const int smp = tile * kTile + wv * 16 + r;
+    int f, agent;
+    if (g.explicit_idx) {
+        f = g.explicit_idx[2 * smp];
+        agent = g.explicit_idx[2 * smp + 1];
+    } else {
+        replay_slot_to_frame(g.perm, replay_perm_apply(g.perm, (uint32_t)smp), g.head, g.ring.frames, f, agent);
+    }
+    int fn = f + 1;
+    if (fn >= g.ring.frames) fn = 0;
+    const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    PRow Rs, Rn;
+    prow_load(Rs, obs + (size_t)row_s * kPackedDwords);
+    const int p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
+    const float p_rew = g.ring.reward[row_s];
+    const float p_done = (float)g.ring.done[row_s];
+    const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    prow_load(Rn, obs + (size_t)row_n * kPackedDwords);
+    if (FIRST) w_issue(vWt, g.target);
+
+    if (FIRST) {
+        w_commit(L.W1l, vWl, pb1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < n2 * kHid) { L.W2l[tid + 256 * k] = pw[k]; L.W2t[tid + 256 * k] = pt[k]; }
+        if (tid < n2) { L.b2l[tid] = pb2; L.b2t[tid] = pb2t; }
+        __syncthreads();                      // local weights staged (the target fc1 is still in flight)
+    }
+    L_STAMP(1);
+    floatx4 hl[4];
+    fwd_strip_packed(L.W1l, Rs, hl);
+    L_STAMP(6);
+    constexpr bool kKeepW2 = NMAX <= 4;
+    W2Frag<NMAX> Fl;
+    w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+    float ql[NMAX];
+    q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+    if (gq == 0) prow_store_lds(L.Ps + (wv * 16 + r) * kPackedDwords, Rs);     // the s rows, for the dW1 product
+    if (FIRST) {
+        w_commit(L.W1t, vWt, pb1t);
+        __syncthreads();                      // target weights staged
+    }
+    L_STAMP(2);
+    int best = 0;
+    floatx4 ht[4];
+    if (g.kind == 1) {                        // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
+        fwd_strip_packed(L.W1l, Rn, ht);
+        float qn_l[NMAX];
+        if (!kKeepW2) w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+        q_strip<NMAX>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
+        float bq = qn_l[0];
+#pragma unroll
+        for (int a = 1; a < NMAX; ++a)
+            if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }           // torch.max: first maximum
+    }
+    fwd_strip_packed(L.W1t, Rn, ht);
+    L_STAMP(7);
+    float qt[NMAX];
+    {
+        W2Frag<NMAX> Ft;
+        w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
+        q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+    }
+    L_STAMP(3);
+    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qt, best, p_act, p_rew, p_done, p_valid, A, L.Hs + (wv * 16 + r) * kLh,
+                      L.dHs + (wv * 16 + r) * kLh, L.douts + (wv * 16 + r) * kMaxOut);
+    __syncthreads();                                  // H, dH, dout and the packed s rows of all 64 samples visible
+    L_STAMP(4);
+    // ---- weight gradients over the 64 samples (K index of MFMA step kk in lane group g: sample (kk & 3) + 16 (kk >> 2) + 4 g)
+    //   dW1^T[k][j] += sum_s X[s][k] dH[s][j]: X[s][16 u + r] comes out of the packed row of s --
+    //     u = 0: scalar (r < 11) or flag; u = 1..4: flags of word u >> 1; u = 5: flags, or scalars 86..89 (r = 6..9);
+    //     u = 6: the ones column (r = 4), else 0: a per-lane constant
+    //   dW2^T[j][a] += sum_s H[s][j] dout[s][a]
+    {
+        const uint32_t *pr = L.Ps + 4 * gq * kPackedDwords;
+        const int ia = 4 + (r < 11 ? r : 10), ib = 15 + (r < 6 ? 0 : (r > 9 ? 3 : r - 6));
+        const bool sc0 = r < 11, sc5 = r >= 6 && r <= 9;
+        const float ones = r == 4 ? 1.0f : 0.0f;
+        const float *db = L.dHs + 4 * gq * kLh + 16 * wv + r;
+        const float *ha = L.Hs + 4 * gq * kLh + 16 * wv + r;
+        const float *ob = L.douts + 4 * gq * kMaxOut + r;
+        // three-stage pipeline: the LDS reads of step kk + 2, the decode of step kk + 1 (VALU) and the MFMAs of step kk
+        // share a scheduling region, VALU and LDS instructions placed in the shadows of the MFMAs
+        struct Raw { uintx4 mk; float sa, sb, bdh, ah, bo; };
+        auto load = [&](int k) {
+            const int s1 = (k & 3) + 16 * (k >> 2);
+            Raw w;
+            w.mk = *reinterpret_cast<const uintx4 *>(pr + s1 * kPackedDwords);
+            w.sa = __uint_as_float(pr[s1 * kPackedDwords + ia]);
+            w.sb = __uint_as_float(pr[s1 * kPackedDwords + ib]);
+            w.bdh = db[s1 * kLh];
+            w.ah = ha[s1 * kLh];
+            w.bo = ob[s1 * kMaxOut];
+            return w;
+        };
+        auto decode = [&](const Raw &w, float (&ax)[6]) {
+            ax[0] = sc0 ? w.sa : (float)((w.mk[0] >> r) & 1u);
+            ax[1] = (float)((w.mk[0] >> (16 + r)) & 1u);
+            ax[2] = (float)((w.mk[1] >> r) & 1u);
+            ax[3] = (float)((w.mk[1] >> (16 + r)) & 1u);
+            ax[4] = (float)((w.mk[2] >> r) & 1u);
+            ax[5] = sc5 ? w.sb : (float)((w.mk[2] >> (16 + r)) & 1u);
+        };
+        Raw cur = load(0), nxt = load(1);
+        float ax[6];
+        decode(cur, ax);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            Raw nn = nxt;
+            if (kk + 2 < 16) nn = load(kk + 2);
+            float axn[6];
+            decode(nxt, axn);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) A.acc1[u] = mfma16(ax[u], cur.bdh, A.acc1[u]);
+            A.acc1[6] = mfma16(ones, cur.bdh, A.acc1[6]);
+            A.acc2 = mfma16(cur.ah, cur.bo, A.acc2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+            nxt = nn;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) ax[u] = axn[u];
+        }
+    }
+    if (more) __syncthreads();                        // the next tile overwrites Ps / Hs / dHs / douts
+}
+
+template <int NMAX>
+__global__ void __launch_bounds__(256) k_dqn_grad_packed(Grad2Args ga)
+{
+    const GradArgs &g = ga.g;
+    extern __shared__ __align__(16) float lds[];
+    GradLdsP L;
+    L.W1l = lds;                            // [64][108] local fc1 (+ b1 in column 100)
+    L.W1t = L.W1l + kTileF;                 // target fc1
+    L.Hs = L.W1t + kTileF;                  // [64][68] relu(fc1(s))
+    L.dHs = L.Hs + kTile * kLh;             // [64][68] dL/dH
+    L.douts = L.dHs + kTile * kLh;          // [64][16] dL/d(layer-2 output)
+    L.W2l = L.douts + kTile * kMaxOut;      // [16][64]
+    L.W2t = L.W2l + kMaxOut * kHid;
+    L.b2l = L.W2t + kMaxOut * kHid;         // [16]
+    L.b2t = L.b2l + kMaxOut;
+    L.red = L.b2t + kMaxOut;                // [4][18] per-wave column sums
+    L.Ps = reinterpret_cast<uint32_t *>(L.red + 4 * (kMaxOut + 2));          // 16-byte aligned (25 704 floats in)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    GradAcc<NMAX> A;
+    A.acc2 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 7; ++u) A.acc1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = 0.0f;
+    L_STAMP(0);
+    const int step = (int)gridDim.x;
+    int tile = (int)blockIdx.x;
+    grad_tile_packed<NMAX, true>(g, L, tile, tile + step < ga.n_tiles, A);
+    for (tile += step; tile < ga.n_tiles; tile += step)
+        grad_tile_packed<NMAX, false>(g, L, tile, tile + step < ga.n_tiles, A);
+    L_STAMP(5);
+    grad_write_partials<NMAX>(g, ga.stride, L.red, A);
+}
+
+constexpr size_t kGradPLds = (size_t)(2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut +
+                                      4 * (kMaxOut + 2) + kTile * kPackedDwords + 4) * 4;
+static_assert((2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2)) % 4 == 0,
+              "packed-row staging must start 16-byte aligned");
+
 template <typename ObsT, int NMAX>
 __global__ void __launch_bounds__(256) k_dqn_grad(Grad2Args ga)
 {
@@ -557,30 +914,7 @@ __global__ void __launch_bounds__(256) k_dqn_grad(Grad2Args ga)
     for (tile += step; tile < ga.n_tiles; tile += step)
         grad_tile<ObsT, NMAX, false>(g, L, tile, tile + step < ga.n_tiles, A);
     L_STAMP(5);
-    // ---- the partial-gradient row of this workgroup
-    float *out = g.partials + (size_t)blockIdx.x * ga.stride;
-    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
-    {
-        const int j = 16 * wv + r;
-#pragma unroll
-        for (int u = 0; u < 6; ++u)
-            *reinterpret_cast<floatx4 *>(out + j * kW + 16 * u + 4 * gq) = A.acc1[u];
-        if (gq == 0) *reinterpret_cast<floatx4 *>(out + j * kW + 96) = A.acc1[6];
-        else if (gq == 1) out[kHid * kW + j] = A.acc1[6][0];            // column 100 = X's ones column -> db1[j]
-        if (r < n2) *reinterpret_cast<floatx4 *>(out + oW2 + r * kHid + 16 * wv + 4 * gq) = A.acc2;
-    }
-    // column sums: every lane of a wave holds the wave's sums; add the four waves through LDS
-    if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < NMAX + 2; ++a) L.red[wv * (kMaxOut + 2) + a] = A.csum[a];
-    }
-    __syncthreads();
-    if (tid < NMAX + 2) {
-        const float s = (L.red[tid] + L.red[(kMaxOut + 2) + tid]) + (L.red[2 * (kMaxOut + 2) + tid] + L.red[3 * (kMaxOut + 2) + tid]);
-        if (tid < n2) out[ob2 + tid] = s;
-        else if (tid == NMAX) out[g.P] = s;
-        else if (tid == NMAX + 1) out[g.P + 1] = s;
-    }
+    grad_write_partials<NMAX>(g, ga.stride, L.red, A);
 }
 
 constexpr int kMaxGradGrid = 256;           // one workgroup per CU (140 KB of LDS each)
@@ -730,13 +1064,7 @@ __global__ void __launch_bounds__(256) k_dqn_act(ActArgs g)
             const int row = c / 25, q = c - row * 25;
             int i = first + row;
             i = i < g.n ? i : g.n - 1;                                 // ragged last tile: clamp (results discarded)
-            const ObsT *src = obs + (size_t)i * kW + 4 * q;
-            if (sizeof(ObsT) == 4) {
-                vX[it] = *reinterpret_cast<const floatx4 *>(src);
-            } else {
-                const uint2 raw = *reinterpret_cast<const uint2 *>(src);
-                vX[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};
-            }
+            vX[it] = x_load<ObsT>(obs, (uint32_t)i, q);
         }
     }
     w_issue(vW, g.local);
@@ -786,7 +1114,69 @@ __global__ void __launch_bounds__(256) k_dqn_act(ActArgs g)
     }
 }
 
+// Packed observations: no observation tile -- every lane loads the packed row of its env and generates the MFMA operand
+// from it (fwd_strip_packed); LDS holds the weights only.
+template <int NMAX>
+__global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
+{
+    extern __shared__ __align__(16) float lds[];
+    float *W1 = lds;                        // [64][108] fc1 (+ b1 in column 100)
+    float *W2 = W1 + kTileF;                // [16][64]
+    float *b2 = W2 + kMaxOut * kHid;        // [16]
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    const NetDev nl = net_view(g.local, n2);
+    const int i = (int)blockIdx.x * kTile + wv * 16 + r;
+    floatx4 vW[kStageIters];
+    w_issue(vW, g.local);
+    const float pb1 = nl.b1[tid < kHid ? tid : kHid - 1];
+    float pw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pw[k] = nl.W2[tid + 256 * k < n2 * kHid ? tid + 256 * k : 0];
+    const float pb2 = nl.b2[tid < n2 ? tid : 0];
+    PRow R;
+    prow_load(R, reinterpret_cast<const uint32_t *>(g.obs) + (size_t)(i < g.n ? i : g.n - 1) * kPackedDwords);
+    // the epsilon-greedy draw of this lane's env: a serial chain, computed under the loads' round trip
+    const uint4 rn = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
+                                   make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
+    w_commit(W1, vW, pb1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (tid + 256 * k < n2 * kHid) W2[tid + 256 * k] = pw[k];
+    if (tid < n2) b2[tid] = pb2;
+    __syncthreads();
+    floatx4 h[4];
+    fwd_strip_packed(W1, R, h);
+    float q[NMAX];
+    {
+        W2Frag<NMAX> F;
+        w2_load<NMAX>(F, W2, b2, n2);
+        q_strip<NMAX>(h, F, n2, g.n_actions, g.dueling, q);
+    }
+    if (lane < 16 && i < g.n) {
+        if (g.q_out) {
+#pragma unroll
+            for (int a = 0; a < NMAX; ++a)
+                if (a < g.n_actions) g.q_out[(size_t)i * g.n_actions + a] = q[a];
+        }
+        const float sample = (float)(rn.x >> 8) * (1.0f / 16777216.0f);
+        int a;
+        if (sample > g.eps) {
+            a = 0;
+            float bq = q[0];
+#pragma unroll
+            for (int k = 1; k < NMAX; ++k)
+                if (k < g.n_actions && q[k] > bq) { bq = q[k]; a = k; }
+        } else {
+            a = (int)(((uint64_t)rn.y * (uint64_t)g.n_actions) >> 32);
+        }
+        if (g.index_out) g.index_out[i] = a;
+        if (g.steer_out) g.steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(g.n_actions - 1));
+    }
+}
+
 constexpr size_t kAct2Lds = (size_t)(2 * kTileF + kMaxOut * kHid + kMaxOut) * 4;
+constexpr size_t kActPLds = (size_t)(kTileF + kMaxOut * kHid + kMaxOut) * 4;
 
 unsigned long long *g_learner_dbg = nullptr;
 
@@ -794,6 +1184,13 @@ bool net_ok(const UavDqnNet *n)
 {
     return n && n->local && n->w == kW && n->hid == kHid && n->n_actions >= 2 &&
            n->n_actions + (n->dueling ? 1 : 0) + 2 <= kMaxOut;     // + 2 spare dout columns (loss sum, valid count)
+}
+
+template <int NMAX>
+static int launch_act_packed(const ActArgs &g, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_dqn_act_packed<NMAX>), dim3(grid), dim3(256), kActPLds, s, g);      // 32 KB: no attribute needed
+    return UAVENV_OK;
 }
 
 template <typename ObsT, int NMAX>
@@ -807,6 +1204,20 @@ static int launch_act(const ActArgs &g, int grid, hipStream_t s)
         attr = true;
     }
     hipLaunchKernelGGL((k_dqn_act<ObsT, NMAX>), dim3(grid), dim3(256), kAct2Lds, s, g);
+    return UAVENV_OK;
+}
+
+template <int NMAX>
+static int launch_grad_packed(const Grad2Args &ga, int grid, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed<NMAX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradPLds) != hipSuccess)
+            return UAVENV_EHIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_dqn_grad_packed<NMAX>), dim3(grid), dim3(256), kGradPLds, s, ga);
     return UAVENV_OK;
 }
 
@@ -872,7 +1283,7 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
     g.head = head; g.filled = filled; g.batch = batch;
     g.seed = seed; g.counter = counter;
     g.explicit_idx = explicit_idx;
-    g.perm = replay_perm(seed, counter, explicit_idx ? 1u : (uint32_t)filled * (uint32_t)ring->n_agents);
+    g.perm = replay_perm(seed, counter, explicit_idx ? 1u : (uint32_t)filled * (uint32_t)ring->n_agents, (uint32_t)ring->n_agents);
     g.local = net->local; g.target = net->target;
     g.n_actions = net->n_actions; g.dueling = net->dueling; g.kind = kind;
     g.gamma = gamma; g.huber = huber;
@@ -887,6 +1298,8 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
     int rc;
     if (ring->obs_dtype == UAVENV_OBS_F32)
         rc = small ? launch_grad<float, 4>(ga, grid, s) : launch_grad<float, kMaxOut - 2>(ga, grid, s);
+    else if (ring->obs_dtype == UAVENV_OBS_PACKED)
+        rc = small ? launch_grad_packed<4>(ga, grid, s) : launch_grad_packed<kMaxOut - 2>(ga, grid, s);
     else
         rc = small ? launch_grad<__half, 4>(ga, grid, s) : launch_grad<__half, kMaxOut - 2>(ga, grid, s);
     if (rc != UAVENV_OK) return rc;
@@ -943,6 +1356,8 @@ int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype,
     const bool small = net->n_actions + (net->dueling ? 1 : 0) <= 4;
     int rc;
     if (obs_dtype == UAVENV_OBS_F32) rc = small ? launch_act<float, 4>(g, grid, s) : launch_act<float, kMaxOut - 2>(g, grid, s);
+    else if (obs_dtype == UAVENV_OBS_PACKED)
+        rc = small ? launch_act_packed<4>(g, grid, s) : launch_act_packed<kMaxOut - 2>(g, grid, s);
     else rc = small ? launch_act<__half, 4>(g, grid, s) : launch_act<__half, kMaxOut - 2>(g, grid, s);
     if (rc != UAVENV_OK) return rc;
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;

@@ -44,7 +44,8 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
     l->filled = cfg->filled;
     l->epoch = cfg->epoch;
     l->counter = cfg->counter;
-    l->obs_row_bytes = (size_t)cfg->ring.n_agents * UAVENV_OBS_DIM * (cfg->ring.obs_dtype == UAVENV_OBS_F16 ? 2 : 4);
+    l->obs_row_bytes = (size_t)cfg->ring.n_agents * (cfg->ring.obs_dtype == UAVENV_OBS_PACKED ? UAVENV_OBS_PACKED_DWORDS * 4
+                                                     : UAVENV_OBS_DIM * (cfg->ring.obs_dtype == UAVENV_OBS_F16 ? 2 : 4));
     *out = l;
     return UAVENV_OK;
 }

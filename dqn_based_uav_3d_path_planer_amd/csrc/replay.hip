@@ -6,6 +6,7 @@
 // ReplayMemory on the learner side is sample2 (replay_buffer.py:48-51): uniform draws + a gather of
 // 2 x 400 B rows per sample, done here as one launch (HBM-bound: 813 B per sample).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #include "../../include/uavenv.h"
@@ -19,13 +20,13 @@ namespace {
 
 // One 16-byte chunk per thread: chunk q of sample s, q in [0, 2*CH) = obs row then next_obs row.
 // CH = 25 (f32 rows, 400 B) or 13 (f16 rows, 200 B = 12.5 chunks -> handled as 8-byte units, CH8 = 25).
-template <int UNIT /*bytes per copy unit*/>
+template <int UNIT /*bytes per copy unit*/, int ROW_UNITS = 25>
 __global__ void k_sample_gather(UavReplayRing ring, int head, int batch, ReplayPerm perm,
                                 unsigned char *__restrict__ obs_b, unsigned char *__restrict__ next_b,
                                 unsigned char *__restrict__ act_b, float *__restrict__ rew_b,
                                 float *__restrict__ done_b, float *__restrict__ valid_b)
 {
-    constexpr int ROW_UNITS = 25;                        // 25 x 16 B (f32) or 25 x 8 B (f16)
+    // ROW_UNITS x UNIT bytes per row: 25 x 16 B (f32), 25 x 8 B (f16), 5 x 16 B (packed)
     const int row_bytes = ROW_UNITS * UNIT;
     const int64_t total = (int64_t)batch * (2 * ROW_UNITS);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -33,7 +34,7 @@ __global__ void k_sample_gather(UavReplayRing ring, int head, int batch, ReplayP
         const int q = (int)(t - (int64_t)s * (2 * ROW_UNITS));
         // every thread of a sample re-derives the same draw (SIMD lanes: no extra instructions per wavefront)
         int f, agent;
-        replay_slot_to_frame(replay_perm_apply(perm, (uint32_t)s), head, ring.frames, ring.n_agents, f, agent);
+        replay_slot_to_frame(perm, replay_perm_apply(perm, (uint32_t)s), head, ring.frames, f, agent);
         int fn = f + 1;
         if (fn >= ring.frames) fn = 0;
         const bool is_next = q >= ROW_UNITS;
@@ -53,12 +54,36 @@ __global__ void k_sample_gather(UavReplayRing ring, int head, int batch, ReplayP
     }
 }
 
+// packed rows -> f32 / f16 rows: one thread per group of four columns (coalesced 16 / 8 byte stores)
+template <bool F16>
+__global__ void k_obs_unpack(const uint32_t *__restrict__ packed, int64_t n, void *__restrict__ out)
+{
+    const int64_t total = n * 25;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / 25;
+        const int q = (int)(t - row * 25);
+        const uint32_t *p = packed + row * kPackedDwords;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = packed_col(p, 4 * q + k);
+        if (!F16) {
+            reinterpret_cast<float4 *>(out)[t] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            __half2 lo = __floats2half2_rn(v[0], v[1]), hi = __floats2half2_rn(v[2], v[3]);
+            uint2 o;
+            o.x = *reinterpret_cast<uint32_t *>(&lo);
+            o.y = *reinterpret_cast<uint32_t *>(&hi);
+            reinterpret_cast<uint2 *>(out)[t] = o;
+        }
+    }
+}
+
 // the draws alone: (frame, agent) of samples 0 .. batch-1 (tests, prioritised replay bookkeeping)
 __global__ void k_replay_draw(int frames, int n_agents, int head, int batch, ReplayPerm perm, int32_t *__restrict__ out)
 {
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < batch; s += gridDim.x * blockDim.x) {
         int f, agent;
-        replay_slot_to_frame(replay_perm_apply(perm, (uint32_t)s), head, frames, n_agents, f, agent);
+        replay_slot_to_frame(perm, replay_perm_apply(perm, (uint32_t)s), head, frames, f, agent);
         out[2 * s] = f;
         out[2 * s + 1] = agent;
     }
@@ -103,20 +128,39 @@ int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled
     if (ring->frames < 2 || ring->n_agents <= 0 || batch <= 0 || filled <= 0 || filled > ring->frames - 1 ||
         head < 0 || head >= ring->frames || (uint64_t)filled * (uint64_t)ring->n_agents >= (1ull << 32))
         return UAVENV_EINVAL;
-    const int64_t total = (int64_t)batch * 50;
+    const int64_t total = (int64_t)batch * (ring->obs_dtype == UAVENV_OBS_PACKED ? 10 : 50);
     const int block = 256;
     int64_t g = (total + block - 1) / block;
     const int grid = (int)(g > 4096 ? 4096 : g);
     hipStream_t s = (hipStream_t)stream;
-    const ReplayPerm perm = replay_perm(seed, counter, (uint32_t)filled * (uint32_t)ring->n_agents);
+    const ReplayPerm perm = replay_perm(seed, counter, (uint32_t)filled * (uint32_t)ring->n_agents, (uint32_t)ring->n_agents);
     if (ring->obs_dtype == UAVENV_OBS_F32)
         hipLaunchKernelGGL((k_sample_gather<16>), dim3(grid), dim3(block), 0, s, *ring, head, batch, perm,
+                           (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
+                           done_b, valid_b);
+    else if (ring->obs_dtype == UAVENV_OBS_PACKED)
+        hipLaunchKernelGGL((k_sample_gather<16, 5>), dim3(grid), dim3(block), 0, s, *ring, head, batch, perm,
                            (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
                            done_b, valid_b);
     else
         hipLaunchKernelGGL((k_sample_gather<8>), dim3(grid), dim3(block), 0, s, *ring, head, batch, perm,
                            (unsigned char *)obs_b, (unsigned char *)next_obs_b, (unsigned char *)action_b, reward_b,
                            done_b, valid_b);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_obs_unpack(const void *packed_dev, int64_t n, void *out_dev, int32_t out_dtype, void *stream)
+{
+    if (!packed_dev || !out_dev || n <= 0 || (out_dtype != UAVENV_OBS_F32 && out_dtype != UAVENV_OBS_F16)) return UAVENV_EINVAL;
+    const int block = 256;
+    int64_t g = (n * 25 + block - 1) / block;
+    const int grid = (int)(g > 8192 ? 8192 : g);
+    if (out_dtype == UAVENV_OBS_F32)
+        hipLaunchKernelGGL((k_obs_unpack<false>), dim3(grid), dim3(block), 0, (hipStream_t)stream,
+                           (const uint32_t *)packed_dev, n, out_dev);
+    else
+        hipLaunchKernelGGL((k_obs_unpack<true>), dim3(grid), dim3(block), 0, (hipStream_t)stream,
+                           (const uint32_t *)packed_dev, n, out_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 
@@ -130,7 +174,7 @@ int uavenv_replay_draw(int32_t frames, int32_t n_agents, int32_t head, int32_t f
     int grid = (batch + block - 1) / block;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_replay_draw, dim3(grid), dim3(block), 0, (hipStream_t)stream, frames, n_agents, head, batch,
-                       replay_perm(seed, counter, (uint32_t)filled * (uint32_t)n_agents), frame_agent_out);
+                       replay_perm(seed, counter, (uint32_t)filled * (uint32_t)n_agents, (uint32_t)n_agents), frame_agent_out);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

@@ -21,7 +21,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/uavenv.h"
@@ -608,7 +611,7 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
 #ifndef UAVENV_KSTEP_WAVES
 #define UAVENV_KSTEP_WAVES 1      // min waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
-template <typename MaskT, bool APF, bool F16>
+template <typename MaskT, bool APF, int OBS>
 __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -689,7 +692,7 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
             if (a.energy64) a.energy64[i] = energy;
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);
-            if (want_obs && a.tile_off < 0) store_obs_row<F16>(a.obs, i, sc, bits);
+            if (want_obs && a.tile_off < 0) store_obs_row<OBS>(a.obs, i, sc, bits);
             UAV_STAMP(6);
             UAV_DRAIN();
             UAV_STAMP(7);
@@ -697,7 +700,7 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         if (a.tile_off >= 0 && want_obs) {      // wave-cooperative coalesced tile store (opt-in)
             const int first = i - ((int)threadIdx.x & 63);
             uint32_t *tile = reinterpret_cast<uint32_t *>(smem + a.tile_off + (threadIdx.x >> 6) * a.wave_slot);
-            store_obs_ctile<F16>(a.obs, first, N - first, tile, sc, bits);
+            store_obs_ctile<OBS>(a.obs, first, N - first, tile, sc, bits);
         }
     }
 }
@@ -729,7 +732,7 @@ struct CoopLds {
     uint32_t tile[64 * kCTileLd];
 };
 
-template <typename MaskT, bool APF, bool F16>
+template <typename MaskT, bool APF, int OBS>
 __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -911,7 +914,17 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     UAV_STAMP(5);
     __syncthreads();                                                         // tile complete
     UAV_STAMP(6);
-    if (want_obs) {
+    if (want_obs && OBS == OBS_KIND_PACKED) {
+        // packed rows: the 64 x 80 B image of the tile is 320 16-byte chunks, 5 KiB contiguous: two store instructions
+        const int nv = N - first < 64 ? N - first : 64;
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(a.obs) + (int64_t)first * kPackedDwords);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int chunk = it * 256 + (int)threadIdx.x;
+            if (chunk < 5 * nv) dst[chunk] = ctile_packed_chunk(C->tile, chunk);
+        }
+    } else if (want_obs) {
+        constexpr bool F16 = OBS == OBS_KIND_F16;
         // 25 coalesced store instructions: 7 for wave 0, 6 each for waves 1..3 (fixed trip counts: unrolled, so the
         // LDS reads of one instruction overlap the selects of the previous)
         const int nv = N - first;
@@ -930,7 +943,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
 }
 
 // state_PathPlan only
-template <typename MaskT, bool F16>
+template <typename MaskT, int OBS>
 __global__ void __launch_bounds__(256) k_observe(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -941,7 +954,7 @@ __global__ void __launch_bounds__(256) k_observe(StepArgs a)
         unpack_flags(g);
         const ObsBits bits = obs_bits(w, g.o.px, g.o.py, g.o.pz);      // lane-per-agent form (reference for the queue)
         const ObsScalars sc = obs_scalars(g.o, g.head);
-        store_obs_row<F16>(a.obs, i, sc, bits);
+        store_obs_row<OBS>(a.obs, i, sc, bits);
     }
 }
 
@@ -1099,6 +1112,27 @@ static int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+// Launch with `lds` bytes of dynamic LDS.  Above the 64 KB default a kernel needs its
+// hipFuncAttributeMaxDynamicSharedMemorySize raised first (a fine broad-phase grid makes the world blob that large);
+// the attribute is raised whenever a launch asks for more than any earlier launch of the same kernel on this device.
+template <typename K>
+static void launch_lds(K kernel, int grid, int block, size_t lds, hipStream_t s, const StepArgs &a)
+{
+    if (lds > 65536) {
+        static std::mutex mu;
+        static std::map<std::pair<const void *, int>, size_t> raised;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        size_t &cur = raised[std::make_pair(reinterpret_cast<const void *>(kernel), dev)];
+        if (lds > cur) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            cur = lds;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, a);
+}
+
 static void launch_geometry(int n, int &block, int &grid)
 {
     static const int thr = env_int("UAVENV_BLOCK64_MAX", 131072);
@@ -1115,7 +1149,8 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     launch_geometry(e->N, block, grid);
     StepArgs a = a_in;
     a.block = block;
-    const bool f16 = e->cfg.obs_dtype == UAVENV_OBS_F16, apf = e->cfg.apf_enabled == 1;
+    const int obs = e->cfg.obs_dtype;
+    const bool apf = e->cfg.apf_enabled == 1;
     static const int tile_env = env_int("UAVENV_TILE_STORE", -1);
     const bool tile_store = tile_env >= 0 ? tile_env != 0 : e->N > 32768;
     const int nw = block / 64;
@@ -1131,27 +1166,28 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     // 32 768: 14.6 -> 10.1; 49 152: 16.1 -> 12.3; 65 536: 16.6 -> 19.5 (k_step kept from there on).
     static const int coop_env = env_int("UAVENV_COOP", -1);
     const bool coop = !(a.flags & UAVENV_STEP_ONE_WAVE) && (coop_env >= 0 ? coop_env != 0 : e->N <= 49152);
+#define UAV_LAUNCH(KERNEL, GRID, BLOCK, LDS)                                                                        \
+    do {                                                                                                            \
+        if (apf) {                                                                                                  \
+            if (obs == UAVENV_OBS_F16) launch_lds((KERNEL<MaskT, true, OBS_KIND_F16>), GRID, BLOCK, LDS, s, a);     \
+            else if (obs == UAVENV_OBS_PACKED) launch_lds((KERNEL<MaskT, true, OBS_KIND_PACKED>), GRID, BLOCK, LDS, s, a); \
+            else launch_lds((KERNEL<MaskT, true, OBS_KIND_F32>), GRID, BLOCK, LDS, s, a);                           \
+        } else {                                                                                                    \
+            if (obs == UAVENV_OBS_F16) launch_lds((KERNEL<MaskT, false, OBS_KIND_F16>), GRID, BLOCK, LDS, s, a);    \
+            else if (obs == UAVENV_OBS_PACKED) launch_lds((KERNEL<MaskT, false, OBS_KIND_PACKED>), GRID, BLOCK, LDS, s, a); \
+            else launch_lds((KERNEL<MaskT, false, OBS_KIND_F32>), GRID, BLOCK, LDS, s, a);                          \
+        }                                                                                                           \
+    } while (0)
     if (coop) {
         a.block = 256;
         a.obsq_off = (e->world_bytes + 15) & ~15;
         const size_t clds = (size_t)a.obsq_off + sizeof(CoopLds);
         const int cgrid = (e->N + 63) / 64;
-        if (apf) {
-            if (f16) hipLaunchKernelGGL((k_step_coop<MaskT, true, true>), dim3(cgrid), dim3(256), clds, s, a);
-            else hipLaunchKernelGGL((k_step_coop<MaskT, true, false>), dim3(cgrid), dim3(256), clds, s, a);
-        } else {
-            if (f16) hipLaunchKernelGGL((k_step_coop<MaskT, false, true>), dim3(cgrid), dim3(256), clds, s, a);
-            else hipLaunchKernelGGL((k_step_coop<MaskT, false, false>), dim3(cgrid), dim3(256), clds, s, a);
-        }
+        UAV_LAUNCH(k_step_coop, cgrid, 256, clds);
         return;
     }
-    if (apf) {
-        if (f16) hipLaunchKernelGGL((k_step<MaskT, true, true>), dim3(grid), dim3(block), lds, s, a);
-        else hipLaunchKernelGGL((k_step<MaskT, true, false>), dim3(grid), dim3(block), lds, s, a);
-    } else {
-        if (f16) hipLaunchKernelGGL((k_step<MaskT, false, true>), dim3(grid), dim3(block), lds, s, a);
-        else hipLaunchKernelGGL((k_step<MaskT, false, false>), dim3(grid), dim3(block), lds, s, a);
-    }
+    UAV_LAUNCH(k_step, grid, block, lds);
+#undef UAV_LAUNCH
 }
 
 extern "C" {
@@ -1168,7 +1204,7 @@ int uavenv_create(const UavEnvConfig *cfg, UavEnv **out)
         return fail(UAVENV_EINVAL, "n_envs/max_subgoals/max_step out of range");
     if (!is_pow2(cfg->uav_per_env) || cfg->uav_per_env > 64)
         return fail(UAVENV_EINVAL, "uav_per_env must be a power of two <= 64 (got %d)", cfg->uav_per_env);
-    if (cfg->obs_dtype != UAVENV_OBS_F32 && cfg->obs_dtype != UAVENV_OBS_F16)
+    if (cfg->obs_dtype != UAVENV_OBS_F32 && cfg->obs_dtype != UAVENV_OBS_F16 && cfg->obs_dtype != UAVENV_OBS_PACKED)
         return fail(UAVENV_EINVAL, "obs_dtype");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1550,15 +1586,17 @@ int uavenv_observe(UavEnv *e, void *obs, void *stream)
     launch_geometry(e->N, block, grid);
     a.block = block;
     const size_t lds = (size_t)e->world_bytes;
-    const bool f16 = e->cfg.obs_dtype == UAVENV_OBS_F16;
+    const int obs_kind = e->cfg.obs_dtype;
     hipStream_t s = (hipStream_t)stream;
-    if (e->mask_bytes == 4) {
-        if (f16) hipLaunchKernelGGL((k_observe<uint32_t, true>), dim3(grid), dim3(block), lds, s, a);
-        else hipLaunchKernelGGL((k_observe<uint32_t, false>), dim3(grid), dim3(block), lds, s, a);
-    } else {
-        if (f16) hipLaunchKernelGGL((k_observe<uint64_t, true>), dim3(grid), dim3(block), lds, s, a);
-        else hipLaunchKernelGGL((k_observe<uint64_t, false>), dim3(grid), dim3(block), lds, s, a);
-    }
+#define UAV_OBSERVE(MASK)                                                                                        \
+    do {                                                                                                         \
+        if (obs_kind == UAVENV_OBS_F16) launch_lds((k_observe<MASK, OBS_KIND_F16>), grid, block, lds, s, a);     \
+        else if (obs_kind == UAVENV_OBS_PACKED) launch_lds((k_observe<MASK, OBS_KIND_PACKED>), grid, block, lds, s, a); \
+        else launch_lds((k_observe<MASK, OBS_KIND_F32>), grid, block, lds, s, a);                                \
+    } while (0)
+    if (e->mask_bytes == 4) UAV_OBSERVE(uint32_t);
+    else UAV_OBSERVE(uint64_t);
+#undef UAV_OBSERVE
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }

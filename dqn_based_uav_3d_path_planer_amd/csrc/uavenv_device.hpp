@@ -620,11 +620,51 @@ __device__ __forceinline__ float obs_col(const ObsScalars &s, const ObsBits &b, 
     return 0.0f;
 }
 
-// Row-per-lane store of one observation: 25 x 16-byte stores (f32) or 25 x 8-byte (f16).
-template <bool F16>
+// ---- packed observation rows (UAVENV_OBS_PACKED) -------------------------------------------------------------------
+// 75 + 5 of the 100 columns of state_PathPlan are 0/1 occupancy flags and 5 are constant zeros (UAV.py:533-566,517):
+// a row is fully described by 15 scalars and 80 bits.  The packed row keeps exactly that, losslessly, in 20 dwords
+// (80 B instead of 400 B):
+//   dword 0..2   mask words: bit (c & 31) of word (c >> 5) = column c, for the flag columns 11..85 and 90..94
+//   dword 3      0
+//   dword 4..14  columns 0..10 as f32
+//   dword 15..18 columns 86..89 as f32
+//   dword 19     0
+// Rows are 16-byte aligned (5 chunks); a wavefront's 64 rows are 5 contiguous KiB.
+constexpr int kPackedDwords = 20;
+constexpr int OBS_KIND_F32 = 0, OBS_KIND_F16 = 1, OBS_KIND_PACKED = 2;
+
+__device__ __forceinline__ void ctile_mask_words(const ObsBits &b, uint32_t &m0, uint32_t &m1, uint32_t &m2);
+
+// Column c (0..99) of the row a packed row stands for; p = its 20 dwords (any address space).
+__host__ __device__ __forceinline__ float packed_col(const uint32_t *p, int c)
+{
+    if (c < 11) return __builtin_bit_cast(float, p[4 + c]);
+    if (c >= 86 && c < 90) return __builtin_bit_cast(float, p[15 + (c - 86)]);
+    if (c >= 95) return 0.0f;
+    return (float)((p[c >> 5] >> (c & 31)) & 1u);
+}
+
+// Row-per-lane store of one packed observation: 5 x 16-byte stores.
+__device__ __forceinline__ void store_obs_row_packed(void *obs_base, int64_t agent, const ObsScalars &s, const ObsBits &b)
+{
+    uint4 *row = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(obs_base) + agent * kPackedDwords);
+    uint32_t m0, m1, m2;
+    ctile_mask_words(b, m0, m1, m2);
+    row[0] = make_uint4(m0, m1, m2, 0u);
+    row[1] = make_uint4(__float_as_uint(s.f[0]), __float_as_uint(s.f[1]), __float_as_uint(s.f[2]), __float_as_uint(s.f[3]));
+    row[2] = make_uint4(__float_as_uint(s.f[4]), __float_as_uint(s.f[5]), __float_as_uint(s.f[6]), __float_as_uint(s.f[7]));
+    row[3] = make_uint4(__float_as_uint(s.f[8]), __float_as_uint(s.f[9]), __float_as_uint(s.f[10]), __float_as_uint(s.f[11]));
+    row[4] = make_uint4(__float_as_uint(s.f[12]), __float_as_uint(s.f[13]), __float_as_uint(s.f[14]), 0u);
+}
+
+// Row-per-lane store of one observation: 25 x 16-byte stores (f32), 25 x 8-byte (f16) or 5 x 16-byte (packed).
+template <int OBS>
 __device__ __forceinline__ void store_obs_row(void *obs_base, int64_t agent, const ObsScalars &s, const ObsBits &b)
 {
-    if (!F16) {
+    constexpr bool F16 = OBS == OBS_KIND_F16;
+    if (OBS == OBS_KIND_PACKED) {
+        store_obs_row_packed(obs_base, agent, s, b);
+    } else if (!F16) {
         float4 *row = reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs_base) + agent * 100);
 #pragma unroll
         for (int k = 0; k < 25; ++k) {
@@ -767,17 +807,50 @@ __device__ __forceinline__ void ctile_emit_lut(void *obs_base, int64_t first_age
     }
 }
 
-template <bool F16>
+// 16-byte chunk `chunk` (0 .. 5 * rows - 1) of the packed image of compact-tile rows: row = chunk / 5, part = chunk % 5.
+// The tile's scalar slots are column-indexed (slot c for columns 0..10, slot c - 72 for 86..89).
+__device__ __forceinline__ uint4 ctile_packed_chunk(const uint32_t *tile, int chunk)
+{
+    const int r = chunk / 5, part = chunk - r * 5;
+    const uint32_t *src = tile + r * kCTileLd;
+    // part 0: masks | part 1: cols 0..3 | part 2: cols 4..7 | part 3: cols 8, 9, 10, 86 | part 4: cols 87, 88, 89, 0
+    const int b0 = part == 0 ? 0 : part == 1 ? 3 : part == 2 ? 7 : part == 3 ? 11 : 18;
+    const int b3 = part == 3 ? 17 : b0 + 3;
+    uint4 v;
+    v.x = src[b0];
+    v.y = src[b0 + 1];
+    v.z = src[b0 + 2];
+    v.w = (part == 0 || part == 4) ? 0u : src[b3];
+    return v;
+}
+
+// a wavefront's 64 packed rows from its compact tile: 5 fully coalesced 1 KiB stores
+__device__ __forceinline__ void ctile_emit_packed_wave(void *obs_base, int64_t first_agent, int n_valid, const uint32_t *tile)
+{
+    const int lane = (int)threadIdx.x & 63;
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(obs_base) + first_agent * kPackedDwords);
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int chunk = it * 64 + lane;
+        const uint4 v = ctile_packed_chunk(tile, chunk);
+        if (chunk < 5 * n_valid) dst[chunk] = v;
+    }
+}
+
+template <int OBS>
 __device__ __forceinline__ void store_obs_ctile(void *obs_base, int64_t first_agent, int n_valid, uint32_t *tile,
                                                 const ObsScalars &s, const ObsBits &b)
 {
+    constexpr bool F16 = OBS == OBS_KIND_F16;
     const int lane = (int)threadIdx.x & 63;
     uint32_t *row = tile + lane * kCTileLd;
     ctile_mask_words(b, row[0], row[1], row[2]);
     ctile_write_scalars(row, s);
     wave_lds_sync();
     const int nv = __builtin_amdgcn_readfirstlane(n_valid);      // same in every lane; tell the compiler
-    if (nv >= 64) {             // every wavefront but the last takes the unguarded, straight-line form
+    if (OBS == OBS_KIND_PACKED) {
+        ctile_emit_packed_wave(obs_base, first_agent, nv < 64 ? nv : 64, tile);
+    } else if (nv >= 64) {             // every wavefront but the last takes the unguarded, straight-line form
 #pragma unroll
         for (int it = 0; it < 25; ++it) ctile_emit<F16>(obs_base, first_agent, n_valid, tile, it, false);
     } else {
@@ -810,16 +883,19 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 
 // ReplayMemory.sample2 = random.sample(self.memory, batch_size) (BaseClass/replay_buffer.py:48-51): `batch` DISTINCT
 // stored transitions, every subset equally likely.  On the device: sample s of update (seed, counter) is P(s), where P
-// is a keyed pseudo-random permutation of the D = filled * n_agents stored transitions -- a balanced Feistel network
-// over 2*hb >= log2(D) bits (6 rounds, murmur3-finaliser round function, round keys from Philox(seed, counter)),
-// cycle-walked back into [0, D) (the network permutes [0, 4^hb) with 4^hb < 4 D, so < 4 passes are expected).
+// is a keyed pseudo-random permutation of the D = filled * n_agents stored transitions -- an alternating (unbalanced)
+// Feistel network over bits = ceil(log2 D) bits, split la = bits / 2 low bits | lb = bits - la high bits: six rounds,
+// even rounds  lo ^= F(hi),  odd rounds  hi ^= F(lo)  (each round is its own inverse, so the whole is a bijection of
+// [0, 2^bits)), F = murmur3's 32-bit finaliser keyed per round from Philox(seed, counter); the result is cycle-walked
+// back into [0, D) (2^bits < 2 D: fewer than two passes expected, exactly one when D is a power of two).
 // Distinct s < D give distinct transitions; s >= D wraps (the reference raises there).  oracle/philox.py restates it.
 struct ReplayPerm {
     uint32_t k[6];
-    uint32_t D, hb;
+    uint32_t D, la, lb;
+    uint32_t n_agents, magic;      // slot / n_agents by multiplication: magic = floor(2^32 / n_agents)
 };
 
-__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;
@@ -827,7 +903,7 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 
 // (host-callable: the round keys are the same for every sample of an update, so the launch code derives them once and
 // passes them as kernel arguments -- two Philox chains less on every wavefront's critical path)
-__host__ __device__ __forceinline__ ReplayPerm replay_perm(uint64_t seed, uint64_t counter, uint32_t D)
+__host__ __device__ __forceinline__ ReplayPerm replay_perm(uint64_t seed, uint64_t counter, uint32_t D, uint32_t n_agents)
 {
     ReplayPerm p;
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
@@ -835,9 +911,13 @@ __host__ __device__ __forceinline__ ReplayPerm replay_perm(uint64_t seed, uint64
     const uint4 b = philox4x32_10(make_uint4(1u, (uint32_t)counter, (uint32_t)(counter >> 32), 0x5a3bu), key);
     p.k[0] = a.x; p.k[1] = a.y; p.k[2] = a.z; p.k[3] = a.w; p.k[4] = b.x; p.k[5] = b.y;
     p.D = D;
-    uint32_t bits = 1u;                                                            // ceil(log2 D), >= 1
+    uint32_t bits = 2u;                                                            // ceil(log2 D), at least 2
     while (bits < 32u && (1ull << bits) < (uint64_t)D) ++bits;
-    p.hb = (bits + 1u) >> 1;
+    p.la = bits >> 1;
+    p.lb = bits - p.la;
+    p.n_agents = n_agents ? n_agents : 1u;
+    const uint64_t mg = (1ull << 32) / p.n_agents;
+    p.magic = mg > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mg;
     return p;
 }
 
@@ -845,25 +925,27 @@ __device__ __forceinline__ uint32_t replay_perm_apply(const ReplayPerm &p, uint3
 {
     if (p.D <= 1u) return 0u;
     uint32_t x = s < p.D ? s : s % p.D;
-    const uint32_t hb = p.hb, mask = (1u << hb) - 1u;
+    const uint32_t la = p.la, lb = p.lb, ma = (1u << la) - 1u, mb = (1u << lb) - 1u;
     do {
-        uint32_t L = x >> hb, R = x & mask;
+        uint32_t lo = x & ma, hi = x >> la;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const uint32_t t = L ^ (fmix32(R ^ p.k[r]) >> (32u - hb));
-            L = R;
-            R = t;
+        for (int r = 0; r < 6; r += 2) {
+            lo ^= fmix32(hi ^ p.k[r]) >> (32u - la);
+            hi ^= fmix32(lo ^ p.k[r + 1]) >> (32u - lb);
         }
-        x = (L << hb) | R;
+        x = (hi << la) | lo;
     } while (x >= p.D);
     return x;
 }
 
 // transition slot -> (frame, agent): slot / n_agents + 1 frames behind the ring head
-__device__ __forceinline__ void replay_slot_to_frame(uint32_t slot, int head, int frames, int n_agents, int &f, int &agent)
+__device__ __forceinline__ void replay_slot_to_frame(const ReplayPerm &p, uint32_t slot, int head, int frames, int &f, int &agent)
 {
-    const uint32_t back = slot / (uint32_t)n_agents;
-    agent = (int)(slot - back * (uint32_t)n_agents);
+    uint32_t back = __umulhi(slot, p.magic);           // floor(slot * floor(2^32 / n) / 2^32): at most 1 short (slot < 2^32)
+    uint32_t rem = slot - back * p.n_agents;
+    if (rem >= p.n_agents) { rem -= p.n_agents; back += 1u; }
+    if (rem >= p.n_agents) { rem -= p.n_agents; back += 1u; }
+    agent = (int)rem;
     f = head - 1 - (int)back;
     if (f < 0) f += frames;
 }

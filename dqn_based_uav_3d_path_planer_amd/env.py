@@ -53,13 +53,18 @@ class VecPathPlanEnv:
         self.device = torch.device(device)
         self.n_envs, self.uav_per_env = int(n_envs), int(uav_per_env)
         self.K = int(max_subgoals)
-        self.obs_dtype = obs_dtype
+        # observation storage: torch.float32 / torch.float16 rows of 100, or "packed" = 20 int32 per row (15 scalars +
+        # 80 flag bits, lossless; include/uavenv.h UAVENV_OBS_PACKED) -- what the fused act / learner kernels read
+        self.packed = isinstance(obs_dtype, str) and obs_dtype == "packed"
+        self.obs_dtype = torch.int32 if self.packed else obs_dtype
+        self.obs_width = _lib.PACKED_DWORDS if self.packed else _lib.OBS_DIM
+        self.obs_code = _lib.OBS_PACKED if self.packed else (_lib.OBS_F16 if obs_dtype == torch.float16 else _lib.OBS_F32)
         cfg = _lib.UavEnvConfig()
         cfg.abi_version = _lib.ABI_VERSION
         cfg.device = self.device.index or 0
         cfg.n_envs, cfg.uav_per_env = self.n_envs, self.uav_per_env
         cfg.max_subgoals, cfg.max_step, cfg.apf_enabled = self.K, int(max_step), int(apf_enabled)
-        cfg.obs_dtype = _lib.OBS_F16 if obs_dtype == torch.float16 else _lib.OBS_F32
+        cfg.obs_dtype = self.obs_code
         cfg.n_actions = int(n_actions)
         cfg.len, cfg.width, cfg.h = float(length), float(width), float(h)
         cfg.max_v, cfg.steering_angle = float(max_v), float(steering_angle)
@@ -168,7 +173,20 @@ class VecPathPlanEnv:
 
     # ------------------------------------------------------------------ hot path
     def new_obs(self) -> torch.Tensor:
-        return torch.empty((self.N, _lib.OBS_DIM), dtype=self.obs_dtype, device=self.device)
+        return torch.empty((self.N, self.obs_width), dtype=self.obs_dtype, device=self.device)
+
+    def unpack(self, obs: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        """[..., 100] rows of `dtype` from observations as this env stores them (a no-op cast unless packed)."""
+        if not self.packed:
+            return obs.to(dtype)
+        flat = obs.contiguous().view(-1, _lib.PACKED_DWORDS)
+        out = torch.empty((flat.shape[0], _lib.OBS_DIM), dtype=dtype, device=obs.device)
+        code = _lib.OBS_F16 if dtype == torch.float16 else _lib.OBS_F32
+        if dtype not in (torch.float16, torch.float32):
+            raise TypeError("unpack to float32 or float16")
+        _lib.check(self.lib.uavenv_obs_unpack(flat.data_ptr(), flat.shape[0], out.data_ptr(), code, self._stream()),
+                   "uavenv_obs_unpack")
+        return out.view(*obs.shape[:-1], _lib.OBS_DIM)
 
     def observe(self, obs: Optional[torch.Tensor] = None) -> torch.Tensor:
         obs = self.new_obs() if obs is None else obs

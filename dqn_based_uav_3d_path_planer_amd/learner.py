@@ -257,7 +257,7 @@ class FusedDQNLearner:
             steer_out: torch.Tensor = None, q_out: torch.Tensor = None):
         """Q(s) + epsilon-greedy for all rows of obs [n,100] in one launch."""
         C, _lib = self._C, self._lib_mod
-        dt = _lib.OBS_F16 if obs.dtype == torch.float16 else _lib.OBS_F32
+        dt = _lib.OBS_PACKED if obs.dtype == torch.int32 else (_lib.OBS_F16 if obs.dtype == torch.float16 else _lib.OBS_F32)
         rc = self.lib.uavenv_dqn_act(C.byref(self.net), obs.data_ptr(), dt, obs.shape[0], float(eps), int(seed),
                                      int(counter), None if index_out is None else index_out.data_ptr(),
                                      None if steer_out is None else steer_out.data_ptr(),

@@ -23,7 +23,7 @@ class DeviceReplayRing:
         self.frames = max(3, -(-int(capacity_transitions) // n) + 1)
         d = env.device
         self.discrete = discrete
-        self.obs = torch.zeros((self.frames, n, _lib.OBS_DIM), dtype=env.obs_dtype, device=d)
+        self.obs = torch.zeros((self.frames, n, env.obs_width), dtype=env.obs_dtype, device=d)
         self.action = torch.zeros((self.frames, n), dtype=torch.int32 if discrete else torch.float32, device=d)
         self.reward = torch.zeros((self.frames, n), dtype=torch.float32, device=d)
         self.done = torch.zeros((self.frames, n), dtype=torch.uint8, device=d)
@@ -32,9 +32,8 @@ class DeviceReplayRing:
         self.filled = 0        # complete transitions frames behind head
         self._c = _lib.UavReplayRing(self.obs.data_ptr(), self.action.data_ptr(), self.reward.data_ptr(),
                                      self.done.data_ptr(), self.valid.data_ptr(), self.frames, n,
-                                     _lib.OBS_F16 if env.obs_dtype == torch.float16 else _lib.OBS_F32,
-                                     1 if discrete else 0)
-        self._obs_stride = n * _lib.OBS_DIM * self.obs.element_size()
+                                     env.obs_code, 1 if discrete else 0)
+        self._obs_stride = n * env.obs_width * self.obs.element_size()
         self._batch_bufs = {}
         self.extra_flags = 0           # diagnostics (e.g. _lib.STEP_NO_OBS to time the step without the observation)
 
@@ -77,8 +76,9 @@ class DeviceReplayRing:
         b = self._batch_bufs.get(batch)
         if b is None:
             d = self.env.device
-            b = dict(states=torch.empty((batch, _lib.OBS_DIM), dtype=self.obs.dtype, device=d),
-                     next_states=torch.empty((batch, _lib.OBS_DIM), dtype=self.obs.dtype, device=d),
+            w = self.env.obs_width
+            b = dict(states=torch.empty((batch, w), dtype=self.obs.dtype, device=d),
+                     next_states=torch.empty((batch, w), dtype=self.obs.dtype, device=d),
                      actions=torch.empty(batch, dtype=self.action.dtype, device=d),
                      rewards=torch.empty(batch, dtype=torch.float32, device=d),
                      dones=torch.empty(batch, dtype=torch.float32, device=d),
@@ -91,8 +91,10 @@ class DeviceReplayRing:
         n = self.env.N
         f = torch.div(slots, n, rounding_mode="floor")
         nxt = ((f + 1) % self.frames) * n + (slots - f * n)
-        flat = self.obs.view(-1, _lib.OBS_DIM)
-        return dict(states=flat[slots], next_states=flat[nxt], actions=self.action.view(-1)[slots],
+        flat = self.obs.view(-1, self.env.obs_width)
+        return dict(states=self.env.unpack(flat[slots]) if self.env.packed else flat[slots],
+                    next_states=self.env.unpack(flat[nxt]) if self.env.packed else flat[nxt],
+                    actions=self.action.view(-1)[slots],
                     rewards=self.reward.view(-1)[slots], dones=self.done.view(-1)[slots].float(),
                     valid=self.valid.view(-1)[slots].float())
 
@@ -107,6 +109,9 @@ class DeviceReplayRing:
                                       b["rewards"].data_ptr(), b["dones"].data_ptr(), b["valid"].data_ptr(),
                                       self.env._stream())
         _lib.check(rc, "uavenv_replay_sample")
+        if self.env.packed:         # torch-side consumers get ordinary f32 rows; the packed batch stays available
+            return dict(b, states=self.env.unpack(b["states"]), next_states=self.env.unpack(b["next_states"]),
+                        packed_states=b["states"], packed_next_states=b["next_states"])
         return b
 
 

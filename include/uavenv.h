@@ -53,6 +53,13 @@ extern "C" {
 /* observation storage */
 #define UAVENV_OBS_F32 0
 #define UAVENV_OBS_F16 1
+/* Packed rows: 75 + 5 of the 100 columns are 0/1 occupancy flags and 5 are constant zeros (Agents/UAV.py:517,533-566),
+ * so a row is 15 scalars + 80 bits.  20 dwords (80 B) per row, lossless with respect to the f32 row:
+ *   dword 0..2 flag words (bit (c & 31) of word (c >> 5) = column c, c in 11..85 and 90..94), dword 3 = 0,
+ *   dword 4..14 columns 0..10 (f32), dword 15..18 columns 86..89 (f32), dword 19 = 0.
+ * uavenv_obs_unpack expands packed rows to f32 / f16 rows; the fused act / learner kernels read them directly. */
+#define UAVENV_OBS_PACKED 2
+#define UAVENV_OBS_PACKED_DWORDS 20
 
 /* uavenv_step flags */
 #define UAVENV_STEP_AUTO_RESET 1u   /* env whose agents are all done is reset from the scenario bank in the same
@@ -72,7 +79,7 @@ typedef struct UavEnvConfig {
     int32_t max_subgoals;       /* K: capacity of each agent's sub-goal list (reference: unbounded, observed <= 34) */
     int32_t max_step;           /* Max_Step */
     int32_t apf_enabled;        /* APF_Enabled (UAV.py:142,448) */
-    int32_t obs_dtype;          /* UAVENV_OBS_F32 / UAVENV_OBS_F16 */
+    int32_t obs_dtype;          /* UAVENV_OBS_F32 / UAVENV_OBS_F16 / UAVENV_OBS_PACKED */
     int32_t n_actions;          /* A for UAVENV_ACT_INDEX_I32 (>=2) */
     int32_t reserved0;
     double len, width, h;       /* world box; NOTE Threaten_rate bounds x AND y by `width` (PathPlan_City.py:218) */
@@ -153,7 +160,7 @@ int uavenv_threaten_rate_allpairs(UavEnv *env, const double *xyz_dev, uint8_t *o
 /* The ring is caller-owned HBM, frame-major: frame t holds obs[t] = state BEFORE action t, plus
  * action/reward/done/valid of transition t; next_state of (t,i) is obs[(t+1) % frames][i]. */
 typedef struct UavReplayRing {
-    void *obs;            /* frames x N x 100, f32 or f16 */
+    void *obs;            /* frames x N x 100, f32 or f16 -- or frames x N x 20 dwords, packed */
     void *action;         /* frames x N, float steer or int32 index */
     float *reward;        /* frames x N */
     uint8_t *done;        /* frames x N  (returned done) */
@@ -168,11 +175,14 @@ typedef struct UavReplayRing {
  * transitions (frame, agent) out of the `filled` frames preceding `head` -- the first `batch` images of a keyed
  * pseudo-random permutation of the filled * n_agents transitions (Feistel network keyed by Philox(seed, counter);
  * batch > filled * n_agents wraps around, where the reference raises) -- gathered into
- * contiguous batch buffers: obs_b/next_obs_b batch x 100 (ring dtype), action_b batch (ring type),
+ * contiguous batch buffers: obs_b/next_obs_b batch x 100 (ring dtype; packed rings give packed rows), action_b batch (ring type),
  * reward_b batch f32, done_b batch f32 (0/1), valid_b batch f32 (0/1). */
 int uavenv_replay_sample(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
                          uint64_t counter, void *obs_b, void *next_obs_b, void *action_b, float *reward_b,
                          float *done_b, float *valid_b, void *stream);
+
+/* Expand n packed rows (UAVENV_OBS_PACKED) into n x 100 f32 (out_dtype UAVENV_OBS_F32) or f16 rows. */
+int uavenv_obs_unpack(const void *packed_dev, int64_t n, void *out_dev, int32_t out_dtype, void *stream);
 
 /* The draws alone: frame_agent_out_dev[2*s], [2*s+1] = (frame, agent) of sample s, s < batch -- exactly the
  * transitions uavenv_replay_sample / uavenv_dqn_grad use for the same (seed, counter, head, filled). */

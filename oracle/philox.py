@@ -6,8 +6,8 @@
 * replay_draws: which stored transitions `uavenv_replay_sample` / `uavenv_dqn_grad` must pick for update
   (seed, counter): ReplayMemory.sample2 = random.sample(memory, batch) (BaseClass/replay_buffer.py:48-51) draws
   DISTINCT transitions; the device realises that as the first `batch` images of a keyed pseudo-random permutation
-  of the D = filled * n_agents stored transitions (6-round balanced Feistel network over 2*hb bits, cycle-walked
-  into [0, D); csrc/uavenv_device.hpp: replay_perm / replay_perm_apply).
+  of the D = filled * n_agents stored transitions (6-round alternating Feistel network over ceil(log2 D) bits,
+  cycle-walked into [0, D); csrc/uavenv_device.hpp: replay_perm / replay_perm_apply).
 * act_draws: the epsilon-greedy stream of uavenv_dqn_act / uavenv_select_actions (DuelingDQN_Trainer.py:86-97).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
@@ -58,23 +58,24 @@ def replay_slots(batch: int, seed: int, counter: int, filled: int, n_agents: int
     D = filled * n_agents
     if D <= 1:
         return np.zeros(batch, dtype=np.int64)
-    lo, hi = counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF
-    a = philox4x32_10(np.array([0, lo, hi, 0x5A3B]), _key(seed))
-    b = philox4x32_10(np.array([1, lo, hi, 0x5A3B]), _key(seed))
+    lo_c, hi_c = counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF
+    a = philox4x32_10(np.array([0, lo_c, hi_c, 0x5A3B]), _key(seed))
+    b = philox4x32_10(np.array([1, lo_c, hi_c, 0x5A3B]), _key(seed))
     keys = [np.uint64(v) for v in (a[0], a[1], a[2], a[3], b[0], b[1])]
-    bits = max(1, int(D - 1).bit_length())
-    hb = (bits + 1) // 2
-    mask = np.uint64((1 << hb) - 1)
-    sh = np.uint64(32 - hb)
+    bits = max(2, int(D - 1).bit_length())
+    la = bits // 2
+    lb = bits - la
+    ma, mb = np.uint64((1 << la) - 1), np.uint64((1 << lb) - 1)
+    sa, sb = np.uint64(32 - la), np.uint64(32 - lb)
     x = (np.arange(batch, dtype=np.uint64) % np.uint64(D))
     todo = np.ones(batch, dtype=bool)
     while todo.any():
         v = x[todo]
-        L, R = v >> np.uint64(hb), v & mask
-        for r in range(6):
-            t = L ^ (fmix32(R ^ keys[r]) >> sh)
-            L, R = R, t
-        v = (L << np.uint64(hb)) | R
+        lo, hi = v & ma, v >> np.uint64(la)
+        for r in range(0, 6, 2):
+            lo = lo ^ (fmix32(hi ^ keys[r]) >> sa)             # even round: low part ^= F(high part)
+            hi = hi ^ (fmix32(lo ^ keys[r + 1]) >> sb)         # odd round: high part ^= F(low part)
+        v = (hi << np.uint64(la)) | lo
         x[todo] = v
         todo[todo] = v >= np.uint64(D)
     return x.astype(np.int64)

@@ -7,7 +7,8 @@ from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
 from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
 
 n, B = 16384, 16384
-env = make_city26_env(n)
+OBS = os.environ.get("OBS", "f32")
+env = make_city26_env(n, obs_dtype="packed" if OBS == "packed" else (torch.float16 if OBS == "f16" else torch.float32))
 ring = DeviceReplayRing(env, 1 << 20)
 ring.reset(seed=1)
 L = FusedDQNLearner({"NetWork": "Qnet2", "w": "100", "hiden_dim": "64", "output": "3"}, "dqn")
@@ -28,7 +29,7 @@ print("fwd_strip local (MFMA only):", (R[:, :, 6] - R[:, :, 1]).mean(), " fwd_st
 d = np.diff(R[:, :, :6], axis=2)
 names = ["draw, issue loads, commit s rows + local fc1", "forward q_local(s) + commit s' rows, target fc1",
          "forward q_target(s') [+ q_local(s')]", "TD target, dL/dH, H / dH / dout -> LDS", "dW1^T, dW2^T products (MFMA)"]
-print("k_dqn_grad, batch", B, "- cycles per workgroup (mean / p95 / max)")
+print("obs", OBS, "k_dqn_grad, batch", B, "- cycles per workgroup (mean / p95 / max)")
 for k, nm in enumerate(names):
     x = d[:, :, k].ravel()
     print(f"  {nm:36s} {x.mean():9.0f} {np.percentile(x, 95):9.0f} {x.max():9.0f}")
