@@ -111,6 +111,18 @@ def cpu_baseline(envs: int, seconds: float):
     head = np.random.default_rng(0).uniform(0, 2 * np.pi, len(c["start_goal"]))
     batch.load_scenarios(c["start_goal"][:, :3], c["start_goal"][:, 3:], head, c["sub_goals"], c["n_sub"])
     cores = int(po.lib(fast=True).orc_max_threads())
+    quota = None
+    try:                                                             # the container's CPU quota, if it has one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception:
+            pass
+    if quota is not None:                                            # more threads than the quota only adds throttling
+        cores = max(1, min(cores, int(quota + 0.5)))
     bank = (c["start_goal"], c["sub_goals"], c["n_sub"])
 
     def timed(threads, budget_s):
@@ -129,21 +141,11 @@ def cpu_baseline(envs: int, seconds: float):
 
     one, done1, dt1 = timed(1, 0.25 * seconds)
     allc, done, dt = timed(cores, 0.75 * seconds)
-    quota = None
-    try:                                                             # the container's CPU quota, if it has one
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q == "max" else float(q) / float(per)
-    except Exception:
-        try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        except Exception:
-            pass
     out = {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port",
            "one_core_value": one, "cgroup_cpu_quota_cores": quota,
            "sample": f"{done} agent-steps ({n} envs x {done // n} steps, every step inside C, update_PathPlan + "
                      f"state_PathPlan, random steering, auto-reset from the packaged bank, no learner) in {dt:.1f} s on "
-                     f"{cores} threads; 1 thread: {done1} agent-steps in {dt1:.1f} s; C port of the reference's Python env "
+                     f"{cores} threads (host CPU quota of the container: {quota} cores); 1 thread: {done1} agent-steps in {dt1:.1f} s; C port of the reference's Python env "
                      f"path (oracle/uav_oracle.c, -O3, OpenMP static blocks)"}
     out["learner"] = cpu_learner_baseline()
     return out

@@ -921,33 +921,63 @@ constexpr int kMaxGradGrid = 256;           // one workgroup per CU (140 KB of L
 constexpr size_t kGrad2Lds = (size_t)(4 * kTileF + kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut +
                                       4 * (kMaxOut + 2)) * 4;
 
-// raw[p] = sum_b partial[b][p] for p in [0, P+2): gradient sums, loss sum, valid count.  32 columns x 8 row-groups
-// per workgroup so that each lane keeps nblk/8 independent, coalesced loads in flight (a one-thread-per-column loop
-// over 256 partial rows was latency-bound at 63 us).
+// Column sums of the partial rows for the 32 parameters of this workgroup: 8 float4 column groups x 32 row groups, every
+// thread's loads (<= 8 rows of 16 bytes per 256 rows) independent and in flight together -- one memory round trip (a
+// dependent walk over the rows was 8 round trips: 6 us for 256 rows).  Returns the sum of column blockIdx.x * 32 + tid
+// to threads tid < 32 (others: 0).  `c_out`: this thread's share of the valid-count column.
+__device__ __forceinline__ float reduce_columns(const float *__restrict__ partials, int nblk, int P, int stride, float &c_out)
+{
+    __shared__ float red[32][33];
+    __shared__ float red2[8][33];
+    const int tid = (int)threadIdx.x;
+    const int cg = tid & 7, rg = tid >> 3;                       // column group (4 columns), row group
+    const int p4 = (int)blockIdx.x * 32 + cg * 4;                // first of this thread's four columns (stride % 4 == 0)
+    const bool col_ok = p4 < stride;
+    floatx4 acc = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    float c = 0.0f;
+    for (int b0 = 0; b0 < nblk; b0 += 256) {
+        floatx4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + rg + 32 * k;
+            const int bb = b < nblk ? b : nblk - 1;
+            t[k] = *reinterpret_cast<const floatx4 *>(partials + (size_t)bb * stride + (col_ok ? p4 : 0));
+        }
+        const int bc = b0 + tid;
+        const float cv = partials[(size_t)(bc < nblk ? bc : nblk - 1) * stride + P + 1];
+        c += bc < nblk ? cv : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool ok = b0 + rg + 32 * k < nblk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += ok ? t[k][e] : 0.0f;
+        }
+    }
+    c_out = c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg][cg * 4 + e] = acc[e];
+    __syncthreads();
+    {
+        const int px = tid & 31, part = tid >> 5;                // 32 row groups -> 8 -> 1
+        red2[part][px] = (red[4 * part][px] + red[4 * part + 1][px]) + (red[4 * part + 2][px] + red[4 * part + 3][px]);
+    }
+    __syncthreads();
+    float t = 0.0f;
+    if (tid < 32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red2[k][tid];
+    }
+    return t;
+}
+
+// raw[p] = sum_b partial[b][p] for p in [0, P+2): gradient sums, loss sum, valid count (the multi-GPU all-reduce payload).
 __global__ void __launch_bounds__(256) k_dqn_reduce(const float *__restrict__ partials, int nblk, int P, int stride,
                                                     float *__restrict__ raw)
 {
-    __shared__ float red[8][33];
-    const int px = (int)threadIdx.x & 31, gy = (int)threadIdx.x >> 5;
-    const int p = (int)blockIdx.x * 32 + px;
-    float s = 0.0f;
-    if (p < P + 2) {
-        int b = gy;
-        for (; b + 24 < nblk; b += 32) {
-            const float v0 = partials[(size_t)b * stride + p], v1 = partials[(size_t)(b + 8) * stride + p];
-            const float v2 = partials[(size_t)(b + 16) * stride + p], v3 = partials[(size_t)(b + 24) * stride + p];
-            s += (v0 + v1) + (v2 + v3);
-        }
-        for (; b < nblk; b += 8) s += partials[(size_t)b * stride + p];
-    }
-    red[gy][px] = s;
-    __syncthreads();
-    if (gy == 0 && p < P + 2) {
-        float t = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][px];
-        raw[p] = t;
-    }
+    float c;
+    const float t = reduce_columns(partials, nblk, P, stride, c);
+    const int p = (int)blockIdx.x * 32 + (int)threadIdx.x;
+    if (threadIdx.x < 32 && p < P + 2) raw[p] = t;
 }
 
 // torch.optim.Adam (amsgrad off, weight_decay 0) on grad = raw / max(valid count, 1), + optional hard target copy
@@ -973,47 +1003,27 @@ __global__ void k_dqn_adam(float *__restrict__ local, float *__restrict__ target
 }
 
 // Single-GPU fast path: k_dqn_reduce + k_dqn_adam in one launch (each workgroup owns 32 parameters end to end; the
-// valid count is re-derived per workgroup from the nblk count cells, 1 load per thread).
+// valid count is re-derived per workgroup from the count cells, one load per thread).
 __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict__ partials, int nblk, int P, int stride,
                                                          float *__restrict__ local, float *__restrict__ target,
                                                          float *__restrict__ m, float *__restrict__ v, float lr,
                                                          float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
                                                          int hard_update, float *__restrict__ loss, float *__restrict__ raw)
 {
-    __shared__ float red[8][33];
     __shared__ float cnt_part[4];
-    __shared__ float s_inv;
     const int tid = (int)threadIdx.x;
-    float c = 0.0f;
-    for (int b = tid; b < nblk; b += 256) c += partials[(size_t)b * stride + P + 1];
+    float c;
+    const float t = reduce_columns(partials, nblk, P, stride, c);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((tid & 63) == 0) cnt_part[tid >> 6] = c;
-    const int px = tid & 31, gy = tid >> 5;
-    const int p = (int)blockIdx.x * 32 + px;
-    float s = 0.0f;
-    if (p < P + 2) {
-        int b = gy;
-        for (; b + 24 < nblk; b += 32) {
-            const float v0 = partials[(size_t)b * stride + p], v1 = partials[(size_t)(b + 8) * stride + p];
-            const float v2 = partials[(size_t)(b + 16) * stride + p], v3 = partials[(size_t)(b + 24) * stride + p];
-            s += (v0 + v1) + (v2 + v3);
-        }
-        for (; b < nblk; b += 8) s += partials[(size_t)b * stride + p];
-    }
-    red[gy][px] = s;
     __syncthreads();
-    if (tid == 0) {
-        const float cnt = (cnt_part[0] + cnt_part[1]) + (cnt_part[2] + cnt_part[3]);
-        s_inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
-    }
-    __syncthreads();
-    if (gy == 0 && p < P + 2) {
-        float t = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][px];
+    const float cnt = (cnt_part[0] + cnt_part[1]) + (cnt_part[2] + cnt_part[3]);
+    const float inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
+    const int p = (int)blockIdx.x * 32 + tid;
+    if (tid < 32 && p < P + 2) {
         if (raw) raw[p] = t;
         if (p < P) {
-            const float gp = t * s_inv;
+            const float gp = t * inv;
             const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);
             const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;
             m[p] = mp;
@@ -1022,7 +1032,7 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
             local[p] = np;
             if (hard_update) target[p] = np;
         } else if (p == P && loss) {
-            *loss = t * s_inv;
+            *loss = t * inv;
         }
     }
 }
