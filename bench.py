@@ -66,6 +66,9 @@ def parse():
     p.add_argument("--obs-dtype", default="packed", choices=["packed", "f32", "f16"],
                    help="replay / observation storage: packed = 15 f32 scalars + 80 flag bits per row (80 B, lossless image "
                         "of the f32 row: include/uavenv.h UAVENV_OBS_PACKED); f32 / f16 = rows of 100 elements")
+    p.add_argument("--mfma", default="f32", choices=["f32", "f16"],
+                   help="operand type of the fused learner's matrix products: f32 (the reference's precision) or f16 with f32 "
+                        "accumulation (BASELINE configs[2]; needs --obs-dtype f16 or packed)")
     p.add_argument("--eps", type=float, default=0.1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -73,7 +76,7 @@ def parse():
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
     p.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                    help="BASELINE.json configs[] preset: 2 = 16384 envs DQN (the benchmark line); 3 = 65536 envs, "
-                        "DuelingDQN + double-DQN target, f16 observations; 5 = 32768 envs per GPU (262144 over 8)")
+                        "DuelingDQN + double-DQN target, f16 MFMA Q-net; 5 = 32768 envs per GPU (262144 over 8)")
     p.add_argument("--apf", action="store_true", help="diagnostic (env-only): APF on, buildings moving with seeded "
                    "velocities U(-1,1)^2 (BASELINE configs[3]'s env settings)")
     p.add_argument("--uav-per-env", type=int, default=1, help="diagnostic (env-only): UAVs per env")
@@ -90,7 +93,7 @@ def parse():
                    help="fused = hand-written HIP kernels (csrc/learner.hip); torch = PyTorch-ROCm ops")
     a = p.parse_args()
     if a.config == 3:
-        a.envs, a.batch, a.trainer, a.obs_dtype = 65536, 65536, "dueling", "f16"
+        a.envs, a.batch, a.trainer, a.mfma = 65536, 65536, "dueling", "f16"
     elif a.config == 5:
         a.envs, a.batch = 32768, 32768
     return a
@@ -176,7 +179,7 @@ def committed_profile(args) -> dict:
     """The rocprofv3 figures of THIS command line as last committed under profiles/ (kernel-trace averages, PMC
     traffic, MFMA busy): scripts/summarize_profile.py writes profiles/summary.json keyed by workload."""
     path = os.path.join(ROOT, "profiles", "summary.json")
-    key = "envs%d_batch%d_%s_%s" % (args.envs, args.batch, args.trainer, args.obs_dtype)
+    key = "envs%d_batch%d_%s_%s" % (args.envs, args.batch, args.trainer, args.obs_dtype) + ("_mfma16" if args.mfma == "f16" else "")
     try:
         d = json.load(open(path)).get(key, {})
         if d:
@@ -256,7 +259,7 @@ def main():
     net_param = {"NetWork": net, "w": "100", "hiden_dim": "64", "output": "3"}
     fused = args.learner == "fused"
     if fused:
-        learner = FusedDQNLearner(net_param, args.trainer, device=dev)
+        learner = FusedDQNLearner(net_param, args.trainer, device=dev, mfma=args.mfma)
     else:
         learner = DQNLearner(net_param, args.trainer, device=dev,
                              amp_dtype=torch.float16 if args.obs_dtype == "f16" else None)
@@ -408,7 +411,7 @@ def main():
         stored = algo - (200 if args.obs_dtype == "f16" else 400) + ring.obs.shape[-1] * ring.obs.element_size()
         achieved = algo * n_agents / (k_ms * 1e-3) / 1e9
         traffic = prof.get("k_step_traffic_bytes_per_launch")
-        ldt = "f16" if (fused and args.obs_dtype == "f16") else "f32"
+        ldt = args.mfma if fused else "f32"
         out = {
             "metric": "env-steps/sec + learner updates/sec, PathPlan_City DQN",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,

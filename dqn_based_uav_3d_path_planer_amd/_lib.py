@@ -16,6 +16,7 @@ INFO_NAMES = ("normal", "success", "lose", "skipped")
 ACT_STEER_F32, ACT_STEER_F64, ACT_INDEX_I32 = 0, 1, 2
 OBS_F32, OBS_F16, OBS_PACKED = 0, 1, 2
 PACKED_DWORDS = 20
+MFMA_F32, MFMA_F16 = 0, 1
 STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE = 1, 2, 4, 8
 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -50,7 +51,8 @@ class UavReplayRing(C.Structure):
 
 class UavDqnNet(C.Structure):
     _fields_ = [("local", C.c_void_p), ("target", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
-                ("w", C.c_int32), ("hid", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32)]
+                ("w", C.c_int32), ("hid", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32),
+                ("mfma_dtype", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class UavPer(C.Structure):

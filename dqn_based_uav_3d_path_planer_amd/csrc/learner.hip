@@ -322,7 +322,10 @@ struct GradAcc {
 
 // TD target, loss, dL/dout of this lane's sample, the strip's column sums, dL/dH and the forward H into LDS -- everything
 // between the forward passes and the weight-gradient products; common to the f32-tile and the packed-row kernels.
-template <int NMAX>
+// HALF_T: H, dH and dout go to LDS transposed and as f16 (hrow / drow / dout_row then point at column s of the [j][s],
+// [j][s] and [a][s] tiles of row stride kLdT halfs) -- the operand layout of the f16 weight-gradient MFMAs.
+constexpr int kLdT = 72;                    // halfs per row of the transposed f16 tiles (64 samples + 8: 16-byte rows)
+template <int NMAX, bool HALF_T = false>
 __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l, const floatx4 (&hl)[4], const W2Frag<NMAX> &Fl,
                                             const float (&ql)[NMAX], const float (&qt)[NMAX], int best, int p_act, float p_rew,
                                             float p_done, float p_valid, GradAcc<NMAX> &A, float *hrow, float *drow,
@@ -393,10 +396,24 @@ __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l,
             hh[rr] = hl[t][rr] > 0.0f ? hl[t][rr] : 0.0f;
             dh[rr] = hl[t][rr] > 0.0f ? dh[rr] : 0.0f;
         }
-        *reinterpret_cast<floatx4 *>(hrow + 16 * t + 4 * gq) = hh;
-        *reinterpret_cast<floatx4 *>(drow + 16 * t + 4 * gq) = dh;
+        if (HALF_T) {
+            _Float16 *hT = reinterpret_cast<_Float16 *>(hrow), *dT = reinterpret_cast<_Float16 *>(drow);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                hT[(16 * t + 4 * gq + rr) * kLdT] = (_Float16)hh[rr];
+                dT[(16 * t + 4 * gq + rr) * kLdT] = (_Float16)dh[rr];
+            }
+        } else {
+            *reinterpret_cast<floatx4 *>(hrow + 16 * t + 4 * gq) = hh;
+            *reinterpret_cast<floatx4 *>(drow + 16 * t + 4 * gq) = dh;
+        }
     }
-    {   // douts[s][4 gq .. 4 gq + 3]
+    if (HALF_T) {       // doutT[a][s], a < NMAX (rows above stay zero); every lane group writes the same values
+        _Float16 *oT = reinterpret_cast<_Float16 *>(dout_row);
+#pragma unroll
+        for (int a = 0; a < NMAX; ++a)
+            if ((a & 3) == gq) oT[a * kLdT] = (_Float16)dv[a];
+    } else {            // douts[s][4 gq .. 4 gq + 3]
         floatx4 d4 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int a = 0; a < NMAX; ++a)
@@ -881,6 +898,330 @@ constexpr size_t kGradPLds = (size_t)(2 * kTileF + 2 * kTile * kLh + kTile * kMa
 static_assert((2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2)) % 4 == 0,
               "packed-row staging must start 16-byte aligned");
 
+// =====================================================================================================================
+// f16 MFMA learner (UavDqnNet.mfma_dtype = 1; BASELINE configs[2]: "fp16 Q-net MFMA").
+//
+// Mixed precision as a tensor-core trainer does it: master weights, Adam moments, layer 2, the TD target, the loss and
+// dL/dH stay f32; the three big products -- layer 1 of q_local / q_target and dW1 = dH^T X -- run on
+// v_mfma_f32_16x16x32_f16 (f16 operands, f32 accumulate, 16x the f32 MFMA rate): fc1 weights are rounded to f16 when
+// they are staged, observations are f16 (f16 rings as stored, packed rings converted), H and dH are rounded to f16 for
+// the gradient products only.  Same wave-strip structure as above: lane = sample, registers = hidden units.
+// Operand tiles (halfs): rows of kLdH = 136 for the K = 128 products of the forward (100 inputs, column 100 = 1 | b1,
+// then zeros), rows of kLdT = 72 for the K = 64 (samples) products of the backward, whose operands are TRANSPOSED
+// ([column][sample]: an MFMA lane supplies 8 consecutive K elements of one row).
+// =====================================================================================================================
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+constexpr int kLdH = 136;
+constexpr int kStageW = 16 * kPackedDwords + 4;   // dwords of packed-row staging per wavefront (+ pad: the expansion over-reads 1)
+
+__device__ __forceinline__ floatx4 mfma16h(half8 a, half8 b, floatx4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// four columns 4 q .. 4 q + 3 of the row whose packed image is at pr (LDS)
+__device__ __forceinline__ floatx4 packed_expand4(const uint32_t *pr, int q)
+{
+    const int c = 4 * q, w = c >> 5;
+    const uint32_t mw = pr[w < 3 ? w : 2];
+    const uint32_t nib = w < 3 ? mw >> (c & 31) : 0u;
+    const uint32_t snib = q < 2 ? 15u : q == 2 ? 7u : q == 21 ? 12u : q == 22 ? 3u : 0u;     // which of the four are scalars
+    const int sb = q < 3 ? 4 + c : q == 21 ? 13 : q == 22 ? 17 : 4;                          // and where they sit in the row
+    const float s0 = __uint_as_float(pr[sb]), s1 = __uint_as_float(pr[sb + 1]);
+    const float s2 = __uint_as_float(pr[sb + 2]), s3 = __uint_as_float(pr[sb + 3]);
+    floatx4 v;
+    v[0] = (snib & 1u) ? s0 : (float)(nib & 1u);
+    v[1] = (snib & 2u) ? s1 : (float)((nib >> 1) & 1u);
+    v[2] = (snib & 4u) ? s2 : (float)((nib >> 2) & 1u);
+    v[3] = (snib & 8u) ? s3 : (float)((nib >> 3) & 1u);
+    return v;
+}
+
+// fc1 (64 x 100 f32 in HBM) -> f16 tile [64][kLdH]: column 100 = bias, 101..127 = 0
+__device__ __forceinline__ void wh_commit(_Float16 *dst, floatx4 (&v)[kStageIters], float bias)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int c = it * 256 + (int)threadIdx.x;
+        if (c < kStageChunks) {
+            const int row = c / 25, q = c - row * 25;
+            *reinterpret_cast<half4 *>(dst + row * kLdH + 4 * q) =
+                half4{(_Float16)v[it][0], (_Float16)v[it][1], (_Float16)v[it][2], (_Float16)v[it][3]};
+        }
+    }
+    if (threadIdx.x < kHid) {
+        _Float16 *row = dst + (int)threadIdx.x * kLdH;
+        *reinterpret_cast<half4 *>(row + 100) = half4{(_Float16)bias, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<half8 *>(row + 104 + 8 * k) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+// KIND: OBS_KIND_F16 (rows of 100 halfs) or OBS_KIND_PACKED.  Loads of this wavefront's 16 rows (2 or 7 per lane).
+template <int KIND>
+__device__ __forceinline__ void xh_issue(floatx4 (&v)[kXIters], const void *obs, uint32_t my_row)
+{
+    constexpr int per_row = KIND == OBS_KIND_PACKED ? 5 : 25, iters = KIND == OBS_KIND_PACKED ? 2 : kXIters;
+    const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < iters; ++it) {
+        int c = it * 64 + lane;
+        c = c < 16 * per_row ? c : 16 * per_row - 1;
+        const int row = c / per_row, q = c - row * per_row;
+        const uint32_t ring_row = (uint32_t)__shfl((int)my_row, row, 64);
+        if (KIND == OBS_KIND_PACKED) {
+            v[it] = *reinterpret_cast<const floatx4 *>(reinterpret_cast<const uint32_t *>(obs) + (size_t)ring_row * kPackedDwords + 4 * q);
+        } else {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(obs) + (size_t)ring_row * kW + 4 * q);
+            v[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};
+        }
+    }
+}
+
+// ... into the f16 strip [16][kLdH] (+ column 100 = 1, 101..127 = 0) and, if xT != nullptr, transposed into
+// xT[column][sample] (sample column of this strip's first row = xT + 16 w).
+template <int KIND>
+__device__ __forceinline__ void xh_commit(_Float16 *strip, floatx4 (&v)[kXIters], uint32_t *stage, _Float16 *xT)
+{
+    const int lane = (int)threadIdx.x & 63;
+    if (KIND == OBS_KIND_PACKED) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = it * 64 + lane;
+            if (c < 80) *reinterpret_cast<floatx4 *>(stage + 4 * c) = v[it];
+        }
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int it = 0; it < kXIters; ++it) {
+        const int c = it * 64 + lane;
+        if (c < 400) {
+            const int row = c / 25, q = c - row * 25;
+            half4 h;
+            if (KIND == OBS_KIND_PACKED) {
+                const floatx4 f = packed_expand4(stage + row * kPackedDwords, q);
+                h = half4{(_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3]};
+            } else {
+                const uint2 raw = make_uint2(__float_as_uint(v[it][0]), __float_as_uint(v[it][1]));
+                h = *reinterpret_cast<const half4 *>(&raw);
+            }
+            *reinterpret_cast<half4 *>(strip + row * kLdH + 4 * q) = h;
+            if (xT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xT[(4 * q + e) * kLdT + row] = h[e];
+            }
+        }
+    }
+    if (lane < 16) {
+        _Float16 *row = strip + lane * kLdH;
+        *reinterpret_cast<half4 *>(row + 100) = half4{(_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<half8 *>(row + 104 + 8 * k) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (xT) xT[100 * kLdT + lane] = (_Float16)1.0f;
+    }
+}
+
+// acc[t][r] = b1[j] + sum_k W1[j][k] X[s][k] on the f16 MFMA: 4 K-steps of 32, 16 MFMAs
+__device__ __forceinline__ void fwd_strip_h(const _Float16 *W, const _Float16 *strip, floatx4 (&acc)[4])
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const _Float16 *xp = strip + r * kLdH + 8 * g;
+    const _Float16 *wp = W + r * kLdH + 8 * g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const half8 b = *reinterpret_cast<const half8 *>(xp + 32 * kk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = mfma16h(*reinterpret_cast<const half8 *>(wp + t * 16 * kLdH + 32 * kk), b, acc[t]);
+    }
+}
+
+struct GradLdsH {
+    _Float16 *W1l, *W1t, *Xs, *Xn, *XsT, *HT, *dHT, *doutT;     // HT / dHT alias the Xn tile (dead after the forward passes)
+    float *W2l, *W2t, *b2l, *b2t, *red;
+    uint32_t *stage;
+};
+
+// what a tile needs from HBM: its 2 x 16 observation rows per wavefront and each lane's transition scalars
+struct TileLoads {
+    floatx4 vXs[kXIters], vXn[kXIters];
+    int p_act;
+    float p_rew, p_done, p_valid;
+};
+
+template <int KIND>
+__device__ __forceinline__ void tile_issue(const GradArgs &g, int tile, TileLoads &T)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15;
+    const int smp = tile * kTile + wv * 16 + r;
+    int f, agent;
+    if (g.explicit_idx) {
+        f = g.explicit_idx[2 * smp];
+        agent = g.explicit_idx[2 * smp + 1];
+    } else {
+        replay_slot_to_frame(g.perm, replay_perm_apply(g.perm, (uint32_t)smp), g.head, g.ring.frames, f, agent);
+    }
+    int fn = f + 1;
+    if (fn >= g.ring.frames) fn = 0;
+    const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    xh_issue<KIND>(T.vXs, g.ring.obs, row_s);
+    T.p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
+    T.p_rew = g.ring.reward[row_s];
+    T.p_done = (float)g.ring.done[row_s];
+    T.p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    xh_issue<KIND>(T.vXn, g.ring.obs, row_n);
+}
+
+// One tile.  T holds this tile's loads (issued by the caller / the previous tile); when `more`, the NEXT tile's loads are
+// issued into T as soon as this tile's rows have been committed to LDS, so that their HBM round trip runs under the
+// TD / backward / gradient-product phases (a workgroup of BASELINE configs[2] walks four tiles).
+template <int KIND, int NMAX, bool FIRST>
+__device__ __forceinline__ void grad_tile_h(const GradArgs &g, const GradLdsH &L, int tile, int next_tile, bool more,
+                                            TileLoads &T, GradAcc<NMAX> &A)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    _Float16 *xs_strip = L.Xs + wv * 16 * kLdH, *xn_strip = L.Xn + wv * 16 * kLdH;
+    floatx4 vWl[kStageIters], vWt[kStageIters];
+    float pb1 = 0.0f, pb1t = 0.0f, pw[4] = {0, 0, 0, 0}, pt[4] = {0, 0, 0, 0}, pb2 = 0.0f, pb2t = 0.0f;
+    if (FIRST) {
+        w_issue(vWl, g.local);
+        const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
+        const int kb = tid < kHid ? tid : kHid - 1;
+        pb1 = nl.b1[kb]; pb1t = nt.b1[kb];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k < n2 * kHid ? tid + 256 * k : 0;
+            pw[k] = nl.W2[idx]; pt[k] = nt.W2[idx];
+        }
+        const int kq = tid < n2 ? tid : 0;
+        pb2 = nl.b2[kq]; pb2t = nt.b2[kq];
+        tile_issue<KIND>(g, tile, T);
+        w_issue(vWt, g.target);
+    }
+    const int p_act = T.p_act;
+    const float p_rew = T.p_rew, p_done = T.p_done, p_valid = T.p_valid;
+
+    uint32_t *stage = L.stage + wv * kStageW;
+    if (FIRST) wh_commit(L.W1l, vWl, pb1);
+    xh_commit<KIND>(xs_strip, T.vXs, stage, L.XsT + wv * 16);
+    wave_lds_sync();
+    if (FIRST) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < n2 * kHid) { L.W2l[tid + 256 * k] = pw[k]; L.W2t[tid + 256 * k] = pt[k]; }
+        if (tid < n2) { L.b2l[tid] = pb2; L.b2t[tid] = pb2t; }
+        for (int k = tid; k < 16 * kLdT / 2; k += 256) reinterpret_cast<uint32_t *>(L.doutT)[k] = 0u;     // rows >= n2 stay zero
+        __syncthreads();
+    }
+    L_STAMP(1);
+    floatx4 hl[4];
+    fwd_strip_h(L.W1l, xs_strip, hl);
+    W2Frag<NMAX> Fl;
+    w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+    float ql[NMAX];
+    q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+    xh_commit<KIND>(xn_strip, T.vXn, stage, nullptr);
+    if (FIRST) {
+        wh_commit(L.W1t, vWt, pb1t);
+        __syncthreads();
+    }
+    wave_lds_sync();
+    if (more) tile_issue<KIND>(g, next_tile, T);      // the next tile's HBM round trip starts here
+    L_STAMP(2);
+    int best = 0;
+    floatx4 ht[4];
+    if (g.kind == 1) {                        // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
+        fwd_strip_h(L.W1l, xn_strip, ht);
+        float qn_l[NMAX];
+        q_strip<NMAX>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
+        float bq = qn_l[0];
+#pragma unroll
+        for (int a = 1; a < NMAX; ++a)
+            if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }
+    }
+    fwd_strip_h(L.W1t, xn_strip, ht);
+    float qt[NMAX];
+    {
+        W2Frag<NMAX> Ft;
+        w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
+        q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+    }
+    L_STAMP(3);
+    __syncthreads();                                  // every wave is done with its s' rows: HT / dHT overwrite that tile
+    const int s = wv * 16 + r;
+    td_backward<NMAX, true>(g, L.W2l, hl, Fl, ql, qt, best, p_act, p_rew, p_done, p_valid, A,
+                            reinterpret_cast<float *>(L.HT + s), reinterpret_cast<float *>(L.dHT + s),
+                            reinterpret_cast<float *>(L.doutT + s));
+    __syncthreads();
+    L_STAMP(4);
+    // ---- weight gradients, K = 64 samples = 2 MFMA steps of 32:
+    //   dW1^T[k][j] += sum_s XsT[k][s] dHT[j][s]   (7 tiles of 16 k-columns, hidden units 16 wv + r)
+    //   dW2^T[j][a] += sum_s HT[j][s] doutT[a][s]
+    {
+        const _Float16 *xa = L.XsT + r * kLdT + 8 * gq;
+        const _Float16 *db = L.dHT + (16 * wv + r) * kLdT + 8 * gq;
+        const _Float16 *ha = L.HT + (16 * wv + r) * kLdT + 8 * gq;
+        const _Float16 *ob = L.doutT + r * kLdT + 8 * gq;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half8 bdh = *reinterpret_cast<const half8 *>(db + 32 * kk);
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                A.acc1[u] = mfma16h(*reinterpret_cast<const half8 *>(xa + 16 * u * kLdT + 32 * kk), bdh, A.acc1[u]);
+            A.acc2 = mfma16h(*reinterpret_cast<const half8 *>(ha + 32 * kk), *reinterpret_cast<const half8 *>(ob + 32 * kk), A.acc2);
+        }
+    }
+    if (more) __syncthreads();
+}
+
+template <int KIND, int NMAX>
+__global__ void __launch_bounds__(256) k_dqn_grad_h(Grad2Args ga)
+{
+    const GradArgs &g = ga.g;
+    extern __shared__ __align__(16) float lds[];
+    GradLdsH L;
+    _Float16 *hb = reinterpret_cast<_Float16 *>(lds);
+    L.W1l = hb;                              // [64][136]
+    L.W1t = L.W1l + kTile * kLdH;
+    L.Xs = L.W1t + kTile * kLdH;
+    L.Xn = L.Xs + kTile * kLdH;              // [64][136] = 8 704 halfs; later HT [64][72] + dHT [64][72] = 9 216 halfs
+    L.HT = L.Xn;
+    L.dHT = L.HT + kTile * kLdT;
+    L.XsT = L.Xn + 2 * kTile * kLdT;         // [112][72]
+    L.doutT = L.XsT + 112 * kLdT;            // [16][72]
+    L.W2l = reinterpret_cast<float *>(L.doutT + 16 * kLdT);
+    L.W2t = L.W2l + kMaxOut * kHid;
+    L.b2l = L.W2t + kMaxOut * kHid;
+    L.b2t = L.b2l + kMaxOut;
+    L.red = L.b2t + kMaxOut;
+    L.stage = reinterpret_cast<uint32_t *>(L.red + 4 * (kMaxOut + 2));
+    // XsT rows 101..111 feed output rows nobody stores; zeroed once so that no NaN bit pattern ever enters an MFMA
+    for (int k = (int)threadIdx.x; k < 11 * kLdT / 2; k += 256) reinterpret_cast<uint32_t *>(L.XsT + 101 * kLdT)[k] = 0u;
+    GradAcc<NMAX> A;
+    A.acc2 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 7; ++u) A.acc1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = 0.0f;
+    L_STAMP(0);
+    const int step = (int)gridDim.x;
+    int tile = (int)blockIdx.x;
+    TileLoads T;
+    grad_tile_h<KIND, NMAX, true>(g, L, tile, tile + step, tile + step < ga.n_tiles, T, A);
+    for (tile += step; tile < ga.n_tiles; tile += step)
+        grad_tile_h<KIND, NMAX, false>(g, L, tile, tile + step, tile + step < ga.n_tiles, T, A);
+    L_STAMP(5);
+    grad_write_partials<NMAX>(g, ga.stride, L.red, A);
+}
+
+constexpr size_t kGradHLds = (size_t)(3 * kTile * kLdH + 2 * kTile * kLdT + 112 * kLdT + 16 * kLdT) * 2 +
+                             (size_t)(2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2) + 4 * kStageW) * 4;
+
 template <typename ObsT, int NMAX>
 __global__ void __launch_bounds__(256) k_dqn_grad(Grad2Args ga)
 {
@@ -1185,6 +1526,86 @@ __global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
     }
 }
 
+// f16 MFMA forward (UavDqnNet.mfma_dtype = 1) on f16 or packed observations
+template <int KIND, int NMAX>
+__global__ void __launch_bounds__(256) k_dqn_act_h(ActArgs g)
+{
+    extern __shared__ __align__(16) float lds[];
+    _Float16 *W1 = reinterpret_cast<_Float16 *>(lds);       // [64][136]
+    _Float16 *Xs = W1 + kTile * kLdH;                         // [64][136]
+    float *W2 = reinterpret_cast<float *>(Xs + kTile * kLdH); // [16][64]
+    float *b2 = W2 + kMaxOut * kHid;                          // [16]
+    uint32_t *stage = reinterpret_cast<uint32_t *>(b2 + kMaxOut);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    const NetDev nl = net_view(g.local, n2);
+    const int first = (int)blockIdx.x * kTile + wv * 16;
+    _Float16 *strip = Xs + wv * 16 * kLdH;
+    floatx4 vX[kXIters], vW[kStageIters];
+    {
+        constexpr int per_row = KIND == OBS_KIND_PACKED ? 5 : 25, iters = KIND == OBS_KIND_PACKED ? 2 : kXIters;
+#pragma unroll
+        for (int it = 0; it < iters; ++it) {
+            int c = it * 64 + lane;
+            c = c < 16 * per_row ? c : 16 * per_row - 1;
+            const int row = c / per_row, q = c - row * per_row;
+            int i = first + row;
+            i = i < g.n ? i : g.n - 1;
+            if (KIND == OBS_KIND_PACKED) {
+                vX[it] = *reinterpret_cast<const floatx4 *>(reinterpret_cast<const uint32_t *>(g.obs) + (size_t)i * kPackedDwords + 4 * q);
+            } else {
+                const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(g.obs) + (size_t)i * kW + 4 * q);
+                vX[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};
+            }
+        }
+    }
+    w_issue(vW, g.local);
+    const int i = first + r;
+    const uint4 rn = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
+                                   make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
+    const float pb1 = nl.b1[tid < kHid ? tid : kHid - 1];
+    float pw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pw[k] = nl.W2[tid + 256 * k < n2 * kHid ? tid + 256 * k : 0];
+    const float pb2 = nl.b2[tid < n2 ? tid : 0];
+    xh_commit<KIND>(strip, vX, stage + wv * kStageW, nullptr);
+    wh_commit(W1, vW, pb1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (tid + 256 * k < n2 * kHid) W2[tid + 256 * k] = pw[k];
+    if (tid < n2) b2[tid] = pb2;
+    __syncthreads();
+    floatx4 h[4];
+    fwd_strip_h(W1, strip, h);
+    float q[NMAX];
+    {
+        W2Frag<NMAX> F;
+        w2_load<NMAX>(F, W2, b2, n2);
+        q_strip<NMAX>(h, F, n2, g.n_actions, g.dueling, q);
+    }
+    if (lane < 16 && i < g.n) {
+        if (g.q_out) {
+#pragma unroll
+            for (int a = 0; a < NMAX; ++a)
+                if (a < g.n_actions) g.q_out[(size_t)i * g.n_actions + a] = q[a];
+        }
+        const float sample = (float)(rn.x >> 8) * (1.0f / 16777216.0f);
+        int a;
+        if (sample > g.eps) {
+            a = 0;
+            float bq = q[0];
+#pragma unroll
+            for (int k = 1; k < NMAX; ++k)
+                if (k < g.n_actions && q[k] > bq) { bq = q[k]; a = k; }
+        } else {
+            a = (int)(((uint64_t)rn.y * (uint64_t)g.n_actions) >> 32);
+        }
+        if (g.index_out) g.index_out[i] = a;
+        if (g.steer_out) g.steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(g.n_actions - 1));
+    }
+}
+
+constexpr size_t kActHLds = (size_t)(2 * kTile * kLdH) * 2 + (size_t)(kMaxOut * kHid + kMaxOut + 4 * kStageW) * 4;
 constexpr size_t kAct2Lds = (size_t)(2 * kTileF + kMaxOut * kHid + kMaxOut) * 4;
 constexpr size_t kActPLds = (size_t)(kTileF + kMaxOut * kHid + kMaxOut) * 4;
 
@@ -1194,6 +1615,27 @@ bool net_ok(const UavDqnNet *n)
 {
     return n && n->local && n->w == kW && n->hid == kHid && n->n_actions >= 2 &&
            n->n_actions + (n->dueling ? 1 : 0) + 2 <= kMaxOut;     // + 2 spare dout columns (loss sum, valid count)
+}
+
+template <int KIND>
+static int launch_grad_h(const Grad2Args &ga, int grid, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_h<KIND, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradHLds) != hipSuccess)
+            return UAVENV_EHIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_dqn_grad_h<KIND, 4>), dim3(grid), dim3(256), kGradHLds, s, ga);
+    return UAVENV_OK;
+}
+
+template <int KIND>
+static int launch_act_h(const ActArgs &g, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_dqn_act_h<KIND, 4>), dim3(grid), dim3(256), kActHLds, s, g);        // 44 KB: no attribute needed
+    return UAVENV_OK;
 }
 
 template <int NMAX>
@@ -1306,7 +1748,10 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
     hipStream_t s = (hipStream_t)stream;
     const bool small = net->n_actions + (net->dueling ? 1 : 0) <= 4;
     int rc;
-    if (ring->obs_dtype == UAVENV_OBS_F32)
+    if (net->mfma_dtype == UAVENV_MFMA_F16) {         // f16 operands, f32 accumulate: f16 / packed rings, <= 4 layer-2 outputs
+        if (!small || ring->obs_dtype == UAVENV_OBS_F32) return UAVENV_EINVAL;
+        rc = ring->obs_dtype == UAVENV_OBS_PACKED ? launch_grad_h<OBS_KIND_PACKED>(ga, grid, s) : launch_grad_h<OBS_KIND_F16>(ga, grid, s);
+    } else if (ring->obs_dtype == UAVENV_OBS_F32)
         rc = small ? launch_grad<float, 4>(ga, grid, s) : launch_grad<float, kMaxOut - 2>(ga, grid, s);
     else if (ring->obs_dtype == UAVENV_OBS_PACKED)
         rc = small ? launch_grad_packed<4>(ga, grid, s) : launch_grad_packed<kMaxOut - 2>(ga, grid, s);
@@ -1365,7 +1810,10 @@ int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype,
     hipStream_t s = (hipStream_t)stream;
     const bool small = net->n_actions + (net->dueling ? 1 : 0) <= 4;
     int rc;
-    if (obs_dtype == UAVENV_OBS_F32) rc = small ? launch_act<float, 4>(g, grid, s) : launch_act<float, kMaxOut - 2>(g, grid, s);
+    if (net->mfma_dtype == UAVENV_MFMA_F16) {
+        if (!small || obs_dtype == UAVENV_OBS_F32) return UAVENV_EINVAL;
+        rc = obs_dtype == UAVENV_OBS_PACKED ? launch_act_h<OBS_KIND_PACKED>(g, grid, s) : launch_act_h<OBS_KIND_F16>(g, grid, s);
+    } else if (obs_dtype == UAVENV_OBS_F32) rc = small ? launch_act<float, 4>(g, grid, s) : launch_act<float, kMaxOut - 2>(g, grid, s);
     else if (obs_dtype == UAVENV_OBS_PACKED)
         rc = small ? launch_act_packed<4>(g, grid, s) : launch_act_packed<kMaxOut - 2>(g, grid, s);
     else rc = small ? launch_act<__half, 4>(g, grid, s) : launch_act<__half, kMaxOut - 2>(g, grid, s);

@@ -167,7 +167,9 @@ class FusedDQNLearner:
 
     def __init__(self, param: dict, kind: str = "dqn", device="cuda:0", lr: Optional[float] = None,
                  gamma: Optional[float] = None, update_loop: Optional[int] = None, loss: str = "mse",
-                 betas=(0.9, 0.999), eps: float = 1e-8):
+                 betas=(0.9, 0.999), eps: float = 1e-8, mfma: str = "f32"):
+        """mfma = "f16": the matrix products of act / learn run on the f16 MFMA with f32 accumulation (BASELINE
+        configs[2]); master weights, Adam and everything else stay f32.  Needs an f16 or packed ring, <= 4 outputs."""
         import ctypes as C
         from . import _lib
         assert kind in KINDS
@@ -196,7 +198,9 @@ class FusedDQNLearner:
         self._bind(self.q_local, self.flat[0], hid, w)
         self._bind(self.q_target, self.flat[1], hid, w)
         self.net = _lib.UavDqnNet(self.flat[0].data_ptr(), self.flat[1].data_ptr(), self.flat[2].data_ptr(),
-                                  self.flat[3].data_ptr(), w, hid, self.n_actions, 1 if self.dueling else 0)
+                                  self.flat[3].data_ptr(), w, hid, self.n_actions, 1 if self.dueling else 0,
+                                  _lib.MFMA_F16 if mfma == "f16" else _lib.MFMA_F32, 0)
+        self.mfma = mfma
         rc = self.lib.uavenv_dqn_num_params(C.byref(self.net))
         if rc != self.P:
             raise _lib.UavEnvError(f"parameter count mismatch {rc} != {self.P}")

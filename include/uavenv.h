@@ -228,11 +228,17 @@ int uavenv_per_fill(const UavPer *per, int64_t first, int64_t count, double prio
 /* ---- fused DQN-family learner for the reference's Q-MLPs (BaseClass/BaseCNN.py:93-139, w=100, hid=64) ---------- */
 /* Flat f32 parameter blocks in HBM (16-byte aligned), layout [W1 hid*w][b1 hid][W2 n2*hid][b2 n2] with n2 = n_actions
  * (+1 value row for the dueling VAnet2: rows 0..A-1 = fc_A, row A = fc_V).  m / v are Adam's moments (same layout). */
+#define UAVENV_MFMA_F32 0            /* f32 operands on v_mfma_f32_16x16x4_f32: the reference's precision */
+#define UAVENV_MFMA_F16 1            /* f16 operands (fc1 weights, observations, H / dH of the gradient products) on
+                                        v_mfma_f32_16x16x32_f16, f32 accumulate; master weights, Adam, layer 2, the TD target
+                                        and the loss stay f32.  f16 / packed rings, at most 4 layer-2 outputs. */
 typedef struct UavDqnNet {
     float *local;     /* q_local  */
     float *target;    /* q_target */
     float *m, *v;
     int32_t w, hid, n_actions, dueling;
+    int32_t mfma_dtype;   /* UAVENV_MFMA_F32 / UAVENV_MFMA_F16: operand type of the fused kernels' matrix products */
+    int32_t reserved0;
 } UavDqnNet;
 
 int uavenv_dqn_num_params(const UavDqnNet *net);

@@ -291,3 +291,50 @@ def test_fused_learner_and_act_with_nine_actions():
         for (k, a), (_, b) in zip(T.q_local.state_dict().items(), F.q_local.state_dict().items()):
             assert (a - b).abs().max().item() <= 2e-5, (kind, k)
     env.close()
+
+
+@pytest.mark.parametrize("obs", ["f16", "packed"])
+@pytest.mark.parametrize("kind,net", [("dueling", "VAnet2"), ("dqn", "Qnet2")])
+def test_f16_mfma_learner_against_the_f32_mfma_learner(obs, kind, net):
+    """BASELINE configs[2] ("fp16 Q-net MFMA"): FusedDQNLearner(mfma="f16") -- fc1 weights, observations and the H / dH
+    operands of the gradient products rounded to f16, f32 accumulation, everything else f32 -- against the f32-MFMA
+    learner on the SAME ring, same weights, same samples.  Stated bars (f16 has an 11-bit significand, 2^-11 = 4.9e-4
+    per operand; errors average over K = 100 / 64 terms):
+      Q values     <= 2e-2 absolute on |Q| <= ~10 (packed rings: observations go f32 -> f16 on the way in);
+      loss         <= 3e-3 relative;
+      raw gradient relative L2 error <= 1e-2, cosine >= 0.9999;
+      after 20 updates from the same start: losses track within 2 %."""
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    n = 2048
+    env = make_city26_env(n, obs_dtype="packed" if obs == "packed" else torch.float16)
+    ring = DeviceReplayRing(env, 6 * n, discrete=True)
+    ring.reset(seed=4)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(5):
+        ring.current_action().copy_(torch.randint(0, 3, (n,), generator=gen, device="cuda", dtype=torch.int32))
+        ring.step_env(auto_reset=True)
+    torch.manual_seed(0)
+    A = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
+    B = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0", mfma="f16")
+    B.flat.copy_(A.flat)
+    A.force_split = B.force_split = True                # exposes the raw gradient bucket
+    qa, qb = torch.empty(n, 3, device="cuda"), torch.empty(n, 3, device="cuda")
+    A.act(ring.current_obs(), 0.0, 3, 0, q_out=qa)
+    B.act(ring.current_obs(), 0.0, 3, 0, q_out=qb)
+    assert (qa - qb).abs().max().item() <= 2e-2, (qa - qb).abs().max().item()
+    la = float(A.learn_from_ring(ring, 2048, 5, 0))
+    lb = float(B.learn_from_ring(ring, 2048, 5, 0))
+    assert abs(la - lb) <= 3e-3 * abs(la), (la, lb)
+    ga, gb = A.raw[:A.P].double(), B.raw[:B.P].double()
+    rel = float((ga - gb).norm() / ga.norm())
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert rel <= 1e-2 and cos >= 0.9999, (rel, cos)
+    assert float(A.raw[A.P + 1]) == float(B.raw[B.P + 1]) == 2048.0         # valid count
+    for it in range(1, 20):
+        la = float(A.learn_from_ring(ring, 2048, 5, it))
+        lb = float(B.learn_from_ring(ring, 2048, 5, it))
+        assert abs(la - lb) <= 2e-2 * abs(la), (it, la, lb)
+    assert torch.isfinite(B.flat).all()
+    env.close()
