@@ -67,7 +67,7 @@ class UavLoopConfig(C.Structure):
                 ("seed", C.c_uint64), ("counter", C.c_uint64),
                 ("eps", C.c_float), ("gamma", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("adam_eps", C.c_float), ("step_flags", C.c_uint32), ("partials_dev", C.c_void_p),
-                ("loss_dev", C.c_void_p), ("time_every", C.c_int32), ("reserved0", C.c_int32)]
+                ("loss_dev", C.c_void_p), ("info_dev", C.c_void_p), ("time_every", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class UavLoopCursor(C.Structure):

@@ -111,7 +111,8 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
             if (e0 && e1) (void)hipEventRecord(e0, s);
         }
         rc = uavenv_step(c.env, act_t, UAVENV_ACT_INDEX_I32, obs_n, nullptr, R.reward + (size_t)t * n, R.done + (size_t)t * n,
-                         nullptr, nullptr, R.valid ? R.valid + (size_t)t * n : nullptr, nullptr, nullptr, c.step_flags, s);
+                         nullptr, c.info_dev ? c.info_dev + (size_t)t * n : nullptr, R.valid ? R.valid + (size_t)t * n : nullptr,
+                         nullptr, nullptr, c.step_flags, s);
         if (timed && e0 && e1) {
             (void)hipEventRecord(e1, s);
             l->ev.push_back(e0);

@@ -257,6 +257,96 @@ class FusedDQNLearner:
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         w /= dist.get_world_size()
 
+    # -- checkpoints: torch.optim.Adam's state-dict format around the kernels' flat moment blocks -------------------
+    def _adam_view(self):
+        """A torch.optim.Adam over q_local's parameters whose state mirrors the flat m / v blocks and the update count
+        (never stepped: it exists so that save() / Load_Mod() exchange `optimizer` dicts with the reference's
+        {'model', 'optimizer', 'epoch'} checkpoints, Trainer/DuelingDQN_Trainer.py:74-84)."""
+        opt = torch.optim.Adam(self.q_local.parameters(), lr=self.lr, betas=self.betas, eps=self.eps)
+        base = self.flat[0].data_ptr()
+        for p in self.q_local.parameters():
+            off = (p.data_ptr() - base) // 4
+            n = p.numel()
+            opt.state[p] = {"step": torch.tensor(float(self.epoch)),
+                            "exp_avg": self.flat[2][off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.flat[3][off:off + n].view_as(p).clone()}
+        return opt
+
+    def optimizer_state_dict(self) -> dict:
+        return self._adam_view().state_dict()
+
+    def load_optimizer_state_dict(self, sd: dict):
+        opt = self._adam_view()
+        opt.load_state_dict(sd)
+        base = self.flat[0].data_ptr()
+        with torch.no_grad():
+            for p in self.q_local.parameters():
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                off = (p.data_ptr() - base) // 4
+                n = p.numel()
+                self.flat[2][off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.flat[3][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+
+    class _OptimFacade:
+        def __init__(self, owner):
+            self._o = owner
+
+        def state_dict(self):
+            return self._o.optimizer_state_dict()
+
+        def load_state_dict(self, sd):
+            self._o.load_optimizer_state_dict(sd)
+
+    @property
+    def optim(self):
+        return FusedDQNLearner._OptimFacade(self)
+
+    def q_values(self, states: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            return self.q_local(states.float())
+
+    def learn(self, batch: dict) -> torch.Tensor:
+        """One update on an arbitrary pre-sampled batch (the reference's update(transition_dict) path): the batch becomes
+        a two-frame ring (frame 0 = states, frame 1 = next states), padded with invalid rows to a multiple of 64."""
+        C, _lib = self._C, self._lib_mod
+        st = batch["states"].to(self.device, torch.float32).reshape(-1, _lib.OBS_DIM)
+        b = st.shape[0]
+        bp = (b + 63) // 64 * 64
+        if not hasattr(self, "_adhoc"):
+            self._adhoc = {}
+        buf = self._adhoc.get(bp)
+        if buf is None:
+            d = self.device
+            buf = dict(obs=torch.zeros((2, bp, _lib.OBS_DIM), dtype=torch.float32, device=d),
+                       action=torch.zeros((2, bp), dtype=torch.int32, device=d),
+                       reward=torch.zeros((2, bp), dtype=torch.float32, device=d),
+                       done=torch.zeros((2, bp), dtype=torch.uint8, device=d),
+                       valid=torch.zeros((2, bp), dtype=torch.uint8, device=d),
+                       idx=torch.stack([torch.zeros(bp, dtype=torch.int32), torch.arange(bp, dtype=torch.int32)], 1)
+                       .contiguous().to(d))
+            buf["c"] = _lib.UavReplayRing(buf["obs"].data_ptr(), buf["action"].data_ptr(), buf["reward"].data_ptr(),
+                                          buf["done"].data_ptr(), buf["valid"].data_ptr(), 2, bp, _lib.OBS_F32, 1)
+            self._adhoc[bp] = buf
+        buf["obs"][0, :b].copy_(st)
+        buf["obs"][1, :b].copy_(batch["next_states"].to(self.device, torch.float32).reshape(-1, _lib.OBS_DIM))
+        buf["action"][0, :b].copy_(batch["actions"].reshape(-1).to(self.device, torch.int32))
+        buf["reward"][0, :b].copy_(batch["rewards"].reshape(-1).to(self.device, torch.float32))
+        buf["done"][0, :b].copy_((batch["dones"].reshape(-1) != 0).to(self.device, torch.uint8))
+        v = batch.get("valid")
+        buf["valid"][0].zero_()
+        if v is None:
+            buf["valid"][0, :b] = 1
+        else:
+            buf["valid"][0, :b].copy_((v.reshape(-1) != 0).to(self.device, torch.uint8))
+
+        class _R:            # what learn_from_ring needs of a ring
+            pass
+        r = _R()
+        r._c, r.head, r.filled = buf["c"], 1, 1
+        return self.learn_from_ring(r, bp, 0, 0, explicit_idx=buf["idx"])
+
     def act(self, obs: torch.Tensor, eps: float, seed: int, counter: int, index_out: torch.Tensor = None,
             steer_out: torch.Tensor = None, q_out: torch.Tensor = None):
         """Q(s) + epsilon-greedy for all rows of obs [n,100] in one launch."""

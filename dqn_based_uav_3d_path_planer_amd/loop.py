@@ -18,7 +18,7 @@ from .replay import DeviceReplayRing
 class HotLoop:
     def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
                  counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
-                 time_every: int = 0):
+                 time_every: int = 0, info: torch.Tensor = None):
         if not ring.discrete:
             raise ValueError("HotLoop drives the discrete (DQN-family) path")
         if batch % 64:
@@ -48,6 +48,10 @@ class HotLoop:
         cfg.partials_dev = self._partials.data_ptr()
         cfg.loss_dev = learner.loss.data_ptr()
         cfg.time_every = int(time_every)
+        if info is not None:        # [frames, N] uint8: the info code of every transition (episode statistics)
+            assert info.dtype == torch.uint8 and tuple(info.shape) == (ring.frames, env.N) and info.is_contiguous()
+            cfg.info_dev = info.data_ptr()
+        self._info = info
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_loop_create")
         self.counter = int(counter)

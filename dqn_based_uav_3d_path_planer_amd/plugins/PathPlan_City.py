@@ -2,7 +2,16 @@
 same duck type simulator.py touches (run_eposide, Agents, Trainer, run_XML_scene, Threaten_rate, Move_Agent,
 update, Check_uav_Done, result-dict keys), backed by `num_envs` vectorised envs in HBM.  Optional new tags
 (all default to the reference's behaviour): <num_envs>, <device>, <obs_dtype>, <scenario_bank>, <seed>.
-Out of scope and therefore absent: rendering, MySQL, federated averaging."""
+Out of scope and therefore absent: rendering, MySQL.
+
+Two ways through run_eposide:
+  * the FUSED path (one UAV per env, a DQN-family trainer on the fused learner, a real GPU backend; <fast_path>0</fast_path>
+    turns it off): observations are packed rows in a DeviceReplayRing, and the act -> step -> store -> sample -> learn
+    cycle of Envs/PathPlan_City.py:364-385 is enqueued by csrc/loop.hip (HotLoop) -- the same kernels, the same order and
+    the same replay as bench.py.  The host looks at the device every <done_check> steps (default 8) to see whether every
+    agent has finished; the episode's counters come from the ring's info / valid planes;
+  * the general path: every trainer plugin (SAC, several UAVs per env, prioritised replay, the PyTorch learner) through
+    batched tensors, one sync per step."""
 from __future__ import annotations
 
 import os
@@ -13,6 +22,31 @@ import torch
 import _backend
 from dqn_based_uav_3d_path_planer_amd.compat import Loc, None2Value, XML2Dict
 from dqn_based_uav_3d_path_planer_amd.factories import AgentFactory, ThreatenFactory, TrainerFactory
+
+
+class _RingMemoryView:
+    """What the reference's callers read off `Trainer.replay_memory` when the replay is the device ring."""
+
+    class _Len:
+        def __init__(self, ring):
+            self._r = ring
+
+        def __len__(self):
+            return len(self._r)
+
+    def __init__(self, ring):
+        self.ring = ring
+        self.buffer = self.memory = _RingMemoryView._Len(ring)
+        self.capacity = ring.capacity
+
+    def __len__(self):
+        return len(self.ring)
+
+    def sample_tensors(self, batch_size: int) -> dict:
+        self._n = getattr(self, "_n", 0) + 1
+        b = self.ring.sample(batch_size, seed=0x51ED, counter=self._n)
+        return dict(states=b["states"], actions=b["actions"].long(), rewards=b["rewards"], next_states=b["next_states"],
+                    dones=b["dones"], valid=b["valid"])
 
 
 class PathPlan_City:
@@ -46,7 +80,16 @@ class PathPlan_City:
         b = np.array([[t.position.x, t.position.y, t.position.z, t._R, t._H] for t in self.buildings], dtype=np.float64)
         obs_dtype = torch.float16 if (param.get("obs_dtype") or "f32") == "f16" else torch.float32
         trainer_xml = os.path.normpath(agents_params["Trainer"].get("Trainer_path"))
-        n_actions = int(None2Value(XML2Dict(trainer_xml).get("Trainer").get("output"), 3))
+        tcfg = XML2Dict(trainer_xml).get("Trainer")
+        n_actions = int(None2Value(tcfg.get("output"), 3))
+        # the fused path keeps observations packed (15 scalars + 80 flag bits per row); decided before the backend exists
+        self._want_fast = (int(None2Value(param.get("fast_path"), 1)) != 0 and self.num_UAV == 1 and
+                           (tcfg.get("Trainer_Type") in ("DQN_Trainer", "DDQN_Trainer", "DuelingDQN_Trainer")) and
+                           int(None2Value(tcfg.get("IsPriority_Replay"), 0)) == 0 and param.get("obs_dtype") is None and
+                           int(None2Value(tcfg.get("Batch_Size"), 128)) % 64 == 0 and
+                           int(None2Value(tcfg.get("fused"), 1)) != 0 and torch.cuda.is_available())
+        if self._want_fast:
+            obs_dtype = "packed"
         fp = (uav_params.get("Power_param") or {}).get("Fly_power") or {}
         power = tuple(float(fp.get(k)) for k in ("P_i", "v_0", "d_0", "rho", "s", "A", "P_b", "F_b")) \
             if all(fp.get(k) is not None for k in ("P_i", "v_0", "d_0", "rho", "s", "A", "P_b", "F_b")) else None
@@ -78,11 +121,23 @@ class PathPlan_City:
         self.FL_Loop = int(None2Value(param.get("FL_Loop"), 3))
         self.executed_time = 0
         self._state_cache = None
-        self._obs = None
+        self._state0 = None
+        self._obs_raw = None
         self._episode = 0
+        self._ring = self._hot = self._info = None
+        self.done_check = max(1, int(None2Value(param.get("done_check"), 8)))
+        tr0 = self.Agents[0].Trainer
+        self.fast = bool(self._want_fast and getattr(self.backend, "packed", False) and getattr(tr0, "fused", False))
+        if self._want_fast and not self.fast:
+            raise ValueError("fast path requested but the backend / trainer cannot take it (set <fast_path>0</fast_path>)")
+        if self.fast:
+            from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+            self._ring = DeviceReplayRing(self.backend, max(tr0.replay_size, 2 * self.backend.N), discrete=True)
+            self._info = torch.zeros((self._ring.frames, self.backend.N), dtype=torch.uint8, device=self.backend.device)
+            tr0.replay_memory = _RingMemoryView(self._ring)
         # UAV.path of env 0 (UAV.py:431) and the path.csv the reference rewrites at every terminal (:461-464,:479-483,
         # :505-509).  One 16-double read-back of env 0's agents per step; <record_path>0</record_path> turns it off.
-        self.record_path = int(None2Value(param.get("record_path"), 1))
+        self.record_path = int(None2Value(param.get("record_path"), 0 if self.fast else 1))
         self.path_csv = None2Value(param.get("path_csv"), "path.csv")
         self._paths = [[] for _ in range(self.num_UAV)]
         self._path_done = [False] * self.num_UAV
@@ -105,8 +160,20 @@ class PathPlan_City:
             raise ValueError("no <scenario_bank> given and no planner available for this world")
 
     # ---- helpers used by the UAV views -------------------------------------------------------------------
+    @property
+    def _obs(self):
+        """[N, 100] observation rows as the host-side code reads them (packed backends are expanded on demand)."""
+        if self._obs_raw is None:
+            return None
+        return self.backend.unpack(self._obs_raw) if getattr(self.backend, "packed", False) else self._obs_raw
+
+    @_obs.setter
+    def _obs(self, v):
+        self._obs_raw = v
+
     def _invalidate(self):
         self._state_cache = None
+        self._state0 = None
 
     def _states(self):
         if self._state_cache is None:
@@ -114,6 +181,10 @@ class PathPlan_City:
         return self._state_cache
 
     def _state_row(self, e, j):
+        if e == 0 and self._state_cache is None:            # the scalar accessors of the UAV views read env 0 only
+            if self._state0 is None:
+                self._state0 = self.backend.get_state(0, self.num_UAV)
+            return self._state0[j]
         return self._states()[0][e * self.num_UAV + j]
 
     def _subgoals(self, e, j):
@@ -185,7 +256,9 @@ class PathPlan_City:
         self._path_done = [False] * self.num_UAV
 
     def Check_uav_Done(self):
-        return bool(self._states()[0][:, 10].all())
+        if self._state_cache is not None:
+            return bool(self._state_cache[0][:, 10].all())
+        return bool(self.backend.get_state(0, self.backend.N)[:, 10].all())
 
     def Move_Agent(self, index: int, action):
         """BaseEnv.py:123-137 -> (next_state, reward, done, info) of env 0."""
@@ -233,9 +306,67 @@ class PathPlan_City:
             self.result["average_score"] += info["average_score"] / max(len(train_info), 1)
             self.result["step"] += info["step"]
 
+    def _run_eposide_fused(self, eps_rate):
+        """run_eposide on the fused path: HotLoop enqueues done_check steps of act -> step (+ replay write) -> sample ->
+        learn at a time; the host then reads, in one transfer, how many agents each of those steps still moved and the
+        info counts.  A step that moved nobody means every agent had finished before it: the episode ended there (the
+        env kernels leave finished agents untouched, so the up to done_check - 1 surplus steps change no env state; the
+        learner does take that many extra replay updates -- the one deviation from the reference's loop, which breaks
+        right after the update of the last moving step, PathPlan_City.py:456-459)."""
+        from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+        self.Reset_Result(eps_rate)
+        uav = self.Agents[0]
+        tr, ring = uav.Trainer, self._ring
+        self._episode += 1
+        self.backend.reset(self.seed + self._episode, obs=ring.obs[ring.head])      # UAV.reset everywhere; the replay stays
+        self._obs_raw = ring.obs[ring.head]
+        self._invalidate()
+        self._paths, self._path_done = [[] for _ in range(self.num_UAV)], [False] * self.num_UAV
+        if self._hot is None:
+            self._hot = HotLoop(ring, tr.learner, tr.Batch_Size if tr.Is_Train else 0, seed=self.seed, eps=eps_rate,
+                                learn_start=tr.Batch_Size + 1, auto_reset=False, skip_done=True, info=self._info)
+        self._hot.set_eps(eps_rate if tr.Is_Train else 0.0)
+        k = 1 if self.record_path else min(self.done_check, ring.frames - 2)
+        n_steps, ended = 0, False
+        dev = self.backend.device
+        while not ended:
+            t0 = ring.head
+            self._hot.run(k)
+            fr = (t0 + torch.arange(k, device=dev)) % ring.frames
+            v = ring.valid[fr].bool()                                                # [k, N] agents moved by each step
+            inf = self._info[fr]
+            stats = torch.stack([v.sum(1)] + [((inf == c) & v).sum(1) for c in range(3)], 1).cpu().numpy()   # one sync
+            for i in range(k):
+                if stats[i, 0] == 0:                                                 # nobody moved: finished before this step
+                    ended = True
+                    break
+                n_steps += 1
+                self.result["normal"] += int(stats[i, 1])
+                self.result["success"] += int(stats[i, 2])
+                self.result["lose"] += int(stats[i, 3])
+            self._obs_raw = ring.obs[ring.head]
+            self._invalidate()
+            if self.record_path:
+                self._record_paths(range(self.num_UAV))
+        tr.loss = tr.learner.loss
+        item = {"loss": tr.learner.loss, "sum_epoch": tr.epoch, "score": uav.score, "average_score": uav.score,
+                "step": uav.Step, "energy_cost": uav.energy_cost_total, "task_collect": uav.task_collect,
+                "Energy_Efficent": uav.task_collect / (uav.energy_cost_total + 0.001), "UE_waiting_time": 0}
+        self.Train_statistics([item])
+        if tr.Is_Train and tr.epoch // tr.save_loop != getattr(self, "_saved_at", 0):   # save() as _learn does, per save_loop updates
+            self._saved_at = tr.epoch // tr.save_loop
+            tr.save()
+        self.steps_last_episode = n_steps
+        self.epoch += 1
+        if self.epoch % self.print_loop == 0:
+            uav.record_list()
+        return self.result
+
     def run_eposide(self, eps_rate=0.1):
         """PathPlan_City.py:410-478 (off-policy branch) for all vectorised envs at once: reset, then
         act -> step -> store -> sample -> learn per time step until every agent of every env is done."""
+        if self.fast:
+            return self._run_eposide_fused(eps_rate)
         self.Reset_Result(eps_rate)
         self.Scene_Random_Reset()
         names = ("normal", "success", "lose")
@@ -276,7 +407,8 @@ class PathPlan_City:
                 if len(mem.buffer) > uav.Trainer.Batch_Size:                                  # :383-385
                     b = mem.sample_tensors(uav.Trainer.Batch_Size)
                     uav.transition_dict = {"states": b["states"], "actions": b["actions"], "next_states": b["next_states"],
-                                           "rewards": b["rewards"], "dones": b["dones"], "idx": None, "weights": None}
+                                           "rewards": b["rewards"], "dones": b["dones"], "idx": b.get("idx"),
+                                           "weights": b.get("weights")}
             train_info = self.update()                                                        # :456
             if self.Check_uav_Done():
                 break

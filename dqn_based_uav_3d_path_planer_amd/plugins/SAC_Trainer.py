@@ -1,5 +1,6 @@
-"""Drop-in for Trainer/SAC_Trainer.py, continuous branch (IS_Continuous=1; the discrete branch and prioritised
-replay are outside the hot path).  Same XML contract as the shipped config/Trainer.xml."""
+"""Drop-in for Trainer/SAC_Trainer.py, continuous branch (IS_Continuous=1; the discrete branch is outside the hot
+path).  IsPriority_Replay = 1 selects the device prioritised replay (replay.DevicePER).
+Same XML contract as the shipped config/Trainer.xml."""
 import os
 
 import numpy as np
@@ -18,8 +19,7 @@ class SAC_Trainer:
         self.IS_Continuous = int(sp.get("IS_Continuous"))
         if self.IS_Continuous != 1:
             raise ValueError("only the continuous SAC branch is on the MI355X hot path")
-        if int(None2Value(param.get("IsPriority_Replay"), 0)) != 0:
-            raise ValueError("prioritised replay is a 'next' row (SURVEY.md section 8f), not built yet")
+        self.IsPriority_Replay = int(None2Value(param.get("IsPriority_Replay"), 0))
         self.replay_size = int(None2Value(param.get("replay_size"), 1000))
         self.Batch_Size = int(None2Value(param.get("Batch_Size"), 128))
         self.save_loop = int(None2Value(param.get("save_loop"), 10))
@@ -28,7 +28,7 @@ class SAC_Trainer:
         self.device = torch.device(dev)
         self.learner = SACLearner(param, self.device)
         self.w = int(param.get("actor").get("w"))
-        self.replay_memory = VecReplayMemory(self.replay_size, self.device, self.w)
+        self.replay_memory = VecReplayMemory(self.replay_size, self.device, self.w, prioritized=self.IsPriority_Replay == 1)
         ad = int(param.get("critic").get("action_dim"))
         self.replay_memory.actions = torch.zeros((self.replay_size, ad), dtype=torch.float32, device=self.device)
         self.model_dir = param.get("model_dir") or os.path.join(os.getcwd(), "Mod")
@@ -67,7 +67,11 @@ class SAC_Trainer:
         t = lambda x: torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(self.device, torch.float32)  # noqa
         batch = dict(states=t(states), actions=t(transition_dict["actions"]), rewards=t(transition_dict["rewards"]),
                      next_states=t(transition_dict["next_states"]), dones=t(transition_dict["dones"]))
-        if self.Is_Train:
+        w, idx = transition_dict.get("weights"), transition_dict.get("idx")
+        if self.Is_Train and w is not None and idx is not None:                    # prioritised replay, :336-352
+            self.loss = self.learner.learn(batch, is_weights=torch.as_tensor(w).to(self.device))
+            self.replay_memory.batch_update(idx, self.learner.abs_errors)
+        elif self.Is_Train:
             self.loss = self.learner.learn(batch)
         else:
             self.learner.epoch += 1

@@ -17,7 +17,7 @@ import torch
 
 from dqn_based_uav_3d_path_planer_amd.compat import None2Value
 from dqn_based_uav_3d_path_planer_amd.factories import NetworkFactory
-from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
+from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
 
 
 class _LenProxy:
@@ -33,8 +33,15 @@ class _LenProxy:
 class VecReplayMemory:
     """ReplayMemory (replay_buffer.py:28-54) as a tensor ring on the trainer's device, with batched insert."""
 
-    def __init__(self, capacity: int, device, obs_dim: int = 100):
+    def __init__(self, capacity: int, device, obs_dim: int = 100, prioritized: bool = False):
         self.capacity, self.device, self.obs_dim = int(capacity), torch.device(device), obs_dim
+        # IsPriority_Replay == 1 (BaseClass/replay_buffer.py:121-223 ReplayTree): priorities live in a DevicePER next to
+        # the tensors; new transitions get the reference's push priority (|0| + epsilon) ** alpha
+        self.per = None
+        if prioritized:
+            from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+            self.per = DevicePER(self.capacity, device=self.device, tree_order=False)
+        self._last_slots = None
         self.position = 0
         self.size = 0
         self.buffer = _LenProxy(self)
@@ -65,8 +72,16 @@ class VecReplayMemory:
             n = self.capacity
         idx = (self.position + torch.arange(n, device=self.device)) % self.capacity      # FIFO overwrite (deque maxlen)
         self.states[idx], self.next_states[idx], self.actions[idx], self.rewards[idx], self.dones[idx] = s, ns, a, r, d
+        if self.per is not None:                                                   # ReplayTree.push(error = 0), :136-144
+            first = self.position
+            head = min(n, self.capacity - first)
+            self.per.fill(first, head, 0.0)
+            if n > head:
+                self.per.fill(0, n - head, 0.0)
         self.position = (self.position + n) % self.capacity
         self.size = min(self.size + n, self.capacity)
+        if self.per is not None:
+            self.per.n_entries = self.size
 
     def add(self, state, action, reward, next_state, done):                       # replay_buffer.py:41-42
         a = int(action.item()) if torch.is_tensor(action) else int(np.asarray(action).reshape(-1)[0])
@@ -81,12 +96,22 @@ class VecReplayMemory:
     def sample_tensors(self, batch_size: int) -> dict:
         if self.size <= 0:
             raise ValueError("sample from an empty replay memory")
+        if self.per is not None:                                                   # ReplayTree.sample, :146-180
+            self._per_calls = getattr(self, "_per_calls", 0) + 1
+            slots, w, _ = self.per.sample(batch_size, seed=0x9E37, counter=self._per_calls)
+            self._last_slots = slots
+            return dict(states=self.states[slots], actions=self.actions[slots], rewards=self.rewards[slots],
+                        next_states=self.next_states[slots], dones=self.dones[slots], idx=slots, weights=w.float())
         if batch_size <= self.size:
             idx = torch.randperm(self.size, device=self.device)[:batch_size]      # random.sample: without replacement
         else:
             idx = torch.randint(0, self.size, (batch_size,), device=self.device)
         return dict(states=self.states[idx], actions=self.actions[idx], rewards=self.rewards[idx],
                     next_states=self.next_states[idx], dones=self.dones[idx])
+
+    def batch_update(self, slots, abs_errors):                                    # ReplayTree.batch_update, :215-222
+        if self.per is not None:
+            self.per.update(slots, abs_errors)
 
     def sample2(self, batch_size):                                                # replay_buffer.py:48-51
         b = self.sample_tensors(batch_size)
@@ -117,9 +142,23 @@ class BaseDQNTrainer:
         dev = param.get("device") or ("cuda:0" if torch.cuda.is_available() else "cpu")
         self.device = torch.device(dev)
         self.NetworkFactory = NetworkFactory()
-        self.learner = DQNLearner(param, self.KIND, device=self.device, lr=self.LEARNING_RATE, gamma=self.gamma,
-                                  update_loop=self.Update_loop, loss=param.get("loss") or "mse")
-        self.replay_memory = VecReplayMemory(self.replay_size, self.device, self.w)
+        self.IsPriority_Replay = int(None2Value(param.get("IsPriority_Replay"), 0))
+        # The fused HIP learner (csrc/learner.hip) when the net has the reference's shape and a GPU is there; the
+        # PyTorch-ROCm learner otherwise (<fused>0</fused> forces it).  Same attribute surface either way.
+        hid = int(None2Value(param.get("hiden_dim"), 64))
+        n2 = self.output + (1 if self.KIND == "dueling" else 0)
+        want = param.get("fused")
+        fusable = (self.device.type == "cuda" and torch.cuda.is_available() and self.w == 100 and hid == 64 and
+                   self.output >= 2 and n2 + 2 <= 16 and self.IsPriority_Replay == 0)
+        self.fused = fusable and (want is None or int(want) != 0)
+        loss_kind = param.get("loss") or "mse"
+        if self.fused:
+            self.learner = FusedDQNLearner(param, self.KIND, device=self.device, lr=self.LEARNING_RATE, gamma=self.gamma,
+                                           update_loop=self.Update_loop, loss=loss_kind, mfma=param.get("mfma") or "f32")
+        else:
+            self.learner = DQNLearner(param, self.KIND, device=self.device, lr=self.LEARNING_RATE, gamma=self.gamma,
+                                      update_loop=self.Update_loop, loss=loss_kind)
+        self.replay_memory = VecReplayMemory(self.replay_size, self.device, self.w, prioritized=self.IsPriority_Replay == 1)
         self.mse_loss = torch.nn.MSELoss()
         self.model_dir = param.get("model_dir") or os.path.join(os.getcwd(), "Mod")
         self.loss = 0
@@ -176,7 +215,11 @@ class BaseDQNTrainer:
 
     # -- learning ------------------------------------------------------------------------------------
     def _learn(self, batch: dict):
-        if self.Is_Train:
+        if self.Is_Train and batch.get("weights") is not None and batch.get("idx") is not None:
+            # prioritised replay: importance weights into the loss, |TD error| back into the priorities
+            self.loss, abs_err = self.learner.learn_weighted(batch, batch["weights"].to(self.device))
+            self.replay_memory.batch_update(batch["idx"], abs_err)
+        elif self.Is_Train:
             self.loss = self.learner.learn(batch)          # epoch += 1, hard update every Update_loop inside
         else:
             self.learner.epoch += 1
@@ -196,6 +239,8 @@ class BaseDQNTrainer:
                      rewards=t(transition_dict["rewards"], torch.float32).reshape(-1),
                      next_states=t(transition_dict["next_states"], torch.float32),
                      dones=t(transition_dict["dones"], torch.float32).reshape(-1))
+        if transition_dict.get("weights") is not None and transition_dict.get("idx") is not None:
+            batch["weights"], batch["idx"] = transition_dict["weights"], transition_dict["idx"]
         result = {"sum_epoch": self.epoch + 1, "loss": self.loss}    # the reference reports the PREVIOUS loss
         self._learn(batch)
         return result

@@ -297,6 +297,7 @@ typedef struct UavLoopConfig {
     uint32_t step_flags;         /* UAVENV_STEP_* for every step */
     float *partials_dev;         /* uavenv_dqn_partial_rows(batch) x uavenv_dqn_partial_stride(net) floats of scratch */
     float *loss_dev;             /* device scalar: mean loss of the last update */
+    uint8_t *info_dev;           /* nullable: frames x N plane receiving uavenv_step's info codes (frame-major like reward) */
     int32_t time_every;          /* > 0: bracket the step kernel of every time_every-th step with HIP events */
     int32_t reserved0;
 } UavLoopConfig;
