@@ -74,9 +74,10 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--env-only-iters", type=int, default=200)
     p.add_argument("--cell", type=float, default=0.0, help="broad-phase cell size in metres (0 = library default)")
-    p.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+    p.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                    help="BASELINE.json configs[] preset: 2 = 16384 envs DQN (the benchmark line); 3 = 65536 envs, "
-                        "DuelingDQN + double-DQN target, f16 MFMA Q-net; 5 = 32768 envs per GPU (262144 over 8)")
+                        "DuelingDQN + double-DQN target, f16 MFMA Q-net; 4 = 32768 envs x 4 UAVs, APF on, SAC continuous "
+                        "(one trainer per UAV slot); 5 = 32768 envs per GPU (262144 over 8)")
     p.add_argument("--apf", action="store_true", help="diagnostic (env-only): APF on, buildings moving with seeded "
                    "velocities U(-1,1)^2 (BASELINE configs[3]'s env settings)")
     p.add_argument("--uav-per-env", type=int, default=1, help="diagnostic (env-only): UAVs per env")
@@ -94,6 +95,8 @@ def parse():
     a = p.parse_args()
     if a.config == 3:
         a.envs, a.batch, a.trainer, a.mfma = 65536, 65536, "dueling", "f16"
+    elif a.config == 4:
+        a.envs, a.batch, a.obs_dtype, a.trainer = 32768, 32768, "packed", "sac"
     elif a.config == 5:
         a.envs, a.batch = 32768, 32768
     return a
@@ -189,8 +192,157 @@ def committed_profile(args) -> dict:
         return {}
 
 
+def run_config4(args, dev):
+    """BASELINE configs[3]: 4 UAVs per env x 32 768 envs, APF avoidance on (every building moving), SAC_Trainer with
+    continuous actions, one trainer per UAV slot (Envs/PathPlan_City.py:63-68).  One pass = SAC act for the four slots
+    (PyTorch-ROCm) -> fused env step with APF into the packed replay ring -> for every slot: sample, one SAC update
+    (Trainer/SAC_Trainer.py:325-379, PyTorch-ROCm ops; rows of agents that were waiting for their team-mates carry
+    weight 0 in the critic losses)."""
+    import ctypes as C
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    from dqn_based_uav_3d_path_planer_amd.sac import SACLearner
+    U, envs = 4, args.envs
+    env = make_city26_env(envs, bank="gpu", bank_size=max(envs, 4096), bank_seed=42, device=dev, obs_dtype="packed",
+                          uav_per_env=U, apf_enabled=1)
+    v = np.random.default_rng(42).uniform(-1.0, 1.0, (len(env.buildings), 3))
+    v[:, 2] = 0.0
+    env.set_buildings(env.buildings, velocities=v)
+    ring = DeviceReplayRing(env, args.replay, discrete=False)
+    ring.reset(seed=1000)
+    a1_plane = torch.zeros((ring.frames, env.N), dtype=torch.float32, device=dev)      # second action component (:444-448)
+    sac_param = {"actor": {"NetWork": "PolicyNetContinuous_SAC", "w": "100", "action_bound": "1", "hiden_dim": "64",
+                           "output": "2", "lr": "0.0001"},
+                 "critic": {"NetWork": "QValueNetContinuous_SAC", "w": "100", "hiden_dim": "64", "action_dim": "2", "lr": "0.001"},
+                 "SAC_param": {"IS_Continuous": "1", "alpha_lr": "0.0001", "target_entropy": "1", "gamma": "0.99", "tau": "0.05"}}
+    torch.manual_seed(42)
+    torch.distributions.Distribution.set_default_validate_args(False)      # Normal(mu, std) otherwise syncs to check std > 0
+    graphed = os.environ.get("BENCH_SAC_GRAPH", "1") != "0"
+    learners = [SACLearner(sac_param, device=dev, capturable=graphed) for _ in range(U)]
+    B = args.batch
+    lib, counter = env.lib, [0]
+    draws = [torch.empty((B, 2), dtype=torch.int32, device=dev) for _ in range(U)]
+    flat = ring.obs.view(-1, ring.obs.shape[-1])
+
+    def update_slot(j):
+        """gather the drawn transitions of UAV slot j (packed rows -> f32) and take one SAC update"""
+        L = learners[j]
+        f, e = draws[j][:, 0].long(), draws[j][:, 1].long()
+        slot = f * env.N + e * U + j
+        nxt = ((f + 1) % ring.frames) * env.N + e * U + j
+        batch = dict(states=env.unpack(flat[slot]), next_states=env.unpack(flat[nxt]),
+                     actions=torch.stack([ring.action.view(-1)[slot], a1_plane.view(-1)[slot]], 1),
+                     rewards=ring.reward.view(-1)[slot], dones=ring.done.view(-1)[slot].float())
+        L.learn(batch, is_weights=ring.valid.view(-1)[slot].float())
+
+    def draw_slot(j):
+        _lib.check(lib.uavenv_replay_draw(ring.frames, envs, ring.head, ring.filled, B, 7 + j, counter[0], draws[j].data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
+
+    def act_and_step():
+        t = ring.head
+        obs = env.unpack(ring.current_obs()).view(envs, U, 100)
+        act = ring.current_action().view(envs, U)
+        a1 = a1_plane[t].view(envs, U)
+        for j, L in enumerate(learners):
+            a = L.act(obs[:, j])
+            act[:, j] = a[:, 0]
+            a1[:, j] = a[:, 1]
+        ring.step_env(auto_reset=True)
+
+    graphs = None
+    if graphed:
+        # One HIP graph per slot: gather + unpack + the ~150 kernels of SAC_Trainer.update, replayed with one launch.
+        # (Eager, the pass is host-bound: 20 ms of Python / launch overhead around < 2 ms of GPU work.)
+        try:
+            for _ in range(3):
+                act_and_step()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    for j in range(U):
+                        draw_slot(j)
+                        update_slot(j)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graphs = []
+            for j in range(U):
+                draw_slot(j)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    update_slot(j)
+                graphs.append(g_)
+            torch.cuda.synchronize(dev)
+        except Exception as ex:        # capture unsupported on this stack: fall back to eager updates
+            print("SAC graph capture failed, running eager:", repr(ex)[:200], file=sys.stderr)
+            graphs = None
+
+    def one_pass():
+        act_and_step()
+        for j in range(U):
+            draw_slot(j)
+            if graphs is not None:
+                graphs[j].replay()
+            else:
+                update_slot(j)
+        counter[0] += 1
+
+    pps = max(1, args.passes_per_step // 16)          # a pass is ~100x longer than config 2's
+    for _ in range(max(args.warmup, 1) * pps):
+        one_pass()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps * pps):
+        one_pass()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    n_pass = args.steps * pps
+    it = args.env_only_iters
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        ring.step_env(auto_reset=True)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    k_ms = e0.elapsed_time(e1) / it
+    prof = committed_profile(args)
+    k_prof = prof.get("k_step_ms")
+    k_use = max(k_ms, k_prof or 0.0)
+    algo = ALGO_BYTES_PER_AGENT_STEP + 2 * 20 * 24      # SURVEY 8(d): APF on adds 2 * n_sub * 24 B (~20 sub-goals)
+    out = {"metric": "env-steps/sec + learner updates/sec, PathPlan_City SAC", "value": n_pass * env.N / dt,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "passes_per_step": pps, "ms_per_pass": dt / n_pass * 1e3, "timed_region_ms": dt * 1e3,
+           "learner_updates_per_s": n_pass * U / dt, "learner_samples_per_s": n_pass * U * B / dt,
+           "config": {"workload": "PathPlan_City 500x500x100, 26 moving buildings, APF on, %d UAVs/env x %d envs, SAC continuous, "
+                                  "one trainer per UAV slot, device replay %d transitions (BASELINE.json configs[3])"
+                                  % (U, envs, ring.capacity),
+                      "step_definition": "1 bench step = %d passes of (SAC act x%d -> env step with APF + replay write -> "
+                                         "%d x (sample + SAC update))" % (pps, U, U),
+                      "envs_per_gpu": envs, "uav_per_env": U, "learn_batch_per_slot": B, "obs_dtype": "packed",
+                      "learner": "SAC on PyTorch-ROCm ops (f32)" + (", each slot's sample + update replayed as one HIP graph"
+                                                                      if graphs is not None else ", eager"),
+                      "env": "fused HIP k_step with APF"},
+           "roofline": {"bound": "hbm", "kernel": "k_step<APF> (update_PathPlan + Adjust_subgoal + cal_force + state_PathPlan + replay write)",
+                        "achieved": algo * env.N / (k_use * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo * env.N / (k_use * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": prof.get("k_step_traffic_bytes_per_launch"),
+                        "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": env.N, "kernel_ms": k_use,
+                        "kernel_ms_back_to_back": k_ms, "kernel_ms_rocprofv3_committed": k_prof}}
+    print(json.dumps(out))
+    env.close()
+
+
 def main():
     args = parse()
+    if args.config == 4:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--config 4 is a single-GPU workload")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the env hot path has no CPU fallback")
+        torch.cuda.set_device(0)
+        return run_config4(args, torch.device("cuda", 0))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
