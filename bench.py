@@ -84,6 +84,10 @@ def parse():
     p.add_argument("--sync", default="grad", choices=["grad", "fedavg"],
                    help="N > 1: all-reduce the gradient bucket every update (default), or average the weights every "
                         "FL_Loop = 3 updates (the reference's federated mode as all-reduce(avg))")
+    p.add_argument("--exchange", default="p2p", choices=["p2p", "rccl", "none"],
+                   help="N > 1, --sync grad: p2p = one-shot sum over HIP-IPC-mapped peer memory on the stream (falls back "
+                        "to rccl if it cannot be set up); rccl = torch.distributed all_reduce per update; none = diagnostic: "
+                        "no exchange at all (the ranks drift apart) -- the baseline the exchange's cost is measured against")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) | gloo (test: several ranks on one GPU)")
     p.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
     p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
@@ -418,7 +422,17 @@ def main():
     learner.sync = args.sync
     seed = 7 + rank
     pps = args.passes_per_step
-    use_c = fused and world_size == 1 and args.host_loop == "c"
+    # N > 1: the gradient bucket is summed over peer-mapped HBM (csrc/p2p.hip, verified against an RCCL all-reduce at
+    # start-up) so that the loop can stay in C; --exchange rccl (or a failed set-up) keeps torch.distributed per update
+    p2p = False
+    if fused and world_size > 1 and args.sync == "grad" and args.exchange == "p2p":
+        p2p = learner.enable_p2p()
+        if rank == 0 and not p2p:
+            print("p2p exchange unavailable: falling back to RCCL all-reduce per update", file=sys.stderr)
+    if args.exchange == "none" and world_size > 1:
+        learner.sync = "fedavg"
+        learner.fl_loop = 1 << 30
+    use_c = fused and args.host_loop == "c" and (world_size == 1 or p2p or args.exchange == "none")
     counter = [0]
     py_events = []
     ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "8"))
@@ -587,8 +601,11 @@ def main():
                        "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
                                       % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
-                       "epsilon": args.eps, "parallelism": "env-shard x%d + %s" % (world_size, "flat-bucket grad all-reduce" if args.sync == "grad"
-                                                               else "weight averaging every 3 updates")},
+                       "epsilon": args.eps, "parallelism": "env-shard x%d + %s" % (
+                           world_size, ("flat-bucket gradient sum, " + ("peer-to-peer over IPC-mapped HBM (csrc/p2p.hip)" if p2p
+                                                                          else "RCCL all-reduce")) if args.sync == "grad"
+                           else "weight averaging every 3 updates"),
+                       "p2p_timeouts": learner.p2p_timeouts() if (fused and p2p) else None},
             "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,

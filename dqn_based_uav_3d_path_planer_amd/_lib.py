@@ -17,6 +17,7 @@ ACT_STEER_F32, ACT_STEER_F64, ACT_INDEX_I32 = 0, 1, 2
 OBS_F32, OBS_F16, OBS_PACKED = 0, 1, 2
 PACKED_DWORDS = 20
 MFMA_F32, MFMA_F16 = 0, 1
+P2P_HANDLE_BYTES = 64
 STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE = 1, 2, 4, 8
 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -26,6 +27,8 @@ SYMBOLS = (
     "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
+    "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
+    "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
 )
@@ -67,7 +70,8 @@ class UavLoopConfig(C.Structure):
                 ("seed", C.c_uint64), ("counter", C.c_uint64),
                 ("eps", C.c_float), ("gamma", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("adam_eps", C.c_float), ("step_flags", C.c_uint32), ("partials_dev", C.c_void_p),
-                ("loss_dev", C.c_void_p), ("info_dev", C.c_void_p), ("time_every", C.c_int32), ("reserved0", C.c_int32)]
+                ("loss_dev", C.c_void_p), ("info_dev", C.c_void_p), ("p2p", C.c_void_p), ("time_every", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 class UavLoopCursor(C.Structure):
@@ -135,6 +139,20 @@ def load() -> C.CDLL:
     lib.uavenv_obs_unpack.argtypes = [vp, i64, vp, i32, vp]
     lib.uavenv_replay_draw.restype = C.c_int
     lib.uavenv_replay_draw.argtypes = [i32, i32, i32, i32, i32, u64, u64, vp, vp]
+    lib.uavenv_p2p_create.restype = C.c_int
+    lib.uavenv_p2p_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    lib.uavenv_p2p_handle.restype = C.c_int
+    lib.uavenv_p2p_handle.argtypes = [vp, vp]
+    lib.uavenv_p2p_connect.restype = C.c_int
+    lib.uavenv_p2p_connect.argtypes = [vp, vp]
+    lib.uavenv_p2p_destroy.restype = C.c_int
+    lib.uavenv_p2p_destroy.argtypes = [vp]
+    lib.uavenv_p2p_errors.restype = C.c_int
+    lib.uavenv_p2p_errors.argtypes = [vp, C.POINTER(i32)]
+    lib.uavenv_dqn_reduce_p2p.restype = C.c_int
+    lib.uavenv_dqn_reduce_p2p.argtypes = [C.POINTER(UavDqnNet), vp, i32, vp, vp]
+    lib.uavenv_dqn_adam_p2p.restype = C.c_int
+    lib.uavenv_dqn_adam_p2p.argtypes = [C.POINTER(UavDqnNet), vp, f32, f32, f32, f32, i32, i32, vp, vp, vp]
     lib.uavenv_loop_create.restype = C.c_int
     lib.uavenv_loop_create.argtypes = [C.POINTER(UavLoopConfig), C.POINTER(vp)]
     lib.uavenv_loop_destroy.restype = C.c_int

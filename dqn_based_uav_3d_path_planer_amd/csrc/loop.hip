@@ -126,8 +126,15 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                                  c.huber, c.partials_dev, s);
             if (rc != UAVENV_OK) return rc;
             l->epoch += 1;
-            rc = uavenv_dqn_reduce_adam(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch,
-                                        l->epoch % c.update_loop == 0 ? 1 : 0, c.loss_dev, nullptr, s);
+            const int hard = l->epoch % c.update_loop == 0 ? 1 : 0;
+            if (c.p2p) {                      // multi-GPU: every rank's column sums to every rank, then the same Adam step
+                rc = uavenv_dqn_reduce_p2p(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.p2p, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_dqn_adam_p2p(&c.net, c.p2p, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);
+            } else {
+                rc = uavenv_dqn_reduce_adam(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2,
+                                            c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);
+            }
             if (rc != UAVENV_OK) return rc;
         }
         l->counter += 1;

@@ -1,0 +1,271 @@
+// p2p.hip -- one-shot all-reduce of the learner's ~26 KB gradient bucket over peer-mapped HBM (xGMI), on the stream.
+//
+// The multi-GPU loop is strictly ordered (act -> step -> learn -> act: the next action needs the updated weights), so
+// the gradient exchange sits on the critical path of every ~40 us pass.  A collective through torch.distributed / RCCL
+// costs a host round trip plus 20-40 us of ring latency for a message this small.  Here every rank owns a receive area
+// in uncached device memory that its peers map through HIP IPC:
+//     push   (tail of the gradient reduction) each workgroup stores its 32 column sums straight into slot [my rank] of
+//            EVERY rank's receive area (its own included); the last workgroup to finish raises flag [my rank] = seq at
+//            every rank (system-scope release);
+//     pull   (head of the Adam kernel) one thread per workgroup waits until all `world` flags of its own rank show
+//            seq (system-scope loads of local memory), then every thread adds the `world` slots IN RANK ORDER -- all
+//            ranks therefore apply bit-identical updates -- and Adam runs as in k_dqn_adam.
+// Two alternating slots per rank (seq parity): a rank can be at most one update ahead of a peer, because its next push
+// is enqueued behind its own pull of the current one.  xGMI is point to point: 7 peers x 26 KB out and in per rank and
+// update, one hop, no ring.  Every wait is bounded; a timeout is counted (uavenv_p2p_errors) instead of hanging.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/uavenv.h"
+
+namespace {
+constexpr int kMaxWorld = 16;
+constexpr uint32_t kSpinLimit = 1u << 22;            // x ~0.25 us per poll: about a second
+}
+
+struct UavP2P {
+    int world = 0, rank = 0, bucket = 0, bucket_pad = 0;
+    size_t bytes = 0;
+    unsigned char *local = nullptr;                   // [flags: kMaxWorld x 64 B][recv: world x 2 x bucket_pad floats]
+    unsigned char *peer[kMaxWorld] = {nullptr};       // peer[r] = rank r's area as mapped here (peer[rank] = local)
+    bool opened[kMaxWorld] = {false};
+    uint32_t *counter = nullptr;                      // [2] workgroup tickets (ordinary device memory)
+    uint32_t *errors = nullptr;                       // timeouts seen by this rank's pulls
+    uint32_t seq = 0;
+    bool connected = false;
+};
+
+namespace {
+
+struct P2PDev {
+    unsigned char *peer[kMaxWorld];
+    int world, rank, bucket_pad;
+    uint32_t seq;
+    uint32_t *counter, *errors;
+};
+
+__device__ __forceinline__ float *recv_slot(unsigned char *area, int from, uint32_t seq, int bucket_pad)
+{
+    return reinterpret_cast<float *>(area + kMaxWorld * 64) + ((size_t)from * 2 + (seq & 1u)) * (size_t)bucket_pad;
+}
+
+__device__ __forceinline__ uint32_t *flag_of(unsigned char *area, int from)
+{
+    return reinterpret_cast<uint32_t *>(area + (size_t)from * 64);
+}
+
+// column sums of the partial rows (as k_dqn_reduce) -> slot [rank] of every rank's receive area
+__global__ void __launch_bounds__(256) k_p2p_reduce_push(const float *__restrict__ partials, int nblk, int P, int stride, P2PDev d)
+{
+    __shared__ float red[32][33];
+    __shared__ float red2[8][33];
+    const int tid = (int)threadIdx.x;
+    const int cg = tid & 7, rg = tid >> 3;
+    const int p4 = (int)blockIdx.x * 32 + cg * 4;
+    const bool col_ok = p4 < stride;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int b0 = 0; b0 < nblk; b0 += 256) {
+        float4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + rg + 32 * k;
+            t[k] = *reinterpret_cast<const float4 *>(partials + (size_t)(b < nblk ? b : nblk - 1) * stride + (col_ok ? p4 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool ok = b0 + rg + 32 * k < nblk;
+            acc[0] += ok ? t[k].x : 0.0f; acc[1] += ok ? t[k].y : 0.0f;
+            acc[2] += ok ? t[k].z : 0.0f; acc[3] += ok ? t[k].w : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg][cg * 4 + e] = acc[e];
+    __syncthreads();
+    {
+        const int px = tid & 31, part = tid >> 5;
+        red2[part][px] = (red[4 * part][px] + red[4 * part + 1][px]) + (red[4 * part + 2][px] + red[4 * part + 3][px]);
+    }
+    __syncthreads();
+    const int p = (int)blockIdx.x * 32 + tid;
+    if (tid < 32 && p < P + 2) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red2[k][tid];
+        for (int r = 0; r < d.world; ++r)                                        // 128 B per workgroup and peer
+            __hip_atomic_store(recv_slot(d.peer[r], d.rank, d.seq, d.bucket_pad) + p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();                                                      // this workgroup's stores are out
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t *ticket = d.counter + (d.seq & 1u);
+        const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {                                              // every workgroup has fenced: publish
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            for (int r = 0; r < d.world; ++r)
+                __hip_atomic_store(flag_of(d.peer[r], d.rank), d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// wait for the `world` flags, add the slots in rank order, Adam (k_dqn_adam's arithmetic)
+__global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restrict__ local, float *__restrict__ target,
+                                                       float *__restrict__ m, float *__restrict__ v, float *__restrict__ raw_out,
+                                                       int P, float lr, float beta1, float beta2, float eps, float bc1,
+                                                       float bc2_sqrt, int hard_update, float *__restrict__ loss)
+{
+    unsigned char *mine = d.peer[d.rank];
+    if (threadIdx.x == 0) {
+        for (int r = 0; r < d.world; ++r) {
+            uint32_t spins = 0;
+            while ((int32_t)(__hip_atomic_load(flag_of(mine, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.seq) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > kSpinLimit) {
+                    atomicAdd(d.errors, 1u);
+                    break;
+                }
+            }
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    float cnt = 0.0f, lsum = 0.0f;
+    for (int r = 0; r < d.world; ++r) {
+        const float *slot = recv_slot(mine, r, d.seq, d.bucket_pad);
+        cnt += __hip_atomic_load(slot + P + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        lsum += __hip_atomic_load(slot + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const float inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
+    if (p == 0 && loss) *loss = lsum * inv;
+    if (p == 0 && raw_out) { raw_out[P] = lsum; raw_out[P + 1] = cnt; }
+    if (p >= P) return;
+    float gsum = 0.0f;
+    for (int r = 0; r < d.world; ++r)
+        gsum += __hip_atomic_load(recv_slot(mine, r, d.seq, d.bucket_pad) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (raw_out) raw_out[p] = gsum;
+    if (!local) return;                                                          // sum only (self-test)
+    const float gp = gsum * inv;
+    const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);
+    const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;
+    m[p] = mp;
+    v[p] = vp;
+    const float np = local[p] - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
+    local[p] = np;
+    if (hard_update) target[p] = np;
+}
+
+P2PDev dev_view(const UavP2P *c)
+{
+    P2PDev d;
+    for (int r = 0; r < kMaxWorld; ++r) d.peer[r] = c->peer[r];
+    d.world = c->world; d.rank = c->rank; d.bucket_pad = c->bucket_pad; d.seq = c->seq;
+    d.counter = c->counter; d.errors = c->errors;
+    return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P **out)
+{
+    if (!out || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || bucket_floats <= 0) return UAVENV_EINVAL;
+    UavP2P *c = new (std::nothrow) UavP2P();
+    if (!c) return UAVENV_ENOMEM;
+    c->world = world; c->rank = rank; c->bucket = bucket_floats;
+    c->bucket_pad = (bucket_floats + 63) & ~63;
+    c->bytes = (size_t)kMaxWorld * 64 + (size_t)world * 2 * c->bucket_pad * sizeof(float);
+    // uncached: peers write it while this device reads it inside running kernels
+    if (hipExtMallocWithFlags((void **)&c->local, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return UAVENV_ENOMEM; }
+    if (hipMalloc((void **)&c->counter, 3 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(c->local); delete c; return UAVENV_ENOMEM; }
+    c->errors = c->counter + 2;
+    (void)hipMemset(c->local, 0, c->bytes);
+    (void)hipMemset(c->counter, 0, 3 * sizeof(uint32_t));
+    (void)hipDeviceSynchronize();
+    c->peer[rank] = c->local;
+    c->connected = world == 1;
+    *out = c;
+    return UAVENV_OK;
+}
+
+int uavenv_p2p_handle(UavP2P *c, void *handle_out)
+{
+    if (!c || !handle_out) return UAVENV_EINVAL;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, c->local) != hipSuccess) return UAVENV_EHIP;
+    static_assert(sizeof(hipIpcMemHandle_t) <= UAVENV_P2P_HANDLE_BYTES, "IPC handle size");
+    memset(handle_out, 0, UAVENV_P2P_HANDLE_BYTES);
+    memcpy(handle_out, &h, sizeof(h));
+    return UAVENV_OK;
+}
+
+int uavenv_p2p_connect(UavP2P *c, const void *all_handles)
+{
+    if (!c || !all_handles) return UAVENV_EINVAL;
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const unsigned char *)all_handles + (size_t)r * UAVENV_P2P_HANDLE_BYTES, sizeof(h));
+        void *p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return UAVENV_EHIP;
+        c->peer[r] = (unsigned char *)p;
+        c->opened[r] = true;
+    }
+    c->connected = true;
+    return UAVENV_OK;
+}
+
+int uavenv_p2p_destroy(UavP2P *c)
+{
+    if (!c) return UAVENV_OK;
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < c->world; ++r)
+        if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+    (void)hipFree(c->local);
+    (void)hipFree(c->counter);
+    delete c;
+    return UAVENV_OK;
+}
+
+int uavenv_p2p_errors(UavP2P *c, int32_t *timeouts_out)
+{
+    if (!c || !timeouts_out) return UAVENV_EINVAL;
+    uint32_t e = 0;
+    if (hipMemcpy(&e, c->errors, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return UAVENV_EHIP;
+    *timeouts_out = (int32_t)e;
+    return UAVENV_OK;
+}
+
+int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials, int32_t n_partials, UavP2P *c, void *stream)
+{
+    if (!net || !partials || n_partials <= 0 || !c || !c->connected) return UAVENV_EINVAL;
+    const int P = uavenv_dqn_num_params(net);
+    if (P <= 0 || P + 2 > c->bucket) return UAVENV_EINVAL;
+    c->seq += 1;
+    hipLaunchKernelGGL(k_p2p_reduce_push, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials, P,
+                       uavenv_dqn_partial_stride(net), dev_view(c));
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *c, float lr, float beta1, float beta2, float eps, int32_t step_t,
+                        int32_t hard_update, float *loss_out, float *raw_out, void *stream)
+{
+    if (!net || !c || !c->connected || c->seq == 0) return UAVENV_EINVAL;
+    const int P = uavenv_dqn_num_params(net);
+    if (P <= 0 || P + 2 > c->bucket) return UAVENV_EINVAL;
+    const bool apply = step_t > 0;                        // step_t == 0: only sum into raw_out (self-test)
+    if (apply && (!net->local || !net->target || !net->m || !net->v)) return UAVENV_EINVAL;
+    if (!apply && !raw_out) return UAVENV_EINVAL;
+    const float bc1 = apply ? 1.0f - powf(beta1, (float)step_t) : 1.0f;
+    const float bc2 = apply ? 1.0f - powf(beta2, (float)step_t) : 1.0f;
+    hipLaunchKernelGGL(k_p2p_pull_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_view(c),
+                       apply ? net->local : (float *)nullptr, net->target, net->m, net->v, raw_out, P, lr, beta1, beta2, eps,
+                       bc1, sqrtf(bc2), hard_update, loss_out);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+}  // extern "C"

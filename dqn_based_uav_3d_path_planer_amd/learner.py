@@ -347,6 +347,64 @@ class FusedDQNLearner:
         r._c, r.head, r.filled = buf["c"], 1, 1
         return self.learn_from_ring(r, bp, 0, 0, explicit_idx=buf["idx"])
 
+    # -- multi-GPU: the gradient bucket summed over peer-mapped HBM instead of a collective call -------------------
+    def enable_p2p(self, verify: bool = True) -> bool:
+        """Set up csrc/p2p.hip between the ranks of the initialised process group (one rank per GPU of ONE node): every
+        rank maps every other rank's receive area through HIP IPC.  With verify, one all-reduce of a known vector is
+        compared with torch.distributed's result on every rank; on any failure (IPC not available, timeout, mismatch)
+        the learner keeps the RCCL path.  Returns whether the peer-to-peer path is active on ALL ranks."""
+        C, _lib = self._C, self._lib_mod
+        self._p2p = None
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return False
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ok, h = True, C.c_void_p()
+        try:
+            _lib.check(self.lib.uavenv_p2p_create(world, rank, self.P + 2, C.byref(h)), "uavenv_p2p_create")
+            mine = (C.c_ubyte * _lib.P2P_HANDLE_BYTES)()
+            _lib.check(self.lib.uavenv_p2p_handle(h, mine), "uavenv_p2p_handle")
+        except Exception:
+            ok, mine = False, (C.c_ubyte * _lib.P2P_HANDLE_BYTES)()
+        allh = [None] * world
+        dist.all_gather_object(allh, (ok, bytes(mine)))
+        ok = all(o for o, _ in allh)
+        if ok:
+            blob = b"".join(b for _, b in allh)
+            ok = self.lib.uavenv_p2p_connect(h, C.create_string_buffer(blob, len(blob))) == 0
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        ok = all(flags)
+        if ok and verify:
+            n = self.lib.uavenv_dqn_partial_rows(64)
+            stride = self.lib.uavenv_dqn_partial_stride(C.byref(self.net))
+            part = torch.zeros((n, stride), dtype=torch.float32, device=self.device)
+            part[0, :self.P + 2] = torch.arange(self.P + 2, device=self.device, dtype=torch.float32) * 1e-3 + (rank + 1)
+            want = part[0, :self.P + 2].clone()
+            dist.all_reduce(want, op=dist.ReduceOp.SUM)
+            got = torch.zeros(self.P + 2, dtype=torch.float32, device=self.device)
+            s = self._stream()
+            rc1 = self.lib.uavenv_dqn_reduce_p2p(C.byref(self.net), part.data_ptr(), n, h, s)
+            rc2 = self.lib.uavenv_dqn_adam_p2p(C.byref(self.net), h, 0.0, 0.9, 0.999, 1e-8, 0, 0, None, got.data_ptr(), s)
+            torch.cuda.synchronize(self.device)
+            err = C.c_int32(0)
+            self.lib.uavenv_p2p_errors(h, C.byref(err))
+            ok = rc1 == 0 and rc2 == 0 and err.value == 0 and bool(torch.allclose(got, want, rtol=1e-6, atol=1e-6))
+            dist.all_gather_object(flags, ok)
+            ok = all(flags)
+        if not ok:
+            if h.value:
+                self.lib.uavenv_p2p_destroy(h)
+            return False
+        self._p2p = h
+        return True
+
+    def p2p_timeouts(self) -> int:
+        if getattr(self, "_p2p", None) is None:
+            return 0
+        err = self._C.c_int32(0)
+        self.lib.uavenv_p2p_errors(self._p2p, self._C.byref(err))
+        return int(err.value)
+
     def act(self, obs: torch.Tensor, eps: float, seed: int, counter: int, index_out: torch.Tensor = None,
             steer_out: torch.Tensor = None, q_out: torch.Tensor = None):
         """Q(s) + epsilon-greedy for all rows of obs [n,100] in one launch."""
@@ -383,6 +441,13 @@ class FusedDQNLearner:
             _lib.check(rc, "uavenv_dqn_reduce_adam")
             if fed and self.epoch % self.fl_loop == 0:
                 self.federated_average()
+            return self.loss
+        if multi and getattr(self, "_p2p", None) is not None:     # peer-to-peer sum over xGMI, on the stream
+            _lib.check(self.lib.uavenv_dqn_reduce_p2p(C.byref(self.net), self._partials.data_ptr(), nblk, self._p2p, s),
+                       "uavenv_dqn_reduce_p2p")
+            _lib.check(self.lib.uavenv_dqn_adam_p2p(C.byref(self.net), self._p2p, self.lr, self.betas[0], self.betas[1],
+                                                    self.eps, self.epoch, hard, self.loss.data_ptr(), self.raw.data_ptr(), s),
+                       "uavenv_dqn_adam_p2p")
             return self.loss
         rc = self.lib.uavenv_dqn_reduce(C.byref(self.net), self._partials.data_ptr(), nblk, self.raw.data_ptr(), s)
         _lib.check(rc, "uavenv_dqn_reduce")

@@ -52,6 +52,8 @@ class HotLoop:
             assert info.dtype == torch.uint8 and tuple(info.shape) == (ring.frames, env.N) and info.is_contiguous()
             cfg.info_dev = info.data_ptr()
         self._info = info
+        if getattr(learner, "_p2p", None) is not None:      # multi-GPU: the gradient sum goes through csrc/p2p.hip
+            cfg.p2p = learner._p2p
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_loop_create")
         self.counter = int(counter)

@@ -271,6 +271,27 @@ int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials_dev, int3
 int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype, int32_t n, float eps, uint64_t seed,
                    uint64_t counter, int32_t *index_out_dev, float *steer_out_dev, float *q_out_dev, void *stream);
 
+/* ---- multi-GPU: one-shot all-reduce of the gradient bucket over peer-mapped HBM (csrc/p2p.hip) ------------------- */
+/* One UavP2P per rank (= per GPU / process).  create -> every rank publishes its UAVENV_P2P_HANDLE_BYTES handle
+ * (uavenv_p2p_handle) -> the `world` handles, in rank order, go to uavenv_p2p_connect on every rank.  Then, per update,
+ *     uavenv_dqn_grad -> uavenv_dqn_reduce_p2p -> uavenv_dqn_adam_p2p
+ * replaces uavenv_dqn_reduce -> RCCL all-reduce -> uavenv_dqn_adam: the column sums are stored straight into every
+ * rank's receive area (xGMI), flags tell the readers, every rank adds the `world` contributions in rank order (bit-
+ * identical updates) and takes the Adam step -- all on the stream, no host round trip.  Waits are bounded: a timeout
+ * is counted (uavenv_p2p_errors, synchronising) instead of hanging. */
+#define UAVENV_P2P_HANDLE_BYTES 64
+typedef struct UavP2P UavP2P;
+int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P **out);
+int uavenv_p2p_handle(UavP2P *p2p, void *handle_out_host);
+int uavenv_p2p_connect(UavP2P *p2p, const void *all_handles_host);
+int uavenv_p2p_destroy(UavP2P *p2p);
+int uavenv_p2p_errors(UavP2P *p2p, int32_t *timeouts_out);
+int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, UavP2P *p2p, void *stream);
+/* step_t == 0: only the rank-ordered sum, into raw_out_dev[num_params + 2] (self-test); otherwise Adam as uavenv_dqn_adam
+ * (raw_out_dev nullable). */
+int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *p2p, float lr, float beta1, float beta2, float eps, int32_t step_t,
+                        int32_t hard_update, float *loss_out_dev, float *raw_out_dev, void *stream);
+
 /* ---- the whole off-policy loop, enqueued from C ------------------------------------------------------------------ */
 /* PathPlan_City.run_thread_OffPolicy (Envs/PathPlan_City.py:364-385) for every env of the shard at once, K times:
  *     act     Q(s) + epsilon-greedy            -> ring.action[head]          (Choose_Action2, :346,370)
@@ -298,6 +319,7 @@ typedef struct UavLoopConfig {
     float *partials_dev;         /* uavenv_dqn_partial_rows(batch) x uavenv_dqn_partial_stride(net) floats of scratch */
     float *loss_dev;             /* device scalar: mean loss of the last update */
     uint8_t *info_dev;           /* nullable: frames x N plane receiving uavenv_step's info codes (frame-major like reward) */
+    UavP2P *p2p;                 /* nullable: multi-GPU -- gradients are summed over the ranks through csrc/p2p.hip */
     int32_t time_every;          /* > 0: bracket the step kernel of every time_every-th step with HIP events */
     int32_t reserved0;
 } UavLoopConfig;

@@ -197,7 +197,7 @@ def test_fused_huber_and_f16_ring_match_torch_learner_on_a_real_ring(kind, net, 
     env.close()
 
 
-def _two_rank_worker(rank, world, port, kind, net, out_dir):
+def _two_rank_worker(rank, world, port, kind, net, out_dir, p2p=False):
     import os
     import torch.distributed as dist
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
@@ -218,23 +218,27 @@ def _two_rank_worker(rank, world, port, kind, net, out_dir):
         ring.step_env(auto_reset=True)
     torch.manual_seed(0)                                # same initial weights everywhere
     L = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
+    if p2p and world > 1:
+        assert L.enable_p2p(), "peer-to-peer exchange could not be set up"
     g = torch.Generator().manual_seed(7)
     idx = torch.stack([torch.randint(0, 3, (512,), generator=g), torch.randint(0, n, (512,), generator=g)], 1).int()
     per = 512 // world
     mine = idx[rank * per:(rank + 1) * per].contiguous().cuda()
     losses = [float(L.learn_from_ring(ring, per, 0, it, explicit_idx=mine)) for it in range(4)]
     torch.cuda.synchronize()
-    torch.save({"flat": L.flat.cpu(), "losses": losses}, os.path.join(out_dir, f"w{world}_r{rank}.pt"))
+    torch.save({"flat": L.flat.cpu(), "losses": losses, "timeouts": L.p2p_timeouts()},
+               os.path.join(out_dir, f"w{world}_r{rank}.pt"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     env.close()
 
 
-@pytest.mark.parametrize("kind,net", [("dqn", "Qnet2"), ("dueling", "VAnet2")])
-def test_fused_learner_two_ranks_equal_one_process(kind, net, tmp_path):
-    """The N > 1 branch of FusedDQNLearner.learn_from_ring (k_dqn_reduce -> all_reduce(sum) of the raw bucket ->
-    k_dqn_adam, learner.py) with two ranks sharing this GPU over gloo: each takes half of a 512-transition list; the
+@pytest.mark.parametrize("kind,net,p2p", [("dqn", "Qnet2", False), ("dueling", "VAnet2", False), ("dqn", "Qnet2", True)])
+def test_fused_learner_two_ranks_equal_one_process(kind, net, p2p, tmp_path):
+    """The N > 1 branch of FusedDQNLearner.learn_from_ring with two ranks sharing this GPU -- either k_dqn_reduce ->
+    all_reduce(sum) of the raw bucket over gloo -> k_dqn_adam, or (p2p) the on-stream exchange of csrc/p2p.hip through
+    HIP-IPC-mapped receive areas (set up and verified by enable_p2p): each takes half of a 512-transition list; the
     result must be the update ONE process applies to the whole list (mean over the valid samples of all ranks)."""
     import os
     import socket
@@ -243,10 +247,11 @@ def test_fused_learner_two_ranks_equal_one_process(kind, net, tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, kind, net, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, kind, net, str(tmp_path), p2p), nprocs=2, join=True)
     mp.spawn(_two_rank_worker, args=(1, port, kind, net, str(tmp_path)), nprocs=1, join=True)
     r0, r1 = torch.load(os.path.join(tmp_path, "w2_r0.pt")), torch.load(os.path.join(tmp_path, "w2_r1.pt"))
     one = torch.load(os.path.join(tmp_path, "w1_r0.pt"))
+    assert r0["timeouts"] == 0 and r1["timeouts"] == 0
     assert torch.equal(r0["flat"], r1["flat"])                         # ranks stay in lock-step, bit for bit
     assert r0["losses"] == r1["losses"]
     assert (r0["flat"][:2] - one["flat"][:2]).abs().max().item() <= 2e-6
