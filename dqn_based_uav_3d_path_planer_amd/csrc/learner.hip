@@ -325,9 +325,22 @@ struct GradAcc {
 // HALF_T: H, dH and dout go to LDS transposed and as f16 (hrow / drow / dout_row then point at column s of the [j][s],
 // [j][s] and [a][s] tiles of row stride kLdT halfs) -- the operand layout of the f16 weight-gradient MFMAs.
 constexpr int kLdT = 72;                    // halfs per row of the transposed f16 tiles (64 samples + 8: 16-byte rows)
+// the bootstrap value of the TD target: max_a Q_target(s', a), or Q_target(s', a*) with a* from q_local (double DQN)
+template <int NMAX>
+__device__ __forceinline__ float pick_qn(const GradArgs &g, const float (&qt)[NMAX], int best)
+{
+    float qn = qt[0];
+#pragma unroll
+    for (int a = 1; a < NMAX; ++a) {
+        if (g.kind == 1) { if (a == best) qn = qt[a]; }
+        else if (a < g.n_actions && qt[a] > qn) qn = qt[a];
+    }
+    return qn;
+}
+
 template <int NMAX, bool HALF_T = false>
 __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l, const floatx4 (&hl)[4], const W2Frag<NMAX> &Fl,
-                                            const float (&ql)[NMAX], const float (&qt)[NMAX], int best, int p_act, float p_rew,
+                                            const float (&ql)[NMAX], float qn, int p_act, float p_rew,
                                             float p_done, float p_valid, GradAcc<NMAX> &A, float *hrow, float *drow,
                                             float *dout_row)
 {
@@ -335,13 +348,11 @@ __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l,
     const int gq = ((int)threadIdx.x & 63) >> 4;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     // ---- TD target, loss, dL/dout of this lane's sample (Trainer/DQN_Trainer.py:107-119)
-    float qn = qt[0], qa = ql[0];
+    // Q(s, a_taken) as a one-hot dot product (exact: one term times 1, the others times 0): a compare-and-select chain
+    // over ql[] is turned by the optimiser into an indexed load from a scratch-memory copy of the array
+    float qa = 0.0f;
 #pragma unroll
-    for (int a = 1; a < NMAX; ++a) {
-        if (g.kind == 1) { if (a == best) qn = qt[a]; }
-        else if (a < g.n_actions && qt[a] > qn) qn = qt[a];
-        if (a == p_act) qa = ql[a];
-    }
+    for (int a = 0; a < NMAX; ++a) qa = fmaf(ql[a], a == p_act ? 1.0f : 0.0f, qa);
     const float y = p_rew + (g.gamma * qn * (1.0f - p_done));
     const float delta = qa - y;
     float per, dq;
@@ -523,7 +534,7 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
     }
     L_STAMP(3);
     // H of sample r of this strip goes where its s' rows were (dead now)
-    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qt, best, p_act, p_rew, p_done, p_valid, A, xn_strip + r * kLh,
+    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, A, xn_strip + r * kLh,
                       L.dHs + (wv * 16 + r) * kLh, L.douts + (wv * 16 + r) * kMaxOut);
     __syncthreads();                                  // H, dH, dout of all 64 samples visible
     L_STAMP(4);
@@ -790,7 +801,7 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
         q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
     }
     L_STAMP(3);
-    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qt, best, p_act, p_rew, p_done, p_valid, A, L.Hs + (wv * 16 + r) * kLh,
+    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, A, L.Hs + (wv * 16 + r) * kLh,
                       L.dHs + (wv * 16 + r) * kLh, L.douts + (wv * 16 + r) * kMaxOut);
     __syncthreads();                                  // H, dH, dout and the packed s rows of all 64 samples visible
     L_STAMP(4);
@@ -892,6 +903,255 @@ __global__ void __launch_bounds__(256) k_dqn_grad_packed(Grad2Args ga)
     L_STAMP(5);
     grad_write_partials<NMAX>(g, ga.stride, L.red, A);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The packed kernel with EIGHT wavefronts per workgroup (two per SIMD), for at most 4 layer-2 outputs.
+// At one 64-sample tile per CU (batch 16 384) a 4-wave workgroup leaves every SIMD with ONE wavefront: each LDS /
+// HBM latency, each dependent VALU chain (layer 2, the TD target) is exposed, and the f32 MFMA does not overlap with
+// VALU work of the same wavefront.  Here wavefronts 0..3 (group 0) own q_local(s) and the backward pass of strip
+// w & 3, wavefronts 4..7 (group 1) own the bootstrap value of the same strip -- q_target(s') (and q_local(s') for the
+// double-DQN action choice) -- and hand it over as ONE float per sample; the two groups run concurrently, each SIMD
+// interleaving a group-0 and a group-1 wavefront.  Both groups stage weights (group 0 the local fc1, group 1 the target
+// fc1) and share the weight-gradient products (group 0: k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and dW2).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void w_issue_half(floatx4 (&v)[kStageIters], const float *W, int t256)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        int c = it * 256 + t256;
+        c = c < kStageChunks ? c : kStageChunks - 1;
+        v[it] = *reinterpret_cast<const floatx4 *>(W + 4 * c);
+    }
+}
+
+__device__ __forceinline__ void w_commit_half(float *dst, floatx4 (&v)[kStageIters], float bias, int t256)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int c = it * 256 + t256;
+        if (c < kStageChunks) {
+            const int row = c / 25, q = c - row * 25;
+            *reinterpret_cast<floatx4 *>(dst + row * kLd + 4 * q) = v[it];
+        }
+    }
+    if (t256 < kHid) *reinterpret_cast<floatx4 *>(dst + t256 * kLd + kW) = floatx4{bias, 0.0f, 0.0f, 0.0f};
+}
+
+struct GradAcc8 {
+    floatx4 acc[4];                  // group 0: dW1^T k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and the dW2^T tile
+    float csum[6];                   // group 0: column sums of dout (NMAX = 4), loss sum, valid count of its strips
+};
+
+template <bool FIRST>
+__device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradLdsP &L, float *qn_lds, int tile, bool more,
+                                                  GradAcc8 &A)
+{
+    constexpr int NMAX = 4;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int r = lane & 15, gq = lane >> 4, t256 = tid & 255;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    const uint32_t *obs = reinterpret_cast<const uint32_t *>(g.ring.obs);
+    const float *net = grp == 0 ? g.local : g.target;
+    floatx4 vW[kStageIters];
+    float pb1 = 0.0f, pw[4] = {0, 0, 0, 0}, pb2 = 0.0f;
+    if (FIRST) {                              // group 0 stages q_local's weights, group 1 q_target's
+        w_issue_half(vW, net, t256);
+        const NetDev nv = net_view(net, n2);
+        pb1 = nv.b1[t256 < kHid ? t256 : kHid - 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[k] = nv.W2[t256 + 256 * k < n2 * kHid ? t256 + 256 * k : 0];
+        pb2 = nv.b2[t256 < n2 ? t256 : 0];
+    }
+    // ---- this lane's transition: group 0 needs the s row and the transition scalars, group 1 the s' row
+    const int smp = tile * kTile + strip * 16 + r;
+    int f, agent;
+    if (g.explicit_idx) {
+        f = g.explicit_idx[2 * smp];
+        agent = g.explicit_idx[2 * smp + 1];
+    } else {
+        replay_slot_to_frame(g.perm, replay_perm_apply(g.perm, (uint32_t)smp), g.head, g.ring.frames, f, agent);
+    }
+    int fn = f + 1;
+    if (fn >= g.ring.frames) fn = 0;
+    const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    PRow R;
+    prow_load(R, obs + (size_t)(grp == 0 ? row_s : row_n) * kPackedDwords);
+    int p_act = 0;
+    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f;
+    if (grp == 0) {
+        p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
+        p_rew = g.ring.reward[row_s];
+        p_done = (float)g.ring.done[row_s];
+        p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    }
+    if (FIRST) {
+        w_commit_half(grp == 0 ? L.W1l : L.W1t, vW, pb1, t256);
+        float *W2 = grp == 0 ? L.W2l : L.W2t, *b2 = grp == 0 ? L.b2l : L.b2t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t256 + 256 * k < n2 * kHid) W2[t256 + 256 * k] = pw[k];
+        if (t256 < n2) b2[t256] = pb2;
+        __syncthreads();                      // both weight sets staged
+    }
+    L_STAMP(1);
+    floatx4 hl[4];
+    W2Frag<NMAX> Fl;
+    float ql[NMAX];
+    if (grp == 0) {
+        // ---- q_local(s): pre-activations stay in registers for the backward pass
+        fwd_strip_packed(L.W1l, R, hl);
+        w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+        q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+        if (gq == 0) prow_store_lds(L.Ps + (strip * 16 + r) * kPackedDwords, R);    // the s rows, for the dW1 product
+    } else {
+        // ---- the bootstrap value of the TD target from s'
+        int best = 0;
+        floatx4 ht[4];
+        if (g.kind == 1) {                    // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
+            fwd_strip_packed(L.W1l, R, ht);
+            W2Frag<NMAX> F;
+            w2_load<NMAX>(F, L.W2l, L.b2l, n2);
+            float qn_l[NMAX];
+            q_strip<NMAX>(ht, F, n2, g.n_actions, g.dueling, qn_l);
+            float bq = qn_l[0];
+#pragma unroll
+            for (int a = 1; a < NMAX; ++a)
+                if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }       // torch.max: first maximum
+        }
+        fwd_strip_packed(L.W1t, R, ht);
+        W2Frag<NMAX> Ft;
+        w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
+        float qt[NMAX];
+        q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+        if (gq == 0) qn_lds[strip * 16 + r] = pick_qn<NMAX>(g, qt, best);
+    }
+    L_STAMP(2);
+    __syncthreads();                                  // bootstrap values handed over
+    L_STAMP(3);
+    if (grp == 0) {
+        GradAcc<NMAX> T;                              // td_backward's accumulator interface: only csum is used here
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) T.csum[a] = A.csum[a];
+        td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qn_lds[strip * 16 + r], p_act, p_rew, p_done, p_valid, T,
+                          L.Hs + (strip * 16 + r) * kLh, L.dHs + (strip * 16 + r) * kLh, L.douts + (strip * 16 + r) * kMaxOut);
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = T.csum[a];
+    }
+    __syncthreads();                                  // H, dH, dout and the packed s rows of all 64 samples visible
+    L_STAMP(4);
+    // ---- weight gradients over the 64 samples (MFMA step kk, lane group gq: sample (kk & 3) + 16 (kk >> 2) + 4 gq);
+    // hidden units 16 strip + r; group 0: X columns 16 u + r for u = 0, 2, 4, 6; group 1: u = 1, 3, 5, and dW2^T
+    {
+        const uint32_t *pr = L.Ps + 4 * gq * kPackedDwords;
+        const int ia = 4 + (r < 11 ? r : 10), ib = 15 + (r < 6 ? 0 : (r > 9 ? 3 : r - 6));
+        const bool sc0 = r < 11, sc5 = r >= 6 && r <= 9;
+        const float ones = r == 4 ? 1.0f : 0.0f;
+        const int sh = grp == 0 ? r : 16 + r;
+        const float *db = L.dHs + 4 * gq * kLh + 16 * strip + r;
+        const float *ha = L.Hs + 4 * gq * kLh + 16 * strip + r;
+        const float *ob = L.douts + 4 * gq * kMaxOut + r;
+        struct Raw { uintx4 mk; float sx, bdh, ah, bo; };
+        auto load = [&](int k) {
+            const int s1 = (k & 3) + 16 * (k >> 2);
+            Raw w;
+            w.mk = *reinterpret_cast<const uintx4 *>(pr + s1 * kPackedDwords);
+            w.sx = __uint_as_float(pr[s1 * kPackedDwords + (grp == 0 ? ia : ib)]);
+            w.bdh = db[s1 * kLh];
+            w.ah = ha[s1 * kLh];
+            w.bo = ob[s1 * kMaxOut];
+            return w;
+        };
+        auto decode = [&](const Raw &w, float (&ax)[4]) {
+            const float b0 = (float)((w.mk[0] >> sh) & 1u), b1 = (float)((w.mk[1] >> sh) & 1u), b2 = (float)((w.mk[2] >> sh) & 1u);
+            if (grp == 0) { ax[0] = sc0 ? w.sx : b0; ax[1] = b1; ax[2] = b2; ax[3] = ones; }
+            else { ax[0] = b0; ax[1] = b1; ax[2] = sc5 ? w.sx : b2; ax[3] = w.ah; }
+        };
+        Raw cur = load(0), nxt = load(1);
+        float ax[4];
+        decode(cur, ax);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            Raw nn = nxt;
+            if (kk + 2 < 16) nn = load(kk + 2);
+            float axn[4];
+            decode(nxt, axn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) A.acc[u] = mfma16(ax[u], cur.bdh, A.acc[u]);
+            A.acc[3] = mfma16(ax[3], grp == 0 ? cur.bdh : cur.bo, A.acc[3]);      // group 0: ones column; group 1: H x dout
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+            nxt = nn;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ax[u] = axn[u];
+        }
+    }
+    if (more) __syncthreads();                        // the next tile overwrites Ps / Hs / dHs / douts / qn
+}
+
+__global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
+{
+    constexpr int NMAX = 4;
+    const GradArgs &g = ga.g;
+    extern __shared__ __align__(16) float lds[];
+    GradLdsP L;
+    L.W1l = lds;
+    L.W1t = L.W1l + kTileF;
+    L.Hs = L.W1t + kTileF;
+    L.dHs = L.Hs + kTile * kLh;
+    L.douts = L.dHs + kTile * kLh;
+    L.W2l = L.douts + kTile * kMaxOut;
+    L.W2t = L.W2l + kMaxOut * kHid;
+    L.b2l = L.W2t + kMaxOut * kHid;
+    L.b2t = L.b2l + kMaxOut;
+    L.red = L.b2t + kMaxOut;
+    L.Ps = reinterpret_cast<uint32_t *>(L.red + 4 * (kMaxOut + 2));
+    float *qn_lds = reinterpret_cast<float *>(L.Ps + kTile * kPackedDwords + 4);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int r = lane & 15, gq = lane >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    GradAcc8 A;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) A.acc[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) A.csum[a] = 0.0f;
+    L_STAMP(0);
+    const int step = (int)gridDim.x;
+    int tile = (int)blockIdx.x;
+    grad_tile_packed8<true>(g, L, qn_lds, tile, tile + step < ga.n_tiles, A);
+    for (tile += step; tile < ga.n_tiles; tile += step)
+        grad_tile_packed8<false>(g, L, qn_lds, tile, tile + step < ga.n_tiles, A);
+    L_STAMP(5);
+    // ---- the partial-gradient row of this workgroup: dW1 | db1 | dW2 | db2 | loss sum | valid count
+    float *out = g.partials + (size_t)blockIdx.x * ga.stride;
+    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
+    const int j = 16 * strip + r;
+    if (grp == 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<floatx4 *>(out + j * kW + 32 * u + 4 * gq) = A.acc[u];     // tiles 0, 2, 4
+        if (gq == 0) *reinterpret_cast<floatx4 *>(out + j * kW + 96) = A.acc[3];                                // tile 6: columns 96..99
+        else if (gq == 1) out[kHid * kW + j] = A.acc[3][0];                                                      // column 100 -> db1[j]
+    } else {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<floatx4 *>(out + j * kW + 16 + 32 * u + 4 * gq) = A.acc[u]; // tiles 1, 3, 5
+        if (r < n2) *reinterpret_cast<floatx4 *>(out + oW2 + r * kHid + 16 * strip + 4 * gq) = A.acc[3];          // dW2^T
+    }
+    if (grp == 0 && lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) L.red[strip * (kMaxOut + 2) + a] = A.csum[a];
+    }
+    __syncthreads();
+    if (tid < NMAX + 2) {
+        const float s = (L.red[tid] + L.red[(kMaxOut + 2) + tid]) + (L.red[2 * (kMaxOut + 2) + tid] + L.red[3 * (kMaxOut + 2) + tid]);
+        if (tid < n2) out[ob2 + tid] = s;
+        else if (tid == NMAX) out[g.P] = s;
+        else if (tid == NMAX + 1) out[g.P + 1] = s;
+    }
+}
+
+constexpr size_t kGradP8Lds = (size_t)(2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut +
+                                       4 * (kMaxOut + 2) + kTile * kPackedDwords + 4 + kTile) * 4;
 
 constexpr size_t kGradPLds = (size_t)(2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut +
                                       4 * (kMaxOut + 2) + kTile * kPackedDwords + 4) * 4;
@@ -1154,7 +1414,7 @@ __device__ __forceinline__ void grad_tile_h(const GradArgs &g, const GradLdsH &L
     L_STAMP(3);
     __syncthreads();                                  // every wave is done with its s' rows: HT / dHT overwrite that tile
     const int s = wv * 16 + r;
-    td_backward<NMAX, true>(g, L.W2l, hl, Fl, ql, qt, best, p_act, p_rew, p_done, p_valid, A,
+    td_backward<NMAX, true>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, A,
                             reinterpret_cast<float *>(L.HT + s), reinterpret_cast<float *>(L.dHT + s),
                             reinterpret_cast<float *>(L.doutT + s));
     __syncthreads();
@@ -1753,8 +2013,22 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
         rc = ring->obs_dtype == UAVENV_OBS_PACKED ? launch_grad_h<OBS_KIND_PACKED>(ga, grid, s) : launch_grad_h<OBS_KIND_F16>(ga, grid, s);
     } else if (ring->obs_dtype == UAVENV_OBS_F32)
         rc = small ? launch_grad<float, 4>(ga, grid, s) : launch_grad<float, kMaxOut - 2>(ga, grid, s);
-    else if (ring->obs_dtype == UAVENV_OBS_PACKED)
-        rc = small ? launch_grad_packed<4>(ga, grid, s) : launch_grad_packed<kMaxOut - 2>(ga, grid, s);
+    else if (ring->obs_dtype == UAVENV_OBS_PACKED) {
+        static const bool four_waves = getenv("UAVENV_GRAD_4WAVES") != nullptr;      // A/B knob
+        if (small && !four_waves) {
+            static bool attr8 = false;
+            if (!attr8) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradP8Lds) != hipSuccess)
+                    return UAVENV_EHIP;
+                attr8 = true;
+            }
+            hipLaunchKernelGGL(k_dqn_grad_packed8, dim3(grid), dim3(512), kGradP8Lds, s, ga);
+            rc = UAVENV_OK;
+        } else {
+            rc = small ? launch_grad_packed<4>(ga, grid, s) : launch_grad_packed<kMaxOut - 2>(ga, grid, s);
+        }
+    }
     else
         rc = small ? launch_grad<__half, 4>(ga, grid, s) : launch_grad<__half, kMaxOut - 2>(ga, grid, s);
     if (rc != UAVENV_OK) return rc;
