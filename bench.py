@@ -493,6 +493,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_pass = args.steps * pps
+    # ---- k_step, three ways (no correction terms):
+    # (a) HIP event pairs around the launch inside the timed loop, on the launch stream (every ev_every-th pass).  A
+    #     pair brackets the kernel PLUS the two marker packets: for a ~9 us kernel it reads 2-3 us above rocprofv3.
+    if hot is not None:
+        pair = hot.step_times_ms(1 << 16)
+        k_pair_ms = float(np.mean(pair)) if len(pair) else float("nan")
+    else:
+        k_pair_ms = float(np.mean([a.elapsed_time(b) for a, b in py_events])) if py_events else float("nan")
     # host cost of enqueueing a pass, measured on a burst short enough not to hit the queue-depth back-pressure (the
     # enqueue time of the whole timed region above tracks the GPU once the HIP queue is full)
     t1 = time.perf_counter()
@@ -504,16 +512,8 @@ def main():
     t_burst = (time.perf_counter() - t1) / 16
     torch.cuda.synchronize(dev)
     if hot is not None:
-        hot.step_times_ms()
+        hot.step_times_ms()               # drop the burst's event pairs
 
-    # ---- k_step, three ways (no correction terms):
-    # (a) HIP event pairs around the launch inside the timed loop, on the launch stream (every ev_every-th pass).  A
-    #     pair brackets the kernel PLUS the two marker packets: for a ~9 us kernel it reads 2-3 us above rocprofv3.
-    if hot is not None:
-        pair = hot.step_times_ms(1 << 16)
-        k_pair_ms = float(np.mean(pair)) if len(pair) else float("nan")
-    else:
-        k_pair_ms = float(np.mean([a.elapsed_time(b) for a, b in py_events])) if py_events else float("nan")
     # (b) back-to-back k_step launches between ONE event pair (each launch includes its ~1.5 us dispatch boundary)
     it = args.env_only_iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -617,7 +617,12 @@ def main():
                          "kernel_ms_definition": "max(back-to-back launches between one HIP event pair in this run, "
                                                  "rocprofv3 --kernel-trace average of the committed profile of this command)",
                          "kernel_ms_back_to_back": k_b2b_ms, "kernel_ms_rocprofv3_committed": k_prof_ms,
-                         "kernel_ms_event_pair_in_loop": k_pair_ms},
+                         # inside the loop the C loop launches the step kernel WITH the policy (Q(s) + epsilon-greedy) in
+                         # its prologue (uavenv_step_policy): that launch replaces k_dqn_act + k_step
+                         "in_loop_kernel": "k_step_coop<policy> (k_dqn_act's forward + k_step)" if (use_c and args.obs_dtype == "packed"
+                                                                                                   and args.mfma == "f32") else "k_step",
+                         "in_loop_kernel_ms_event_pair": k_pair_ms,
+                         "in_loop_kernel_ms_rocprofv3_committed": prof.get("k_step_policy_ms")},
         }
         if g_b2b_ms is not None:
             fl = learner_flops_per_sample(args.trainer)

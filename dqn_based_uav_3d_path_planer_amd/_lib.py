@@ -24,7 +24,7 @@ STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE = 1, 2, 4, 8
 SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
-    "uavenv_step", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
+    "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
@@ -125,6 +125,8 @@ def load() -> C.CDLL:
     lib.uavenv_get_state.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.uavenv_step.restype = C.c_int
     lib.uavenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
+    lib.uavenv_step_policy.restype = C.c_int
+    lib.uavenv_step_policy.argtypes = [vp, C.POINTER(UavDqnNet), vp, f32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.uavenv_set_debug_buffer.restype = C.c_int
     lib.uavenv_set_debug_buffer.argtypes = [vp, vp]
     lib.uavenv_observe.restype = C.c_int

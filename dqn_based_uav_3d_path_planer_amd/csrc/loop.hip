@@ -8,16 +8,23 @@
 // uavenv_dqn_act / uavenv_step / uavenv_dqn_grad / uavenv_dqn_reduce_adam issued by the caller.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <new>
 #include <vector>
 
 #include "../../include/uavenv.h"
 
+#include <chrono>
+#include <stdio.h>
+
 struct UavLoop {
+    double t_host[4] = {0, 0, 0, 0};   // UAVENV_LOOP_PROFILE: host seconds spent in the act/step, grad, adam calls, calls
+    bool prof = false;
     UavLoopConfig c;
     int32_t head, filled, epoch;
     uint64_t counter;
     size_t obs_row_bytes;
+    bool fuse_act = true;            // act in the step kernel's prologue (uavenv_step_policy) until it says it cannot
     std::vector<hipEvent_t> ev;      // pairs (start, stop), recorded so far
     std::vector<hipEvent_t> pool;    // idle events
 };
@@ -44,6 +51,8 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
     l->filled = cfg->filled;
     l->epoch = cfg->epoch;
     l->counter = cfg->counter;
+    l->fuse_act = getenv("UAVENV_NO_FUSED_ACT") == nullptr;
+    l->prof = getenv("UAVENV_LOOP_PROFILE") != nullptr;
     l->obs_row_bytes = (size_t)cfg->ring.n_agents * (cfg->ring.obs_dtype == UAVENV_OBS_PACKED ? UAVENV_OBS_PACKED_DWORDS * 4
                                                      : UAVENV_OBS_DIM * (cfg->ring.obs_dtype == UAVENV_OBS_F16 ? 2 : 4));
     *out = l;
@@ -53,6 +62,9 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
 int uavenv_loop_destroy(UavLoop *l)
 {
     if (!l) return UAVENV_OK;
+    if (l->prof && l->t_host[3] > 0)
+        fprintf(stderr, "uavenv_loop host us per pass: act+step %.2f grad %.2f adam %.2f (%.0f passes)\n", 1e6 * l->t_host[0] / l->t_host[3],
+                1e6 * l->t_host[1] / l->t_host[3], 1e6 * l->t_host[2] / l->t_host[3], l->t_host[3]);
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : l->pool) (void)hipEventDestroy(e);
     delete l;
@@ -101,30 +113,49 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
         unsigned char *obs_t = (unsigned char *)R.obs + (size_t)t * l->obs_row_bytes;
         unsigned char *obs_n = (unsigned char *)R.obs + (size_t)nxt * l->obs_row_bytes;
         int32_t *act_t = (int32_t *)R.action + (size_t)t * n;
-        int rc = uavenv_dqn_act(&c.net, obs_t, R.obs_dtype, R.n_agents, c.eps, c.seed, l->counter, act_t, nullptr, nullptr, s);
-        if (rc != UAVENV_OK) return rc;
         const bool timed = c.time_every > 0 && (l->counter % (uint64_t)c.time_every) == 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (timed) {
-            e0 = take_event(l);
-            e1 = take_event(l);
-            if (e0 && e1) (void)hipEventRecord(e0, s);
+        int rc = UAVENV_EINVAL;
+        std::chrono::steady_clock::time_point tp0, tp1, tp2, tp3;
+        if (l->prof) tp0 = std::chrono::steady_clock::now();
+        uint8_t *info_t = c.info_dev ? c.info_dev + (size_t)t * n : nullptr;
+        uint8_t *valid_t = R.valid ? R.valid + (size_t)t * n : nullptr;
+        if (l->fuse_act) {               // Q(s) + epsilon-greedy in the prologue of the step kernel: one launch less
+            if (timed) {
+                e0 = take_event(l);
+                e1 = take_event(l);
+                if (e0 && e1) (void)hipEventRecord(e0, s);
+            }
+            rc = uavenv_step_policy(c.env, &c.net, obs_t, c.eps, c.seed, l->counter, act_t, obs_n, nullptr, R.reward + (size_t)t * n,
+                                    R.done + (size_t)t * n, nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, s);
+            if (rc == UAVENV_EINVAL) l->fuse_act = false;         // not this env / net: the two-launch form from here on
+            else if (rc != UAVENV_OK) return rc;
         }
-        rc = uavenv_step(c.env, act_t, UAVENV_ACT_INDEX_I32, obs_n, nullptr, R.reward + (size_t)t * n, R.done + (size_t)t * n,
-                         nullptr, c.info_dev ? c.info_dev + (size_t)t * n : nullptr, R.valid ? R.valid + (size_t)t * n : nullptr,
-                         nullptr, nullptr, c.step_flags, s);
+        if (!l->fuse_act) {
+            rc = uavenv_dqn_act(&c.net, obs_t, R.obs_dtype, R.n_agents, c.eps, c.seed, l->counter, act_t, nullptr, nullptr, s);
+            if (rc != UAVENV_OK) return rc;
+            if (timed && !e0) {
+                e0 = take_event(l);
+                e1 = take_event(l);
+                if (e0 && e1) (void)hipEventRecord(e0, s);
+            }
+            rc = uavenv_step(c.env, act_t, UAVENV_ACT_INDEX_I32, obs_n, nullptr, R.reward + (size_t)t * n, R.done + (size_t)t * n,
+                             nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, s);
+        }
         if (timed && e0 && e1) {
             (void)hipEventRecord(e1, s);
             l->ev.push_back(e0);
             l->ev.push_back(e1);
         }
         if (rc != UAVENV_OK) return rc;
+        if (l->prof) tp1 = std::chrono::steady_clock::now();
         l->head = nxt;
         if (l->filled < R.frames - 1) l->filled += 1;
         if (c.batch > 0 && (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch)) {
             rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
                                  c.huber, c.partials_dev, s);
             if (rc != UAVENV_OK) return rc;
+            if (l->prof) tp2 = std::chrono::steady_clock::now();
             l->epoch += 1;
             const int hard = l->epoch % c.update_loop == 0 ? 1 : 0;
             if (c.p2p) {                      // multi-GPU: every rank's column sums to every rank, then the same Adam step
@@ -136,6 +167,13 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                                             c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);
             }
             if (rc != UAVENV_OK) return rc;
+            if (l->prof) {
+                tp3 = std::chrono::steady_clock::now();
+                l->t_host[0] += std::chrono::duration<double>(tp1 - tp0).count();
+                l->t_host[1] += std::chrono::duration<double>(tp2 - tp1).count();
+                l->t_host[2] += std::chrono::duration<double>(tp3 - tp2).count();
+                l->t_host[3] += 1.0;
+            }
         }
         l->counter += 1;
     }

@@ -29,6 +29,7 @@
 
 #include "../../include/uavenv.h"
 #include "uavenv_device.hpp"
+#include "qnet_device.hpp"
 
 using namespace uav;
 
@@ -119,6 +120,13 @@ struct StepArgs {
     // auto reset
     Bank bank;
     uint64_t seed, tick;
+    // the policy in the prologue of k_step_coop (uavenv_step_policy): Q(s) + epsilon-greedy of Trainer/DuelingDQN_Trainer.py:86-97
+    const float *pol_local;            // nullable: q_local's flat parameter block
+    const uint32_t *pol_obs;           // [N][20] packed rows of the CURRENT frame
+    int32_t *pol_act;                  // [N] chosen action indices out (the replay ring's action plane)
+    int32_t pol_dueling, pol_off;      // pol_off: LDS byte offset of the policy's tiles
+    float pol_eps;
+    uint64_t pol_seed, pol_counter;
 };
 
 struct UavEnv {
@@ -732,7 +740,12 @@ struct CoopLds {
     uint32_t tile[64 * kCTileLd];
 };
 
-template <typename MaskT, bool APF, int OBS>
+// POLICY: the actions are not read from memory but computed in the prologue from the packed observation rows of the
+// current frame -- the forward pass of k_dqn_act_packed (qnet_device.hpp: same code, same Philox stream, bit-identical
+// actions), every wavefront taking the 16 agents of its strip.  The weights, the packed rows and this kernel's own state
+// / world loads are in flight together, and the ~5.6 k-cycle forward runs under the state and world round trips; a
+// separate act launch cost 6 us plus a launch boundary in front of this kernel's 8 us.
+template <typename MaskT, bool APF, int OBS, bool POLICY = false>
 __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -748,15 +761,38 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     const bool auto_reset = (a.flags & UAVENV_STEP_AUTO_RESET) != 0;
     UAV_STAMP(0);
 
+    // ---- policy prologue, part 1: fc1 + the packed row of this lane's agent (strip wv, row lane & 15) in flight
+    float *pW1 = reinterpret_cast<float *>(smem + a.pol_off);               // [64][108]
+    float *pW2 = pW1 + uavq::kTileF;                                        // [16][64]
+    float *pb2 = pW2 + uavq::kMaxOut * uavq::kHid;                          // [16]
+    int32_t *pact = reinterpret_cast<int32_t *>(pb2 + uavq::kMaxOut);       // [64] chosen actions of the workgroup's agents
+    uavq::floatx4 vW[uavq::kStageIters];
+    uavq::PRow prow;
+    float pol_b1 = 0.0f, pol_w2[4] = {0, 0, 0, 0}, pol_b2v = 0.0f;
+    uint4 pol_rn = make_uint4(0u, 0u, 0u, 0u);
+    const int pol_i = first + wv * 16 + (lane & 15);
+    const int pol_n2 = a.n_actions + (a.pol_dueling ? 1 : 0);
+    if (POLICY) {
+        const int tid = (int)threadIdx.x;
+        uavq::w_issue(vW, a.pol_local);
+        const uavq::NetDev nl = uavq::net_view(a.pol_local, pol_n2);
+        pol_b1 = nl.b1[tid < uavq::kHid ? tid : uavq::kHid - 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pol_w2[k] = nl.W2[tid + 256 * k < pol_n2 * uavq::kHid ? tid + 256 * k : 0];
+        pol_b2v = nl.b2[tid < pol_n2 ? tid : 0];
+        uavq::prow_load(prow, a.pol_obs + (size_t)(pol_i < N ? pol_i : N - 1) * kPackedDwords);
+        pol_rn = philox4x32_10(make_uint4((uint32_t)pol_i, (uint32_t)a.pol_counter, (uint32_t)(a.pol_counter >> 32), 0xac7u),
+                               make_uint2((uint32_t)a.pol_seed, (uint32_t)(a.pol_seed >> 32)));
+    }
     Agent g;
     RawAction ra = {0u, 0u};
     double head_old = 0.0;
     if (wv == 0) {                       // the state loads fly while the other three wavefronts stage the world blob
         load_agent(S, ii, g);
-        ra = load_action_raw(a.actions, a.action_kind, ii);
+        if (!POLICY) ra = load_action_raw(a.actions, a.action_kind, ii);
     } else if (wv == 2) {                // wave 2 computes the heading after the move (:423): old heading + action only
         head_old = S.F(F_HEAD)[ii];
-        ra = load_action_raw(a.actions, a.action_kind, ii);
+        if (!POLICY) ra = load_action_raw(a.actions, a.action_kind, ii);
     }
     // wave 1: every agent's reset candidate.  Philox and the bank rows need nothing but the agent index: their round
     // trip runs under the world staging.
@@ -792,17 +828,58 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     bool did_reset = false, skip = false, head_set = false;
     PreStep pre;
     pre.moved = false;
+    if (POLICY) {                        // policy prologue, part 2: weights into LDS
+        const int tid = (int)threadIdx.x;
+        uavq::w_commit(pW1, vW, pol_b1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < pol_n2 * uavq::kHid) pW2[tid + 256 * k] = pol_w2[k];
+        if (tid < pol_n2) pb2[tid] = pol_b2v;
+    }
     if (wv >= 2) {                       // the world blob comes in through waves 2 and 3 (wave 1's loads depend on
         stage_copy(smem, a, (int)threadIdx.x - 128, 128);                    // its state loads: it would hold the barrier)
     } else if (wv == 0) {                             // first half of update_PathPlan: needs the agent's own state only
         unpack_flags(g);
-        a0 = decode_action(ra, a.action_kind, a.n_actions);
         const bool masked = a.active && a.active[ii] == 0;
         skip = masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done);
-        if (!skip) step_pre(a, a0, g, pre);
+        if (!POLICY) {
+            a0 = decode_action(ra, a.action_kind, a.n_actions);
+            if (!skip) step_pre(a, a0, g, pre);
+        }
     }
-    __syncthreads();                                                         // world staged
+    __syncthreads();                                                         // world (and fc1) staged
     const WorldLds<MaskT> w = world_view<MaskT>(smem, a);
+    if (POLICY) {                        // policy prologue, part 3: forward, layer 2, epsilon-greedy
+        uavq::floatx4 h[4];
+        uavq::fwd_strip_packed(pW1, prow, h);
+        float q[4];
+        {
+            uavq::W2Frag<4> F;
+            uavq::w2_load<4>(F, pW2, pb2, pol_n2);
+            uavq::q_strip<4>(h, F, pol_n2, a.n_actions, a.pol_dueling, q);
+        }
+        if (lane < 16) {
+            const float sample = (float)(pol_rn.x >> 8) * (1.0f / 16777216.0f);
+            int act;
+            if (sample > a.pol_eps) {
+                act = 0;
+                float bq = q[0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (k < a.n_actions && q[k] > bq) { bq = q[k]; act = k; }
+            } else {
+                act = (int)(((uint64_t)pol_rn.y * (uint64_t)a.n_actions) >> 32);
+            }
+            pact[wv * 16 + lane] = act;
+            if (pol_i < N) a.pol_act[pol_i] = act;
+        }
+        __syncthreads();                                                     // the 64 actions of the workgroup are known
+        if (wv == 0 || wv == 2) ra.lo = (uint32_t)pact[lane];
+        if (wv == 0) {
+            a0 = decode_action(ra, UAVENV_ACT_INDEX_I32, a.n_actions);
+            if (!skip) step_pre(a, a0, g, pre);
+        }
+    }
     UAV_STAMP(1);
 
     if (wv == 1 && auto_reset) {
@@ -816,7 +893,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             C->cand_scn[lane] = -1;                                          // no candidate prepared
         }
     }
-    if (wv == 2) C->head[lane] = heading_after<true>(a, head_old, decode_action(ra, a.action_kind, a.n_actions));
+    if (wv == 2) C->head[lane] = heading_after<true>(a, head_old, decode_action(ra, POLICY ? UAVENV_ACT_INDEX_I32 : a.action_kind, a.n_actions));
     if (wv == 0) {
         if (skip) {
             ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
@@ -1183,6 +1260,12 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
         a.obsq_off = (e->world_bytes + 15) & ~15;
         const size_t clds = (size_t)a.obsq_off + sizeof(CoopLds);
         const int cgrid = (e->N + 63) / 64;
+        if (a.pol_local) {               // uavenv_step_policy (validated there: packed rows, APF off)
+            a.pol_off = (int32_t)((clds + 15) & ~(size_t)15);
+            const size_t plds = (size_t)a.pol_off + (size_t)(uavq::kTileF + uavq::kMaxOut * uavq::kHid + uavq::kMaxOut + 64) * 4;
+            launch_lds((k_step_coop<MaskT, false, OBS_KIND_PACKED, true>), cgrid, 256, plds, s, a);
+            return;
+        }
         UAV_LAUNCH(k_step_coop, cgrid, 256, clds);
         return;
     }
@@ -1562,6 +1645,48 @@ int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, 
     a.energy64 = energy64;
     a.active = active;
     a.flags = flags;
+    if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
+    else launch_step<uint64_t>(e, a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    e->tick += 1;
+    return UAVENV_OK;
+}
+
+int uavenv_step_policy(UavEnv *e, const UavDqnNet *net, const void *obs_cur, float eps, uint64_t seed, uint64_t counter,
+                       int32_t *action_out, void *obs, double *reward64, float *reward32, uint8_t *ret_done, uint8_t *agent_done,
+                       uint8_t *info, uint8_t *valid, double *energy64, const uint8_t *active, uint32_t flags, void *stream)
+{
+    if (!e || !net || !net->local || !obs_cur || !action_out) return fail(UAVENV_EINVAL, "null argument");
+    if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step_policy before uavenv_set_buildings");
+    if ((flags & UAVENV_STEP_AUTO_RESET) && e->bank_m <= 0)
+        return fail(UAVENV_EINVAL, "AUTO_RESET needs a scenario bank (uavenv_load_scenarios)");
+    static const int coop_env = env_int("UAVENV_COOP", -1);
+    const int n2 = net->n_actions + (net->dueling ? 1 : 0);
+    if (e->cfg.obs_dtype != UAVENV_OBS_PACKED || e->cfg.apf_enabled == 1 || e->N > 49152 || coop_env == 0 ||
+        (flags & UAVENV_STEP_ONE_WAVE) || net->w != uavq::kW || net->hid != uavq::kHid || n2 > 4 || net->n_actions < 2 ||
+        net->n_actions != e->cfg.n_actions || net->mfma_dtype != UAVENV_MFMA_F32 ||
+        ((((uintptr_t)net->local) | ((uintptr_t)obs_cur)) & 15u) != 0)
+        return fail(UAVENV_EINVAL, "uavenv_step_policy: this env / net takes uavenv_dqn_act + uavenv_step");
+    StepArgs a = base_args(e);
+    a.actions = action_out;
+    a.action_kind = UAVENV_ACT_INDEX_I32;
+    a.obs = obs;
+    a.reward64 = reward64;
+    a.reward32 = reward32;
+    a.ret_done = ret_done;
+    a.agent_done = agent_done;
+    a.info = info;
+    a.valid = valid;
+    a.energy64 = energy64;
+    a.active = active;
+    a.flags = flags;
+    a.pol_local = net->local;
+    a.pol_obs = reinterpret_cast<const uint32_t *>(obs_cur);
+    a.pol_act = action_out;
+    a.pol_dueling = net->dueling;
+    a.pol_eps = eps;
+    a.pol_seed = seed;
+    a.pol_counter = counter;
     if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
     else launch_step<uint64_t>(e, a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());

@@ -146,6 +146,17 @@ int uavenv_get_state(UavEnv *env, int32_t first, int32_t count, double *out16, d
 int uavenv_step(UavEnv *env, const void *actions_dev, int32_t action_kind, void *obs_dev, double *reward64_dev,
                 float *reward32_dev, uint8_t *ret_done_dev, uint8_t *agent_done_dev, uint8_t *info_dev,
                 uint8_t *valid_dev, double *energy64_dev, const uint8_t *active_dev, uint32_t flags, void *stream);
+/* uavenv_dqn_act + uavenv_step in ONE launch: the actions are computed in the step kernel's prologue from the packed
+ * observation rows of the current frame (obs_cur_dev: N x 20 dwords, e.g. replay frame t) with the same forward pass and
+ * the same epsilon-greedy stream as uavenv_dqn_act(net, obs_cur, ..., seed, counter) -- bit-identical actions -- and are
+ * also written to action_out_dev (N int32, e.g. the replay's action plane of frame t).  Everything else as uavenv_step.
+ * Takes packed-row envs of <= 49 152 agents without APF and nets with <= 4 layer-2 outputs on the f32 MFMA; returns
+ * UAVENV_EINVAL otherwise (callers then issue the two calls). */
+struct UavDqnNet;
+int uavenv_step_policy(UavEnv *env, const struct UavDqnNet *net, const void *obs_cur_dev, float eps, uint64_t seed,
+                       uint64_t counter, int32_t *action_out_dev, void *obs_dev, double *reward64_dev, float *reward32_dev,
+                       uint8_t *ret_done_dev, uint8_t *agent_done_dev, uint8_t *info_dev, uint8_t *valid_dev,
+                       double *energy64_dev, const uint8_t *active_dev, uint32_t flags, void *stream);
 /* Diagnostics: when dev_buf != NULL, wave w of uavenv_step writes 8 s_memtime stamps to dev_buf[8*w .. 8*w+7]
  * (start, world staged, state landed, step done, reset done, obs computed, stores issued, stores retired). */
 int uavenv_set_debug_buffer(UavEnv *env, unsigned long long *dev_buf);

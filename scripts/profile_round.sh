@@ -30,7 +30,10 @@ try:
         k = r.get("Kernel_Name", "")
         for short in ("k_step", "k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam", "k_sac"):
             if short in k:
+                if short == "k_step" and k.rstrip().endswith("true>(StepArgs)"):
+                    short = "k_step_policy"          # the step kernel with the policy in its prologue
                 agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                break
     for k, d in agg.items():
         for c, v in d.items():
             print(sys.argv[2], k, c, "n=%d mean=%.1f" % (len(v), sum(v) / len(v)))

@@ -17,10 +17,21 @@ stats = os.path.join(src, f"{tag}_kernel_stats.csv")
 pmc = os.path.join(src, f"{tag}_pmc.txt")
 entry = {"files": f"profiles/{tag}_kernel_stats.csv, profiles/{tag}_pmc.txt"}
 avg = {}
+def short_name(full):
+    """kernel family of a rocprofv3 kernel name; the step kernel that carries the policy in its prologue
+    (k_step_coop<..., true>) is its own family"""
+    if "k_step" in full:
+        return "k_step_policy" if full.rstrip().endswith("true>(StepArgs)") else "k_step"
+    for short in ("k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam"):
+        if short in full:
+            return short
+    return None
+
+
 for r in csv.DictReader(open(stats)):
-    for short in ("k_step", "k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam"):
-        if short in r["Name"] and short not in avg:
-            avg[short] = (float(r["AverageNs"]) * 1e-6, int(r["Calls"]))
+    short = short_name(r["Name"])
+    if short and short not in avg:
+        avg[short] = (float(r["AverageNs"]) * 1e-6, int(r["Calls"]))
 for short, (ms, calls) in avg.items():
     entry[f"{short}_ms"] = ms
     entry[f"{short}_calls"] = calls

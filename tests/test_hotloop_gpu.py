@@ -1,5 +1,7 @@
 """csrc/loop.hip: K steps enqueued from C == the same K steps driven call by call from Python (same kernels, same
-Philox counters): ring contents, weights, Adam moments, cursor -- bit for bit."""
+Philox counters): ring contents, weights, Adam moments, cursor -- bit for bit.  On packed rings the C loop runs the
+policy in the prologue of the step kernel (uavenv_step_policy) while the Python loop issues uavenv_dqn_act and uavenv_step
+separately: the comparison also pins that fusion."""
 import pytest
 import torch
 
@@ -8,7 +10,8 @@ pytestmark = pytest.mark.gpu
 PARAM = {"w": "100", "hiden_dim": "64", "output": "3", "LEARNING_RATE": "0.001", "gamma": "0.99", "Update_loop": "3"}
 
 
-@pytest.mark.parametrize("kind,net,dtype", [("dqn", "Qnet2", torch.float32), ("dueling", "VAnet2", torch.float16)])
+@pytest.mark.parametrize("kind,net,dtype", [("dqn", "Qnet2", torch.float32), ("dueling", "VAnet2", torch.float16),
+                                            ("dqn", "Qnet2", "packed"), ("dueling", "VAnet2", "packed")])
 def test_c_loop_equals_python_loop(kind, net, dtype):
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
     from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
