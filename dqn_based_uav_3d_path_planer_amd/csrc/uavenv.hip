@@ -103,6 +103,7 @@ struct StepArgs {
     int32_t tile_off;                  // LDS byte offset of the obs tile (TILE kernels)
     int32_t wave_slot;                 // bytes of per-wavefront LDS (work queue / observation tile share it)
     int32_t obsq_off;                  // LDS byte offset of the per-wave observation work queues (ObsWaveLds[waves])
+    int32_t apf_wave;                  // != 0: k_step adjusts the sub-goals with the whole wavefront (the per-wave LDS slot holds an ApfWaveLds)
     int32_t block;                     // workgroup size, passed as an argument: reading blockDim.x costs a vector load
                                        // from the dispatch packet + s_waitcnt vmcnt(0) in front of the staging barrier
     // io
@@ -483,62 +484,147 @@ __device__ __forceinline__ double heading_after(const StepArgs &a, double head_o
     return angle_of<INL>(vx, vy);
 }
 
-// `head_set`: true when this function assigned g.head itself (:489, Calc_V rescaled the velocity again).
+// update_PathPlan's second half in three pieces, so that the APF sub-goal adjustment in the middle can be done by the
+// whole wavefront (adjust_subgoals_wave) instead of one lane per agent:
+//   step_post_a   :400-406 (no sub-goal left) and :425-444 -- collision, reward terms, path length
+//   adjust_subgoals_lane / _wave   :448-449, Adjust_subgoal :156-166 -- every remaining sub-goal += cal_force(sub-goal)
+//   step_post_b   :450-453 (force on the UAV) and the termination cascade :456-513
+struct PostMid {
+    double r, tvx, tvy, dis_new, g_new;
+    bool live;                 // false: the step ended in step_post_a (:400-406)
+};
+
 template <typename MaskT, bool APF, bool INL>
-__device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
-                                          const PreStep &P, double &r, int &ret_done, int &info, bool &head_set)
+__device__ __forceinline__ void step_post_a(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
+                                            const PreStep &P, PostMid &M, int &ret_done, int &info, bool &head_set)
 {
     ObsIn &o = g.o;
-    const int max_step = a.max_step;
-    r = 0.0; ret_done = 0; info = UAVENV_INFO_NORMAL;
+    M.r = 0.0; M.tvx = M.tvy = M.dis_new = M.g_new = 0.0;
+    ret_done = 0; info = UAVENV_INFO_NORMAL;
     head_set = false;
+    M.live = P.moved;
     if (!P.moved) {                                                            // :400-406
         g.done = 1;
-        r += (double)(max_step - o.step);
-        g.score += r;
+        M.r += (double)(a.max_step - o.step);
+        g.score += M.r;
         ret_done = 1; info = UAVENV_INFO_SUCCESS;
         return;
     }
-    const double ox = P.ox, oy = P.oy, oz = P.oz, dis_old = P.dis_old, g_old = P.g_old, tgx = P.tgx, tgy = P.tgy;
+    double r = 0.0;
     // :425-428 as selects, not a branch.  (hipcc 7.2 was seen to merge the divergent `if (collided) { pos = old; }` with
     // a stale copy of the new position feeding the distances below -- in one kernel, not in the other, same source.
     // Selects leave it nothing to merge.)
     const bool hit = probe(w, o.px, o.py, o.pz);
     r = hit ? r - 0.3 : r;
-    o.px = hit ? ox : o.px;
-    o.py = hit ? oy : o.py;
-    o.pz = hit ? oz : o.pz;
+    o.px = hit ? P.ox : o.px;
+    o.py = hit ? P.oy : o.py;
+    o.pz = hit ? P.oz : o.pz;
     g.alias = hit ? 0 : g.alias;
-    const double tvx = hit ? o.s0x - o.px : o.vx, tvy = hit ? o.s0y - o.py : o.vy;
-    const double dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);       // :429
-    const double g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);            // :430
+    M.tvx = hit ? o.s0x - o.px : o.vx;
+    M.tvy = hit ? o.s0y - o.py : o.vy;
+    M.dis_new = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);                  // :429
+    M.g_new = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);                       // :430
     r -= 0.13 * fabs(a0);                                                      // :434
-    r += 0.2 * cos_between(tgx, tgy, tvx, tvy);                                // :435
-    r += 0.4 * (dis_old - dis_new);                                            // :436
-    r += 0.4 * (g_old - g_new);                                                // :437
+    r += 0.2 * cos_between(P.tgx, P.tgy, M.tvx, M.tvy);                        // :435
+    r += 0.4 * (P.dis_old - M.dis_new);                                        // :436
+    r += 0.4 * (P.g_old - M.g_new);                                            // :437
     r -= 0.1;                                                                  // :438
     r -= 0.01 * fabs(o.pz - o.s0z);                                            // :439-440
     g.path_len += o.V;                                                         // :443
     g.epoch += 1;                                                              // :444
+    M.r = r;
+}
 
-    if (APF) {                                                                 // :448-453 (private list only)
-        double *lst = a.st.sub + (size_t)ii * a.K * 3;
-        if (g.alias) { lst[g.sub_idx * 3] = o.s0x; lst[g.sub_idx * 3 + 1] = o.s0y; lst[g.sub_idx * 3 + 2] = o.s0z; }
-        for (int k = g.sub_idx; k < g.n_total; ++k) {                          // Adjust_subgoal :156-166
-            double fx, fy, fz;
-            const double sx = lst[k * 3], sy = lst[k * 3 + 1], sz = lst[k * 3 + 2];
-            cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, sx, sy, sz, fx, fy, fz);
-            lst[k * 3] = sx + fx; lst[k * 3 + 1] = sy + fy; lst[k * 3 + 2] = sz + fz;
-        }
+// Adjust_subgoal (:156-166) for ONE agent by its own lane (private list only)
+__device__ __forceinline__ void adjust_subgoals_lane(const StepArgs &a, int ii, Agent &g)
+{
+    ObsIn &o = g.o;
+    double *lst = a.st.sub + (size_t)ii * a.K * 3;
+    if (g.alias) { lst[g.sub_idx * 3] = o.s0x; lst[g.sub_idx * 3 + 1] = o.s0y; lst[g.sub_idx * 3 + 2] = o.s0z; }
+    for (int k = g.sub_idx; k < g.n_total; ++k) {
+        double fx, fy, fz;
+        const double sx = lst[k * 3], sy = lst[k * 3 + 1], sz = lst[k * 3 + 2];
+        cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, sx, sy, sz, fx, fy, fz);
+        lst[k * 3] = sx + fx; lst[k * 3 + 1] = sy + fy; lst[k * 3 + 2] = sz + fz;
+    }
+    g.alias = 0;
+    o.s0x = lst[g.sub_idx * 3]; o.s0y = lst[g.sub_idx * 3 + 1]; o.s0z = lst[g.sub_idx * 3 + 2];
+    if (g.sub_idx + 1 < g.n_total) {
+        o.s1x = lst[g.sub_idx * 3 + 3]; o.s1y = lst[g.sub_idx * 3 + 4]; o.s1z = lst[g.sub_idx * 3 + 5];
+    }
+}
+
+// The same for the 64 agents of a wavefront, by the wavefront: the (agent, sub-goal) pairs of all its agents form one
+// list (prefix sum of the remaining counts), pair p goes to lane p mod 64 -- ~n/64 pairs per lane instead of the longest
+// list of the 64 (random policy: 12-15 on average, up to 34), consecutive lanes on consecutive 24-byte entries of one
+// list.  Every pair is computed exactly as adjust_subgoals_lane computes it (cal_force on the same operands), so the
+// results are bit-identical.  Values another lane needs in the same launch (the aliased first sub-goal going in, the new
+// first two sub-goals coming out) travel through LDS, not through global memory.  ALL lanes must call it.
+struct ApfWaveLds {
+    int32_t start[64];         // exclusive prefix sum of the pair counts
+    int32_t sidx[64];          // sub_idx | alias << 30
+    double s0[64][3];          // the aliased first sub-goal (valid where alias)
+    double n0[64][3], n1[64][3];   // new sub_goals[0], sub_goals[1] of every agent
+};
+
+__device__ __forceinline__ void adjust_subgoals_wave(const StepArgs &a, ApfWaveLds *L, int first_agent, Agent &g, bool in_apf)
+{
+    const int lane = (int)threadIdx.x & 63;
+    ObsIn &o = g.o;
+    const int cnt = in_apf ? g.n_total - g.sub_idx : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    const int total = __shfl(inc, 63, 64);
+    L->start[lane] = inc - cnt;
+    L->sidx[lane] = g.sub_idx | (g.alias ? (1 << 30) : 0);
+    if (in_apf && g.alias) { L->s0[lane][0] = o.s0x; L->s0[lane][1] = o.s0y; L->s0[lane][2] = o.s0z; }
+    wave_lds_sync();
+    for (int p = lane; p < total; p += 64) {
+        int own = 0;                                   // the largest lane index with start <= p owns pair p
+#pragma unroll
+        for (int st = 32; st > 0; st >>= 1)
+            if (L->start[own + st] <= p) own += st;
+        const int sraw = L->sidx[own];
+        const int sub = sraw & 0xffff, k = sub + (p - L->start[own]);
+        double *e = a.st.sub + ((size_t)(first_agent + own) * a.K + k) * 3;
+        const bool from_lds = (sraw >> 30) != 0 && k == sub;
+        const double sx = from_lds ? L->s0[own][0] : e[0], sy = from_lds ? L->s0[own][1] : e[1],
+                     sz = from_lds ? L->s0[own][2] : e[2];
+        double fx, fy, fz;
+        cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, sx, sy, sz, fx, fy, fz);
+        const double nx = sx + fx, ny = sy + fy, nz = sz + fz;
+        e[0] = nx; e[1] = ny; e[2] = nz;
+        if (k == sub) { L->n0[own][0] = nx; L->n0[own][1] = ny; L->n0[own][2] = nz; }
+        if (k == sub + 1) { L->n1[own][0] = nx; L->n1[own][1] = ny; L->n1[own][2] = nz; }
+    }
+    wave_lds_sync();
+    if (in_apf) {
         g.alias = 0;
-        o.s0x = lst[g.sub_idx * 3]; o.s0y = lst[g.sub_idx * 3 + 1]; o.s0z = lst[g.sub_idx * 3 + 2];
-        if (g.sub_idx + 1 < g.n_total) {
-            o.s1x = lst[g.sub_idx * 3 + 3]; o.s1y = lst[g.sub_idx * 3 + 4]; o.s1z = lst[g.sub_idx * 3 + 5];
-        }
+        o.s0x = L->n0[lane][0]; o.s0y = L->n0[lane][1]; o.s0z = L->n0[lane][2];
+        if (g.sub_idx + 1 < g.n_total) { o.s1x = L->n1[lane][0]; o.s1y = L->n1[lane][1]; o.s1z = L->n1[lane][2]; }
+    }
+    wave_lds_sync();
+}
+
+// `head_set`: true when this function assigned g.head itself (:489, Calc_V rescaled the velocity again).
+template <typename MaskT, bool APF, bool INL>
+__device__ __forceinline__ void step_post_b(const StepArgs &a, const WorldLds<MaskT> &w, int ii, Agent &g, const PostMid &M,
+                                            double &r, int &ret_done, int &info, bool &head_set)
+{
+    ObsIn &o = g.o;
+    const int max_step = a.max_step;
+    r = M.r;
+    if (!M.live) return;
+    const double tvx = M.tvx, tvy = M.tvy, dis_new = M.dis_new, g_new = M.g_new;
+    if (APF) {                                                                 // :450-453
         double fx, fy, fz;
         cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, o.px, o.py, o.pz, fx, fy, fz);
         const double force = sqrt(fx * fx + fy * fy + fz * fz);
-        r += 0.2 * force * cos_between(fx, fy, tvx, tvy);                      // :451-453
+        r += 0.2 * force * cos_between(fx, fy, tvx, tvy);
     }
 
     const double d_sub = APF ? dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z) : dis_new;   // same operands when !APF
@@ -587,6 +673,17 @@ __device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<Mask
     } else {                                                                   // :510-513
         g.score += r; g.total += r;
     }
+}
+
+// the whole second half by one lane (cooperative kernel, and k_step when the wave-level adjustment is not available)
+template <typename MaskT, bool APF, bool INL>
+__device__ __forceinline__ void step_post(const StepArgs &a, const WorldLds<MaskT> &w, int ii, double a0, Agent &g,
+                                          const PreStep &P, double &r, int &ret_done, int &info, bool &head_set)
+{
+    PostMid M;
+    step_post_a<MaskT, APF, INL>(a, w, ii, a0, g, P, M, ret_done, info, head_set);
+    if (APF && M.live) adjust_subgoals_lane(a, ii, g);
+    step_post_b<MaskT, APF, INL>(a, w, ii, g, M, r, ret_done, info, head_set);
 }
 
 // Agents/UAV.py:397-513  update_PathPlan(action) on the register copy of one agent.
@@ -653,7 +750,25 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         double r = 0.0;
         int ret_done = 0, info = UAVENV_INFO_NORMAL, valid = 1;
         const bool masked = a.active && a.active[ii] == 0;
-        if (masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done)) {
+        const bool stepping = !(masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done));
+        if (APF && a.apf_wave) {
+            // update_PathPlan in three pieces: the sub-goal adjustment in the middle is done by the whole wavefront
+            PreStep P;
+            PostMid M;
+            M.live = false;
+            bool head_set = false;
+            if (stepping) {
+                step_pre(a, a0, g, P);
+                if (P.moved) g.head = angle_of<true>(g.o.vx, g.o.vy);              // :423
+                step_post_a<MaskT, APF, true>(a, w, ii, a0, g, P, M, ret_done, info, head_set);
+            } else {
+                ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;         // PathPlan_City.py:365-366
+            }
+            ApfWaveLds *LA = reinterpret_cast<ApfWaveLds *>(smem + a.obsq_off + (threadIdx.x >> 6) * a.wave_slot);
+            // (lanes past N run on a copy of the last agent and store nothing: they must not contribute pairs either)
+            adjust_subgoals_wave(a, LA, i - ((int)threadIdx.x & 63), g, active && stepping && M.live);
+            if (stepping) step_post_b<MaskT, APF, true>(a, w, ii, g, M, r, ret_done, info, head_set);
+        } else if (!stepping) {
             ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
         } else {
             step_agent<MaskT, APF, true>(a, w, ii, a0, g, r, ret_done, info);
@@ -1234,6 +1349,11 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     a.obsq_off = (e->world_bytes + 15) & ~15;
     int slot = (int)sizeof(ObsWaveLds);            // per-wave LDS slot: the work queue, then (same bytes) the tile
     if (tile_store && kCTileBytes > slot) slot = kCTileBytes;
+    static const int apf_lane_env = env_int("UAVENV_APF_LANE", 0);       // A/B knob: 1 = the per-lane sub-goal adjustment
+    if (apf && !apf_lane_env) {
+        if ((int)sizeof(ApfWaveLds) > slot) slot = (int)sizeof(ApfWaveLds);
+        a.apf_wave = 1;
+    }
     slot = (slot + 15) & ~15;
     a.wave_slot = slot;
     a.tile_off = tile_store ? a.obsq_off : -1;
