@@ -18,7 +18,7 @@ OBS_F32, OBS_F16, OBS_PACKED = 0, 1, 2
 PACKED_DWORDS = 20
 MFMA_F32, MFMA_F16 = 0, 1
 P2P_HANDLE_BYTES = 64
-STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE = 1, 2, 4, 8
+STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE, STEP_APF_LANE = 1, 2, 4, 8, 16
 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = (

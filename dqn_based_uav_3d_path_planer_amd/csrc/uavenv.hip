@@ -16,6 +16,7 @@
 // transcendental chain of the step (4 atan2, 2 sin/cos pairs, ~8 sqrt) is the compute floor.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -95,7 +96,11 @@ struct StepArgs {
     int32_t nb, gn;
     double inv_cell, W, Hbox;
     const BldApf *apf_b;
-    const uint64_t *apf_grid;          // [gn][gn] masks of the MOVING cylinders whose 60 m force range can reach the cell
+    const uint64_t *apf_grid;          // [apf_nz][apf_gn][apf_gn] masks of the MOVING cylinders whose 60 m force range can
+                                       // reach the cell (its own, finer, 3-D resolution: see uavenv_set_buildings)
+    int32_t apf_gn, apf_nz;
+    double apf_inv_cell, apf_inv_cz;
+    uint64_t apf_all;                  // mask of all moving cylinders (points outside the box)
     // agent params
     double max_v, steer;
     PowerParams pw;
@@ -103,7 +108,7 @@ struct StepArgs {
     int32_t tile_off;                  // LDS byte offset of the obs tile (TILE kernels)
     int32_t wave_slot;                 // bytes of per-wavefront LDS (work queue / observation tile share it)
     int32_t obsq_off;                  // LDS byte offset of the per-wave observation work queues (ObsWaveLds[waves])
-    int32_t apf_wave;                  // != 0: k_step adjusts the sub-goals with the whole wavefront (the per-wave LDS slot holds an ApfWaveLds)
+    int32_t apf_split;                 // != 0: k_apf_adjust ran before this k_step launch (see there)
     int32_t block;                     // workgroup size, passed as an argument: reading blockDim.x costs a vector load
                                        // from the dispatch packet + s_waitcnt vmcnt(0) in front of the staging barrier
     // io
@@ -142,6 +147,9 @@ struct UavEnv {
     double cell = 10.0;
     BldApf *apf_b = nullptr;
     uint64_t *apf_grid = nullptr;
+    uint64_t apf_all = 0;
+    int apf_gn = 1, apf_nz = 1;
+    double apf_cell = 10.0, apf_cz = 10.0;
     uint2 *emit_lut = nullptr;
     bool have_world = false;
     // bank
@@ -207,63 +215,88 @@ __device__ __forceinline__ WorldLds<MaskT> stage_world(unsigned char *smem, cons
 // Agents/UAV.py:174-210  cal_force(point): attraction/repulsion + motion force of every MOVING building
 // within 60 m of its rim.  Returns false where the reference would call Cal_SubTask_Dynamic() (raises).
 // One (point, moving cylinder) pair of cal_force.  Returns false when the accumulated force passed 100 (:205-208).
-__device__ __forceinline__ bool cal_force_pair(const BldApf &B, double x, double y, double z, double &cum, double &tx,
-                                               double &ty)
+struct ForceTerms {
+    double s, f1x, f1y, f2x, f2y;      // f1 + f2, and the two force vectors (UAV.py:190-201)
+};
+// false: the cylinder is out of range (dis - R > 60, :186-187) and contributes nothing
+__device__ __forceinline__ bool cal_force_terms(const BldApf &B, double x, double y, double z, ForceTerms &t)
 {
     const double dx = B.cx - x, dy = B.cy - y, dz = B.cz - z;
     const double h2 = dx * dx + dy * dy;
-    if (h2 + dz * dz > B.far2) return true;                                 // certainly dis - R > 60
-    const double dis = dist3(x, y, z, B.cx, B.cy, B.cz);                    // :183 (same operands as before)
+    if (h2 + dz * dz > B.far2) return false;                                // certainly dis - R > 60
+    const double dis = sqrt(h2 + dz * dz);                                  // :183 Eu_Loc_distance ((a-b)^2 == (b-a)^2 exactly)
     const double d2e = dis - B.R;
-    if (d2e > 60.0) return true;                                            // :186-187
-    const double q = B.R / (d2e * d2e);
+    if (d2e > 60.0) return false;                                           // :186-187
+    // :190,:200  both magnitudes divide by dis2edge^2: one reciprocal, two products (each within 1 ulp of the
+    // reference's quotient; every pair runs through here, and an f64 division is ~12 instructions)
+    const double inv_dd = 1.0 / (d2e * d2e);
+    const double q = B.R * inv_dd;
     double f1 = (q < 1.0) ? q : 1.0;                                        // :190
     if (d2e < 0.0) f1 = (-d2e > 2.0) ? -d2e : 2.0;                          // :196-197
     // :191,:198  direction sub-goal -> centre: (cos, sin) of calculate_angle = the unit vector of (dx, dy); the
     // zero vector has angle 0.  (The reference goes atan2 -> cos/sin; same direction to ~1e-16.)
     double cx1 = 1.0, sy1 = 0.0;
     if (h2 > 0.0) {
-        const double inv = 1.0 / sqrt(h2);
+        const double inv = rsqrt(h2);
         cx1 = dx * inv;
         sy1 = dy * inv;
     }
-    const double f1x = -f1 * cx1, f1y = -f1 * sy1;
-    const double q2 = B.vnorm * B.R / (d2e * d2e);
+    t.f1x = -f1 * cx1;
+    t.f1y = -f1 * sy1;
+    const double q2 = (B.vnorm * B.R) * inv_dd;
     const double f2 = (q2 < 1.0) ? q2 : 1.0;                                // :200
-    const double f2x = f2 * B.ux, f2y = f2 * B.uy;                          // :201
-    cum += (f1 + f2);
-    tx = (tx + f1x) + f2x;
-    ty = (ty + f1y) + f2y;
+    t.f2x = f2 * B.ux;                                                      // :201
+    t.f2y = f2 * B.uy;
+    t.s = f1 + f2;
+    return true;
+}
+// adds one in-range cylinder's terms; false when the accumulated force passed 100 (:205-208)
+__device__ __forceinline__ bool force_accumulate(const ForceTerms &t, double &cum, double &tx, double &ty)
+{
+    cum += t.s;
+    tx = (tx + t.f1x) + t.f2x;
+    ty = (ty + t.f1y) + t.f2y;
     return !(cum > 100.0);
 }
+__device__ __forceinline__ bool cal_force_pair(const BldApf &B, double x, double y, double z, double &cum, double &tx,
+                                               double &ty)
+{
+    ForceTerms t;
+    if (!cal_force_terms(B, x, y, z, t)) return true;
+    return force_accumulate(t, cum, tx, ty);
+}
 
-// Inside the box only the cylinders listed for the point's cell are visited (ascending index = the reference's loop
-// order with the out-of-range ones, which contribute nothing, left out); outside it, all of them.
-__device__ __noinline__ bool cal_force(const BldApf *__restrict__ b, int nb, const uint64_t *__restrict__ grid, int gn,
-                                       double inv_cell, double W, double x, double y, double z, double &fx, double &fy,
-                                       double &fz)
+// cal_force's broad phase.  Inside the box only the cylinders listed for the point's cell are visited (ascending index
+// = the reference's loop order with the out-of-range ones, which contribute nothing, left out); outside it, all the
+// moving ones.
+__device__ __forceinline__ uint64_t apf_mask(const StepArgs &a, double x, double y, double z)
+{
+    if (a.apf_grid && x >= 0.0 && x <= a.W && y >= 0.0 && y <= a.W && z >= 0.0 && z <= a.Hbox) {
+        int ix = (int)(x * a.apf_inv_cell), iy = (int)(y * a.apf_inv_cell), iz = (int)(z * a.apf_inv_cz);
+        ix = ix > a.apf_gn - 1 ? a.apf_gn - 1 : ix;
+        iy = iy > a.apf_gn - 1 ? a.apf_gn - 1 : iy;
+        iz = iz > a.apf_nz - 1 ? a.apf_nz - 1 : iz;
+        return a.apf_grid[((size_t)iz * a.apf_gn + iy) * a.apf_gn + ix];
+    }
+    return a.apf_all;
+}
+
+__device__ __noinline__ bool cal_force_masked(const BldApf *__restrict__ b, uint64_t m, double x, double y, double z,
+                                              double &fx, double &fy, double &fz)
 {
     double cum = 0.0, tx = 0.0, ty = 0.0;
     bool ok = true;
-    if (grid && x >= 0.0 && x <= W && y >= 0.0 && y <= W) {
-        int ix = (int)(x * inv_cell), iy = (int)(y * inv_cell);
-        ix = ix > gn - 1 ? gn - 1 : ix;
-        iy = iy > gn - 1 ? gn - 1 : iy;
-        uint64_t m = grid[iy * gn + ix];
-        while (m) {
-            const int i = __builtin_ctzll(m);
-            m &= m - 1;
-            if (!cal_force_pair(b[i], x, y, z, cum, tx, ty)) { ok = false; break; }
-        }
-    } else {
-        for (int i = 0; i < nb; ++i) {
-            const BldApf B = b[i];
-            if (B.moving == 0.0) continue;                                      // :180-182 v == 0: no force
-            if (!cal_force_pair(B, x, y, z, cum, tx, ty)) { ok = false; break; }
-        }
+    while (m) {
+        const int i = __builtin_ctzll(m);
+        m &= m - 1;
+        if (!cal_force_pair(b[i], x, y, z, cum, tx, ty)) { ok = false; break; }
     }
     fx = tx; fy = ty; fz = 0.0;
     return ok;
+}
+__device__ __forceinline__ bool cal_force(const StepArgs &a, double x, double y, double z, double &fx, double &fy, double &fz)
+{
+    return cal_force_masked(a.apf_b, apf_mask(a, x, y, z), x, y, z, fx, fy, fz);
 }
 
 // Actions are fetched as raw bits (so the load can be issued early, with no dependent conversion) and decoded
@@ -402,7 +435,8 @@ __device__ __forceinline__ void reset_candidate(const StepArgs &a, int i, ResetC
     reset_candidate_finish(a, heading, c);
 }
 
-template <bool APF>
+// COPY = false: the caller copies the list itself (k_step with the wave-level APF path: copy_reset_lists_wave)
+template <bool APF, bool COPY = true>
 __device__ __forceinline__ void apply_reset(const StepArgs &a, int i, Agent &g, const ResetCand &c)
 {
     ObsIn &o = g.o;
@@ -421,7 +455,7 @@ __device__ __forceinline__ void apply_reset(const StepArgs &a, int i, Agent &g, 
     if (APF) {
         const double *src = a.bank.sub + (size_t)c.scn * a.K * 3;
         double *dst = a.st.sub + (size_t)i * a.K * 3;
-        for (int k = 0; k < c.n_total * 3; ++k) dst[k] = src[k];
+        if (COPY) for (int k = 0; k < c.n_total * 3; ++k) dst[k] = src[k];
         g.scn = -1;
     } else {
         g.scn = c.scn;
@@ -435,6 +469,30 @@ __device__ __forceinline__ void reset_agent(const StepArgs &a, int i, Agent &g)
     ResetCand c;
     reset_candidate(a, i, c);
     apply_reset<APF>(a, i, g, c);
+}
+
+// APF resets of one wavefront: the reset itself per lane, then the scenario's sub-goal list into the agent's private
+// slot by the whole wavefront, one reset agent after the other (a lane copying its own <= K x 3 doubles alone is a
+// chain of dependent load -> store round trips: ~15 us of a 131 072-agent launch).  ALL lanes must call it.
+__device__ __forceinline__ void reset_agents_wave(const StepArgs &a, int first_agent, int ii, Agent &g, bool do_reset)
+{
+    int scn = 0;
+    if (do_reset) {
+        ResetCand c;
+        reset_candidate(a, ii, c);
+        apply_reset<true, false>(a, ii, g, c);
+        scn = c.scn;
+    }
+    const int lane = (int)threadIdx.x & 63;
+    unsigned long long rm = __ballot(do_reset);
+    while (rm) {
+        const int l = __builtin_ctzll(rm);
+        rm &= rm - 1;
+        const int n3 = __shfl(g.n_total, l, 64) * 3;
+        const double *src = a.bank.sub + (size_t)__shfl(scn, l, 64) * a.K * 3;
+        double *dst = a.st.sub + (size_t)(first_agent + l) * a.K * 3;
+        for (int k = lane; k < n3; k += 64) dst[k] = src[k];
+    }
 }
 
 // Agents/UAV.py:397-513  update_PathPlan(action), first and second half.
@@ -485,9 +543,9 @@ __device__ __forceinline__ double heading_after(const StepArgs &a, double head_o
 }
 
 // update_PathPlan's second half in three pieces, so that the APF sub-goal adjustment in the middle can be done by the
-// whole wavefront (adjust_subgoals_wave) instead of one lane per agent:
+// kernel in front (k_apf_adjust + adjust_subgoals_split) instead of one lane per agent:
 //   step_post_a   :400-406 (no sub-goal left) and :425-444 -- collision, reward terms, path length
-//   adjust_subgoals_lane / _wave   :448-449, Adjust_subgoal :156-166 -- every remaining sub-goal += cal_force(sub-goal)
+//   adjust_subgoals_lane / _split  :448-449, Adjust_subgoal :156-166 -- every remaining sub-goal += cal_force(sub-goal)
 //   step_post_b   :450-453 (force on the UAV) and the termination cascade :456-513
 struct PostMid {
     double r, tvx, tvy, dis_new, g_new;
@@ -544,7 +602,7 @@ __device__ __forceinline__ void adjust_subgoals_lane(const StepArgs &a, int ii, 
     for (int k = g.sub_idx; k < g.n_total; ++k) {
         double fx, fy, fz;
         const double sx = lst[k * 3], sy = lst[k * 3 + 1], sz = lst[k * 3 + 2];
-        cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, sx, sy, sz, fx, fy, fz);
+        cal_force(a, sx, sy, sz, fx, fy, fz);
         lst[k * 3] = sx + fx; lst[k * 3 + 1] = sy + fy; lst[k * 3 + 2] = sz + fz;
     }
     g.alias = 0;
@@ -554,60 +612,202 @@ __device__ __forceinline__ void adjust_subgoals_lane(const StepArgs &a, int ii, 
     }
 }
 
-// The same for the 64 agents of a wavefront, by the wavefront: the (agent, sub-goal) pairs of all its agents form one
-// list (prefix sum of the remaining counts), pair p goes to lane p mod 64 -- ~n/64 pairs per lane instead of the longest
-// list of the 64 (random policy: 12-15 on average, up to 34), consecutive lanes on consecutive 24-byte entries of one
-// list.  Every pair is computed exactly as adjust_subgoals_lane computes it (cal_force on the same operands), so the
-// results are bit-identical.  Values another lane needs in the same launch (the aliased first sub-goal going in, the new
-// first two sub-goals coming out) travel through LDS, not through global memory.  ALL lanes must call it.
-struct ApfWaveLds {
-    int32_t start[64];         // exclusive prefix sum of the pair counts
-    int32_t sidx[64];          // sub_idx | alias << 30
-    double s0[64][3];          // the aliased first sub-goal (valid where alias)
-    double n0[64][3], n1[64][3];   // new sub_goals[0], sub_goals[1] of every agent
+// Adjust_subgoal for a whole launch as its OWN kernel, in front of k_step (k_step's registers allow two wavefronts per
+// SIMD and a 131 072-agent launch has only 2 048 of them: the per-agent loop over ~20 sub-goals x the cylinders of each
+// one's cell was a chain of dependent loads with nothing to overlap it -- 210 of 249 us).
+//
+// What makes the split legal: sub-goal k's new value depends on its old value and the (static) force field alone
+// (:156-166, cal_force :174-210), not on the UAV -- EXCEPT the first remaining one while it still IS the position object
+// (alias: the first step after a reset; Adjust_subgoal rebinds the list entries, so the alias ends there).  Whether the
+// adjustment happens at all (:447: the step got past :400-406) is known before the step: the agent steps (not masked,
+// not skip-done) and has a sub-goal left.  So this kernel adjusts every remaining sub-goal of every such agent, minus the
+// aliased first one, which k_step does itself after the move (one cal_force on that lane); k_step then reads the new
+// sub_goals[0] / [1] back from the list.  It must run BEFORE k_step (which pops sub-goals and, on auto-reset, rewrites
+// the lists).  The values are computed by the same cal_force_pair calls on the same operands in the same order as
+// adjust_subgoals_lane's: bit-identical lists.
+//
+// Geometry: a workgroup of four wavefronts takes 64 agents; their (agent, sub-goal) pairs form one list (prefix sum of
+// the counts, owner of pair p by binary search in LDS), dealt to the four wavefronts 64 at a time, up to 256 in work per wavefront -- so the wavefronts of a workgroup finish together whatever the agents' list lengths are.  A pair costs one
+// cal_force_pair (~130 f64-heavy instructions: two square roots, three divisions) per cylinder of its cell's mask, and
+// the masks have 2.6 bits on average but 6-7 for the longest of 64 consecutive pairs, which the other 63 lanes would wait
+// for.  So per chunk:
+//   pass 1  lane p mod 64 reads pair p (consecutive lanes on consecutive 24-byte entries), looks its mask up and parks
+//           (x, y, z, mask) in LDS; a histogram of min(popcount, 15) through ds_add_rtn gives bucket + rank in the bucket;
+//   sort    counting sort of the chunk's pairs by mask size (16-bit indices scattered to their places);
+//   pass 2  the forces, 64 pairs of (nearly) equal trip count at a time, LDS to LDS;
+//   pass 3  the new entries back to the lists, again in list order.
+// The order in which pairs are processed is free: every pair is an independent read-modify-write of its own entry.
+// The moving-cylinder table sits in LDS.
+constexpr int kApfAgentsPerBlock = 64;
+constexpr int kApfBuckets = 16;
+constexpr int kApfChunk = 192;
+struct ApfPairLds {
+    double x, y, z;
+    unsigned long long m;
 };
-
-__device__ __forceinline__ void adjust_subgoals_wave(const StepArgs &a, ApfWaveLds *L, int first_agent, Agent &g, bool in_apf)
+struct ApfSortLds {
+    ApfPairLds rec[kApfChunk];
+    uint16_t off[kApfChunk];       // list offset (agent-in-workgroup * K + k)
+    uint16_t key[kApfChunk];       // bucket << 12 | rank
+    uint16_t sorted[kApfChunk];
+    uint32_t hist[kApfBuckets];
+    int32_t ends[64], rels[64];    // inclusive prefix sum of the agents' pair counts; list offset - pair index
+};
+#ifdef UAVENV_PHASE_PROFILE   // diagnostic build only (scripts/phase_profile_apf.py): cycles per phase, summed per wavefront
+#define APF_T0() unsigned long long apf_t = __builtin_amdgcn_s_memtime(), apf_acc[6] = {0, 0, 0, 0, 0, 0}
+#define APF_LAP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); apf_acc[k] += n_ - apf_t; apf_t = n_; } while (0)
+#define APF_DUMP() do { if (a.dbg && lane == 0) for (int k_ = 0; k_ < 6; ++k_) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + k_] = apf_acc[k_]; } while (0)
+#else
+#define APF_T0() do { } while (0)
+#define APF_LAP(k) do { } while (0)
+#define APF_DUMP() do { } while (0)
+#endif
+__global__ void __launch_bounds__(256) k_apf_adjust(StepArgs a)
 {
-    const int lane = (int)threadIdx.x & 63;
-    ObsIn &o = g.o;
-    const int cnt = in_apf ? g.n_total - g.sub_idx : 0;
-    int inc = cnt;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const DevState &S = a.st;
+    APF_T0();
+    {
+        const double *src = reinterpret_cast<const double *>(a.apf_b);
+        double *dst = reinterpret_cast<double *>(smem);
+        for (int k = (int)threadIdx.x; k < a.nb * (int)(sizeof(BldApf) / 8); k += 256) dst[k] = src[k];
+    }
+    const BldApf *bl = reinterpret_cast<const BldApf *>(smem);
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    ApfSortLds *L = reinterpret_cast<ApfSortLds *>(smem + (((a.nb > 0 ? a.nb : 1) * (int)sizeof(BldApf) + 31) & ~31)) + wave;
+    const int first = blockIdx.x * kApfAgentsPerBlock;
+    int cnt = 0, k0 = 0;
+    if (first + lane < a.N) {                          // (every wavefront computes the workgroup's prefix sum for itself)
+        const int ii = first + lane;
+        const int sub = S.I(I_SUBIDX)[ii], nt = S.I(I_NTOTAL)[ii], fl = S.I(I_FLAGS)[ii];
+        const bool masked = a.active && a.active[ii] == 0;
+        const bool stepping = !(masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && (fl & kFlagDone)));
+        if (stepping && sub < nt) {
+            k0 = sub + ((fl & kFlagAlias) ? 1 : 0);
+            cnt = nt - k0;
+        }
+    }
+    int end = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
+        const int t = __shfl_up(end, d, 64);
+        if (lane >= d) end += t;
     }
-    const int total = __shfl(inc, 63, 64);
-    L->start[lane] = inc - cnt;
-    L->sidx[lane] = g.sub_idx | (g.alias ? (1 << 30) : 0);
-    if (in_apf && g.alias) { L->s0[lane][0] = o.s0x; L->s0[lane][1] = o.s0y; L->s0[lane][2] = o.s0z; }
-    wave_lds_sync();
-    for (int p = lane; p < total; p += 64) {
-        int own = 0;                                   // the largest lane index with start <= p owns pair p
+    L->ends[lane] = end;
+    L->rels[lane] = lane * a.K + k0 - (end - cnt);     // list offset (agent-in-workgroup * K + k) = p + rel
+    const int total = __shfl(end, 63, 64);
+    double *lists = a.st.sub + (size_t)first * a.K * 3;
+    __syncthreads();                                   // the table (and ends / rels)
+    APF_LAP(0);
+    // The list is dealt to the four wavefronts 64 pairs (one "group": 64 consecutive entries) at a time, wavefront w
+    // taking groups w, w + 4, ...; a wavefront works on up to kApfChunk / 64 of its groups at once.
+    constexpr int kPer = kApfChunk / 64;
+    const int n_groups = (total + 63) >> 6;
+    const int my_groups = (n_groups - wave + 3) >> 2;
+    const int n_chunks = (my_groups + kPer - 1) / kPer;
+    const int gpc = n_chunks > 0 ? (my_groups + n_chunks - 1) / n_chunks : 1;     // groups per chunk, evened out
+    for (int g0 = 0; g0 < my_groups; g0 += gpc) {
+        const int ng = my_groups - g0 < gpc ? my_groups - g0 : gpc;
+        const int last_base = (((g0 + ng - 1) << 2) + wave) << 6;                 // only the list's last group can be short
+        const int n = (ng - 1) * 64 + (total - last_base < 64 ? total - last_base : 64);
+        if (lane < kApfBuckets) L->hist[lane] = 0;
+        wave_lds_sync();
+        // ---- pass 1 (the chunk's four loads per lane issued back to back, then the four table lookups: a wavefront's
+        // chunks are a serial chain of HBM round trips otherwise)
+        double ex[kPer], ey[kPer], ez[kPer];
+        int offv[kPer];
 #pragma unroll
-        for (int st = 32; st > 0; st >>= 1)
-            if (L->start[own + st] <= p) own += st;
-        const int sraw = L->sidx[own];
-        const int sub = sraw & 0xffff, k = sub + (p - L->start[own]);
-        double *e = a.st.sub + ((size_t)(first_agent + own) * a.K + k) * 3;
-        const bool from_lds = (sraw >> 30) != 0 && k == sub;
-        const double sx = from_lds ? L->s0[own][0] : e[0], sy = from_lds ? L->s0[own][1] : e[1],
-                     sz = from_lds ? L->s0[own][2] : e[2];
+        for (int u = 0; u < kPer; ++u) {
+            const int i = lane + 64 * u;
+            const int p = i < n ? ((((g0 + u) << 2) + wave) << 6) + lane : 0;     // slot i of the chunk <-> pair p
+            int own = 0;                                       // ends[] is non-decreasing: the owner is #{j : ends[j] <= p}
+#pragma unroll
+            for (int st = 32; st > 0; st >>= 1)
+                if (L->ends[own + st - 1] <= p) own += st;
+            offv[u] = p + L->rels[own];
+            const double *e = lists + (size_t)offv[u] * 3;
+            ex[u] = e[0]; ey[u] = e[1]; ez[u] = e[2];
+        }
+        unsigned long long mv[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) mv[u] = apf_mask(a, ex[u], ey[u], ez[u]);
+        APF_LAP(1);
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int i = lane + 64 * u;
+            if (i < n) {
+                const int pc = __popcll(mv[u]) < kApfBuckets - 1 ? __popcll(mv[u]) : kApfBuckets - 1;
+                const uint32_t rank = atomicAdd(&L->hist[pc], 1u);
+                L->rec[i] = ApfPairLds{ex[u], ey[u], ez[u], mv[u]};
+                L->off[i] = (uint16_t)offv[u];
+                L->key[i] = (uint16_t)((pc << 12) | rank);
+            }
+        }
+        wave_lds_sync();
+        APF_LAP(2);
+        {   // bucket starts (exclusive scan of the histogram), in place
+            const uint32_t h = lane < kApfBuckets ? L->hist[lane] : 0;
+            uint32_t inc = h;
+#pragma unroll
+            for (int d = 1; d < kApfBuckets; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += t;
+            }
+            wave_lds_sync();
+            if (lane < kApfBuckets) L->hist[lane] = inc - h;
+        }
+        wave_lds_sync();
+        for (int i = lane; i < n; i += 64) {
+            const int key = L->key[i];
+            L->sorted[L->hist[key >> 12] + (key & 4095)] = (uint16_t)i;
+        }
+        wave_lds_sync();
+        APF_LAP(3);
+        // ---- pass 2: the forces, in bucket order
+        for (int q = lane; q < n; q += 64) {
+            const int i = L->sorted[q];
+            const ApfPairLds rec = L->rec[i];
+            unsigned long long m = rec.m;
+            double cum = 0.0, tx = 0.0, ty = 0.0;
+            while (m) {
+                const int bi = __builtin_ctzll(m);
+                m &= m - 1;
+                if (!cal_force_pair(bl[bi], rec.x, rec.y, rec.z, cum, tx, ty)) break;
+            }
+            L->rec[i].x = rec.x + tx;
+            L->rec[i].y = rec.y + ty;
+        }
+        wave_lds_sync();
+        APF_LAP(4);
+        // ---- pass 3
+        for (int i = lane; i < n; i += 64) {
+            double *e = lists + (size_t)L->off[i] * 3;
+            e[0] = L->rec[i].x; e[1] = L->rec[i].y; e[2] = L->rec[i].z + 0.0;
+        }
+        wave_lds_sync();
+        APF_LAP(5);
+    }
+    APF_DUMP();
+}
+
+// k_step's share of the adjustment when k_apf_adjust ran: the aliased first sub-goal (`pre_alias`: the alias flag before
+// the move), then the new sub_goals[0] / [1] from the list.
+__device__ __forceinline__ void adjust_subgoals_split(const StepArgs &a, int ii, Agent &g, bool pre_alias)
+{
+    ObsIn &o = g.o;
+    double *lst = a.st.sub + ((size_t)ii * a.K + g.sub_idx) * 3;
+    if (pre_alias) {
+        // (a collision this step ended the alias before the adjustment: then the list's own entry is the operand)
+        const double sx = g.alias ? o.s0x : lst[0], sy = g.alias ? o.s0y : lst[1], sz = g.alias ? o.s0z : lst[2];
         double fx, fy, fz;
-        cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, sx, sy, sz, fx, fy, fz);
-        const double nx = sx + fx, ny = sy + fy, nz = sz + fz;
-        e[0] = nx; e[1] = ny; e[2] = nz;
-        if (k == sub) { L->n0[own][0] = nx; L->n0[own][1] = ny; L->n0[own][2] = nz; }
-        if (k == sub + 1) { L->n1[own][0] = nx; L->n1[own][1] = ny; L->n1[own][2] = nz; }
+        cal_force(a, sx, sy, sz, fx, fy, fz);
+        o.s0x = sx + fx; o.s0y = sy + fy; o.s0z = sz + fz;
+        lst[0] = o.s0x; lst[1] = o.s0y; lst[2] = o.s0z;
+    } else {
+        o.s0x = lst[0]; o.s0y = lst[1]; o.s0z = lst[2];
     }
-    wave_lds_sync();
-    if (in_apf) {
-        g.alias = 0;
-        o.s0x = L->n0[lane][0]; o.s0y = L->n0[lane][1]; o.s0z = L->n0[lane][2];
-        if (g.sub_idx + 1 < g.n_total) { o.s1x = L->n1[lane][0]; o.s1y = L->n1[lane][1]; o.s1z = L->n1[lane][2]; }
-    }
-    wave_lds_sync();
+    g.alias = 0;
+    if (g.sub_idx + 1 < g.n_total) { o.s1x = lst[3]; o.s1y = lst[4]; o.s1z = lst[5]; }
 }
 
 // `head_set`: true when this function assigned g.head itself (:489, Calc_V rescaled the velocity again).
@@ -622,7 +822,7 @@ __device__ __forceinline__ void step_post_b(const StepArgs &a, const WorldLds<Ma
     const double tvx = M.tvx, tvy = M.tvy, dis_new = M.dis_new, g_new = M.g_new;
     if (APF) {                                                                 // :450-453
         double fx, fy, fz;
-        cal_force(a.apf_b, a.nb, a.apf_grid, a.gn, a.inv_cell, a.W, o.px, o.py, o.pz, fx, fy, fz);
+        cal_force(a, o.px, o.py, o.pz, fx, fy, fz);
         const double force = sqrt(fx * fx + fy * fy + fz * fz);
         r += 0.2 * force * cos_between(fx, fy, tvx, tvy);
     }
@@ -751,23 +951,21 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         int ret_done = 0, info = UAVENV_INFO_NORMAL, valid = 1;
         const bool masked = a.active && a.active[ii] == 0;
         const bool stepping = !(masked || ((a.flags & UAVENV_STEP_SKIP_DONE) && g.done));
-        if (APF && a.apf_wave) {
-            // update_PathPlan in three pieces: the sub-goal adjustment in the middle is done by the whole wavefront
-            PreStep P;
-            PostMid M;
-            M.live = false;
-            bool head_set = false;
+        if (APF && a.apf_split) {
+            // update_PathPlan in three pieces: k_apf_adjust has done the sub-goal lists (see there)
             if (stepping) {
+                PreStep P;
+                PostMid M;
+                bool head_set = false;
+                const bool pre_alias = g.alias != 0;
                 step_pre(a, a0, g, P);
                 if (P.moved) g.head = angle_of<true>(g.o.vx, g.o.vy);              // :423
                 step_post_a<MaskT, APF, true>(a, w, ii, a0, g, P, M, ret_done, info, head_set);
+                if (M.live) adjust_subgoals_split(a, ii, g, pre_alias);
+                step_post_b<MaskT, APF, true>(a, w, ii, g, M, r, ret_done, info, head_set);
             } else {
                 ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;         // PathPlan_City.py:365-366
             }
-            ApfWaveLds *LA = reinterpret_cast<ApfWaveLds *>(smem + a.obsq_off + (threadIdx.x >> 6) * a.wave_slot);
-            // (lanes past N run on a copy of the last agent and store nothing: they must not contribute pairs either)
-            adjust_subgoals_wave(a, LA, i - ((int)threadIdx.x & 63), g, active && stepping && M.live);
-            if (stepping) step_post_b<MaskT, APF, true>(a, w, ii, g, M, r, ret_done, info, head_set);
         } else if (!stepping) {
             ret_done = g.done; info = UAVENV_INFO_SKIPPED; valid = 0;             // PathPlan_City.py:365-366
         } else {
@@ -785,10 +983,9 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
             const int lane = threadIdx.x & 63;
             const int g0 = lane & ~(a.U - 1);          // U is a power of two (uavenv_create)
             const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
-            if (active && ((dm & gm) == gm)) {
-                reset_agent<APF>(a, ii, g);
-                did_reset = true;
-            }
+            did_reset = active && ((dm & gm) == gm);
+            if (APF && a.apf_split) reset_agents_wave(a, i - lane, ii, g, did_reset);
+            else if (did_reset) reset_agent<APF>(a, ii, g);
         }
 
         UAV_STAMP(4);
@@ -1267,6 +1464,11 @@ static StepArgs base_args(const UavEnv *e)
     a.Hbox = e->cfg.h;
     a.apf_b = e->apf_b;
     a.apf_grid = e->apf_grid;
+    a.apf_all = e->apf_all;
+    a.apf_gn = e->apf_gn;
+    a.apf_nz = e->apf_nz;
+    a.apf_inv_cell = 1.0 / e->apf_cell;
+    a.apf_inv_cz = 1.0 / e->apf_cz;
     a.emit_lut = e->emit_lut;
     a.max_v = e->cfg.max_v;
     a.steer = e->cfg.steering_angle;
@@ -1349,11 +1551,6 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     a.obsq_off = (e->world_bytes + 15) & ~15;
     int slot = (int)sizeof(ObsWaveLds);            // per-wave LDS slot: the work queue, then (same bytes) the tile
     if (tile_store && kCTileBytes > slot) slot = kCTileBytes;
-    static const int apf_lane_env = env_int("UAVENV_APF_LANE", 0);       // A/B knob: 1 = the per-lane sub-goal adjustment
-    if (apf && !apf_lane_env) {
-        if ((int)sizeof(ApfWaveLds) > slot) slot = (int)sizeof(ApfWaveLds);
-        a.apf_wave = 1;
-    }
     slot = (slot + 15) & ~15;
     a.wave_slot = slot;
     a.tile_off = tile_store ? a.obsq_off : -1;
@@ -1388,6 +1585,12 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
         }
         UAV_LAUNCH(k_step_coop, cgrid, 256, clds);
         return;
+    }
+    if (apf && !(a.flags & UAVENV_STEP_APF_LANE) && kApfAgentsPerBlock * a.K <= 65536) {       // the lists first, in their own kernel (16-bit offsets)
+        a.apf_split = 1;
+        const int agents_per_block = kApfAgentsPerBlock;
+        const size_t albs = ((size_t)((e->nb > 0 ? e->nb : 1) * sizeof(BldApf) + 31) & ~(size_t)31) + 4 * sizeof(ApfSortLds);
+        launch_lds(k_apf_adjust, (e->N + agents_per_block - 1) / agents_per_block, 256, albs, s, a);
     }
     UAV_LAUNCH(k_step, grid, block, lds);
 #undef UAV_LAUNCH
@@ -1549,26 +1752,43 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
     HIP_TRY(hipMemcpy(e->world_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&e->apf_b, ba.size() * sizeof(BldApf)));
     HIP_TRY(hipMemcpy(e->apf_b, ba.data(), ba.size() * sizeof(BldApf), hipMemcpyHostToDevice));
-    {   // APF broad phase: per cell, the moving cylinders whose force range (60 m beyond the rim) can reach the cell.
-        // Same conservative rasterisation as the collision grids (2-D distance <= 3-D distance, 1e-6-scale margins).
-        std::vector<uint64_t> ag((size_t)gn * gn, 0);
-        for (int iy = 0; iy < gn; ++iy)
-            for (int ix = 0; ix < gn; ++ix) {
-                const double x0 = ix * cell - margin, x1 = (ix + 1) * cell + margin;
-                const double y0 = iy * cell - margin, y1 = (iy + 1) * cell + margin;
-                uint64_t m = 0;
-                for (int i = 0; i < nb; ++i) {
-                    if (ba[i].moving == 0.0) continue;
-                    const double qx = ba[i].cx < x0 ? x0 : (ba[i].cx > x1 ? x1 : ba[i].cx);
-                    const double qy = ba[i].cy < y0 ? y0 : (ba[i].cy > y1 ? y1 : ba[i].cy);
-                    if (std::hypot(qx - ba[i].cx, qy - ba[i].cy) < ba[i].R + 60.0 + 1e-6 + margin) m |= (1ull << i);
+    {   // APF broad phase: per cell, the moving cylinders whose force range (60 m beyond the rim, measured from the
+        // CENTRE point (cx, cy, cz) in 3-D: UAV.py:183) can reach the cell.  Its own table, 3-D and finer than the
+        // collision grids (it stays in global memory): the per-point loop is over the mask's bits and the lanes of a
+        // wavefront wait for the longest one, so every spurious candidate costs.  Same conservative rasterisation
+        // (minimum distance from the centre to the grown cell box, 1e-6-scale margins).
+        double acell = 10.0, acz = 10.0;
+        const double Hbox = e->cfg.h > 0 ? e->cfg.h : 1.0;
+        auto cells = [&](double c, double cz) { return std::ceil(W / c) * std::ceil(W / c) * std::ceil(Hbox / cz); };
+        while (cells(acell, acz) > 1048576.0) { acell *= 2.0; acz *= 2.0; }
+        const int agn = std::max(1, (int)std::ceil(W / acell)), anz = std::max(1, (int)std::ceil(Hbox / acz));
+        const double am = 1e-6 * (acell > 1.0 ? acell : 1.0);
+        std::vector<uint64_t> ag((size_t)anz * agn * agn, 0);
+        for (int iz = 0; iz < anz; ++iz)
+            for (int iy = 0; iy < agn; ++iy)
+                for (int ix = 0; ix < agn; ++ix) {
+                    const double x0 = ix * acell - am, x1 = (ix + 1) * acell + am;
+                    const double y0 = iy * acell - am, y1 = (iy + 1) * acell + am;
+                    const double z0 = iz * acz - am, z1 = (iz + 1) * acz + am;
+                    uint64_t m = 0;
+                    for (int i = 0; i < nb; ++i) {
+                        if (ba[i].moving == 0.0) continue;
+                        const double qx = ba[i].cx < x0 ? x0 : (ba[i].cx > x1 ? x1 : ba[i].cx);
+                        const double qy = ba[i].cy < y0 ? y0 : (ba[i].cy > y1 ? y1 : ba[i].cy);
+                        const double qz = ba[i].cz < z0 ? z0 : (ba[i].cz > z1 ? z1 : ba[i].cz);
+                        const double dx = qx - ba[i].cx, dy = qy - ba[i].cy, dz = qz - ba[i].cz;
+                        if (std::sqrt(dx * dx + dy * dy + dz * dz) < ba[i].R + 60.0 + 1e-6 + am) m |= (1ull << i);
+                    }
+                    ag[((size_t)iz * agn + iy) * agn + ix] = m;
                 }
-                ag[(size_t)iy * gn + ix] = m;
-            }
         (void)hipFree(e->apf_grid);
         e->apf_grid = nullptr;
+        e->apf_all = 0;
+        for (int i = 0; i < nb; ++i)
+            if (ba[i].moving != 0.0) e->apf_all |= 1ull << i;
         HIP_TRY(hipMalloc((void **)&e->apf_grid, ag.size() * 8));
         HIP_TRY(hipMemcpy(e->apf_grid, ag.data(), ag.size() * 8, hipMemcpyHostToDevice));
+        e->apf_gn = agn; e->apf_nz = anz; e->apf_cell = acell; e->apf_cz = acz;
     }
     e->world_bytes = (int)blob.size();
     e->aux_off = bld_only;

@@ -203,9 +203,10 @@ class VecPathPlanEnv:
 
     def step(self, actions: torch.Tensor, out: Optional[StepOut] = None, *, auto_reset: bool = False,
              skip_done: bool = False, want_energy: bool = False, active: Optional[torch.Tensor] = None,
-             one_wave: bool = False) -> StepOut:
+             one_wave: bool = False, apf_lane: bool = False) -> StepOut:
         """One update_PathPlan + state_PathPlan for every agent.  actions: [N] float32/float64 steer or int32 index.
-        one_wave (diagnostics) forces the one-wavefront-per-64-agents kernel on small launches."""
+        one_wave (diagnostics) forces the one-wavefront-per-64-agents kernel on small launches, apf_lane (diagnostics) the
+        in-kernel per-lane Adjust_subgoal instead of the k_apf_adjust launch; results are identical either way."""
         if out is None:
             out = self.alloc_out(want_energy)
         if actions.dtype == torch.float32:
@@ -219,7 +220,7 @@ class VecPathPlanEnv:
         if actions.numel() != self.N or not actions.is_contiguous() or actions.device != self.device:
             raise ValueError("actions must be a contiguous [N] tensor on the env device")
         flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | \
-            (_lib.STEP_ONE_WAVE if one_wave else 0)
+            (_lib.STEP_ONE_WAVE if one_wave else 0) | (_lib.STEP_APF_LANE if apf_lane else 0)
         if out.obs is None:
             flags |= _lib.STEP_NO_OBS
         _lib.check(self.lib.uavenv_step(self._h, actions.data_ptr(), kind, _ptr(out.obs), _ptr(out.reward),

@@ -67,6 +67,8 @@ extern "C" {
 #define UAVENV_STEP_SKIP_DONE 2u    /* agents with done==1 do not move (PathPlan_City.py:365-366) */
 #define UAVENV_STEP_NO_OBS 4u       /* do not compute/write the observation */
 #define UAVENV_STEP_ONE_WAVE 8u     /* diagnostics: small launches also take the one-wavefront-per-64-agents kernel (same results) */
+#define UAVENV_STEP_APF_LANE 16u    /* diagnostics: Adjust_subgoal by one lane per agent inside the step kernel instead of the
+                                     * separate k_apf_adjust launch (same results) */
 
 typedef struct UavEnv UavEnv;       /* opaque; owns the per-agent state in HBM */
 
