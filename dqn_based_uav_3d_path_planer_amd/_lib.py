@@ -23,7 +23,7 @@ STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE, STEP_APF_LANE = 1, 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
-    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
+    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
@@ -115,6 +115,8 @@ def load() -> C.CDLL:
     lib.uavenv_load_scenarios.argtypes = [vp, vp, vp, vp, i32]
     lib.uavenv_plan_scenarios.restype = C.c_int
     lib.uavenv_plan_scenarios.argtypes = [vp, i32, u64, i32, vp]
+    lib.uavenv_bank_stats.restype = C.c_int
+    lib.uavenv_bank_stats.argtypes = [vp, vp, vp]
     lib.uavenv_rrt_plan.restype = C.c_int
     lib.uavenv_rrt_plan.argtypes = [vp, i32, vp, vp, i32, u64, i32, C.c_double, C.c_double, vp, vp, vp, vp, vp]
     lib.uavenv_reset_all.restype = C.c_int

@@ -98,11 +98,16 @@ __global__ void __launch_bounds__(256) k_per_sample(UavPer p, int n_chunks, int 
         const double a = seg * (double)i, b = seg * (double)(i + 1);
         v = a + (b - a) * u53(r.x, r.y);
     }
-    // chunk: the first b with v <= prefix[b + 1]  (wave-uniform binary search)
+    // chunk: the first b with v <= prefix[b + 1] and something in front of that boundary (wave-uniform binary search).
+    // A draw past the total (caller's stream, or rounding of seg * batch) is pulled back onto it, and a draw of exactly 0
+    // skips leading all-zero chunks: either would otherwise end in a chunk without a single positive priority.
+    const double total = p.chunk_prefix[n_chunks];
+    v = v < total ? v : total;
     int lo = 0, hi = n_chunks - 1;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (v <= p.chunk_prefix[mid + 1]) hi = mid; else lo = mid + 1;
+        const double up = p.chunk_prefix[mid + 1];
+        if (v <= up && up > 0.0) hi = mid; else lo = mid + 1;
     }
     const int b = lo;
     const double r = v - p.chunk_prefix[b];
@@ -124,23 +129,39 @@ __global__ void __launch_bounds__(256) k_per_sample(UavPer p, int n_chunks, int 
     }
     const double excl = incl - s;
     const unsigned long long hit = __ballot(r <= incl);
-    // rounding can leave r above the chunk's fresh sum: fall back to the last leaf of the chunk (or of the tree)
     int owner = hit ? __builtin_ctzll(hit) : 63;
-    int64_t last = (int64_t)b * kChunk + kChunk - 1;
-    if (last >= p.capacity) last = p.capacity - 1;
-    if (lane == owner) {
-        int64_t q = last;
-        double pq = 0.0;
-        bool found = false;
-        if (hit) {
-            double run = excl;
+    int64_t q = -1;
+    double pq = 0.0;
+    bool found = false;
+    if (hit && lane == owner) {
+        double run = excl;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                run += pv[j];
-                if (!found && r <= run && q0 + j < p.capacity) { q = q0 + j; pq = pv[j]; found = true; }
-            }
+        for (int j = 0; j < 16; ++j) {
+            run += pv[j];
+            if (!found && r <= run && pv[j] > 0.0 && q0 + j < p.capacity) { q = q0 + j; pq = pv[j]; found = true; }
         }
-        if (!found) { q = last; pq = p.prio[slot_of(p, last)]; }
+    }
+    if (__ballot(found) == 0) {
+        // Rounding can leave r above the chunk's fresh sum (or on a zero-priority leaf): take the chunk's LAST leaf with
+        // p > 0 -- never a retired / invalid slot (priority 0), whose importance weight pow(0, -beta) would be inf.
+        // Only a chunk that is all zero falls through to its last leaf with priority 0 (the caller masks those).
+        int jl = -1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (pv[j] > 0.0 && q0 + j < p.capacity) { jl = j; pq = pv[j]; }
+        const unsigned long long pos = __ballot(jl >= 0);
+        if (pos) {
+            owner = 63 - __builtin_clzll(pos);
+            q = q0 + jl;
+        } else {
+            owner = 0;
+            int64_t last = (int64_t)b * kChunk + kChunk - 1;
+            if (last >= p.capacity) last = p.capacity - 1;
+            q = last;
+            pq = 0.0;
+        }
+    }
+    if (lane == owner) {
         out_slot[i] = slot_of(p, q);
         if (out_prio) out_prio[i] = pq;
     }

@@ -148,6 +148,7 @@ struct UavEnv {
     BldApf *apf_b = nullptr;
     uint64_t *apf_grid = nullptr;
     uint64_t apf_all = 0;
+    int bank_replaced = 0;
     int apf_gn = 1, apf_nz = 1;
     double apf_cell = 10.0, apf_cz = 10.0;
     uint2 *emit_lut = nullptr;
@@ -1824,6 +1825,7 @@ int uavenv_load_scenarios(UavEnv *e, const double *sg, const double *sub, const 
     HIP_TRY(hipMemcpy(e->bank_sub, sub, (size_t)m * K * 3 * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->bank_nsub, nsub, (size_t)m * 4, hipMemcpyHostToDevice));
     e->bank_m = m;
+    e->bank_replaced = 0;
     return UAVENV_OK;
 }
 
@@ -1839,11 +1841,13 @@ int uavenv__world_view(const UavEnv *e, const unsigned char **blob, int32_t *byt
 }
 
 // Scenarios the planner could not fit (n_sub outside [2, K]) take the next valid scenario's row.
-__global__ void k_bank_fix(double *sg, double *sub, int32_t *nsub, int m, int K)
+// counters[0]: scenarios without a usable path (planner gave up, or the path needs more than K slots)
+__global__ void k_bank_fix(double *sg, double *sub, int32_t *nsub, int m, int K, int32_t *counters)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const int n = nsub[i];
         if (n >= 2 && n <= K) continue;
+        atomicAdd(&counters[0], 1);
         int j = -1;
         for (int d = 1; d < m; ++d) {
             const int c = (i + d) % m;
@@ -1885,11 +1889,31 @@ int uavenv_plan_scenarios(UavEnv *e, int32_t m, uint64_t seed, int32_t max_iter,
     // UAV.py:216-218: RRTPlanner(step = sub_granularity = 30, obstacle_step 5)
     int rc = uavenv_rrt_plan(e, m, nullptr, nullptr, 0, seed, max_iter, 30.0, 5.0, sg, sub, ns, nullptr, stream);
     if (rc != UAVENV_OK) { (void)hipFree(sg); (void)hipFree(sub); (void)hipFree(ns); return fail(rc, "uavenv_rrt_plan failed"); }
-    hipLaunchKernelGGL(k_bank_fix, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, sg, sub, ns, m, K);
+    int32_t *counters = nullptr, replaced = 0;
+    HIP_TRY(hipMalloc((void **)&counters, 8));
+    HIP_TRY(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_bank_fix, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, sg, sub, ns, m, K, counters);
     hipLaunchKernelGGL(k_bank_fix2, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, ns, m);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&replaced, counters, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    (void)hipFree(counters);
+    if (replaced >= m) {      // nothing valid to copy from: publishing this bank would install n_total < 2 at every reset
+        (void)hipFree(sg); (void)hipFree(sub); (void)hipFree(ns);
+        return fail(UAVENV_EINVAL, "uavenv_plan_scenarios: none of the %d scenarios could be planned (max_iter=%d, K=%d)", m,
+                    max_iter, K);
+    }
     (void)hipFree(e->bank_sg); (void)hipFree(e->bank_sub); (void)hipFree(e->bank_nsub);   // hipFree waits for the device
+    e->bank_replaced = replaced;
     e->bank_sg = sg; e->bank_sub = sub; e->bank_nsub = ns; e->bank_m = m;
+    return UAVENV_OK;
+}
+
+int uavenv_bank_stats(const UavEnv *e, int32_t *m, int32_t *replaced)
+{
+    if (!e) return fail(UAVENV_EINVAL, "null env");
+    if (m) *m = e->bank_m;
+    if (replaced) *replaced = e->bank_replaced;
     return UAVENV_OK;
 }
 

@@ -124,6 +124,12 @@ class VecPathPlanEnv:
                    "uavenv_plan_scenarios")
         self.n_scenarios = int(m)
 
+    def bank_stats(self):
+        """-> (scenarios in the bank, how many of them are copies of a neighbour because their own plan failed)."""
+        m, r = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.uavenv_bank_stats(self._h, C.byref(m), C.byref(r)), "uavenv_bank_stats")
+        return m.value, r.value
+
     def rrt_plan(self, m: int, *, start_goal=None, uniforms=None, seed: int = 0, max_iter: int = 10000,
                  step_size: float = 30.0, obstacle_step: float = 5.0):
         """The GPU planner alone -> (start_goal [m,6], sub_goals [m,K,3], n_sub [m], iters [m]) device tensors."""

@@ -196,9 +196,14 @@ class DevicePER:
         rc = self.lib.uavenv_per_sample(C.byref(self._c), batch, None if draws is None else draws.data_ptr(), int(seed),
                                         int(counter), slots.data_ptr(), p.data_ptr(), self._stream())
         _lib.check(rc, "uavenv_per_sample")
-        total_int = torch.floor(self._chunk_prefix[-1])                            # SumTree.total() :117-118
-        w = torch.pow(self.n_entries * (p / total_int), -self.beta)
-        w = w / w.max()
+        # SumTree.total() :117-118 is int(total): 0 while the priorities sum to less than 1, and the reference then
+        # divides by zero (:176).  Here the divisor is clamped to 1, and a zero-priority pick (only an all-zero chunk can
+        # yield one, csrc/per.hip) gets weight 0 instead of pow(0, -beta) = inf turning the whole batch into NaN.
+        total_int = torch.floor(self._chunk_prefix[-1]).clamp_min(1.0)
+        live = p > 0
+        w = torch.pow(self.n_entries * (torch.where(live, p, torch.ones_like(p)) / total_int), -self.beta)
+        w = torch.where(live, w, torch.zeros_like(w))
+        w = w / w.max().clamp_min(torch.finfo(torch.float64).tiny)
         return slots, w, p
 
 

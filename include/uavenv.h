@@ -111,8 +111,15 @@ int uavenv_load_scenarios(UavEnv *env, const double *host_start_goal, const doub
                           const int32_t *host_nsub, int32_t m);
 /* The same bank planned ON THE GPU: m scenarios, each = UAV.reset()'s start/goal draws (UAV.py:353-358) + the RRT
  * sub-goal planner (PathPlan/RRT.py:63-105, step 30 m, obstacle test every 5 m), one wavefront per scenario, Philox
- * stream (seed, scenario).  Replaces the env's bank; scenarios whose path does not fit K take a neighbour's. */
+ * stream (seed, scenario).  Replaces the env's bank.  The tree is capped at 2048 nodes whatever max_iter is (its nodes
+ * live in LDS next to the world; the reference's list is unbounded): a search that fills it counts as "gave up" like one
+ * that runs out of iterations.  Scenarios whose planner gave up or whose path does not fit K take the next valid
+ * scenario's start / goal / path (this changes the reset distribution by that fraction: read it back with
+ * uavenv_bank_stats).  Fails with UAVENV_EINVAL, leaving the old bank in place, when NO scenario could be planned.
+ * Synchronises the stream. */
 int uavenv_plan_scenarios(UavEnv *env, int32_t m, uint64_t seed, int32_t max_iter, void *stream);
+/* Size of the scenario bank in use and how many of its scenarios are copies of a neighbour (0 for a loaded bank). */
+int uavenv_bank_stats(const UavEnv *env, int32_t *m, int32_t *replaced);
 /* The planner itself, for callers that bring their own start/goal (m x 6, nullable) and/or their own U[0,1) stream
  * (m x stream_len, nullable; parity tests replay CPython's Mersenne stream).  out_nsub < 0: path needs -n > K slots. */
 int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,

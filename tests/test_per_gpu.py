@@ -114,3 +114,29 @@ def test_ring_integration_new_frames_are_prioritised_and_the_head_is_retired():
     want = torch.clamp(abs_err.double() + 0.01, max=1.0) ** 0.6
     assert torch.allclose(per.prio[slots], want, rtol=1e-12)
     env.close()
+
+
+def test_zero_priority_leaves_are_never_picked_and_weights_stay_finite():
+    """Rounding (or a draw on the boundary) used to fall back to the chunk's last leaf even when it was a retired slot
+    with priority 0 -> pow(0, -beta) = inf -> NaN weights for the whole batch (the reference's tree has the same hole)."""
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+    cap = 5000
+    prio = torch.zeros(cap, dtype=torch.float64)
+    prio[100:200] = 0.37                 # every chunk ends in zeros, most chunks are entirely zero
+    prio[3000:3003] = 1e-9
+    per = DevicePER(cap, tree_order=False)
+    per.set_priorities(prio, n_entries=103)
+    total = per.total()
+    draws = torch.tensor([0.0, total, total * (1 + 1e-15), 37.0 - 1e-13, 37.0, 37.0 + 2e-9, total - 1e-12] + [1e-3 * k for k in range(57)],
+                         dtype=torch.float64).clamp_(0.0, total * (1 + 1e-15))
+    slots, w, p = per.sample(draws.numel(), draws=draws)
+    s = slots.cpu().numpy()
+    assert np.all(prio.numpy()[s] > 0) and np.all(p.cpu().numpy() > 0)
+    assert torch.isfinite(w).all() and float(w.max()) == 1.0 and float(w.min()) > 0
+    # priorities summing to less than 1: int(total) == 0 in the reference; here the divisor is clamped
+    per2 = DevicePER(256, tree_order=False)
+    q = torch.zeros(256, dtype=torch.float64)
+    q[10:20] = 0.01
+    per2.set_priorities(q, n_entries=10)
+    _, w2, _ = per2.sample(32, seed=1, counter=0)
+    assert torch.isfinite(w2).all() and float(w2.max()) == 1.0

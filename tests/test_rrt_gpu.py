@@ -92,3 +92,17 @@ def test_philox_bank_invariants_and_feeds_the_env(env):
         env.step(torch.zeros(env.N, dtype=torch.int32, device="cuda") + 1, out, auto_reset=True)
     st = env.get_state(0, env.N)
     assert np.isfinite(st).all() and np.all(st[:, 11] >= 1)
+
+
+def test_bank_stats_and_a_bank_nobody_could_plan(env):
+    """Scenarios whose plan failed take a neighbour's: the count is reported; a bank without a single valid plan is
+    refused (it would install n_total < 2 at every reset) and the bank in use stays."""
+    from dqn_based_uav_3d_path_planer_amd._lib import UavEnvError
+    env.plan_scenarios(2048, seed=3, max_iter=10000)
+    m, replaced = env.bank_stats()
+    assert m == 2048 and 0 <= replaced < 0.01 * m
+    with pytest.raises(UavEnvError, match="none of the"):
+        env.plan_scenarios(64, seed=3, max_iter=1)           # one RRT iteration never spans 300+ m in 30 m steps
+    assert env.bank_stats() == (2048, replaced)
+    obs = env.reset(seed=2)
+    assert torch.isfinite(obs).all()
