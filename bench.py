@@ -227,15 +227,27 @@ def run_config4(args, dev):
     torch.manual_seed(42)
     torch.distributions.Distribution.set_default_validate_args(False)      # Normal(mu, std) otherwise syncs to check std > 0
     graphed = os.environ.get("BENCH_SAC_GRAPH", "1") != "0"
-    learners = [SACLearner(sac_param, device=dev, capturable=graphed) for _ in range(U)]
+    fused = args.learner == "fused"
+    if fused:
+        from dqn_based_uav_3d_path_planer_amd.sac import FusedSACLearner
+        graphed = False                       # four launches per update: nothing to capture
+        learners = [FusedSACLearner(sac_param, device=dev) for _ in range(U)]
+    else:
+        learners = [SACLearner(sac_param, device=dev, capturable=graphed) for _ in range(U)]
     B = args.batch
     lib, counter = env.lib, [0]
     draws = [torch.empty((B, 2), dtype=torch.int32, device=dev) for _ in range(U)]
     flat = ring.obs.view(-1, ring.obs.shape[-1])
+    fbatch = [L.make_batch(flat, ring.action.view(-1), a1_plane.view(-1), ring.reward.view(-1), ring.done.view(-1),
+                           valid=ring.valid.view(-1), draws=draws[j], n_agents=env.N, uav_per_env=U, slot=j, frames=ring.frames)
+              for j, L in enumerate(learners)] if fused else None
 
     def update_slot(j):
         """gather the drawn transitions of UAV slot j (packed rows -> f32) and take one SAC update"""
         L = learners[j]
+        if fused:                              # csrc/sac.hip reads the drawn rows in place: four launches
+            L.learn(fbatch[j])
+            return
         f, e = draws[j][:, 0].long(), draws[j][:, 1].long()
         slot = f * env.N + e * U + j
         nxt = ((f + 1) % ring.frames) * env.N + e * U + j
@@ -330,8 +342,9 @@ def run_config4(args, dev):
                       "step_definition": "1 bench step = %d passes of (SAC act x%d -> env step with APF + replay write -> "
                                          "%d x (sample + SAC update))" % (pps, U, U),
                       "envs_per_gpu": envs, "uav_per_env": U, "learn_batch_per_slot": B, "obs_dtype": "packed",
-                      "learner": "SAC on PyTorch-ROCm ops (f32)" + (", each slot's sample + update replayed as one HIP graph"
-                                                                      if graphs is not None else ", eager"),
+                      "learner": ("fused HIP SAC update (csrc/sac.hip: critic_grad, critic_adam, actor_grad, actor_adam; f32 MFMA)"
+                                  if fused else "SAC on PyTorch-ROCm ops (f32)" +
+                                  (", each slot's sample + update replayed as one HIP graph" if graphs is not None else ", eager")),
                       "env": "fused HIP k_step with APF"},
            "roofline": {"bound": "hbm", "kernel": "k_step<APF> (update_PathPlan + Adjust_subgoal + cal_force + state_PathPlan + replay write)",
                         "achieved": algo * env.N / (k_use * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -31,7 +31,10 @@ SYMBOLS = (
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
+    "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
+    "uavenv_sac_actor_adam",
 )
+SAC_CRITIC_IN, SAC_ACTOR_PARAMS, SAC_CRITIC_PARAMS, SAC_ACTOR_STRIDE, SAC_CRITIC_STRIDE = 102, 6724, 10882, 6728, 21768
 
 
 class UavEnvConfig(C.Structure):
@@ -77,6 +80,23 @@ class UavLoopConfig(C.Structure):
 class UavLoopCursor(C.Structure):
     _fields_ = [("head", C.c_int32), ("filled", C.c_int32), ("epoch", C.c_int32), ("reserved0", C.c_int32),
                 ("counter", C.c_uint64)]
+
+
+class UavSacNets(C.Structure):
+    _fields_ = [("actor", C.c_void_p), ("critic1", C.c_void_p), ("critic2", C.c_void_p), ("target1", C.c_void_p),
+                ("target2", C.c_void_p), ("log_alpha", C.c_void_p)]
+
+
+class UavSacBatch(C.Structure):
+    _fields_ = [("obs_packed", C.c_void_p), ("idx_s", C.c_void_p), ("idx_n", C.c_void_p), ("draws", C.c_void_p),
+                ("n_agents", C.c_int32), ("uav_per_env", C.c_int32), ("slot", C.c_int32), ("frames", C.c_int32),
+                ("act0", C.c_void_p), ("act1", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("valid", C.c_void_p),
+                ("eps", C.c_void_p), ("batch", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class UavSacAdam(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("tau", C.c_float), ("reserved0", C.c_float)]
 
 
 class UavEnvError(RuntimeError):
@@ -169,6 +189,17 @@ def load() -> C.CDLL:
     lib.uavenv_loop_get.argtypes = [vp, C.POINTER(UavLoopCursor)]
     lib.uavenv_loop_step_times.restype = C.c_int
     lib.uavenv_loop_step_times.argtypes = [vp, vp, i32, C.POINTER(i32)]
+    lib.uavenv_sac_partial_rows.restype = C.c_int
+    lib.uavenv_sac_partial_rows.argtypes = [i32]
+    lib.uavenv_sac_last_error.restype = C.c_char_p
+    lib.uavenv_sac_critic_grad.restype = C.c_int
+    lib.uavenv_sac_critic_grad.argtypes = [C.POINTER(UavSacNets), C.POINTER(UavSacBatch), f32, f32, vp, vp]
+    lib.uavenv_sac_critic_adam.restype = C.c_int
+    lib.uavenv_sac_critic_adam.argtypes = [C.POINTER(UavSacNets), vp, i32, vp, vp, vp, vp, C.POINTER(UavSacAdam), vp, vp]
+    lib.uavenv_sac_actor_grad.restype = C.c_int
+    lib.uavenv_sac_actor_grad.argtypes = [C.POINTER(UavSacNets), C.POINTER(UavSacBatch), f32, vp, vp]
+    lib.uavenv_sac_actor_adam.restype = C.c_int
+    lib.uavenv_sac_actor_adam.argtypes = [C.POINTER(UavSacNets), vp, i32, i32, vp, vp, vp, C.POINTER(UavSacAdam), f32, f32, vp, vp]
     lib.uavenv_select_actions.restype = C.c_int
     lib.uavenv_select_actions.argtypes = [vp, i32, i32, f32, u64, u64, vp, vp, vp]
     net = C.POINTER(UavDqnNet)

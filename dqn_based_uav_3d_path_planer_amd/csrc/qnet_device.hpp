@@ -197,8 +197,10 @@ __device__ __forceinline__ uint32_t prow_slice(const PRow &R, int g)
     return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> sh);
 }
 
-// columns 26 g + 2 i and 26 g + 2 i + 1 of the row (column 100 = the ones column, 101..103 = 0); i is a constant after unrolling
-__device__ __forceinline__ float2 prow_pair(const PRow &R, uint32_t slice, bool g0, bool g3, int i)
+// columns 26 g + 2 i and 26 g + 2 i + 1 of the row (column 100 = the ones column, 101..103 = 0); i is a constant after unrolling.
+// EXT: columns 101 and 102 carry two extra inputs (the action of the SAC critics' cat([state, action]), sac.hip).
+template <bool EXT = false>
+__device__ __forceinline__ float2 prow_pair(const PRow &R, uint32_t slice, bool g0, bool g3, int i, float e0 = 0.0f, float e1 = 0.0f)
 {
     float x0 = (float)((slice >> (2 * i)) & 1u), x1 = (float)((slice >> (2 * i + 1)) & 1u);
     if (i <= 4) { x0 = g0 ? R.sc[i <= 4 ? 2 * i : 0] : x0; x1 = g0 ? R.sc[i <= 4 ? 2 * i + 1 : 0] : x1; }   // columns 0..9
@@ -206,11 +208,14 @@ __device__ __forceinline__ float2 prow_pair(const PRow &R, uint32_t slice, bool 
     if (i == 4) { x0 = g3 ? R.sg[0] : x0; x1 = g3 ? R.sg[1] : x1; }                                          // 86, 87
     if (i == 5) { x0 = g3 ? R.sg[2] : x0; x1 = g3 ? R.sg[3] : x1; }                                          // 88, 89
     if (i == 11) x0 = g3 ? 1.0f : x0;                                                                        // 100
+    if (EXT && i == 11) x1 = g3 ? e0 : x1;                                                                   // 101
+    if (EXT && i == 12) x0 = g3 ? e1 : x0;                                                                   // 102
     return make_float2(x0, x1);
 }
 
 // fwd_strip with the B operand generated from the lane's packed row
-__device__ __forceinline__ void fwd_strip_packed(const float *W, const PRow &R, floatx4 (&acc)[4])
+template <bool EXT = false>
+__device__ __forceinline__ void fwd_strip_packed(const float *W, const PRow &R, floatx4 (&acc)[4], float e0 = 0.0f, float e1 = 0.0f)
 {
     const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const float *wp = W + r * kLd + 26 * g;
@@ -218,7 +223,7 @@ __device__ __forceinline__ void fwd_strip_packed(const float *W, const PRow &R, 
     const bool g0 = g == 0, g3 = g == 3;
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-    float2 b = prow_pair(R, slice, g0, g3, 0);
+    float2 b = prow_pair<EXT>(R, slice, g0, g3, 0, e0, e1);
     float2 a[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float2 *>(wp + t * 16 * kLd);
@@ -232,7 +237,7 @@ __device__ __forceinline__ void fwd_strip_packed(const float *W, const PRow &R, 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t].x, b.x, acc[t]);
-        if (i + 1 < 13) bn = prow_pair(R, slice, g0, g3, i + 1);       // ~8 VALU: issue in the shadow of the MFMAs around them
+        if (i + 1 < 13) bn = prow_pair<EXT>(R, slice, g0, g3, i + 1, e0, e1);       // ~8 VALU: issue in the shadow of the MFMAs around them
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t].y, b.y, acc[t]);
         // order inside this region: MFMA, then two VALU, ... (an MFMA occupies the matrix pipe for 32 cycles; the VALU pipe is free)

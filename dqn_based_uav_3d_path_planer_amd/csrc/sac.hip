@@ -1,0 +1,823 @@
+// sac.hip -- fused SAC (continuous actions) update for the reference's nets on gfx950.
+//
+// Replaces, per update, the ~270 PyTorch launches of Trainer/SAC_Trainer.py:325-379 (update, continuous branch), :122-131
+// (calc_target), :145-147 (soft_update) on the nets of BaseClass/BaseCNN.py:459-500 (PolicyNetContinuous_SAC 100-64-(2+2),
+// QValueNetContinuous_SAC 102-64-64-2) by four kernels:
+//
+//   k_sac_critic_grad   a' , log pi(a'|s') from the actor; Q_target1/2(s', a'); td target; Q1/Q2(s, a), their (weighted)
+//                       MSE against it, backward -> one partial-gradient row (both critics) per workgroup
+//   k_sac_reduce_adam   column sums of the partial rows -> Adam on critic_1 / critic_2 -> soft update of the targets
+//   k_sac_actor_grad    a~, log pi(a~|s) from the actor; Q1/Q2(s, a~) with the UPDATED critics; dL/da~ back through the
+//                       critic that holds the minimum; actor backward -> one partial row per workgroup (+ sum of log pi)
+//   k_sac_reduce_adam   ... -> Adam on the actor, Adam on log_alpha
+//
+// Same wave-strip formulation as learner.hip (qnet_device.hpp): H^T = W X^T on v_mfma_f32_16x16x4_f32, lane = sample,
+// registers = hidden units, observation operands generated in registers from the packed 80-byte rows.  The 64 -> 64
+// layer chains on the MFMA without leaving the registers: the K index of a step may be ANY permutation of the hidden
+// units, so step (t, reg) takes hidden unit 16 t + 4 (lane >> 4) + reg -- which is exactly the register the previous
+// layer's C/D fragment left in this lane.  Weight gradients: H / dH / X tiles of the 64 samples through LDS, MFMA over
+// K = samples, persistent accumulators, no atomics, deterministic.  A workgroup owns up to kTMax tiles and walks them
+// once per net (the five nets of a phase do not fit LDS together: each is staged once per workgroup, not once per tile);
+// what a later stage needs from an earlier one (a', log pi, td target, Q1, dL/da) is a few floats per sample in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/uavenv.h"
+#include "uavenv_device.hpp"
+#include "qnet_device.hpp"
+
+using namespace uav;
+using namespace uavq;
+
+namespace {
+
+thread_local char g_sac_err[256];
+int sac_fail(int code, const char *msg)
+{
+    snprintf(g_sac_err, sizeof g_sac_err, "%s", msg);
+    return code;
+}
+
+constexpr int kIn = UAVENV_SAC_CRITIC_IN;          // 102 = cat([state, action])
+// flat parameter blocks (the partial-gradient rows use the same layout)
+//   actor : fc1.w 64x100 | fc1.b 64 | fc_mu.w 2x64 | fc_std.w 2x64 | fc_mu.b 2 | fc_std.b 2         (= net_view(flat, 4))
+//   critic: fc1.w 64x102 | fc1.b 64 | fc2.w 64x64 | fc2.b 64 | fc_out.w 2x64 | fc_out.b 2
+constexpr int kPa = UAVENV_SAC_ACTOR_PARAMS;       // 6724
+constexpr int kAoW2 = kHid * kW + kHid, kAob2 = kAoW2 + 4 * kHid;
+constexpr int kCob1 = kHid * kIn, kCoW2 = kCob1 + kHid, kCob2 = kCoW2 + kHid * kHid, kCoWo = kCob2 + kHid, kCobo = kCoWo + 2 * kHid;
+constexpr int kPc = UAVENV_SAC_CRITIC_PARAMS;      // 10882
+static_assert(kAob2 + 4 == kPa && kCobo + 2 == kPc, "flat layouts");
+constexpr int kStrideA = UAVENV_SAC_ACTOR_STRIDE;  // kPa + [actor loss sum, sum of log pi, 0, 0]
+constexpr int kStrideC = UAVENV_SAC_CRITIC_STRIDE; // 2 kPc + [loss 1 sum, loss 2 sum, 0, 0]
+static_assert(kStrideA == kPa + 4 && kStrideC == 2 * kPc + 4, "partial-row strides");
+constexpr int kTMax = 4;                           // tiles per workgroup
+constexpr int kSt = 8;                             // floats of per-sample state
+
+struct SacArgs {
+    const uint32_t *obs;                  // packed rows
+    const int32_t *idx_s, *idx_n;         // row of s / s' per sample (when draws == nullptr)
+    const int32_t *draws;                 // batch x (frame, env): row = frame * n_agents + env * uav + slot (s' : next frame)
+    int n_agents, uav, slot, frames;
+    const float *act0, *act1, *reward;    // planes indexed by the row of s
+    const uint8_t *done, *valid;          // valid nullable (= all 1)
+    const float *eps;                     // [batch][2] N(0,1) draws of this phase's rsample()
+    int batch, tiles_per_wg;
+    const float *actor, *c1, *c2, *t1, *t2, *log_alpha;
+    float gamma, bound;
+    float *partials;
+};
+
+struct SacLds {
+    float *W1s, *W2s, *b2s, *Xs, *H1s, *H2s, *dH1s, *dH2s, *dqs, *st, *red;
+};
+constexpr int kSacLdsFloats = kTileF + kHid * kLh + kHid + kTileF + 4 * kTile * kLh + kTile * 4 + kTMax * kTile * kSt + 64;
+constexpr size_t kSacLds = (size_t)kSacLdsFloats * 4;
+
+__device__ __forceinline__ SacLds carve(float *lds)
+{
+    SacLds L;
+    L.W1s = lds;
+    L.W2s = L.W1s + kTileF;
+    L.b2s = L.W2s + kHid * kLh;
+    L.Xs = L.b2s + kHid;
+    L.H1s = L.Xs + kTileF;
+    L.H2s = L.H1s + kTile * kLh;
+    L.dH1s = L.H2s + kTile * kLh;
+    L.dH2s = L.dH1s + kTile * kLh;
+    L.dqs = L.dH2s + kTile * kLh;
+    L.st = L.dqs + kTile * 4;
+    L.red = L.st + kTMax * kTile * kSt;
+    return L;
+}
+
+__device__ __forceinline__ void sample_rows(const SacArgs &g, int smp, uint32_t &rs, uint32_t &rn)
+{
+    if (g.draws) {
+        const int f = g.draws[2 * smp], e = g.draws[2 * smp + 1];
+        const int fn = f + 1 < g.frames ? f + 1 : 0;
+        rs = (uint32_t)(f * g.n_agents + e * g.uav + g.slot);
+        rn = (uint32_t)(fn * g.n_agents + e * g.uav + g.slot);
+    } else {
+        rs = (uint32_t)g.idx_s[smp];
+        rn = (uint32_t)g.idx_n[smp];
+    }
+}
+
+// actor fc1 (64 x 100, 16-byte aligned rows) -> W1s, column 100 = b1
+__device__ __forceinline__ void stage_actor(const SacLds &L, const float *flat)
+{
+    floatx4 v[kStageIters];
+    w_issue(v, flat);
+    const float bias = threadIdx.x < kHid ? flat[kHid * kW + threadIdx.x] : 0.0f;
+    w_commit(L.W1s, v, bias);
+}
+
+// critic fc1 (64 x 102: input column c < 100 -> tile column c, the two action columns -> 101, 102, b1 -> 100) and fc2
+__device__ __forceinline__ void stage_critic(const SacLds &L, const float *flat)
+{
+    const int tid = (int)threadIdx.x;
+    for (int idx = tid; idx < kHid * kIn; idx += 256) {
+        const int row = idx / kIn, c = idx - row * kIn;
+        L.W1s[row * kLd + (c < kW ? c : c + 1)] = flat[idx];
+    }
+    if (tid < kHid) {
+        L.W1s[tid * kLd + kW] = flat[kCob1 + tid];
+        L.W1s[tid * kLd + kW + 3] = 0.0f;
+        L.b2s[tid] = flat[kCob2 + tid];
+    }
+    for (int c = tid; c < kHid * kHid / 4; c += 256) {
+        const int row = c >> 4, q = c & 15;
+        *reinterpret_cast<floatx4 *>(L.W2s + row * kLh + 4 * q) = *reinterpret_cast<const floatx4 *>(flat + kCoW2 + 4 * c);
+    }
+}
+
+__device__ __forceinline__ void relu4(const floatx4 (&a)[4], floatx4 (&h)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = a[t][r] > 0.0f ? a[t][r] : 0.0f;
+}
+
+// pre-activations of the 64 -> 64 layer from the (post-ReLU) registers of the layer below: step (t, reg) of the K loop
+// is hidden unit 16 t + 4 g + reg -- the register this lane already holds
+__device__ __forceinline__ void layer2_fwd(const SacLds &L, const floatx4 (&h1)[4], floatx4 (&acc2)[4])
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) acc2[t2] = *reinterpret_cast<const floatx4 *>(L.b2s + 16 * t2 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        floatx4 a[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) a[t2] = *reinterpret_cast<const floatx4 *>(L.W2s + (16 * t2 + r) * kLh + 16 * t + 4 * g);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) acc2[t2] = mfma16(a[t2][reg], h1[t][reg], acc2[t2]);
+    }
+}
+
+// dL/dh1 = W2^T dL/dh2 (before the ReLU mask of layer 1), same trick with the roles of the two index sets swapped
+__device__ __forceinline__ void layer2_bwd(const SacLds &L, const floatx4 (&dh2)[4], floatx4 (&dh1)[4])
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dh1[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float *row = L.W2s + (16 * t2 + 4 * g + reg) * kLh + r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dh1[t] = mfma16(row[16 * t], dh2[t2][reg], dh1[t]);
+        }
+}
+
+// Q(s, a) of the staged critic for this lane's sample; acc1 / acc2 keep the pre-activations
+__device__ __forceinline__ void critic_fwd(const SacLds &L, const PRow &R, float a0, float a1, const W2Frag<2> &Fo,
+                                           floatx4 (&acc1)[4], floatx4 (&acc2)[4], float (&q)[2])
+{
+    fwd_strip_packed<true>(L.W1s, R, acc1, a0, a1);
+    floatx4 h1[4];
+    relu4(acc1, h1);
+    layer2_fwd(L, h1, acc2);
+    q_strip<2>(acc2, Fo, 2, 2, 0, q);
+}
+
+// dL/dq -> dL/dh2, dL/dh1 (both after their ReLU masks)
+__device__ __forceinline__ void critic_bwd(const SacLds &L, const W2Frag<2> &Fo, const floatx4 (&acc1)[4], const floatx4 (&acc2)[4],
+                                           float dq0, float dq1, floatx4 (&dh1)[4], floatx4 (&dh2)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh2[t][r] = acc2[t][r] > 0.0f ? fmaf(Fo.w[1][t][r], dq1, Fo.w[0][t][r] * dq0) : 0.0f;
+    layer2_bwd(L, dh2, dh1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh1[t][r] = acc1[t][r] > 0.0f ? dh1[t][r] : 0.0f;
+}
+
+// PolicyNetContinuous_SAC.forward after fc_mu / fc_std (BaseCNN.py:470-483, quirks included: std = tanh(softplus(.)),
+// the log-prob correction applies tanh to the already squashed action)
+struct ActorOut {
+    float act[2], lp[2], mu[2], sd[2], spre[2];
+};
+__device__ __forceinline__ void actor_head(const float (&o)[4], float e0, float e1, ActorOut &A)
+{
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float m = o[d], s = o[2 + d], e = d ? e1 : e0;
+        const float mu = tanhf(m);
+        const float sp = s > 20.0f ? s : log1pf(expf(s));          // F.softplus (beta 1, threshold 20)
+        const float sd = tanhf(sp);
+        const float ns = mu + sd * e;                               // rsample()
+        const float df = ns - mu;
+        float lp = -(df * df) / (2.0f * (sd * sd)) - logf(sd) - 0.9189385332046727f;     // Normal.log_prob
+        const float act = tanhf(ns);
+        const float th = tanhf(act);
+        lp -= logf(1.0f - th * th + 1e-7f);
+        A.act[d] = act; A.lp[d] = lp; A.mu[d] = mu; A.sd[d] = sd; A.spre[d] = s;
+    }
+}
+
+// this strip's 16 rows of the f32 X tile (columns 0..103) from the lanes' packed rows
+template <bool EXT>
+__device__ __forceinline__ void x_strip_store(const SacLds &L, const PRow &R, float a0, float a1)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const uint32_t slice = prow_slice(R, g);
+    float *dst = L.Xs + (16 * wv + r) * kLd + 26 * g;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) *reinterpret_cast<float2 *>(dst + 2 * i) = prow_pair<EXT>(R, slice, g == 0, g == 3, i, a0, a1);
+}
+
+__device__ __forceinline__ void h_strip_store(float *Hs, const floatx4 (&h)[4])
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<floatx4 *>(Hs + (16 * wv + r) * kLh + 16 * t + 4 * g) = h[t];
+}
+
+// acc[u][reg] += sum over the tile's 64 samples s of A[s][16 wave + 4 g + reg] * B[s][16 u + r]
+// (MFMA step k, lane group g: sample (k & 3) + 16 (k >> 2) + 4 g -- rows 4 apart are 16 banks apart in both tiles)
+template <int NT>
+__device__ __forceinline__ void wgrad(const float *As, const float *Bs, int ldb, floatx4 (&acc)[NT])
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const float *ap = As + 4 * g * kLh + 16 * wv + r;
+    const float *bp = Bs + 4 * g * ldb + r;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int s = (k & 3) + 16 * (k >> 2);
+        const float a = ap[s * kLh];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[u] = mfma16(a, bp[s * ldb + 16 * u], acc[u]);
+    }
+}
+// ... with B[s][n] = n < nb ? small[s][n] : 0  (small: [64][4])
+__device__ __forceinline__ void wgrad_small(const float *As, const float *small, int nb, floatx4 &acc)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const float *ap = As + 4 * g * kLh + 16 * wv + r;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int s = (k & 3) + 16 * (k >> 2) + 4 * g;
+        const float b = r < nb ? small[s * 4 + r] : 0.0f;
+        acc = mfma16(ap[((k & 3) + 16 * (k >> 2)) * kLh], b, acc);
+    }
+}
+// ... with B[s][n] = (n == 0): column sums of A
+__device__ __forceinline__ void wgrad_ones(const float *As, floatx4 &acc)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const float *ap = As + 4 * g * kLh + 16 * wv + r;
+    const float b = r == 0 ? 1.0f : 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) acc = mfma16(ap[((k & 3) + 16 * (k >> 2)) * kLh], b, acc);
+}
+
+// fc1 gradient tiles -> the partial row: tile column c < 100 -> input column c, 100 -> b1, 101 / 102 -> the action columns
+__device__ __forceinline__ void store_dw1(float *out, int in_dim, int ob1, const floatx4 (&acc)[7])
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int c = 16 * u + r;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int j = 16 * wv + 4 * g + reg;
+            if (c < kW) out[j * in_dim + c] = acc[u][reg];
+            else if (c == kW) out[ob1 + j] = acc[u][reg];
+            else if (c < kW + 1 + (in_dim - kW)) out[j * in_dim + c - 1] = acc[u][reg];
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase A: the critics
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
+{
+    extern __shared__ __align__(16) float lds[];
+    const SacLds L = carve(lds);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int n_tiles = g.batch / kTile;
+    const int t0 = (int)blockIdx.x * g.tiles_per_wg;
+    const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
+    const float alpha = expf(*g.log_alpha);
+    const float inv_b = 1.0f / (float)g.batch;
+
+    // ---- a', log pi(a' | s')
+    stage_actor(L, g.actor);
+    __syncthreads();
+    {
+        W2Frag<4> Fa;
+        w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+        for (int j = 0; j < nt; ++j) {
+            const int smp = (t0 + j) * kTile + 16 * wv + r;
+            uint32_t rs, rn;
+            sample_rows(g, smp, rs, rn);
+            PRow R;
+            prow_load(R, g.obs + (size_t)rn * kPackedDwords);
+            floatx4 acc[4];
+            fwd_strip_packed(L.W1s, R, acc);
+            float o[4];
+            q_strip<4>(acc, Fa, 4, 4, 0, o);
+            ActorOut A;
+            actor_head(o, g.eps[2 * smp], g.eps[2 * smp + 1], A);
+            if (gq == 0) {
+                float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
+                st[0] = A.act[0] * g.bound; st[1] = A.act[1] * g.bound; st[2] = A.lp[0]; st[3] = A.lp[1];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- td target = r + gamma (min(Q_t1, Q_t2)(s', a') - alpha log pi) (1 - done)      (:122-131)
+    for (int c = 0; c < 2; ++c) {
+        const float *flat = c ? g.t2 : g.t1;
+        stage_critic(L, flat);
+        __syncthreads();
+        W2Frag<2> Fo;
+        w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
+        for (int j = 0; j < nt; ++j) {
+            const int smp = (t0 + j) * kTile + 16 * wv + r;
+            uint32_t rs, rn;
+            sample_rows(g, smp, rs, rn);
+            PRow R;
+            prow_load(R, g.obs + (size_t)rn * kPackedDwords);
+            float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
+            floatx4 acc1[4], acc2[4];
+            float q[2];
+            critic_fwd(L, R, st[0], st[1], Fo, acc1, acc2, q);
+            if (gq == 0) {
+                if (c == 0) {
+                    st[4] = q[0]; st[5] = q[1];
+                } else {
+                    const float rew = g.reward[rs], nd = 1.0f - (float)g.done[rs];
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const float qm = fminf(st[4 + d], q[d]);
+                        st[4 + d] = rew + g.gamma * (qm + alpha * (-st[2 + d])) * nd;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- Q1 / Q2 (s, a): loss, backward, weight gradients
+    for (int c = 0; c < 2; ++c) {
+        const float *flat = c ? g.c2 : g.c1;
+        stage_critic(L, flat);
+        __syncthreads();
+        W2Frag<2> Fo;
+        w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
+        floatx4 aw1[7], aw2[4], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f}, ab2 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) aw2[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        float s_bo0 = 0.0f, s_bo1 = 0.0f, s_loss = 0.0f;
+        for (int j = 0; j < nt; ++j) {
+            const int smp = (t0 + j) * kTile + 16 * wv + r;
+            uint32_t rs, rn;
+            sample_rows(g, smp, rs, rn);
+            PRow R;
+            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
+            const float a0 = g.act0[rs], a1 = g.act1[rs];
+            const float w = g.valid ? (float)g.valid[rs] : 1.0f;
+            const float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
+            floatx4 acc1[4], acc2[4];
+            float q[2];
+            critic_fwd(L, R, a0, a1, Fo, acc1, acc2, q);
+            const float e0 = q[0] - st[4], e1 = q[1] - st[5];
+            const float dq0 = w * e0 * inv_b, dq1 = w * e1 * inv_b;      // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
+            if (gq == 0) { s_loss += w * (e0 * e0 + e1 * e1); s_bo0 += dq0; s_bo1 += dq1; }
+            floatx4 dh1[4], dh2[4], h1[4], h2[4];
+            critic_bwd(L, Fo, acc1, acc2, dq0, dq1, dh1, dh2);
+            relu4(acc1, h1);
+            relu4(acc2, h2);
+            x_strip_store<true>(L, R, a0, a1);
+            h_strip_store(L.H1s, h1);
+            h_strip_store(L.H2s, h2);
+            h_strip_store(L.dH1s, dh1);
+            h_strip_store(L.dH2s, dh2);
+            if (gq == 0) { L.dqs[(16 * wv + r) * 4] = dq0; L.dqs[(16 * wv + r) * 4 + 1] = dq1; }
+            __syncthreads();
+            wgrad<7>(L.dH1s, L.Xs, kLd, aw1);         // dW1 (+ db1 as column 100)
+            wgrad<4>(L.dH2s, L.H1s, kLh, aw2);        // dW2
+            wgrad_small(L.H2s, L.dqs, 2, awo);        // dWout^T
+            wgrad_ones(L.dH2s, ab2);                  // db2
+            __syncthreads();
+        }
+        float *out = g.partials + (size_t)blockIdx.x * kStrideC + c * kPc;
+        store_dw1(out, kIn, kCob1, aw1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) out[kCoW2 + (16 * wv + 4 * gq + reg) * kHid + 16 * u + r] = aw2[u][reg];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (r < 2) out[kCoWo + r * kHid + 16 * wv + 4 * gq + reg] = awo[reg];
+            if (r == 0) out[kCob2 + 16 * wv + 4 * gq + reg] = ab2[reg];
+        }
+        s_bo0 = wave_sum(s_bo0); s_bo1 = wave_sum(s_bo1); s_loss = wave_sum(s_loss);
+        if (lane == 0) { L.red[wv * 4] = s_bo0; L.red[wv * 4 + 1] = s_bo1; L.red[wv * 4 + 2] = s_loss; }
+        __syncthreads();
+        if (tid < 3) {
+            const float s = (L.red[tid] + L.red[4 + tid]) + (L.red[8 + tid] + L.red[12 + tid]);
+            if (tid < 2) out[kCobo + tid] = s;
+            else g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + c] = s * 0.5f * inv_b;      // mean over [B, 2]
+        }
+        if (tid == 3 && c == 0) {
+            g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + 2] = 0.0f;
+            g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + 3] = 0.0f;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase B: the actor (critics already updated)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
+{
+    extern __shared__ __align__(16) float lds[];
+    const SacLds L = carve(lds);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int n_tiles = g.batch / kTile;
+    const int t0 = (int)blockIdx.x * g.tiles_per_wg;
+    const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
+    const float alpha = expf(*g.log_alpha);
+    const float inv_2b = 0.5f / (float)g.batch;
+    float s_lp = 0.0f, s_loss = 0.0f;
+
+    // ---- a~, log pi(a~ | s)
+    stage_actor(L, g.actor);
+    __syncthreads();
+    {
+        W2Frag<4> Fa;
+        w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+        for (int j = 0; j < nt; ++j) {
+            const int smp = (t0 + j) * kTile + 16 * wv + r;
+            uint32_t rs, rn;
+            sample_rows(g, smp, rs, rn);
+            PRow R;
+            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
+            floatx4 acc[4];
+            fwd_strip_packed(L.W1s, R, acc);
+            float o[4];
+            q_strip<4>(acc, Fa, 4, 4, 0, o);
+            ActorOut A;
+            actor_head(o, g.eps[2 * smp], g.eps[2 * smp + 1], A);
+            if (gq == 0) {
+                float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
+                st[0] = A.act[0] * g.bound; st[1] = A.act[1] * g.bound; st[2] = A.lp[0]; st[3] = A.lp[1];
+                s_lp += A.lp[0] + A.lp[1];
+                s_loss += alpha * (A.lp[0] + A.lp[1]);               // -alpha * entropy  (:364-365)
+            }
+        }
+    }
+    __syncthreads();
+    // ---- Q1(s, a~), then Q2(s, a~): the minimum picks, per (sample, output), the critic dL/dq = -1 / (2B) flows into
+    // (c = 0: forward only; c = 1: critic 2 forward + its backward; c = 2: critic 1 again, forward + backward)
+    for (int c = 0; c < 3; ++c) {
+        const float *flat = c == 1 ? g.c2 : g.c1;
+        stage_critic(L, flat);
+        __syncthreads();
+        W2Frag<2> Fo;
+        w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
+        for (int j = 0; j < nt; ++j) {
+            const int smp = (t0 + j) * kTile + 16 * wv + r;
+            uint32_t rs, rn;
+            sample_rows(g, smp, rs, rn);
+            PRow R;
+            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
+            float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
+            floatx4 acc1[4], acc2[4];
+            float q[2];
+            critic_fwd(L, R, st[0], st[1], Fo, acc1, acc2, q);
+            if (c == 0) {
+                if (gq == 0) { st[4] = q[0]; st[5] = q[1]; }
+                continue;
+            }
+            float dq0, dq1;
+            if (c == 1) {
+                const float q10 = st[4], q11 = st[5];
+                const bool s0 = q[0] < q10, s1 = q[1] < q11;            // critic 2 holds the minimum (ties: critic 1)
+                dq0 = s0 ? -inv_2b : 0.0f;
+                dq1 = s1 ? -inv_2b : 0.0f;
+                if (gq == 0) s_loss -= (s0 ? q[0] : q10) + (s1 ? q[1] : q11);
+            } else {
+                dq0 = st[4]; dq1 = st[5];
+            }
+            floatx4 dh1[4], dh2[4];
+            critic_bwd(L, Fo, acc1, acc2, dq0, dq1, dh1, dh2);
+            // dL/da_k = sum_j fc1.w[j][100 + k] dL/dh1[j]
+            float da0 = 0.0f, da1 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float *wr = L.W1s + (16 * t + 4 * gq + reg) * kLd + kW + 1;
+                    da0 = fmaf(wr[0], dh1[t][reg], da0);
+                    da1 = fmaf(wr[1], dh1[t][reg], da1);
+                }
+            da0 = group_sum4(da0);
+            da1 = group_sum4(da1);
+            if (gq == 0) {
+                if (c == 1) {
+                    st[6] = da0; st[7] = da1;
+                    st[4] = dq0 == 0.0f ? -inv_2b : 0.0f;               // what critic 1 gets
+                    st[5] = dq1 == 0.0f ? -inv_2b : 0.0f;
+                } else {
+                    st[6] += da0; st[7] += da1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the actor's backward
+    stage_actor(L, g.actor);
+    __syncthreads();
+    {
+        W2Frag<4> Fa;
+        w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+        floatx4 aw1[7], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        float s_b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float g_lp = alpha * inv_2b;                             // d loss / d log pi per element
+        for (int j = 0; j < nt; ++j) {
+            const int smp = (t0 + j) * kTile + 16 * wv + r;
+            uint32_t rs, rn;
+            sample_rows(g, smp, rs, rn);
+            PRow R;
+            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
+            const float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
+            floatx4 acc[4];
+            fwd_strip_packed(L.W1s, R, acc);
+            float o[4];
+            q_strip<4>(acc, Fa, 4, 4, 0, o);
+            const float ev[2] = {g.eps[2 * smp], g.eps[2 * smp + 1]};
+            ActorOut A;
+            actor_head(o, ev[0], ev[1], A);
+            float dout[4];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float th = tanhf(A.act[d]);
+                const float u = 1.0f - th * th + 1e-7f;
+                const float dact = g_lp * (2.0f * th * (1.0f - th * th) / u) + g.bound * st[6 + d];
+                const float dns = dact * (1.0f - A.act[d] * A.act[d]);
+                const float dsd = dns * ev[d] - g_lp / A.sd[d];
+                const float s = A.spre[d];
+                const float sig = s > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-s));
+                dout[d] = dns * (1.0f - A.mu[d] * A.mu[d]);                       // fc_mu pre-activation
+                dout[2 + d] = dsd * (1.0f - A.sd[d] * A.sd[d]) * sig;             // fc_std pre-activation
+            }
+            floatx4 h[4], dh[4];
+            relu4(acc, h);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float v = fmaf(Fa.w[3][t][reg], dout[3], fmaf(Fa.w[2][t][reg], dout[2],
+                                    fmaf(Fa.w[1][t][reg], dout[1], Fa.w[0][t][reg] * dout[0])));
+                    dh[t][reg] = acc[t][reg] > 0.0f ? v : 0.0f;
+                }
+            x_strip_store<false>(L, R, 0.0f, 0.0f);
+            h_strip_store(L.H1s, h);
+            h_strip_store(L.dH1s, dh);
+            if (gq == 0) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { L.dqs[(16 * wv + r) * 4 + a] = dout[a]; s_b[a] += dout[a]; }
+            }
+            __syncthreads();
+            wgrad<7>(L.dH1s, L.Xs, kLd, aw1);
+            wgrad_small(L.H1s, L.dqs, 4, awo);
+            __syncthreads();
+        }
+        float *out = g.partials + (size_t)blockIdx.x * kStrideA;
+        store_dw1(out, kW, kHid * kW, aw1);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            if (r < 4) out[kAoW2 + r * kHid + 16 * wv + 4 * gq + reg] = awo[reg];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_b[a] = wave_sum(s_b[a]);
+        s_lp = wave_sum(s_lp);
+        s_loss = wave_sum(s_loss);
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) L.red[wv * 8 + a] = s_b[a];
+            L.red[wv * 8 + 4] = s_loss;
+            L.red[wv * 8 + 5] = s_lp;
+        }
+        __syncthreads();
+        if (tid < 6) {
+            const float s = (L.red[tid] + L.red[8 + tid]) + (L.red[16 + tid] + L.red[24 + tid]);
+            if (tid < 4) out[kAob2 + tid] = s;
+            else if (tid == 4) out[kPa] = s * inv_2b;
+            else out[kPa + 1] = s;
+        }
+        if (tid == 6) { out[kPa + 2] = 0.0f; out[kPa + 3] = 0.0f; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// column sums of the partial rows + torch.optim.Adam (+ soft target update, + the log_alpha step)
+// ---------------------------------------------------------------------------------------------------------------------
+struct AdamSeg {
+    float *p, *m, *v, *tgt;      // tgt nullable: tgt = tgt (1 - tau) + p tau after the step (soft_update, :145-147)
+    int n;
+    float lr;
+};
+struct AdamArgs {
+    const float *partials;
+    int rows, stride, nseg, extras;          // columns: seg 0 | seg 1 | `extras` scalars
+    AdamSeg seg[2];
+    float beta1, beta2, eps, bc1, bc2_sqrt, tau;
+    float *scalars_out;                      // [extras] column sums of the extras (losses, sum of log pi)
+    // log_alpha step (actor phase): extras column 1 holds sum log pi over [B, 2]
+    float *log_alpha, *alpha_mv;             // nullable; alpha_mv = {exp_avg, exp_avg_sq}
+    float alpha_lr, target_entropy, inv_2b;
+};
+
+__device__ __forceinline__ float adam_step(float p, float g, float &m, float &v, const AdamArgs &a, float lr)
+{
+    m = m + (g - m) * (1.0f - a.beta1);                           // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + (1.0f - a.beta2) * g * g;
+    return p - (lr / a.bc1) * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+}
+
+__global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgs a)
+{
+    const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int total = a.seg[0].n + (a.nseg > 1 ? a.seg[1].n : 0) + a.extras;
+    if (col >= total) return;
+    const float *src = a.partials + col;
+    float s = 0.0f;
+    int b = 0;
+    for (; b + 8 <= a.rows; b += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(b + k) * a.stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += t[k];
+    }
+    for (; b < a.rows; ++b) s += src[(size_t)b * a.stride];
+    int c = col;
+    for (int k = 0; k < a.nseg; ++k) {
+        const AdamSeg &sg = a.seg[k];
+        if (c < sg.n) {
+            float m = sg.m[c], v = sg.v[c];
+            const float np = adam_step(sg.p[c], s, m, v, a, sg.lr);
+            sg.m[c] = m; sg.v[c] = v; sg.p[c] = np;
+            if (sg.tgt) sg.tgt[c] = sg.tgt[c] * (1.0f - a.tau) + np * a.tau;
+            return;
+        }
+        c -= sg.n;
+    }
+    if (a.scalars_out) a.scalars_out[c] = s;
+    if (c == 1 && a.log_alpha) {
+        // alpha_loss = mean((entropy - target_entropy).detach() * exp(log_alpha))   (:372-375)
+        const float la = *a.log_alpha;
+        const float gl = expf(la) * (-s * a.inv_2b - a.target_entropy);
+        float m = a.alpha_mv[0], v = a.alpha_mv[1];
+        const float nla = adam_step(la, gl, m, v, a, a.alpha_lr);
+        a.alpha_mv[0] = m; a.alpha_mv[1] = v;
+        *a.log_alpha = nla;
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArgs &g, int &grid)
+{
+    if (!n || !b || !partials) return sac_fail(UAVENV_EINVAL, "uavenv_sac: null argument");
+    if (!n->actor || !n->critic1 || !n->critic2 || !n->target1 || !n->target2 || !n->log_alpha)
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac: null parameter block");
+    if (!aligned16(n->actor) || !aligned16(n->critic1) || !aligned16(n->critic2) || !aligned16(n->target1) || !aligned16(n->target2) ||
+        !aligned16(partials) || !aligned16(b->obs_packed))
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac: parameter blocks, partial rows and the observation rows must be 16-byte aligned");
+    if (b->batch <= 0 || b->batch % kTile) return sac_fail(UAVENV_EINVAL, "uavenv_sac: batch must be a positive multiple of 64");
+    if (!b->obs_packed || !b->act0 || !b->act1 || !b->reward || !b->done || !b->eps)
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac: null batch plane");
+    if (!b->draws && (!b->idx_s || !b->idx_n)) return sac_fail(UAVENV_EINVAL, "uavenv_sac: neither draws nor row indices");
+    if (b->draws && (b->n_agents <= 0 || b->uav_per_env <= 0 || b->slot < 0 || b->slot >= b->uav_per_env || b->frames < 2))
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac: draws need n_agents / uav_per_env / slot / frames");
+    g.obs = reinterpret_cast<const uint32_t *>(b->obs_packed);
+    g.idx_s = b->idx_s; g.idx_n = b->idx_n; g.draws = b->draws;
+    g.n_agents = b->n_agents; g.uav = b->uav_per_env; g.slot = b->slot; g.frames = b->frames;
+    g.act0 = b->act0; g.act1 = b->act1; g.reward = b->reward; g.done = b->done; g.valid = b->valid;
+    g.eps = b->eps;
+    g.batch = b->batch;
+    const int n_tiles = b->batch / kTile;
+    int tpw = (n_tiles + 255) / 256;
+    if (tpw > kTMax) tpw = kTMax;
+    g.tiles_per_wg = tpw;
+    grid = (n_tiles + tpw - 1) / tpw;
+    g.actor = n->actor; g.c1 = n->critic1; g.c2 = n->critic2; g.t1 = n->target1; g.t2 = n->target2; g.log_alpha = n->log_alpha;
+    g.partials = partials;
+    return UAVENV_OK;
+}
+
+template <typename K>
+int launch_phase(K kernel, bool &attr, const SacArgs &g, int grid, hipStream_t s)
+{
+    if (!attr) {                         // (once per kernel; one process = one device for this library's learners)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSacLds) !=
+            hipSuccess)
+            return sac_fail(UAVENV_EHIP, "uavenv_sac: cannot raise the dynamic LDS limit");
+        attr = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), kSacLds, s, g);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac: launch failed");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *uavenv_sac_last_error(void) { return g_sac_err; }
+
+int uavenv_sac_partial_rows(int32_t batch)
+{
+    if (batch <= 0 || batch % kTile) return UAVENV_EINVAL;
+    const int n_tiles = batch / kTile;
+    int tpw = (n_tiles + 255) / 256;
+    if (tpw > kTMax) tpw = kTMax;
+    return (n_tiles + tpw - 1) / tpw;
+}
+
+int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, float gamma, float action_bound, float *partials,
+                           void *stream)
+{
+    SacArgs g;
+    int grid = 0;
+    const int rc = fill_args(nets, batch, partials, g, grid);
+    if (rc != UAVENV_OK) return rc;
+    g.gamma = gamma;
+    g.bound = action_bound;
+    static bool attr = false;
+    return launch_phase(k_sac_critic_grad, attr, g, grid, (hipStream_t)stream);
+}
+
+int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, float action_bound, float *partials, void *stream)
+{
+    SacArgs g;
+    int grid = 0;
+    const int rc = fill_args(nets, batch, partials, g, grid);
+    if (rc != UAVENV_OK) return rc;
+    g.gamma = 0.0f;
+    g.bound = action_bound;
+    static bool attr = false;
+    return launch_phase(k_sac_actor_grad, attr, g, grid, (hipStream_t)stream);
+}
+
+int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
+                           const UavSacAdam *h, float *losses_out, void *stream)
+{
+    if (!nets || !partials || rows <= 0 || !m1 || !v1 || !m2 || !v2 || !h) return sac_fail(UAVENV_EINVAL, "uavenv_sac_critic_adam: null argument");
+    AdamArgs a = {};
+    a.partials = partials; a.rows = rows; a.stride = kStrideC; a.nseg = 2; a.extras = 4;
+    a.seg[0] = AdamSeg{nets->critic1, m1, v1, nets->target1, kPc, h->lr};
+    a.seg[1] = AdamSeg{nets->critic2, m2, v2, nets->target2, kPc, h->lr};
+    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
+    a.tau = h->tau;
+    a.scalars_out = losses_out;
+    const int total = 2 * kPc + 4;
+    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_critic_adam: launch failed");
+}
+
+int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t rows, int32_t batch, float *m, float *v,
+                          float *alpha_mv, const UavSacAdam *h, float alpha_lr, float target_entropy, float *scalars_out,
+                          void *stream)
+{
+    if (!nets || !partials || rows <= 0 || batch <= 0 || !m || !v || !alpha_mv || !h)
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac_actor_adam: null argument");
+    AdamArgs a = {};
+    a.partials = partials; a.rows = rows; a.stride = kStrideA; a.nseg = 1; a.extras = 4;
+    a.seg[0] = AdamSeg{nets->actor, m, v, nullptr, kPa, h->lr};
+    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
+    a.tau = 0.0f;
+    a.scalars_out = scalars_out;
+    a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
+    a.inv_2b = 0.5f / (float)batch;
+    const int total = kPa + 4;
+    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_actor_adam: launch failed");
+}
+
+}  // extern "C"

@@ -108,3 +108,166 @@ class SACLearner:
         """[n,100] -> actions [n,2] (only [:,0] steers: Agents/UAV.py:414)."""
         with torch.no_grad():
             return self.actor(states.to(self.device).float(), eps)[0]
+
+
+class FusedSACLearner:
+    """The same update as SACLearner.learn (SAC_Trainer.py:325-379, continuous branch) as four hand-written HIP launches
+    (csrc/sac.hip: critic_grad -> critic_adam -> actor_grad -> actor_adam) on packed observation rows in place.
+    `actor`, `critic_1`, ... are ordinary modules with the reference's parameter names whose parameters are VIEWS of the
+    kernels' flat blocks, so acting, state_dict() and load_state_dict() work as on SACLearner.  Shapes are the
+    reference's shipped config (w 100, hiden_dim 64, two action components); anything else raises."""
+
+    def __init__(self, param: dict, device="cuda:0"):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.lib = _lib.load()
+        ap, cp, sp = param.get("actor"), param.get("critic"), param.get("SAC_param")
+        if (int(ap.get("w")), int(ap.get("hiden_dim")), int(ap.get("output"))) != (100, 64, 2) or \
+           (int(cp.get("w")), int(cp.get("hiden_dim")), int(cp.get("action_dim"))) != (100, 64, 2):
+            raise ValueError("FusedSACLearner handles the reference's 100-64-(2+2) actor and 102-64-64-2 critics only")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.UavEnvError("FusedSACLearner needs a GPU (no CPU fallback); use SACLearner")
+        d = self.device
+        pa, pc = _lib.SAC_ACTOR_PARAMS, _lib.SAC_CRITIC_PARAMS
+        pad = lambda n: (n + 3) & ~3      # noqa: E731
+        self._blocks = torch.zeros((3, pad(pa)), dtype=torch.float32, device=d)            # actor: params, exp_avg, exp_avg_sq
+        self._cblocks = torch.zeros((8, pad(pc)), dtype=torch.float32, device=d)           # c1 c2 t1 t2 | m1 v1 m2 v2
+        mk = lambda p: create_network(p).to(d)   # noqa: E731
+        self.actor = mk(ap)
+        self.critic_1, self.critic_2 = mk(cp), mk(cp)
+        self.target_critic_1, self.target_critic_2 = mk(cp), mk(cp)
+        self.target_critic_1.load_state_dict(self.critic_1.state_dict())
+        self.target_critic_2.load_state_dict(self.critic_2.state_dict())
+        self._bind(self.actor, self._blocks[0], ("fc1.weight", "fc1.bias", "fc_mu.weight", "fc_std.weight", "fc_mu.bias", "fc_std.bias"))
+        for k, net in enumerate((self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2)):
+            self._bind(net, self._cblocks[k], ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc_out.weight", "fc_out.bias"))
+        self.log_alpha = torch.tensor(np.log(0.01), dtype=torch.float32, device=d)
+        self._alpha_mv = torch.zeros(2, dtype=torch.float32, device=d)
+        self.actor_lr, self.critic_lr, self.alpha_lr = float(ap.get("lr")), float(cp.get("lr")), float(sp.get("alpha_lr"))
+        self.target_entropy = float(sp.get("target_entropy"))
+        self.gamma, self.tau = float(sp.get("gamma")), float(sp.get("tau"))
+        self.action_bound = float(ap.get("action_bound"))
+        self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-8                           # torch.optim.Adam defaults
+        self.epoch = 0
+        self._scalars = torch.zeros(8, dtype=torch.float32, device=d)                      # critic losses [0:4], actor [4:8]
+        self._partials = {}
+        self._nets = _lib.UavSacNets(self._blocks[0].data_ptr(), self._cblocks[0].data_ptr(), self._cblocks[1].data_ptr(),
+                                     self._cblocks[2].data_ptr(), self._cblocks[3].data_ptr(), self.log_alpha.data_ptr())
+
+    @staticmethod
+    def _bind(net, flat, names):
+        params = dict(net.named_parameters())
+        off = 0
+        with torch.no_grad():
+            for nm in names:
+                p = params[nm]
+                n = p.numel()
+                flat[off:off + n].copy_(p.reshape(-1))
+                p.data = flat[off:off + n].view_as(p)
+                off += n
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _scratch(self, batch: int):
+        s = self._partials.get(batch)
+        if s is None:
+            rows = self.lib.uavenv_sac_partial_rows(int(batch))
+            if rows <= 0:
+                raise ValueError("batch must be a positive multiple of 64")
+            s = (rows, torch.empty((rows, self._lib.SAC_CRITIC_STRIDE), dtype=torch.float32, device=self.device),
+                 torch.empty((rows, self._lib.SAC_ACTOR_STRIDE), dtype=torch.float32, device=self.device))
+            self._partials[batch] = s
+        return s
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise self._lib.UavEnvError(f"{what} failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()}")
+
+    def make_batch(self, obs_packed: torch.Tensor, act0, act1, reward, done, *, valid=None, idx_s=None, idx_n=None,
+                   draws=None, n_agents=0, uav_per_env=1, slot=0, frames=0):
+        """Describe the sampled transitions in place (see UavSacBatch in include/uavenv.h).  Keeps the tensors alive."""
+        keep = (obs_packed, act0, act1, reward, done, valid, idx_s, idx_n, draws)
+        n = int(draws.shape[0]) if draws is not None else int(idx_s.numel())
+        ptr = lambda t: None if t is None else t.data_ptr()      # noqa: E731
+        for t, dt in ((act0, torch.float32), (act1, torch.float32), (reward, torch.float32), (done, torch.uint8)):
+            assert t.dtype == dt and t.is_contiguous()
+        assert valid is None or valid.dtype == torch.uint8
+        assert draws is None or (draws.dtype == torch.int32 and draws.is_contiguous())
+        assert idx_s is None or (idx_s.dtype == torch.int32 and idx_n.dtype == torch.int32)
+        b = self._lib.UavSacBatch(obs_packed.data_ptr(), ptr(idx_s), ptr(idx_n), ptr(draws), int(n_agents), int(uav_per_env),
+                                  int(slot), int(frames), act0.data_ptr(), act1.data_ptr(), reward.data_ptr(), done.data_ptr(),
+                                  ptr(valid), None, n, 0)
+        b._keep = keep
+        return b
+
+    def _adam(self, lr, tau=0.0):
+        t = self.epoch
+        return self._lib.UavSacAdam(lr, self.beta1, self.beta2, self.adam_eps, 1.0 - self.beta1 ** t,
+                                    float(np.sqrt(1.0 - self.beta2 ** t)), tau, 0.0)
+
+    # the four launches, separately (tests drive them one by one)
+    def critic_grad(self, batch, eps_next: torch.Tensor):
+        C = self._C
+        rows, pc, _ = self._scratch(batch.batch)
+        batch.eps = eps_next.data_ptr()
+        self._check(self.lib.uavenv_sac_critic_grad(C.byref(self._nets), C.byref(batch), self.gamma, self.action_bound,
+                                                    pc.data_ptr(), self._stream()), "uavenv_sac_critic_grad")
+        return pc
+
+    def critic_step(self, n: int):
+        C = self._C
+        rows, pc, _ = self._scratch(n)
+        h = self._adam(self.critic_lr, self.tau)
+        cb = self._cblocks
+        self._check(self.lib.uavenv_sac_critic_adam(C.byref(self._nets), pc.data_ptr(), rows, cb[4].data_ptr(), cb[5].data_ptr(),
+                                                    cb[6].data_ptr(), cb[7].data_ptr(), C.byref(h), self._scalars.data_ptr(),
+                                                    self._stream()), "uavenv_sac_critic_adam")
+
+    def actor_grad(self, batch, eps_cur: torch.Tensor):
+        C = self._C
+        rows, _, pa = self._scratch(batch.batch)
+        batch.eps = eps_cur.data_ptr()
+        self._check(self.lib.uavenv_sac_actor_grad(C.byref(self._nets), C.byref(batch), self.action_bound, pa.data_ptr(),
+                                                   self._stream()), "uavenv_sac_actor_grad")
+        return pa
+
+    def actor_step(self, n: int):
+        C = self._C
+        rows, _, pa = self._scratch(n)
+        h = self._adam(self.actor_lr)
+        self._check(self.lib.uavenv_sac_actor_adam(C.byref(self._nets), pa.data_ptr(), rows, int(n), self._blocks[1].data_ptr(),
+                                                   self._blocks[2].data_ptr(), self._alpha_mv.data_ptr(), C.byref(h),
+                                                   self.alpha_lr, self.target_entropy, self._scalars[4:].data_ptr(),
+                                                   self._stream()), "uavenv_sac_actor_adam")
+
+    def learn(self, batch, noise=None):
+        """One SAC_Trainer.update on `batch` (make_batch).  noise = (eps_next, eps_cur), [B, 2] f32 each, pins the two
+        rsample() draws; default: fresh torch.randn."""
+        n = batch.batch
+        if noise is None:
+            z = torch.randn((2, n, 2), dtype=torch.float32, device=self.device)
+            noise = (z[0], z[1])
+        e_next, e_cur = (t.contiguous() for t in noise)
+        assert e_next.shape == (n, 2) and e_next.dtype == torch.float32
+        self.epoch += 1
+        self.critic_grad(batch, e_next)
+        self.critic_step(n)
+        self.actor_grad(batch, e_cur)
+        self.actor_step(n)
+        batch._noise = (e_next, e_cur)
+        return self._scalars[4]
+
+    @property
+    def loss(self):
+        return self._scalars[4]
+
+    @property
+    def critic_losses(self):
+        return self._scalars[0:2]
+
+    def act(self, states: torch.Tensor, eps=None) -> torch.Tensor:
+        with torch.no_grad():
+            return self.actor(states.to(self.device).float(), eps)[0]

@@ -358,6 +358,60 @@ int uavenv_loop_get(const UavLoop *loop, UavLoopCursor *out);
  * clears the record. */
 int uavenv_loop_step_times(UavLoop *loop, float *ms_out, int32_t max_n, int32_t *n_out);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Fused SAC (continuous actions) update -- Trainer/SAC_Trainer.py:325-379 (update, continuous branch), :122-131
+ * (calc_target), :145-147 (soft_update), nets BaseClass/BaseCNN.py:459-500 (PolicyNetContinuous_SAC 100-64-(2+2),
+ * QValueNetContinuous_SAC 102-64-64-2, critics emitting action_dim = 2 values as in the reference).  csrc/sac.hip.
+ * One update = critic_grad -> critic_adam -> actor_grad -> actor_adam on one stream (four launches, nothing synchronises).
+ * Flat f32 parameter blocks, 16-byte aligned; the torch modules' parameters are views of them:
+ *   actor : fc1.weight 64x100 | fc1.bias 64 | fc_mu.weight 2x64 | fc_std.weight 2x64 | fc_mu.bias 2 | fc_std.bias 2
+ *   critic: fc1.weight 64x102 | fc1.bias 64 | fc2.weight 64x64 | fc2.bias 64 | fc_out.weight 2x64 | fc_out.bias 2
+ * A partial-gradient row (one per workgroup, uavenv_sac_partial_rows(batch) of them) has the same layout:
+ *   critic rows: critic 1 | critic 2 | loss 1 | loss 2 | 0 | 0        actor rows: actor | actor loss | sum log pi | 0 | 0 */
+#define UAVENV_SAC_CRITIC_IN 102
+#define UAVENV_SAC_ACTOR_PARAMS 6724
+#define UAVENV_SAC_CRITIC_PARAMS 10882
+#define UAVENV_SAC_ACTOR_STRIDE 6728
+#define UAVENV_SAC_CRITIC_STRIDE 21768
+typedef struct UavSacNets {
+    float *actor, *critic1, *critic2, *target1, *target2;
+    float *log_alpha;            /* device scalar */
+} UavSacNets;
+/* The sampled transitions, in place: packed observation rows (UAVENV_OBS_PACKED) + planes indexed by the row of s.
+ * Rows either explicit (idx_s / idx_n: row of s and of s' per sample) or derived from uavenv_replay_draw's (frame, env)
+ * pairs for UAV slot `slot` of a ring whose frames hold n_agents = n_envs * uav_per_env rows:
+ * row(s) = frame * n_agents + env * uav_per_env + slot, s' one frame later. */
+typedef struct UavSacBatch {
+    const void *obs_packed;
+    const int32_t *idx_s, *idx_n;        /* nullable when draws != NULL */
+    const int32_t *draws;                /* nullable: batch x (frame, env) */
+    int32_t n_agents, uav_per_env, slot, frames;
+    const float *act0, *act1, *reward;   /* the two action components (:444-448), the reward */
+    const uint8_t *done, *valid;         /* valid nullable: sample weight of the critic losses (0 / 1) */
+    const float *eps;                    /* batch x 2 N(0,1) draws standing for Normal.rsample() of this phase */
+    int32_t batch, reserved0;            /* batch: a multiple of 64 */
+} UavSacBatch;
+typedef struct UavSacAdam {
+    float lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt;   /* 1 - beta1^t, sqrt(1 - beta2^t) */
+    float tau, reserved0;                /* soft target update (critic_adam only) */
+} UavSacAdam;
+int uavenv_sac_partial_rows(int32_t batch);
+const char *uavenv_sac_last_error(void);
+/* eps = the draws of actor(next_states).  partials: rows x UAVENV_SAC_CRITIC_STRIDE floats. */
+int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, float gamma, float action_bound, float *partials,
+                           void *stream);
+/* Adam on both critics (m / v: UAVENV_SAC_CRITIC_PARAMS floats each) + target <- target (1 - tau) + critic tau.
+ * losses_out (nullable, 4 floats): the two critic losses. */
+int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
+                           const UavSacAdam *h, float *losses_out, void *stream);
+/* eps = the draws of actor(states).  partials: rows x UAVENV_SAC_ACTOR_STRIDE floats. */
+int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, float action_bound, float *partials, void *stream);
+/* Adam on the actor and on log_alpha (alpha_mv: its exp_avg, exp_avg_sq).  scalars_out (nullable, 4 floats): actor loss,
+ * sum of log pi over [batch, 2]. */
+int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t rows, int32_t batch, float *m, float *v,
+                          float *alpha_mv, const UavSacAdam *h, float alpha_lr, float target_entropy, float *scalars_out,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

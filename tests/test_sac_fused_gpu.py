@@ -1,0 +1,151 @@
+"""Fused SAC update (csrc/sac.hip, sac.FusedSACLearner) against the PyTorch-ROCm SACLearner -- itself pinned to the executed
+reference's SAC_Trainer.update by tests/test_sac_golden.py -- on the same sampled transitions and the same rsample() draws:
+raw gradients of both phases, losses, then whole updates (parameters, targets, log_alpha)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PARAM = {"actor": {"NetWork": "PolicyNetContinuous_SAC", "w": "100", "action_bound": "1", "hiden_dim": "64", "output": "2", "lr": "0.0001"},
+         "critic": {"NetWork": "QValueNetContinuous_SAC", "w": "100", "hiden_dim": "64", "action_dim": "2", "lr": "0.001"},
+         "SAC_param": {"IS_Continuous": "1", "alpha_lr": "0.0001", "target_entropy": "1", "gamma": "0.99", "tau": "0.05"}}
+A_NAMES = ("fc1.weight", "fc1.bias", "fc_mu.weight", "fc_std.weight", "fc_mu.bias", "fc_std.bias")
+C_NAMES = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc_out.weight", "fc_out.bias")
+
+
+@pytest.fixture(scope="module")
+def world():
+    """a continuous-action ring with a few hundred frames of random flying (packed rows), 2 UAVs per env"""
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    env = make_city26_env(512, uav_per_env=2, obs_dtype="packed")
+    ring = DeviceReplayRing(env, 40 * env.N, discrete=False)
+    ring.reset(seed=5)
+    a1 = torch.zeros((ring.frames, env.N), dtype=torch.float32, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(30):
+        ring.current_action().copy_(torch.rand(env.N, generator=gen, device="cuda") * 2 - 1)
+        a1[ring.head].copy_(torch.rand(env.N, generator=gen, device="cuda") * 2 - 1)
+        ring.step_env(auto_reset=True)
+    yield env, ring, a1
+    env.close()
+
+
+def _pair(seed=0):
+    from dqn_based_uav_3d_path_planer_amd.sac import SACLearner, FusedSACLearner
+    torch.manual_seed(seed)
+    fused = FusedSACLearner(PARAM)
+    ref = SACLearner(PARAM)
+    for name in ("actor", "critic_1", "critic_2", "target_critic_1", "target_critic_2"):
+        getattr(ref, name).load_state_dict(getattr(fused, name).state_dict())
+    # decorrelate critic 2 / the targets from critic 1 (the constructor gives the targets the critics' weights)
+    with torch.no_grad():
+        for net in (fused.target_critic_1, fused.target_critic_2):
+            for p in net.parameters():
+                p.add_(0.01 * torch.randn_like(p))
+        for name in ("target_critic_1", "target_critic_2"):
+            getattr(ref, name).load_state_dict(getattr(fused, name).state_dict())
+    return fused, ref
+
+
+def _batch(world, fused, B, seed, slot=1):
+    env, ring, a1 = world
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    f = torch.randint(0, ring.head - 1, (B,), generator=gen, device="cuda", dtype=torch.int32)
+    e = torch.randint(0, env.N // 2, (B,), generator=gen, device="cuda", dtype=torch.int32)
+    draws = torch.stack([f, e], 1).contiguous()
+    rows = (f.long() * env.N + e.long() * 2 + slot)
+    nxt = rows + env.N
+    flat = ring.obs.view(-1, ring.obs.shape[-1])
+    b = fused.make_batch(flat, ring.action.view(-1), a1.view(-1), ring.reward.view(-1), ring.done.view(-1),
+                         valid=ring.valid.view(-1), draws=draws, n_agents=env.N, uav_per_env=2, slot=slot, frames=ring.frames)
+    td = dict(states=env.unpack(flat[rows]), next_states=env.unpack(flat[nxt]),
+              actions=torch.stack([ring.action.view(-1)[rows], a1.view(-1)[rows]], 1),
+              rewards=ring.reward.view(-1)[rows], dones=ring.done.view(-1)[rows].float())
+    w = ring.valid.view(-1)[rows].float()
+    eps = torch.randn((2, B, 2), generator=gen, device="cuda")
+    return b, td, w, (eps[0].contiguous(), eps[1].contiguous())
+
+
+def _flat(tensors):
+    return torch.cat([t.reshape(-1) for t in tensors])
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def test_gradients_of_both_phases_match_autograd(world):
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    fused, ref = _pair()
+    B = 2048
+    b, td, w, (e_next, e_cur) = _batch(world, fused, B, seed=11)
+    assert 0.5 < float(w.mean()) <= 1.0
+    # ---- phase A: td target, the two (weighted) critic losses and their gradients
+    states, nstates, actions = td["states"], td["next_states"], td["actions"]
+    rewards, dones = td["rewards"].view(-1, 1), td["dones"].view(-1, 1)
+    target = ref.calc_target(rewards, nstates, dones, e_next).detach()
+    pc = fused.critic_grad(b, e_next).sum(0)
+    for k, net in enumerate((ref.critic_1, ref.critic_2)):
+        q = net(states, actions)
+        loss = torch.mean(w.view(-1, 1) * (q - target) ** 2)
+        params = dict(net.named_parameters())
+        g = _flat(torch.autograd.grad(loss, [params[n] for n in C_NAMES]))
+        mine = pc[k * _lib.SAC_CRITIC_PARAMS:(k + 1) * _lib.SAC_CRITIC_PARAMS]
+        assert _rel(mine, g) <= 2e-5, (k, _rel(mine, g))
+        assert float((mine - g).abs().max()) <= 2e-5 * float(g.abs().max())
+        assert abs(float(pc[2 * _lib.SAC_CRITIC_PARAMS + k]) - float(loss)) <= 2e-5 * abs(float(loss))
+    # ---- phase B on the SAME critics (no critic step in between here): actor loss, its gradient, sum of log pi
+    new_actions, log_prob = ref.actor(states, e_cur)
+    actor_loss = torch.mean(ref.log_alpha.exp() * log_prob - torch.min(ref.critic_1(states, new_actions), ref.critic_2(states, new_actions)))
+    params = dict(ref.actor.named_parameters())
+    g = _flat(torch.autograd.grad(actor_loss, [params[n] for n in A_NAMES]))
+    pa = fused.actor_grad(b, e_cur).sum(0)
+    mine = pa[:_lib.SAC_ACTOR_PARAMS]
+    assert _rel(mine, g) <= 5e-5, _rel(mine, g)
+    assert abs(float(pa[_lib.SAC_ACTOR_PARAMS]) - float(actor_loss)) <= 2e-5 * max(1.0, abs(float(actor_loss)))
+    assert abs(float(pa[_lib.SAC_ACTOR_PARAMS + 1]) - float(log_prob.sum())) <= 2e-5 * abs(float(log_prob.sum()))
+
+
+@pytest.mark.parametrize("B", [64, 4096, 20480])
+def test_whole_updates_track_the_torch_learner(world, B):
+    """B = 64: one workgroup, one tile; 4096: one tile per workgroup; 20480: 320 tiles -> two per workgroup."""
+    fused, ref = _pair(seed=B)
+    for it in range(4):
+        b, td, w, noise = _batch(world, fused, B, seed=100 + it, slot=it & 1)
+        ref.learn(td, noise=noise, is_weights=w)
+        fused.learn(b, noise=noise)
+        torch.cuda.synchronize()
+        # losses of this update (computed before the steps)
+        assert abs(float(fused.loss) - float(ref.loss)) <= 1e-4 * max(1.0, abs(float(ref.loss))), it
+        for name, names, lr in (("actor", A_NAMES, 1e-4), ("critic_1", C_NAMES, 1e-3), ("critic_2", C_NAMES, 1e-3),
+                                ("target_critic_1", C_NAMES, 1e-3), ("target_critic_2", C_NAMES, 1e-3)):
+            pf, pr = dict(getattr(fused, name).named_parameters()), dict(getattr(ref, name).named_parameters())
+            d = torch.cat([(pf[n] - pr[n]).abs().reshape(-1) for n in names])
+            # Adam normalises the step: an element whose gradient is ~0 can move by up to lr in either learner; everywhere
+            # else the two agree to rounding.  Bars: 99 % of the elements within 2 % of one step, none beyond 2 steps/update.
+            assert float(torch.quantile(d, 0.99)) <= 0.02 * lr * (it + 1), (it, name, float(torch.quantile(d, 0.99)))
+            assert float(d.max()) <= 2.0 * lr * (it + 1), (it, name, float(d.max()))
+        assert abs(float(fused.log_alpha) - float(ref.log_alpha)) <= 1e-6 * (it + 1)
+    # and the policies still act alike
+    env, ring, _ = world
+    s = env.unpack(ring.current_obs())[:256]
+    e = torch.randn((256, 2), device="cuda")
+    assert float((fused.act(s, e) - ref.act(s, e)).abs().max()) <= 2e-3
+
+
+def test_rejects_what_it_cannot_do(world):
+    from dqn_based_uav_3d_path_planer_amd.sac import FusedSACLearner
+    from dqn_based_uav_3d_path_planer_amd._lib import UavEnvError
+    bad = {k: dict(v) for k, v in PARAM.items()}
+    bad["actor"]["hiden_dim"] = "128"
+    with pytest.raises(ValueError):
+        FusedSACLearner(bad)
+    fused = FusedSACLearner(PARAM)
+    env, ring, a1 = world
+    idx = torch.arange(100, dtype=torch.int32, device="cuda")
+    flat = ring.obs.view(-1, ring.obs.shape[-1])
+    b = fused.make_batch(flat, ring.action.view(-1), a1.view(-1), ring.reward.view(-1), ring.done.view(-1), idx_s=idx, idx_n=idx + env.N)
+    with pytest.raises((UavEnvError, ValueError)):
+        fused.learn(b, noise=(torch.zeros((100, 2), device="cuda"), torch.zeros((100, 2), device="cuda")))
