@@ -262,6 +262,11 @@ def run_config4(args, dev):
 
     def act_and_step():
         t = ring.head
+        if fused:                              # one launch per slot: actor forward on the packed rows of the current frame
+            for j, L in enumerate(learners):
+                L.act_rows(flat, t * env.N + j, U, envs, ring.action.view(-1), a1_plane.view(-1))
+            ring.step_env(auto_reset=True)
+            return
         obs = env.unpack(ring.current_obs()).view(envs, U, 100)
         act = ring.current_action().view(envs, U)
         a1 = a1_plane[t].view(envs, U)

@@ -635,6 +635,50 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// get_action (SAC_Trainer.py:444-448): a = actor(s) for `count` agents whose packed rows are first + i * stride; the two
+// action components go to act0[row] / act1[row] (the planes the env step and the learner read)
+// ---------------------------------------------------------------------------------------------------------------------
+struct SacActArgs {
+    const float *actor;
+    const uint32_t *obs;
+    int first, stride, count;
+    const float *eps;
+    float bound;
+    float *act0, *act1;
+};
+constexpr size_t kSacActLds = (size_t)kTileF * 4;
+
+__global__ void __launch_bounds__(256) k_sac_act(SacActArgs g)
+{
+    extern __shared__ __align__(16) float lds[];
+    SacLds L;
+    L.W1s = lds;
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+    stage_actor(L, g.actor);
+    __syncthreads();
+    W2Frag<4> Fa;
+    w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+    const int n_tiles = (g.count + kTile - 1) / kTile;
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int i = tile * kTile + 16 * wv + r;
+        const int ii = i < g.count ? i : g.count - 1;
+        const size_t row = (size_t)g.first + (size_t)ii * g.stride;
+        PRow R;
+        prow_load(R, g.obs + row * kPackedDwords);
+        floatx4 acc[4];
+        fwd_strip_packed(L.W1s, R, acc);
+        float o[4];
+        q_strip<4>(acc, Fa, 4, 4, 0, o);
+        ActorOut A;
+        actor_head(o, g.eps[2 * ii], g.eps[2 * ii + 1], A);
+        if (gq == 0 && i < g.count) {
+            g.act0[row] = A.act[0] * g.bound;
+            g.act1[row] = A.act[1] * g.bound;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // column sums of the partial rows + torch.optim.Adam (+ soft target update, + the log_alpha step)
 // ---------------------------------------------------------------------------------------------------------------------
 struct AdamSeg {
@@ -758,6 +802,18 @@ int uavenv_sac_partial_rows(int32_t batch)
     int tpw = (n_tiles + 255) / 256;
     if (tpw > kTMax) tpw = kTMax;
     return (n_tiles + tpw - 1) / tpw;
+}
+
+int uavenv_sac_act(const float *actor, const void *obs_packed, int32_t first_row, int32_t row_stride, int32_t count,
+                   const float *eps, float action_bound, float *act0, float *act1, void *stream)
+{
+    if (!actor || !obs_packed || !eps || !act0 || !act1 || count <= 0 || first_row < 0 || row_stride <= 0)
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac_act: bad argument");
+    if (!aligned16(actor) || !aligned16(obs_packed)) return sac_fail(UAVENV_EINVAL, "uavenv_sac_act: 16-byte alignment");
+    SacActArgs g = {actor, reinterpret_cast<const uint32_t *>(obs_packed), first_row, row_stride, count, eps, action_bound, act0, act1};
+    const int n_tiles = (count + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_sac_act, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), kSacActLds, (hipStream_t)stream, g);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_act: launch failed");
 }
 
 int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, float gamma, float action_bound, float *partials,

@@ -271,3 +271,14 @@ class FusedSACLearner:
     def act(self, states: torch.Tensor, eps=None) -> torch.Tensor:
         with torch.no_grad():
             return self.actor(states.to(self.device).float(), eps)[0]
+
+    def act_rows(self, obs_packed: torch.Tensor, first_row: int, row_stride: int, count: int, act0: torch.Tensor,
+                 act1: torch.Tensor, eps: torch.Tensor = None):
+        """get_action for the agents whose packed rows are first_row + i * row_stride of `obs_packed` (a flat view of the
+        ring), one launch; the two action components are written to act0[row] / act1[row] (flat planes)."""
+        if eps is None:
+            eps = torch.randn((count, 2), dtype=torch.float32, device=self.device)
+        assert eps.shape == (count, 2) and eps.dtype == torch.float32 and eps.is_contiguous()
+        self._check(self.lib.uavenv_sac_act(self._blocks[0].data_ptr(), obs_packed.data_ptr(), int(first_row), int(row_stride),
+                                            int(count), eps.data_ptr(), self.action_bound, act0.data_ptr(), act1.data_ptr(),
+                                            self._stream()), "uavenv_sac_act")

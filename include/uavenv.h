@@ -395,6 +395,10 @@ typedef struct UavSacAdam {
     float lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt;   /* 1 - beta1^t, sqrt(1 - beta2^t) */
     float tau, reserved0;                /* soft target update (critic_adam only) */
 } UavSacAdam;
+/* get_action (SAC_Trainer.py:444-448) for `count` agents whose packed rows are first_row + i * row_stride: the two
+ * action components land in act0[row] / act1[row].  eps: count x 2 N(0,1) draws (Normal.rsample()). */
+int uavenv_sac_act(const float *actor, const void *obs_packed, int32_t first_row, int32_t row_stride, int32_t count,
+                   const float *eps, float action_bound, float *act0, float *act1, void *stream);
 int uavenv_sac_partial_rows(int32_t batch);
 const char *uavenv_sac_last_error(void);
 /* eps = the draws of actor(next_states).  partials: rows x UAVENV_SAC_CRITIC_STRIDE floats. */

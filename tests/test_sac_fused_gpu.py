@@ -135,6 +135,29 @@ def test_whole_updates_track_the_torch_learner(world, B):
     assert float((fused.act(s, e) - ref.act(s, e)).abs().max()) <= 2e-3
 
 
+def test_act_rows_equals_the_module_forward(world):
+    """uavenv_sac_act on the packed rows of the current frame (one UAV slot, strided rows, ragged count) against the
+    PolicyNetContinuous_SAC module on the unpacked rows with the same rsample() draws."""
+    from dqn_based_uav_3d_path_planer_amd.sac import FusedSACLearner
+    env, ring, _ = world
+    torch.manual_seed(1)
+    fused = FusedSACLearner(PARAM)
+    flat = ring.obs.view(-1, ring.obs.shape[-1])
+    n_rows = flat.shape[0]
+    for slot, count in ((0, env.N // 2), (1, 333)):
+        a0 = torch.full((n_rows,), 7.0, device="cuda")
+        a1 = torch.full((n_rows,), 7.0, device="cuda")
+        eps = torch.randn((count, 2), device="cuda")
+        first = ring.head * env.N + slot
+        fused.act_rows(flat, first, 2, count, a0, a1, eps)
+        rows = first + 2 * torch.arange(count, device="cuda")
+        ref = fused.act(env.unpack(flat[rows]), eps)
+        assert float((a0[rows] - ref[:, 0]).abs().max()) <= 2e-6 and float((a1[rows] - ref[:, 1]).abs().max()) <= 2e-6
+        untouched = torch.ones(n_rows, dtype=torch.bool, device="cuda")
+        untouched[rows] = False
+        assert bool((a0[untouched] == 7.0).all()) and bool((a1[untouched] == 7.0).all())
+
+
 def test_rejects_what_it_cannot_do(world):
     from dqn_based_uav_3d_path_planer_amd.sac import FusedSACLearner
     from dqn_based_uav_3d_path_planer_amd._lib import UavEnvError
