@@ -15,10 +15,12 @@
 // registers = hidden units, observation operands generated in registers from the packed 80-byte rows.  The 64 -> 64
 // layer chains on the MFMA without leaving the registers: the K index of a step may be ANY permutation of the hidden
 // units, so step (t, reg) takes hidden unit 16 t + 4 (lane >> 4) + reg -- which is exactly the register the previous
-// layer's C/D fragment left in this lane.  Weight gradients: H / dH / X tiles of the 64 samples through LDS, MFMA over
-// K = samples, persistent accumulators, no atomics, deterministic.  A workgroup owns up to kTMax tiles and walks them
-// once per net (the five nets of a phase do not fit LDS together: each is staged once per workgroup, not once per tile);
-// what a later stage needs from an earlier one (a', log pi, td target, Q1, dL/da) is a few floats per sample in LDS.
+// layer's C/D fragment left in this lane.  Weight gradients: H / dH tiles of the 64 samples and their packed rows through
+// LDS, MFMA over K = samples (the observation operand decoded from the packed row), persistent accumulators, no atomics,
+// deterministic.  A workgroup owns up to kTMax tiles.  Critic phase: actor + both target critics stay in LDS for one pass
+// over the tiles (-> td targets, two floats per sample), then critic 1 and critic 2 one after the other, each staged once
+// per workgroup.  Actor phase: actor + both critics resident, one pass.  The next tile's rows are requested before the
+// current tile is computed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -53,7 +55,6 @@ constexpr int kStrideA = UAVENV_SAC_ACTOR_STRIDE;  // kPa + [actor loss sum, sum
 constexpr int kStrideC = UAVENV_SAC_CRITIC_STRIDE; // 2 kPc + [loss 1 sum, loss 2 sum, 0, 0]
 static_assert(kStrideA == kPa + 4 && kStrideC == 2 * kPc + 4, "partial-row strides");
 constexpr int kTMax = 4;                           // tiles per workgroup
-constexpr int kSt = 8;                             // floats of per-sample state
 
 struct SacArgs {
     const uint32_t *obs;                  // packed rows
@@ -67,30 +68,34 @@ struct SacArgs {
     const float *actor, *c1, *c2, *t1, *t2, *log_alpha;
     float gamma, bound;
     float *partials;
+    unsigned long long *dbg;              // diagnostics build: 16 s_memtime stamps per workgroup
 };
 
-struct SacLds {
-    float *W1s, *W2s, *b2s, *Xs, *H1s, *H2s, *dH1s, *dH2s, *dqs, *st, *red;
-};
-constexpr int kSacLdsFloats = kTileF + kHid * kLh + kHid + kTileF + 4 * kTile * kLh + kTile * 4 + kTMax * kTile * kSt + 64;
-constexpr size_t kSacLds = (size_t)kSacLdsFloats * 4;
+#ifdef UAVENV_PHASE_PROFILE
+#define S_STAMP(slot) do { if (g.dbg && threadIdx.x == 0) g.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S_STAMP(slot) do { } while (0)
+#endif
+unsigned long long *g_sac_dbg = nullptr;
 
-__device__ __forceinline__ SacLds carve(float *lds)
+// One staged critic in LDS: fc1 as a [64][kLd] tile (column 100 = b1, 101 / 102 = the action columns), fc2 [64][kLh], b2
+struct WSet {
+    float *W1s, *W2s, *b2s;
+};
+constexpr int kWSetF = kTileF + kHid * kLh + kHid;
+__device__ __forceinline__ WSet wset_at(float *p)
 {
-    SacLds L;
-    L.W1s = lds;
-    L.W2s = L.W1s + kTileF;
-    L.b2s = L.W2s + kHid * kLh;
-    L.Xs = L.b2s + kHid;
-    L.H1s = L.Xs + kTileF;
-    L.H2s = L.H1s + kTile * kLh;
-    L.dH1s = L.H2s + kTile * kLh;
-    L.dH2s = L.dH1s + kTile * kLh;
-    L.dqs = L.dH2s + kTile * kLh;
-    L.st = L.dqs + kTile * 4;
-    L.red = L.st + kTMax * kTile * kSt;
-    return L;
+    return WSet{p, p + kTileF, p + kTileF + kHid * kLh};
 }
+constexpr int kPsLd = 28;                          // dwords per sample of the packed-row tile: 20 + {1, a0, a1, 0} + pad (rows
+                                                   // 4 apart are 48 banks apart)
+// LDS maps (floats).  Critic phase, stage I: actor fc1 | target 1 | target 2; stage II: critic | Ps | H1 H2 dH1 dH2 | dq | red;
+// the td targets of the workgroup's tiles live behind both.  Actor phase: actor fc1 | critic 1 | critic 2 | Ps | H dH | dq | red.
+constexpr int kCritStage2F = kWSetF + kTile * kPsLd + 4 * kTile * kLh + kTile * 4 + 64;
+constexpr int kCritTdOff = kCritStage2F > kTileF + 2 * kWSetF ? kCritStage2F : kTileF + 2 * kWSetF;
+constexpr size_t kSacCriticLds = (size_t)(kCritTdOff + kTMax * kTile * 2) * 4;
+constexpr size_t kSacActorLds = (size_t)(kTileF + 2 * kWSetF + kTile * kPsLd + 2 * kTile * kLh + kTile * 4 + 64) * 4;
+static_assert(kSacActorLds <= 160 * 1024 && kSacCriticLds <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void sample_rows(const SacArgs &g, int smp, uint32_t &rs, uint32_t &rn)
 {
@@ -106,31 +111,68 @@ __device__ __forceinline__ void sample_rows(const SacArgs &g, int smp, uint32_t 
 }
 
 // actor fc1 (64 x 100, 16-byte aligned rows) -> W1s, column 100 = b1
-__device__ __forceinline__ void stage_actor(const SacLds &L, const float *flat)
+__device__ __forceinline__ void stage_actor(float *W1s, const float *flat)
 {
     floatx4 v[kStageIters];
     w_issue(v, flat);
     const float bias = threadIdx.x < kHid ? flat[kHid * kW + threadIdx.x] : 0.0f;
-    w_commit(L.W1s, v, bias);
+    w_commit(W1s, v, bias);
 }
 
-// critic fc1 (64 x 102: input column c < 100 -> tile column c, the two action columns -> 101, 102, b1 -> 100) and fc2
-__device__ __forceinline__ void stage_critic(const SacLds &L, const float *flat)
+// critic fc1 (64 x 102: input column c < 100 -> tile column c, the two action columns -> 101, 102, b1 -> 100) and fc2,
+// in two halves so that the loads of one net are in flight while another is being written: every thread's 13 + 4 + 2
+// loads are issued back to back (a load -> store loop pays one L2 round trip per iteration: 6.6 us per net, measured).
+// (fc1 rows are 408 bytes: 8-byte pieces, 51 per row)
+constexpr int kCritPieces = kHid * kIn / 2;                        // 3 264
+constexpr int kCritIters = (kCritPieces + 255) / 256;              // 13
+struct CritRegs {
+    float2 w1[kCritIters];
+    floatx4 w2[4];
+    float b1, b2;
+};
+__device__ __forceinline__ void critic_issue(CritRegs &C, const float *flat)
 {
     const int tid = (int)threadIdx.x;
-    for (int idx = tid; idx < kHid * kIn; idx += 256) {
-        const int row = idx / kIn, c = idx - row * kIn;
-        L.W1s[row * kLd + (c < kW ? c : c + 1)] = flat[idx];
+#pragma unroll
+    for (int it = 0; it < kCritIters; ++it) {
+        int idx = it * 256 + tid;
+        idx = idx < kCritPieces ? idx : kCritPieces - 1;
+        C.w1[it] = *reinterpret_cast<const float2 *>(flat + 2 * idx);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) C.w2[it] = *reinterpret_cast<const floatx4 *>(flat + kCoW2 + 4 * (it * 256 + tid));
+    C.b1 = flat[kCob1 + (tid & 63)];
+    C.b2 = flat[kCob2 + (tid & 63)];
+}
+__device__ __forceinline__ void critic_commit(const WSet &S, const CritRegs &C)
+{
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < kCritIters; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < kCritPieces) {
+            const int row = idx / (kIn / 2), q = idx - row * (kIn / 2);
+            float *dst = S.W1s + row * kLd + 2 * q;
+            if (q < kW / 2) *reinterpret_cast<float2 *>(dst) = C.w1[it];
+            else { dst[1] = C.w1[it].x; dst[2] = C.w1[it].y; }     // input columns 100, 101 -> tile columns 101, 102
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = it * 256 + tid, row = c >> 4, q = c & 15;
+        *reinterpret_cast<floatx4 *>(S.W2s + row * kLh + 4 * q) = C.w2[it];
     }
     if (tid < kHid) {
-        L.W1s[tid * kLd + kW] = flat[kCob1 + tid];
-        L.W1s[tid * kLd + kW + 3] = 0.0f;
-        L.b2s[tid] = flat[kCob2 + tid];
+        S.W1s[tid * kLd + kW] = C.b1;
+        S.W1s[tid * kLd + kW + 3] = 0.0f;
+        S.b2s[tid] = C.b2;
     }
-    for (int c = tid; c < kHid * kHid / 4; c += 256) {
-        const int row = c >> 4, q = c & 15;
-        *reinterpret_cast<floatx4 *>(L.W2s + row * kLh + 4 * q) = *reinterpret_cast<const floatx4 *>(flat + kCoW2 + 4 * c);
-    }
+}
+__device__ __forceinline__ void stage_critic(const WSet &S, const float *flat)
+{
+    CritRegs C;
+    critic_issue(C, flat);
+    critic_commit(S, C);
 }
 
 __device__ __forceinline__ void relu4(const floatx4 (&a)[4], floatx4 (&h)[4])
@@ -143,16 +185,16 @@ __device__ __forceinline__ void relu4(const floatx4 (&a)[4], floatx4 (&h)[4])
 
 // pre-activations of the 64 -> 64 layer from the (post-ReLU) registers of the layer below: step (t, reg) of the K loop
 // is hidden unit 16 t + 4 g + reg -- the register this lane already holds
-__device__ __forceinline__ void layer2_fwd(const SacLds &L, const floatx4 (&h1)[4], floatx4 (&acc2)[4])
+__device__ __forceinline__ void layer2_fwd(const WSet &S, const floatx4 (&h1)[4], floatx4 (&acc2)[4])
 {
     const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int t2 = 0; t2 < 4; ++t2) acc2[t2] = *reinterpret_cast<const floatx4 *>(L.b2s + 16 * t2 + 4 * g);
+    for (int t2 = 0; t2 < 4; ++t2) acc2[t2] = *reinterpret_cast<const floatx4 *>(S.b2s + 16 * t2 + 4 * g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         floatx4 a[4];
 #pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) a[t2] = *reinterpret_cast<const floatx4 *>(L.W2s + (16 * t2 + r) * kLh + 16 * t + 4 * g);
+        for (int t2 = 0; t2 < 4; ++t2) a[t2] = *reinterpret_cast<const floatx4 *>(S.W2s + (16 * t2 + r) * kLh + 16 * t + 4 * g);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
@@ -161,7 +203,7 @@ __device__ __forceinline__ void layer2_fwd(const SacLds &L, const floatx4 (&h1)[
 }
 
 // dL/dh1 = W2^T dL/dh2 (before the ReLU mask of layer 1), same trick with the roles of the two index sets swapped
-__device__ __forceinline__ void layer2_bwd(const SacLds &L, const floatx4 (&dh2)[4], floatx4 (&dh1)[4])
+__device__ __forceinline__ void layer2_bwd(const WSet &S, const floatx4 (&dh2)[4], floatx4 (&dh1)[4])
 {
     const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -170,36 +212,50 @@ __device__ __forceinline__ void layer2_bwd(const SacLds &L, const floatx4 (&dh2)
     for (int t2 = 0; t2 < 4; ++t2)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float *row = L.W2s + (16 * t2 + 4 * g + reg) * kLh + r;
+            const float *row = S.W2s + (16 * t2 + 4 * g + reg) * kLh + r;
 #pragma unroll
             for (int t = 0; t < 4; ++t) dh1[t] = mfma16(row[16 * t], dh2[t2][reg], dh1[t]);
         }
 }
 
-// Q(s, a) of the staged critic for this lane's sample; acc1 / acc2 keep the pre-activations
-__device__ __forceinline__ void critic_fwd(const SacLds &L, const PRow &R, float a0, float a1, const W2Frag<2> &Fo,
+// Q(s, a) of a staged critic for this lane's sample; acc1 / acc2 keep the pre-activations
+__device__ __forceinline__ void critic_fwd(const WSet &S, const PRow &R, float a0, float a1, const W2Frag<2> &Fo,
                                            floatx4 (&acc1)[4], floatx4 (&acc2)[4], float (&q)[2])
 {
-    fwd_strip_packed<true>(L.W1s, R, acc1, a0, a1);
+    fwd_strip_packed<true>(S.W1s, R, acc1, a0, a1);
     floatx4 h1[4];
     relu4(acc1, h1);
-    layer2_fwd(L, h1, acc2);
+    layer2_fwd(S, h1, acc2);
     q_strip<2>(acc2, Fo, 2, 2, 0, q);
 }
 
 // dL/dq -> dL/dh2, dL/dh1 (both after their ReLU masks)
-__device__ __forceinline__ void critic_bwd(const SacLds &L, const W2Frag<2> &Fo, const floatx4 (&acc1)[4], const floatx4 (&acc2)[4],
+__device__ __forceinline__ void critic_bwd(const WSet &S, const W2Frag<2> &Fo, const floatx4 (&acc1)[4], const floatx4 (&acc2)[4],
                                            float dq0, float dq1, floatx4 (&dh1)[4], floatx4 (&dh2)[4])
 {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh2[t][r] = acc2[t][r] > 0.0f ? fmaf(Fo.w[1][t][r], dq1, Fo.w[0][t][r] * dq0) : 0.0f;
-    layer2_bwd(L, dh2, dh1);
+    layer2_bwd(S, dh2, dh1);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh1[t][r] = acc1[t][r] > 0.0f ? dh1[t][r] : 0.0f;
+}
+
+// this lane's share of dL/da_k = sum_j fc1.w[j][100 + k] dL/dh1[j] (sum over the four lane groups still to be taken)
+__device__ __forceinline__ void action_grad_part(const WSet &S, const floatx4 (&dh1)[4], float &da0, float &da1)
+{
+    const int g = ((int)threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float *wr = S.W1s + (16 * t + 4 * g + reg) * kLd + kW + 1;
+            da0 = fmaf(wr[0], dh1[t][reg], da0);
+            da1 = fmaf(wr[1], dh1[t][reg], da1);
+        }
 }
 
 // PolicyNetContinuous_SAC.forward after fc_mu / fc_std (BaseCNN.py:470-483, quirks included: std = tanh(softplus(.)),
@@ -225,15 +281,12 @@ __device__ __forceinline__ void actor_head(const float (&o)[4], float e0, float 
     }
 }
 
-// this strip's 16 rows of the f32 X tile (columns 0..103) from the lanes' packed rows
-template <bool EXT>
-__device__ __forceinline__ void x_strip_store(const SacLds &L, const PRow &R, float a0, float a1)
+// the lane's packed row (+ {1, a0, a1, 0}: tile columns 100..103) into the packed-row tile; one lane per sample calls it
+__device__ __forceinline__ void ps_store(uint32_t *Ps, int row, const PRow &R, float a0, float a1)
 {
-    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const uint32_t slice = prow_slice(R, g);
-    float *dst = L.Xs + (16 * wv + r) * kLd + 26 * g;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) *reinterpret_cast<float2 *>(dst + 2 * i) = prow_pair<EXT>(R, slice, g == 0, g == 3, i, a0, a1);
+    uint32_t *dst = Ps + row * kPsLd;
+    prow_store_lds(dst, R);
+    reinterpret_cast<uintx4 *>(dst)[5] = uintx4{__float_as_uint(1.0f), __float_as_uint(a0), __float_as_uint(a1), 0u};
 }
 
 __device__ __forceinline__ void h_strip_store(float *Hs, const floatx4 (&h)[4])
@@ -243,42 +296,97 @@ __device__ __forceinline__ void h_strip_store(float *Hs, const floatx4 (&h)[4])
     for (int t = 0; t < 4; ++t) *reinterpret_cast<floatx4 *>(Hs + (16 * wv + r) * kLh + 16 * t + 4 * g) = h[t];
 }
 
-// acc[u][reg] += sum over the tile's 64 samples s of A[s][16 wave + 4 g + reg] * B[s][16 u + r]
-// (MFMA step k, lane group g: sample (k & 3) + 16 (k >> 2) + 4 g -- rows 4 apart are 16 banks apart in both tiles)
-template <int NT>
-__device__ __forceinline__ void wgrad(const float *As, const float *Bs, int ldb, floatx4 (&acc)[NT])
+// Weight-gradient products over the tile's 64 samples (K = samples): acc[reg] += sum_s A[s][16 wave + 4 g + reg] B[s][n].
+// MFMA step k, lane group g: sample (k & 3) + 16 (k >> 2) + 4 g -- rows 4 apart are 16 (48 for the packed rows) banks apart.
+// The operands of four steps are requested together, then their MFMAs run (one ds_read -> wait -> MFMA per step left
+// the matrix pipe idle two thirds of the time: 109 cycles per MFMA, measured).
+//
+// dW1: B = the f32 row the packed-row tile stands for (tile columns 0..111; 100 = 1, 101 / 102 = the action when EXT).
+// The lane's column per u is fixed, so where its value sits in a row (a scalar dword, or a bit of a flag word) is
+// worked out once, outside the sample loop.
+template <bool EXT>
+__device__ __forceinline__ void wgrad_x(const float *As, const uint32_t *Ps, floatx4 (&acc)[7])
 {
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const float *ap = As + 4 * g * kLh + 16 * wv + r;
-    const float *bp = Bs + 4 * g * ldb + r;
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-        const int s = (k & 3) + 16 * (k >> 2);
-        const float a = ap[s * kLh];
+    int dw[7], sh[7];
+    bool sc[7];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) acc[u] = mfma16(a, bp[s * ldb + 16 * u], acc[u]);
+    for (int u = 0; u < 7; ++u) {
+        const int c = 16 * u + r;
+        sh[u] = 0;
+        sc[u] = true;
+        if (c < 11) dw[u] = 4 + c;
+        else if (c >= 86 && c < 90) dw[u] = 15 + (c - 86);
+        else if (c == kW) dw[u] = 20;
+        else if (EXT && (c == kW + 1 || c == kW + 2)) dw[u] = 20 + (c - kW);
+        else if (c >= 95) dw[u] = 3;                                // constant-zero columns (dword 3 of a row is 0)
+        else { dw[u] = c >> 5; sh[u] = c & 31; sc[u] = false; }
+    }
+    const float *ap = As + 4 * g * kLh + 16 * wv + r;
+    const uint32_t *pp = Ps + 4 * g * kPsLd;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        float a[4];
+        uint32_t w[4][7];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int s = kk + 16 * kc;
+            a[kk] = ap[s * kLh];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) w[kk][u] = pp[s * kPsLd + dw[u]];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const float b = sc[u] ? __uint_as_float(w[kk][u]) : (float)((w[kk][u] >> sh[u]) & 1u);
+                acc[u] = mfma16(a[kk], b, acc[u]);
+            }
     }
 }
-// ... with B[s][n] = n < nb ? small[s][n] : 0  (small: [64][4])
+// the critic's other products in one sweep: dW2 = dH2^T H1 (4 tiles), dWout^T = H2^T dq, db2 = column sums of dH2
+__device__ __forceinline__ void wgrad_critic_rest(const float *dH2s, const float *H1s, const float *H2s, const float *dqs,
+                                                  floatx4 (&aw2)[4], floatx4 &awo, floatx4 &ab2)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int ao = 4 * g * kLh + 16 * wv + r;
+    const float *bp = H1s + 4 * g * kLh + r;
+    const float one = r == 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        float ad[4], ah[4], b[4][4], bq[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int s = kk + 16 * kc;
+            ad[kk] = dH2s[ao + s * kLh];
+            ah[kk] = H2s[ao + s * kLh];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[kk][u] = bp[s * kLh + 16 * u];
+            bq[kk] = r < 2 ? dqs[(s + 4 * g) * 4 + r] : 0.0f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) aw2[u] = mfma16(ad[kk], b[kk][u], aw2[u]);
+            awo = mfma16(ah[kk], bq[kk], awo);
+            ab2 = mfma16(ad[kk], one, ab2);
+        }
+    }
+}
+// acc += A^T small, small: [64][4], columns n >= nb read as 0
 __device__ __forceinline__ void wgrad_small(const float *As, const float *small, int nb, floatx4 &acc)
 {
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const float *ap = As + 4 * g * kLh + 16 * wv + r;
-#pragma unroll 4
+    float a[16], b[16];
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int s = (k & 3) + 16 * (k >> 2) + 4 * g;
-        const float b = r < nb ? small[s * 4 + r] : 0.0f;
-        acc = mfma16(ap[((k & 3) + 16 * (k >> 2)) * kLh], b, acc);
+        const int s0 = (k & 3) + 16 * (k >> 2);
+        a[k] = ap[s0 * kLh];
+        b[k] = r < nb ? small[(s0 + 4 * g) * 4 + r] : 0.0f;
     }
-}
-// ... with B[s][n] = (n == 0): column sums of A
-__device__ __forceinline__ void wgrad_ones(const float *As, floatx4 &acc)
-{
-    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const float *ap = As + 4 * g * kLh + 16 * wv + r;
-    const float b = r == 0 ? 1.0f : 0.0f;
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) acc = mfma16(ap[((k & 3) + 16 * (k >> 2)) * kLh], b, acc);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = mfma16(a[k], b[k], acc);
 }
 
 // fc1 gradient tiles -> the partial row: tile column c < 100 -> input column c, 100 -> b1, 101 / 102 -> the action columns
@@ -305,84 +413,101 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// what a tile's pass needs from HBM for this lane's sample (requested one tile ahead)
+struct TileIn {
+    PRow R;
+    float a0, a1, rew, nd, w, e0, e1;
+};
+template <bool NEXT, bool CRITIC>
+__device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15;
+    const int smp = tile * kTile + 16 * wv + r;
+    uint32_t rs, rn;
+    sample_rows(g, smp, rs, rn);
+    prow_load(T.R, g.obs + (size_t)(NEXT ? rn : rs) * kPackedDwords);
+    T.a0 = T.a1 = T.rew = T.nd = 0.0f;
+    T.w = 1.0f;
+    if (CRITIC) {
+        if (NEXT) { T.rew = g.reward[rs]; T.nd = 1.0f - (float)g.done[rs]; }
+        else { T.a0 = g.act0[rs]; T.a1 = g.act1[rs]; T.w = g.valid ? (float)g.valid[rs] : 1.0f; }
+    }
+    if (NEXT || !CRITIC) { T.e0 = g.eps[2 * smp]; T.e1 = g.eps[2 * smp + 1]; } else { T.e0 = T.e1 = 0.0f; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // phase A: the critics
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
 {
     extern __shared__ __align__(16) float lds[];
-    const SacLds L = carve(lds);
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
     const int n_tiles = g.batch / kTile;
     const int t0 = (int)blockIdx.x * g.tiles_per_wg;
     const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
     const float alpha = expf(*g.log_alpha);
     const float inv_b = 1.0f / (float)g.batch;
+    float *tds = lds + kCritTdOff;                     // [tile][sample][2]
+    S_STAMP(0);
 
-    // ---- a', log pi(a' | s')
-    stage_actor(L, g.actor);
-    __syncthreads();
+    // ---- stage I: td target = r + gamma (min(Q_t1, Q_t2)(s', a') - alpha log pi(a' | s')) (1 - done)      (:122-131)
     {
+        float *Wa = lds;
+        const WSet S1 = wset_at(lds + kTileF), S2 = wset_at(lds + kTileF + kWSetF);
+        TileIn T;
+        tile_in<true, true>(g, t0, T);                 // in flight under the staging
+        {
+            CritRegs C1, C2;
+            critic_issue(C1, g.t1);
+            critic_issue(C2, g.t2);
+            stage_actor(Wa, g.actor);
+            critic_commit(S1, C1);
+            critic_commit(S2, C2);
+        }
         W2Frag<4> Fa;
         w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+        W2Frag<2> Fo1, Fo2;
+        w2_load<2>(Fo1, g.t1 + kCoWo, g.t1 + kCobo, 2);
+        w2_load<2>(Fo2, g.t2 + kCoWo, g.t2 + kCobo, 2);
+        __syncthreads();
+        S_STAMP(1);
         for (int j = 0; j < nt; ++j) {
-            const int smp = (t0 + j) * kTile + 16 * wv + r;
-            uint32_t rs, rn;
-            sample_rows(g, smp, rs, rn);
-            PRow R;
-            prow_load(R, g.obs + (size_t)rn * kPackedDwords);
-            floatx4 acc[4];
-            fwd_strip_packed(L.W1s, R, acc);
+            TileIn Tn = T;
+            if (j + 1 < nt) tile_in<true, true>(g, t0 + j + 1, Tn);
+            floatx4 acc[4], acc2[4];
+            fwd_strip_packed(Wa, T.R, acc);
             float o[4];
             q_strip<4>(acc, Fa, 4, 4, 0, o);
             ActorOut A;
-            actor_head(o, g.eps[2 * smp], g.eps[2 * smp + 1], A);
+            actor_head(o, T.e0, T.e1, A);
+            const float a0 = A.act[0] * g.bound, a1 = A.act[1] * g.bound;
+            float q1[2], q2[2];
+            critic_fwd(S1, T.R, a0, a1, Fo1, acc, acc2, q1);
+            critic_fwd(S2, T.R, a0, a1, Fo2, acc, acc2, q2);
             if (gq == 0) {
-                float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
-                st[0] = A.act[0] * g.bound; st[1] = A.act[1] * g.bound; st[2] = A.lp[0]; st[3] = A.lp[1];
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    tds[(j * kTile + 16 * wv + r) * 2 + d] = T.rew + g.gamma * (fminf(q1[d], q2[d]) + alpha * (-A.lp[d])) * T.nd;
             }
+            T = Tn;
         }
     }
     __syncthreads();
-    // ---- td target = r + gamma (min(Q_t1, Q_t2)(s', a') - alpha log pi) (1 - done)      (:122-131)
-    for (int c = 0; c < 2; ++c) {
-        const float *flat = c ? g.t2 : g.t1;
-        stage_critic(L, flat);
-        __syncthreads();
-        W2Frag<2> Fo;
-        w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
-        for (int j = 0; j < nt; ++j) {
-            const int smp = (t0 + j) * kTile + 16 * wv + r;
-            uint32_t rs, rn;
-            sample_rows(g, smp, rs, rn);
-            PRow R;
-            prow_load(R, g.obs + (size_t)rn * kPackedDwords);
-            float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
-            floatx4 acc1[4], acc2[4];
-            float q[2];
-            critic_fwd(L, R, st[0], st[1], Fo, acc1, acc2, q);
-            if (gq == 0) {
-                if (c == 0) {
-                    st[4] = q[0]; st[5] = q[1];
-                } else {
-                    const float rew = g.reward[rs], nd = 1.0f - (float)g.done[rs];
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        const float qm = fminf(st[4 + d], q[d]);
-                        st[4 + d] = rew + g.gamma * (qm + alpha * (-st[2 + d])) * nd;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- Q1 / Q2 (s, a): loss, backward, weight gradients
+    S_STAMP(2);
+    // ---- stage II: Q1 / Q2 (s, a): loss, backward, weight gradients
+    const WSet S = wset_at(lds);
+    uint32_t *Ps = reinterpret_cast<uint32_t *>(lds + kWSetF);
+    float *H1s = lds + kWSetF + kTile * kPsLd, *H2s = H1s + kTile * kLh, *dH1s = H2s + kTile * kLh, *dH2s = dH1s + kTile * kLh;
+    float *dqs = dH2s + kTile * kLh, *red = dqs + kTile * 4;
     for (int c = 0; c < 2; ++c) {
         const float *flat = c ? g.c2 : g.c1;
-        stage_critic(L, flat);
-        __syncthreads();
+        TileIn T;
+        tile_in<false, true>(g, t0, T);
+        stage_critic(S, flat);
         W2Frag<2> Fo;
         w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
+        __syncthreads();
+        S_STAMP(3 + 6 * c);
         floatx4 aw1[7], aw2[4], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f}, ab2 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -390,37 +515,37 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
         for (int u = 0; u < 4; ++u) aw2[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
         float s_bo0 = 0.0f, s_bo1 = 0.0f, s_loss = 0.0f;
         for (int j = 0; j < nt; ++j) {
-            const int smp = (t0 + j) * kTile + 16 * wv + r;
-            uint32_t rs, rn;
-            sample_rows(g, smp, rs, rn);
-            PRow R;
-            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
-            const float a0 = g.act0[rs], a1 = g.act1[rs];
-            const float w = g.valid ? (float)g.valid[rs] : 1.0f;
-            const float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
+            TileIn Tn = T;
+            if (j + 1 < nt) tile_in<false, true>(g, t0 + j + 1, Tn);
+            const float *td = tds + (j * kTile + 16 * wv + r) * 2;
             floatx4 acc1[4], acc2[4];
             float q[2];
-            critic_fwd(L, R, a0, a1, Fo, acc1, acc2, q);
-            const float e0 = q[0] - st[4], e1 = q[1] - st[5];
-            const float dq0 = w * e0 * inv_b, dq1 = w * e1 * inv_b;      // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
-            if (gq == 0) { s_loss += w * (e0 * e0 + e1 * e1); s_bo0 += dq0; s_bo1 += dq1; }
+            critic_fwd(S, T.R, T.a0, T.a1, Fo, acc1, acc2, q);
+            const float e0 = q[0] - td[0], e1 = q[1] - td[1];
+            const float dq0 = T.w * e0 * inv_b, dq1 = T.w * e1 * inv_b;  // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
+            if (gq == 0) { s_loss += T.w * (e0 * e0 + e1 * e1); s_bo0 += dq0; s_bo1 += dq1; }
             floatx4 dh1[4], dh2[4], h1[4], h2[4];
-            critic_bwd(L, Fo, acc1, acc2, dq0, dq1, dh1, dh2);
+            critic_bwd(S, Fo, acc1, acc2, dq0, dq1, dh1, dh2);
             relu4(acc1, h1);
             relu4(acc2, h2);
-            x_strip_store<true>(L, R, a0, a1);
-            h_strip_store(L.H1s, h1);
-            h_strip_store(L.H2s, h2);
-            h_strip_store(L.dH1s, dh1);
-            h_strip_store(L.dH2s, dh2);
-            if (gq == 0) { L.dqs[(16 * wv + r) * 4] = dq0; L.dqs[(16 * wv + r) * 4 + 1] = dq1; }
+            h_strip_store(H1s, h1);
+            h_strip_store(H2s, h2);
+            h_strip_store(dH1s, dh1);
+            h_strip_store(dH2s, dh2);
+            if (gq == 0) {
+                ps_store(Ps, 16 * wv + r, T.R, T.a0, T.a1);
+                dqs[(16 * wv + r) * 4] = dq0; dqs[(16 * wv + r) * 4 + 1] = dq1;
+            }
             __syncthreads();
-            wgrad<7>(L.dH1s, L.Xs, kLd, aw1);         // dW1 (+ db1 as column 100)
-            wgrad<4>(L.dH2s, L.H1s, kLh, aw2);        // dW2
-            wgrad_small(L.H2s, L.dqs, 2, awo);        // dWout^T
-            wgrad_ones(L.dH2s, ab2);                  // db2
+            if (j == 0) S_STAMP(4 + 6 * c);
+            wgrad_x<true>(dH1s, Ps, aw1);              // dW1 (+ db1 as column 100)
+            if (j == 0) S_STAMP(5 + 6 * c);
+            wgrad_critic_rest(dH2s, H1s, H2s, dqs, aw2, awo, ab2);     // dW2, dWout^T, db2
             __syncthreads();
+            if (j == 0) S_STAMP(6 + 6 * c);
+            T = Tn;
         }
+        S_STAMP(7 + 6 * c);
         float *out = g.partials + (size_t)blockIdx.x * kStrideC + c * kPc;
         store_dw1(out, kIn, kCob1, aw1);
 #pragma unroll
@@ -433,10 +558,10 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
             if (r == 0) out[kCob2 + 16 * wv + 4 * gq + reg] = ab2[reg];
         }
         s_bo0 = wave_sum(s_bo0); s_bo1 = wave_sum(s_bo1); s_loss = wave_sum(s_loss);
-        if (lane == 0) { L.red[wv * 4] = s_bo0; L.red[wv * 4 + 1] = s_bo1; L.red[wv * 4 + 2] = s_loss; }
+        if (lane == 0) { red[wv * 4] = s_bo0; red[wv * 4 + 1] = s_bo1; red[wv * 4 + 2] = s_loss; }
         __syncthreads();
         if (tid < 3) {
-            const float s = (L.red[tid] + L.red[4 + tid]) + (L.red[8 + tid] + L.red[12 + tid]);
+            const float s = (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]);
             if (tid < 2) out[kCobo + tid] = s;
             else g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + c] = s * 0.5f * inv_b;      // mean over [B, 2]
         }
@@ -445,193 +570,139 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
             g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + 3] = 0.0f;
         }
         __syncthreads();
+        S_STAMP(8 + 6 * c);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// phase B: the actor (critics already updated)
+// phase B: the actor (critics already updated).  Actor fc1 and both critics stay in LDS; one pass over the tiles.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
 {
     extern __shared__ __align__(16) float lds[];
-    const SacLds L = carve(lds);
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
     const int n_tiles = g.batch / kTile;
     const int t0 = (int)blockIdx.x * g.tiles_per_wg;
     const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
     const float alpha = expf(*g.log_alpha);
     const float inv_2b = 0.5f / (float)g.batch;
-    float s_lp = 0.0f, s_loss = 0.0f;
-
-    // ---- a~, log pi(a~ | s)
-    stage_actor(L, g.actor);
-    __syncthreads();
+    const float g_lp = alpha * inv_2b;                                 // d loss / d log pi per element
+    float *Wa = lds;
+    const WSet S1 = wset_at(lds + kTileF), S2 = wset_at(lds + kTileF + kWSetF);
+    uint32_t *Ps = reinterpret_cast<uint32_t *>(lds + kTileF + 2 * kWSetF);
+    float *H1s = lds + kTileF + 2 * kWSetF + kTile * kPsLd, *dH1s = H1s + kTile * kLh, *dqs = dH1s + kTile * kLh, *red = dqs + kTile * 4;
+    TileIn T;
+    tile_in<false, false>(g, t0, T);
     {
-        W2Frag<4> Fa;
-        w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
-        for (int j = 0; j < nt; ++j) {
-            const int smp = (t0 + j) * kTile + 16 * wv + r;
-            uint32_t rs, rn;
-            sample_rows(g, smp, rs, rn);
-            PRow R;
-            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
-            floatx4 acc[4];
-            fwd_strip_packed(L.W1s, R, acc);
-            float o[4];
-            q_strip<4>(acc, Fa, 4, 4, 0, o);
-            ActorOut A;
-            actor_head(o, g.eps[2 * smp], g.eps[2 * smp + 1], A);
-            if (gq == 0) {
-                float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
-                st[0] = A.act[0] * g.bound; st[1] = A.act[1] * g.bound; st[2] = A.lp[0]; st[3] = A.lp[1];
-                s_lp += A.lp[0] + A.lp[1];
-                s_loss += alpha * (A.lp[0] + A.lp[1]);               // -alpha * entropy  (:364-365)
-            }
-        }
+        CritRegs C1, C2;
+        critic_issue(C1, g.c1);
+        critic_issue(C2, g.c2);
+        stage_actor(Wa, g.actor);
+        critic_commit(S1, C1);
+        critic_commit(S2, C2);
     }
+    W2Frag<4> Fa;
+    w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+    W2Frag<2> Fo1, Fo2;
+    w2_load<2>(Fo1, g.c1 + kCoWo, g.c1 + kCobo, 2);
+    w2_load<2>(Fo2, g.c2 + kCoWo, g.c2 + kCobo, 2);
     __syncthreads();
-    // ---- Q1(s, a~), then Q2(s, a~): the minimum picks, per (sample, output), the critic dL/dq = -1 / (2B) flows into
-    // (c = 0: forward only; c = 1: critic 2 forward + its backward; c = 2: critic 1 again, forward + backward)
-    for (int c = 0; c < 3; ++c) {
-        const float *flat = c == 1 ? g.c2 : g.c1;
-        stage_critic(L, flat);
-        __syncthreads();
-        W2Frag<2> Fo;
-        w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
-        for (int j = 0; j < nt; ++j) {
-            const int smp = (t0 + j) * kTile + 16 * wv + r;
-            uint32_t rs, rn;
-            sample_rows(g, smp, rs, rn);
-            PRow R;
-            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
-            float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
-            floatx4 acc1[4], acc2[4];
-            float q[2];
-            critic_fwd(L, R, st[0], st[1], Fo, acc1, acc2, q);
-            if (c == 0) {
-                if (gq == 0) { st[4] = q[0]; st[5] = q[1]; }
-                continue;
-            }
-            float dq0, dq1;
-            if (c == 1) {
-                const float q10 = st[4], q11 = st[5];
-                const bool s0 = q[0] < q10, s1 = q[1] < q11;            // critic 2 holds the minimum (ties: critic 1)
-                dq0 = s0 ? -inv_2b : 0.0f;
-                dq1 = s1 ? -inv_2b : 0.0f;
-                if (gq == 0) s_loss -= (s0 ? q[0] : q10) + (s1 ? q[1] : q11);
-            } else {
-                dq0 = st[4]; dq1 = st[5];
-            }
+    floatx4 aw1[7], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    float s_b[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s_lp = 0.0f, s_loss = 0.0f;
+    for (int j = 0; j < nt; ++j) {
+        TileIn Tn = T;
+        if (j + 1 < nt) tile_in<false, false>(g, t0 + j + 1, Tn);
+        // a~, log pi(a~ | s)
+        floatx4 acc[4];
+        fwd_strip_packed(Wa, T.R, acc);
+        float o[4];
+        q_strip<4>(acc, Fa, 4, 4, 0, o);
+        ActorOut A;
+        actor_head(o, T.e0, T.e1, A);
+        const float a0 = A.act[0] * g.bound, a1 = A.act[1] * g.bound;
+        // Q1, Q2 (s, a~): the minimum picks, per (sample, output), the critic that dL/dq = -1 / (2B) flows into (ties: critic 1)
+        floatx4 c1a[4], c1b[4], c2a[4], c2b[4];
+        float q1[2], q2[2];
+        critic_fwd(S1, T.R, a0, a1, Fo1, c1a, c1b, q1);
+        critic_fwd(S2, T.R, a0, a1, Fo2, c2a, c2b, q2);
+        const bool m0 = q2[0] < q1[0], m1 = q2[1] < q1[1];
+        if (gq == 0) {
+            s_lp += A.lp[0] + A.lp[1];
+            s_loss += alpha * (A.lp[0] + A.lp[1]) - ((m0 ? q2[0] : q1[0]) + (m1 ? q2[1] : q1[1]));       // :364-365
+        }
+        float da0 = 0.0f, da1 = 0.0f;
+        {
             floatx4 dh1[4], dh2[4];
-            critic_bwd(L, Fo, acc1, acc2, dq0, dq1, dh1, dh2);
-            // dL/da_k = sum_j fc1.w[j][100 + k] dL/dh1[j]
-            float da0 = 0.0f, da1 = 0.0f;
+            critic_bwd(S2, Fo2, c2a, c2b, m0 ? -inv_2b : 0.0f, m1 ? -inv_2b : 0.0f, dh1, dh2);
+            action_grad_part(S2, dh1, da0, da1);
+            critic_bwd(S1, Fo1, c1a, c1b, m0 ? 0.0f : -inv_2b, m1 ? 0.0f : -inv_2b, dh1, dh2);
+            action_grad_part(S1, dh1, da0, da1);
+        }
+        da0 = group_sum4(da0);
+        da1 = group_sum4(da1);
+        // the actor's backward
+        float dout[4];
+        const float ev[2] = {T.e0, T.e1}, dav[2] = {da0, da1};
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int d = 0; d < 2; ++d) {
+            const float th = tanhf(A.act[d]);
+            const float u = 1.0f - th * th + 1e-7f;
+            const float dact = g_lp * (2.0f * th * (1.0f - th * th) / u) + g.bound * dav[d];
+            const float dns = dact * (1.0f - A.act[d] * A.act[d]);
+            const float dsd = dns * ev[d] - g_lp / A.sd[d];
+            const float s = A.spre[d];
+            const float sig = s > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-s));
+            dout[d] = dns * (1.0f - A.mu[d] * A.mu[d]);                       // fc_mu pre-activation
+            dout[2 + d] = dsd * (1.0f - A.sd[d] * A.sd[d]) * sig;             // fc_std pre-activation
+        }
+        floatx4 h[4], dh[4];
+        relu4(acc, h);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float *wr = L.W1s + (16 * t + 4 * gq + reg) * kLd + kW + 1;
-                    da0 = fmaf(wr[0], dh1[t][reg], da0);
-                    da1 = fmaf(wr[1], dh1[t][reg], da1);
-                }
-            da0 = group_sum4(da0);
-            da1 = group_sum4(da1);
-            if (gq == 0) {
-                if (c == 1) {
-                    st[6] = da0; st[7] = da1;
-                    st[4] = dq0 == 0.0f ? -inv_2b : 0.0f;               // what critic 1 gets
-                    st[5] = dq1 == 0.0f ? -inv_2b : 0.0f;
-                } else {
-                    st[6] += da0; st[7] += da1;
-                }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float v = fmaf(Fa.w[3][t][reg], dout[3], fmaf(Fa.w[2][t][reg], dout[2],
+                                fmaf(Fa.w[1][t][reg], dout[1], Fa.w[0][t][reg] * dout[0])));
+                dh[t][reg] = acc[t][reg] > 0.0f ? v : 0.0f;
             }
+        h_strip_store(H1s, h);
+        h_strip_store(dH1s, dh);
+        if (gq == 0) {
+            ps_store(Ps, 16 * wv + r, T.R, 0.0f, 0.0f);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { dqs[(16 * wv + r) * 4 + a] = dout[a]; s_b[a] += dout[a]; }
         }
         __syncthreads();
+        wgrad_x<false>(dH1s, Ps, aw1);
+        wgrad_small(H1s, dqs, 4, awo);
+        __syncthreads();
+        T = Tn;
     }
-    // ---- the actor's backward
-    stage_actor(L, g.actor);
+    float *out = g.partials + (size_t)blockIdx.x * kStrideA;
+    store_dw1(out, kW, kHid * kW, aw1);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+        if (r < 4) out[kAoW2 + r * kHid + 16 * wv + 4 * gq + reg] = awo[reg];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s_b[a] = wave_sum(s_b[a]);
+    s_lp = wave_sum(s_lp);
+    s_loss = wave_sum(s_loss);
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) red[wv * 8 + a] = s_b[a];
+        red[wv * 8 + 4] = s_loss;
+        red[wv * 8 + 5] = s_lp;
+    }
     __syncthreads();
-    {
-        W2Frag<4> Fa;
-        w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
-        floatx4 aw1[7], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-        float s_b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float g_lp = alpha * inv_2b;                             // d loss / d log pi per element
-        for (int j = 0; j < nt; ++j) {
-            const int smp = (t0 + j) * kTile + 16 * wv + r;
-            uint32_t rs, rn;
-            sample_rows(g, smp, rs, rn);
-            PRow R;
-            prow_load(R, g.obs + (size_t)rs * kPackedDwords);
-            const float *st = L.st + (j * kTile + 16 * wv + r) * kSt;
-            floatx4 acc[4];
-            fwd_strip_packed(L.W1s, R, acc);
-            float o[4];
-            q_strip<4>(acc, Fa, 4, 4, 0, o);
-            const float ev[2] = {g.eps[2 * smp], g.eps[2 * smp + 1]};
-            ActorOut A;
-            actor_head(o, ev[0], ev[1], A);
-            float dout[4];
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const float th = tanhf(A.act[d]);
-                const float u = 1.0f - th * th + 1e-7f;
-                const float dact = g_lp * (2.0f * th * (1.0f - th * th) / u) + g.bound * st[6 + d];
-                const float dns = dact * (1.0f - A.act[d] * A.act[d]);
-                const float dsd = dns * ev[d] - g_lp / A.sd[d];
-                const float s = A.spre[d];
-                const float sig = s > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-s));
-                dout[d] = dns * (1.0f - A.mu[d] * A.mu[d]);                       // fc_mu pre-activation
-                dout[2 + d] = dsd * (1.0f - A.sd[d] * A.sd[d]) * sig;             // fc_std pre-activation
-            }
-            floatx4 h[4], dh[4];
-            relu4(acc, h);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float v = fmaf(Fa.w[3][t][reg], dout[3], fmaf(Fa.w[2][t][reg], dout[2],
-                                    fmaf(Fa.w[1][t][reg], dout[1], Fa.w[0][t][reg] * dout[0])));
-                    dh[t][reg] = acc[t][reg] > 0.0f ? v : 0.0f;
-                }
-            x_strip_store<false>(L, R, 0.0f, 0.0f);
-            h_strip_store(L.H1s, h);
-            h_strip_store(L.dH1s, dh);
-            if (gq == 0) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) { L.dqs[(16 * wv + r) * 4 + a] = dout[a]; s_b[a] += dout[a]; }
-            }
-            __syncthreads();
-            wgrad<7>(L.dH1s, L.Xs, kLd, aw1);
-            wgrad_small(L.H1s, L.dqs, 4, awo);
-            __syncthreads();
-        }
-        float *out = g.partials + (size_t)blockIdx.x * kStrideA;
-        store_dw1(out, kW, kHid * kW, aw1);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-            if (r < 4) out[kAoW2 + r * kHid + 16 * wv + 4 * gq + reg] = awo[reg];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) s_b[a] = wave_sum(s_b[a]);
-        s_lp = wave_sum(s_lp);
-        s_loss = wave_sum(s_loss);
-        if (lane == 0) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) L.red[wv * 8 + a] = s_b[a];
-            L.red[wv * 8 + 4] = s_loss;
-            L.red[wv * 8 + 5] = s_lp;
-        }
-        __syncthreads();
-        if (tid < 6) {
-            const float s = (L.red[tid] + L.red[8 + tid]) + (L.red[16 + tid] + L.red[24 + tid]);
-            if (tid < 4) out[kAob2 + tid] = s;
-            else if (tid == 4) out[kPa] = s * inv_2b;
-            else out[kPa + 1] = s;
-        }
-        if (tid == 6) { out[kPa + 2] = 0.0f; out[kPa + 3] = 0.0f; }
+    if (tid < 6) {
+        const float s = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
+        if (tid < 4) out[kAob2 + tid] = s;
+        else if (tid == 4) out[kPa] = s * inv_2b;
+        else out[kPa + 1] = s;
     }
+    if (tid == 6) { out[kPa + 2] = 0.0f; out[kPa + 3] = 0.0f; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -651,10 +722,9 @@ constexpr size_t kSacActLds = (size_t)kTileF * 4;
 __global__ void __launch_bounds__(256) k_sac_act(SacActArgs g)
 {
     extern __shared__ __align__(16) float lds[];
-    SacLds L;
-    L.W1s = lds;
+    float *W1s = lds;
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
-    stage_actor(L, g.actor);
+    stage_actor(W1s, g.actor);
     __syncthreads();
     W2Frag<4> Fa;
     w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
@@ -666,7 +736,7 @@ __global__ void __launch_bounds__(256) k_sac_act(SacActArgs g)
         PRow R;
         prow_load(R, g.obs + row * kPackedDwords);
         floatx4 acc[4];
-        fwd_strip_packed(L.W1s, R, acc);
+        fwd_strip_packed(W1s, R, acc);
         float o[4];
         q_strip<4>(acc, Fa, 4, 4, 0, o);
         ActorOut A;
@@ -704,22 +774,29 @@ __device__ __forceinline__ float adam_step(float p, float g, float &m, float &v,
     return p - (lr / a.bc1) * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
 }
 
+// 64 columns per workgroup, four row groups (wavefront w sums rows w, w + 4, ...: 8 loads in flight per thread), combined
+// through LDS in a fixed order -- deterministic.
 __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgs a)
 {
-    const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    __shared__ float part[4][64];
+    const int cl = (int)threadIdx.x & 63, rg = (int)threadIdx.x >> 6;
+    const int col = (int)blockIdx.x * 64 + cl;
     const int total = a.seg[0].n + (a.nseg > 1 ? a.seg[1].n : 0) + a.extras;
-    if (col >= total) return;
-    const float *src = a.partials + col;
+    const float *src = a.partials + (col < total ? col : total - 1);
     float s = 0.0f;
-    int b = 0;
-    for (; b + 8 <= a.rows; b += 8) {
+    int b = rg;
+    for (; b + 28 < a.rows; b += 32) {
         float t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(b + k) * a.stride];
+        for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(b + 4 * k) * a.stride];
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += t[k];
     }
-    for (; b < a.rows; ++b) s += src[(size_t)b * a.stride];
+    for (; b < a.rows; b += 4) s += src[(size_t)b * a.stride];
+    part[rg][cl] = s;
+    __syncthreads();
+    if (rg != 0 || col >= total) return;
+    s = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
     int c = col;
     for (int k = 0; k < a.nseg; ++k) {
         const AdamSeg &sg = a.seg[k];
@@ -773,19 +850,20 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
     grid = (n_tiles + tpw - 1) / tpw;
     g.actor = n->actor; g.c1 = n->critic1; g.c2 = n->critic2; g.t1 = n->target1; g.t2 = n->target2; g.log_alpha = n->log_alpha;
     g.partials = partials;
+    g.dbg = g_sac_dbg;
     return UAVENV_OK;
 }
 
 template <typename K>
-int launch_phase(K kernel, bool &attr, const SacArgs &g, int grid, hipStream_t s)
+int launch_phase(K kernel, bool &attr, size_t lds, const SacArgs &g, int grid, hipStream_t s)
 {
     if (!attr) {                         // (once per kernel; one process = one device for this library's learners)
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSacLds) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return sac_fail(UAVENV_EHIP, "uavenv_sac: cannot raise the dynamic LDS limit");
         attr = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), kSacLds, s, g);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, g);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac: launch failed");
 }
 
@@ -794,6 +872,12 @@ int launch_phase(K kernel, bool &attr, const SacArgs &g, int grid, hipStream_t s
 extern "C" {
 
 const char *uavenv_sac_last_error(void) { return g_sac_err; }
+
+int uavenv_sac_set_debug_buffer(unsigned long long *dev_buf)
+{
+    g_sac_dbg = dev_buf;
+    return UAVENV_OK;
+}
 
 int uavenv_sac_partial_rows(int32_t batch)
 {
@@ -826,7 +910,7 @@ int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, flo
     g.gamma = gamma;
     g.bound = action_bound;
     static bool attr = false;
-    return launch_phase(k_sac_critic_grad, attr, g, grid, (hipStream_t)stream);
+    return launch_phase(k_sac_critic_grad, attr, kSacCriticLds, g, grid, (hipStream_t)stream);
 }
 
 int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, float action_bound, float *partials, void *stream)
@@ -838,7 +922,7 @@ int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, floa
     g.gamma = 0.0f;
     g.bound = action_bound;
     static bool attr = false;
-    return launch_phase(k_sac_actor_grad, attr, g, grid, (hipStream_t)stream);
+    return launch_phase(k_sac_actor_grad, attr, kSacActorLds, g, grid, (hipStream_t)stream);
 }
 
 int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
@@ -853,7 +937,7 @@ int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_
     a.tau = h->tau;
     a.scalars_out = losses_out;
     const int total = 2 * kPc + 4;
-    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_critic_adam: launch failed");
 }
 
@@ -872,7 +956,7 @@ int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t
     a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
     a.inv_2b = 0.5f / (float)batch;
     const int total = kPa + 4;
-    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_actor_adam: launch failed");
 }
 

@@ -401,6 +401,8 @@ int uavenv_sac_act(const float *actor, const void *obs_packed, int32_t first_row
                    const float *eps, float action_bound, float *act0, float *act1, void *stream);
 int uavenv_sac_partial_rows(int32_t batch);
 const char *uavenv_sac_last_error(void);
+/* Diagnostics (UAVENV_PHASE_PROFILE builds): 16 s_memtime stamps per workgroup of uavenv_sac_critic_grad; NULL disables. */
+int uavenv_sac_set_debug_buffer(unsigned long long *dev_buf);
 /* eps = the draws of actor(next_states).  partials: rows x UAVENV_SAC_CRITIC_STRIDE floats. */
 int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, float gamma, float action_bound, float *partials,
                            void *stream);
