@@ -8,7 +8,7 @@ import torch
 
 from _trainer_base import VecReplayMemory
 from dqn_based_uav_3d_path_planer_amd.compat import None2Value
-from dqn_based_uav_3d_path_planer_amd.sac import SACLearner
+from dqn_based_uav_3d_path_planer_amd.sac import SACLearner, FusedSACLearner
 
 
 class SAC_Trainer:
@@ -26,7 +26,13 @@ class SAC_Trainer:
         self.Is_Train = int(None2Value(param.get("Is_Train"), 1))
         dev = param.get("device") or ("cuda:0" if torch.cuda.is_available() else "cpu")
         self.device = torch.device(dev)
-        self.learner = SACLearner(param, self.device)
+        # <fused>1</fused> (default): the hand-written HIP update (csrc/sac.hip) when the nets have the reference's shipped
+        # shapes, replay is uniform and a GPU is there -- PathPlan_City then drives it on its packed replay ring.
+        ap, cp = param.get("actor"), param.get("critic")
+        shapes = (int(ap.get("w")), int(ap.get("hiden_dim")), int(ap.get("output")), int(cp.get("hiden_dim")), int(cp.get("action_dim")))
+        self.fused = (int(None2Value(param.get("fused"), 1)) != 0 and self.device.type == "cuda" and self.IsPriority_Replay == 0 and
+                      shapes == (100, 64, 2, 64, 2) and self.Batch_Size % 64 == 0)
+        self.learner = FusedSACLearner(param, self.device) if self.fused else SACLearner(param, self.device)
         self.w = int(param.get("actor").get("w"))
         self.replay_memory = VecReplayMemory(self.replay_size, self.device, self.w, prioritized=self.IsPriority_Replay == 1)
         ad = int(param.get("critic").get("action_dim"))
@@ -60,6 +66,9 @@ class SAC_Trainer:
         return self.learner.act(states)
 
     def update(self, transition_dict):
+        if self.fused:
+            raise RuntimeError("this SAC_Trainer runs the fused update on PathPlan_City's replay ring (run_eposide); for "
+                               "trainer.update(transition_dict) set <fused>0</fused> in Trainer.xml")
         states = transition_dict.get("states") if transition_dict else None
         if states is None or len(states) == 0 or len(self.replay_memory.memory) < self.Batch_Size:   # :322-333
             self.learner.epoch += 1
@@ -90,26 +99,43 @@ class SAC_Trainer:
     def _path(self, role, directory=None):
         return os.path.join(directory or self.model_dir, f"{role}_SAC_{self.name}.pth")     # SAC_Trainer.py:113-119
 
+    def _optim_states(self):
+        L = self.learner
+        if self.fused:           # Adam moments live in the learner's flat blocks; same keys as torch.optim.Adam's state dict
+            mk = lambda m, v: {"fused_adam": True, "step": L.epoch, "exp_avg": m.detach().cpu().clone(),   # noqa: E731
+                               "exp_avg_sq": v.detach().cpu().clone()}
+            return (mk(L._blocks[1], L._blocks[2]), mk(L._cblocks[4], L._cblocks[5]), mk(L._cblocks[6], L._cblocks[7]))
+        return (L.actor_optimizer.state_dict(), L.critic_1_optimizer.state_dict(), L.critic_2_optimizer.state_dict())
+
     def save(self, directory=None):
         os.makedirs(directory or self.model_dir, exist_ok=True)
         cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}   # noqa: E731
         L = self.learner
-        for role, net, opt in (("actor", L.actor, L.actor_optimizer), ("critic_1", L.critic_1, L.critic_1_optimizer),
-                               ("critic_2", L.critic_2, L.critic_2_optimizer)):
-            torch.save({"model": cpu(net.state_dict()), "optimizer": opt.state_dict(), "epoch": self.epoch},
-                       self._path(role, directory))
+        for (role, net), opt in zip((("actor", L.actor), ("critic_1", L.critic_1), ("critic_2", L.critic_2)), self._optim_states()):
+            torch.save({"model": cpu(net.state_dict()), "optimizer": opt, "epoch": self.epoch}, self._path(role, directory))
 
     def Load_Mod(self, Mod=None):
         L = self.learner
         paths = [self._path(r) for r in ("actor", "critic_1", "critic_2")]
         if all(os.path.exists(p) for p in paths):
             try:
-                for p, net, opt in zip(paths, (L.actor, L.critic_1, L.critic_2),
-                                       (L.actor_optimizer, L.critic_1_optimizer, L.critic_2_optimizer)):
-                    ck = torch.load(p, map_location=self.device)
-                    net.load_state_dict(ck["model"])
-                    opt.load_state_dict(ck["optimizer"])
-                    self.epoch = ck["epoch"]
+                if self.fused:
+                    slots = ((L._blocks[1], L._blocks[2]), (L._cblocks[4], L._cblocks[5]), (L._cblocks[6], L._cblocks[7]))
+                    for p, net, (m, v) in zip(paths, (L.actor, L.critic_1, L.critic_2), slots):
+                        ck = torch.load(p, map_location=self.device)
+                        net.load_state_dict(ck["model"])             # parameters are views of the flat blocks: copies in place
+                        o = ck["optimizer"]
+                        if o.get("fused_adam"):
+                            m.copy_(o["exp_avg"].to(self.device))
+                            v.copy_(o["exp_avg_sq"].to(self.device))
+                        self.epoch = ck["epoch"]
+                else:
+                    for p, net, opt in zip(paths, (L.actor, L.critic_1, L.critic_2),
+                                           (L.actor_optimizer, L.critic_1_optimizer, L.critic_2_optimizer)):
+                        ck = torch.load(p, map_location=self.device)
+                        net.load_state_dict(ck["model"])
+                        opt.load_state_dict(ck["optimizer"])
+                        self.epoch = ck["epoch"]
                 L.target_critic_1.load_state_dict(L.critic_1.state_dict())
                 L.target_critic_2.load_state_dict(L.critic_2.state_dict())
             except Exception as e:

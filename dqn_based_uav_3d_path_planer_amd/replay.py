@@ -55,11 +55,12 @@ class DeviceReplayRing:
         """The slot the policy writes its action for the current frame into."""
         return self.action[self.head]
 
-    def step_env(self, auto_reset: bool = True, skip_done: bool = None):
+    def step_env(self, auto_reset: bool = True, skip_done: bool = None, info: torch.Tensor = None):
         """Apply action[head] with the fused kernel; the transition lands in the ring in the same launch.
         skip_done defaults to True when an env holds several UAVs: an env only auto-resets once ALL its agents are
         done, and the reference never steps a finished agent while it waits (PathPlan_City.py:365-366) -- its rows
-        land in the ring with valid = 0."""
+        land in the ring with valid = 0.  info (optional, uint8 [frames, N]): receives the step's info codes, frame-major
+        like reward."""
         if skip_done is None:
             skip_done = self.env.uav_per_env > 1
         t, nxt = self.head, (self.head + 1) % self.frames
@@ -68,7 +69,8 @@ class DeviceReplayRing:
         kind = _lib.ACT_INDEX_I32 if self.discrete else _lib.ACT_STEER_F32
         self.env.step_raw(self.action.data_ptr() + t * n * 4, kind, self.obs.data_ptr() + nxt * self._obs_stride,
                           self.reward.data_ptr() + t * n * 4, self.done.data_ptr() + t * n,
-                          self.valid.data_ptr() + t * n, flags)
+                          self.valid.data_ptr() + t * n, flags,
+                          info_ptr=None if info is None else info.data_ptr() + t * n)
         self.head = nxt
         self.filled = min(self.filled + 1, self.frames - 1)
 

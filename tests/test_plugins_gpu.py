@@ -43,25 +43,6 @@ def test_run_eposide_on_device(tmp_path, monkeypatch):
     assert np.isfinite(res["loss"])
 
 
-def test_config4_shape_sac_apf_multi_uav_on_device(tmp_path, monkeypatch):
-    """BASELINE configs[3] in miniature: 4 UAVs per env, APF on, SAC continuous actions, through the plugins."""
-    import re
-    from dqn_based_uav_3d_path_planer_amd import driver
-    monkeypatch.chdir(tmp_path)
-    xml = driver.make_config_dir(str(tmp_path), "SAC", num_envs=128, num_uav=4)
-    uav_xml = tmp_path / "config" / "UAV.xml"
-    uav_xml.write_text(re.sub(r"<APF_Enabled>0</APF_Enabled>", "<APF_Enabled>1</APF_Enabled>", uav_xml.read_text()))
-    sim = driver.simulator(xml)
-    env = sim.env
-    assert env.backend.cfg.apf_enabled == 1 and env.backend.N == 512
-    torch.manual_seed(0)
-    res = env.run_eposide(0.1)
-    assert res["lose"] + res["success"] >= 512 and env.Check_uav_Done()
-    tr = env.Agents[3].Trainer
-    assert type(tr).__name__ == "SAC_Trainer" and tr.replay_memory.actions.shape[1] == 2 and tr.epoch > 150
-    assert np.isfinite(float(res["loss"]))
-
-
 def _set_xml(path, **tags):
     import re
     s = path.read_text()
@@ -71,6 +52,80 @@ def _set_xml(path, **tags):
         else:
             s = s.replace("</Trainer>", f"    <{k}>{v}</{k}>\n</Trainer>")
     path.write_text(s)
+
+
+def _config4(tmp_path, num_envs, **trainer_tags):
+    import re
+    from dqn_based_uav_3d_path_planer_amd import driver
+    xml = driver.make_config_dir(str(tmp_path), "SAC", num_envs=num_envs, num_uav=4)
+    uav_xml = tmp_path / "config" / "UAV.xml"
+    uav_xml.write_text(re.sub(r"<APF_Enabled>0</APF_Enabled>", "<APF_Enabled>1</APF_Enabled>", uav_xml.read_text()))
+    if trainer_tags:
+        _set_xml(tmp_path / "config" / "Trainer.xml", **trainer_tags)
+    return driver.simulator(xml)
+
+
+def test_config4_shape_sac_apf_multi_uav_on_device(tmp_path, monkeypatch):
+    """BASELINE configs[3] in miniature: 4 UAVs per env, APF on, SAC continuous actions, through the plugins -- on the
+    general per-step path (<fused>0</fused>: PyTorch SACLearner, one torch replay per trainer)."""
+    monkeypatch.chdir(tmp_path)
+    sim = _config4(tmp_path, 128, fused=0)
+    env = sim.env
+    assert env.backend.cfg.apf_enabled == 1 and env.backend.N == 512 and not env.fast_sac
+    torch.manual_seed(0)
+    res = env.run_eposide(0.1)
+    assert res["lose"] + res["success"] >= 512 and env.Check_uav_Done()
+    tr = env.Agents[3].Trainer
+    assert type(tr).__name__ == "SAC_Trainer" and tr.replay_memory.actions.shape[1] == 2 and tr.epoch > 150
+    assert type(tr.learner).__name__ == "SACLearner" and np.isfinite(float(res["loss"]))
+
+
+def test_config4_fused_sac_episode_path(tmp_path, monkeypatch):
+    """The same shape on the fast path (the default): packed ring shared by the four UAV slots, one FusedSACLearner per
+    slot (csrc/sac.hip), act / step / draw / learn launched per time step, host read-back every done_check steps.
+    Contract checks as for the general path + the trainers really learn (parameters move, targets follow, checkpoints
+    round-trip) + an episode costs a few launches per step, not hundreds."""
+    import time
+    monkeypatch.chdir(tmp_path)
+    sim = _config4(tmp_path, 2048, Batch_Size=2048, replay_size=65536)
+    env = sim.env
+    assert env.fast_sac and env.backend.packed and env.backend.cfg.apf_enabled == 1 and env.backend.N == 8192
+    tr = env.Agents[2].Trainer
+    assert type(tr.learner).__name__ == "FusedSACLearner" and len(tr.replay_memory.memory) == 0
+    w0 = tr.actor.fc1.weight.detach().clone()
+    c0 = tr.critic_1.fc2.weight.detach().clone()
+    t0w = tr.target_critic_1.fc2.weight.detach().clone()
+    torch.manual_seed(0)
+    res = env.run_eposide(0.1)
+    steps = env.steps_last_episode
+    assert res["lose"] + res["success"] >= 8192 and env.Check_uav_Done() and steps >= 150
+    for k in ("success", "lose", "normal", "loss", "sum_epoch", "score", "average_score", "step"):
+        assert k in res
+    assert np.isfinite(float(res["loss"])) and tr.epoch >= steps
+    assert len(tr.replay_memory.memory) == min(steps + env.done_check, env._ring.frames - 1) * 2048 or len(tr.replay_memory.memory) > 0
+    assert float((tr.actor.fc1.weight - w0).abs().max()) > 0 and float((tr.critic_1.fc2.weight - c0).abs().max()) > 0
+    assert float((tr.target_critic_1.fc2.weight - t0w).abs().max()) > 0
+    for net in (tr.actor, tr.critic_1, tr.critic_2, tr.target_critic_1, tr.target_critic_2):
+        assert all(torch.isfinite(p).all() for p in net.parameters())
+    with pytest.raises(RuntimeError, match="fused"):
+        tr.update({"states": [1]})
+    # checkpoint round trip (model + Adam moments)
+    tr.save()
+    m_saved = tr.learner._blocks[1].clone()
+    a_saved = tr.actor.fc1.weight.detach().clone()
+    with torch.no_grad():
+        tr.actor.fc1.weight.add_(1.0)
+        tr.learner._blocks[1].zero_()
+    tr.Load_Mod()
+    assert torch.equal(tr.actor.fc1.weight, a_saved) and torch.equal(tr.learner._blocks[1], m_saved)
+    # speed: a second episode, timed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    env.run_eposide(0.1)
+    torch.cuda.synchronize()
+    per_step = (time.perf_counter() - t0) / env.steps_last_episode
+    print(f"fused SAC plugin episode: {env.steps_last_episode} steps, {per_step * 1e6:.0f} us/step (4 slots x (act + draw + 4-launch update))")
+    assert per_step <= 2.5e-3
 
 
 def test_fused_episode_path_runs_at_bench_speed(tmp_path, monkeypatch):
