@@ -31,7 +31,7 @@ SYMBOLS = (
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
-    "uavenv_sac_act", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
+    "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
     "uavenv_sac_actor_adam",
 )
 SAC_CRITIC_IN, SAC_ACTOR_PARAMS, SAC_CRITIC_PARAMS, SAC_ACTOR_STRIDE, SAC_CRITIC_STRIDE = 102, 6724, 10882, 6728, 21768
@@ -96,7 +96,7 @@ class UavSacBatch(C.Structure):
 
 class UavSacAdam(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("tau", C.c_float), ("reserved0", C.c_float)]
+                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("tau", C.c_float), ("grad_scale", C.c_float)]
 
 
 class UavEnvError(RuntimeError):
@@ -191,6 +191,8 @@ def load() -> C.CDLL:
     lib.uavenv_loop_step_times.argtypes = [vp, vp, i32, C.POINTER(i32)]
     lib.uavenv_sac_act.restype = C.c_int
     lib.uavenv_sac_act.argtypes = [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp]
+    lib.uavenv_sac_reduce.restype = C.c_int
+    lib.uavenv_sac_reduce.argtypes = [vp, i32, i32, vp, vp]
     lib.uavenv_sac_partial_rows.restype = C.c_int
     lib.uavenv_sac_partial_rows.argtypes = [i32]
     lib.uavenv_sac_last_error.restype = C.c_char_p

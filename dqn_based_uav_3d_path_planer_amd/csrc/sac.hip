@@ -762,6 +762,9 @@ struct AdamArgs {
     AdamSeg seg[2];
     float beta1, beta2, eps, bc1, bc2_sqrt, tau;
     float *scalars_out;                      // [extras] column sums of the extras (losses, sum of log pi)
+    float *raw_out;                          // non-null: only write the column sums there (multi-GPU: all-reduce them, then
+                                             // run the kernel again on that one row) -- no parameter is touched
+    float grad_scale;                        // gradient = column sum * grad_scale (1 / world size after an all-reduce SUM)
     // log_alpha step (actor phase): extras column 1 holds sum log pi over [B, 2]
     float *log_alpha, *alpha_mv;             // nullable; alpha_mv = {exp_avg, exp_avg_sq}
     float alpha_lr, target_entropy, inv_2b;
@@ -797,6 +800,11 @@ __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgs a)
     __syncthreads();
     if (rg != 0 || col >= total) return;
     s = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+    if (a.raw_out) {
+        a.raw_out[col] = s;
+        return;
+    }
+    s *= a.grad_scale;
     int c = col;
     for (int k = 0; k < a.nseg; ++k) {
         const AdamSeg &sg = a.seg[k];
@@ -925,6 +933,18 @@ int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, floa
     return launch_phase(k_sac_actor_grad, attr, kSacActorLds, g, grid, (hipStream_t)stream);
 }
 
+// multi-GPU: column sums only (rows x stride -> raw[stride]); the caller all-reduces raw and passes it back as ONE row
+int uavenv_sac_reduce(const float *partials, int32_t rows, int32_t stride, float *raw, void *stream)
+{
+    if (!partials || !raw || rows <= 0 || (stride != kStrideA && stride != kStrideC)) return sac_fail(UAVENV_EINVAL, "uavenv_sac_reduce: bad argument");
+    AdamArgs a = {};
+    a.partials = partials; a.rows = rows; a.stride = stride; a.nseg = 1; a.extras = 0;
+    a.seg[0].n = stride;
+    a.raw_out = raw;
+    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((stride + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_reduce: launch failed");
+}
+
 int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
                            const UavSacAdam *h, float *losses_out, void *stream)
 {
@@ -935,6 +955,7 @@ int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_
     a.seg[1] = AdamSeg{nets->critic2, m2, v2, nets->target2, kPc, h->lr};
     a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
     a.tau = h->tau;
+    a.grad_scale = h->grad_scale > 0.0f ? h->grad_scale : 1.0f;
     a.scalars_out = losses_out;
     const int total = 2 * kPc + 4;
     hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
@@ -952,6 +973,7 @@ int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t
     a.seg[0] = AdamSeg{nets->actor, m, v, nullptr, kPa, h->lr};
     a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
     a.tau = 0.0f;
+    a.grad_scale = h->grad_scale > 0.0f ? h->grad_scale : 1.0f;
     a.scalars_out = scalars_out;
     a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
     a.inv_2b = 0.5f / (float)batch;

@@ -153,6 +153,7 @@ class FusedSACLearner:
         self.epoch = 0
         self._scalars = torch.zeros(8, dtype=torch.float32, device=d)                      # critic losses [0:4], actor [4:8]
         self._partials = {}
+        self._raw = {}
         self._nets = _lib.UavSacNets(self._blocks[0].data_ptr(), self._cblocks[0].data_ptr(), self._cblocks[1].data_ptr(),
                                      self._cblocks[2].data_ptr(), self._cblocks[3].data_ptr(), self.log_alpha.data_ptr())
 
@@ -203,10 +204,22 @@ class FusedSACLearner:
         b._keep = keep
         return b
 
-    def _adam(self, lr, tau=0.0):
+    def _adam(self, lr, tau=0.0, scale=0.0):
         t = self.epoch
         return self._lib.UavSacAdam(lr, self.beta1, self.beta2, self.adam_eps, 1.0 - self.beta1 ** t,
-                                    float(np.sqrt(1.0 - self.beta2 ** t)), tau, 0.0)
+                                    float(np.sqrt(1.0 - self.beta2 ** t)), tau, scale)
+
+    def _exchange(self, partials: torch.Tensor, rows: int):
+        """Multi-GPU (one process per GPU, torch.distributed initialised): this rank's column sums, summed over the ranks
+        -- the means of SACLearner._sync_grads once the Adam kernel scales by 1 / world.  -> (row tensor, 1, scale)"""
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            return partials, rows, 0.0
+        stride = partials.shape[1]
+        raw = self._raw.setdefault(stride, torch.empty(stride, dtype=torch.float32, device=self.device))
+        self._check(self.lib.uavenv_sac_reduce(partials.data_ptr(), rows, stride, raw.data_ptr(), self._stream()), "uavenv_sac_reduce")
+        dist.all_reduce(raw, op=dist.ReduceOp.SUM)
+        return raw, 1, 1.0 / world
 
     # the four launches, separately (tests drive them one by one)
     def critic_grad(self, batch, eps_next: torch.Tensor):
@@ -220,7 +233,8 @@ class FusedSACLearner:
     def critic_step(self, n: int):
         C = self._C
         rows, pc, _ = self._scratch(n)
-        h = self._adam(self.critic_lr, self.tau)
+        pc, rows, scale = self._exchange(pc, rows)
+        h = self._adam(self.critic_lr, self.tau, scale)
         cb = self._cblocks
         self._check(self.lib.uavenv_sac_critic_adam(C.byref(self._nets), pc.data_ptr(), rows, cb[4].data_ptr(), cb[5].data_ptr(),
                                                     cb[6].data_ptr(), cb[7].data_ptr(), C.byref(h), self._scalars.data_ptr(),
@@ -237,7 +251,8 @@ class FusedSACLearner:
     def actor_step(self, n: int):
         C = self._C
         rows, _, pa = self._scratch(n)
-        h = self._adam(self.actor_lr)
+        pa, rows, scale = self._exchange(pa, rows)
+        h = self._adam(self.actor_lr, 0.0, scale)
         self._check(self.lib.uavenv_sac_actor_adam(C.byref(self._nets), pa.data_ptr(), rows, int(n), self._blocks[1].data_ptr(),
                                                    self._blocks[2].data_ptr(), self._alpha_mv.data_ptr(), C.byref(h),
                                                    self.alpha_lr, self.target_entropy, self._scalars[4:].data_ptr(),

@@ -393,7 +393,8 @@ typedef struct UavSacBatch {
 } UavSacBatch;
 typedef struct UavSacAdam {
     float lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt;   /* 1 - beta1^t, sqrt(1 - beta2^t) */
-    float tau, reserved0;                /* soft target update (critic_adam only) */
+    float tau;                           /* soft target update (critic_adam only) */
+    float grad_scale;                    /* gradient = column sum x grad_scale; 0 = 1 (1 / world size after an all-reduce SUM) */
 } UavSacAdam;
 /* get_action (SAC_Trainer.py:444-448) for `count` agents whose packed rows are first_row + i * row_stride: the two
  * action components land in act0[row] / act1[row].  eps: count x 2 N(0,1) draws (Normal.rsample()). */
@@ -410,6 +411,9 @@ int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, flo
  * losses_out (nullable, 4 floats): the two critic losses. */
 int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
                            const UavSacAdam *h, float *losses_out, void *stream);
+/* Multi-GPU: column sums of the partial rows only -> raw[stride] (stride = one of the two UAVENV_SAC_*_STRIDE); all-reduce
+ * raw over the ranks, then call the *_adam entry point with partials = raw, rows = 1 and grad_scale = 1 / world size. */
+int uavenv_sac_reduce(const float *partials, int32_t rows, int32_t stride, float *raw, void *stream);
 /* eps = the draws of actor(states).  partials: rows x UAVENV_SAC_ACTOR_STRIDE floats. */
 int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, float action_bound, float *partials, void *stream);
 /* Adam on the actor and on log_alpha (alpha_mv: its exp_avg, exp_avg_sq).  scalars_out (nullable, 4 floats): actor loss,

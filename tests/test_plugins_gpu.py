@@ -103,8 +103,8 @@ def test_config4_fused_sac_episode_path(tmp_path, monkeypatch):
         assert k in res
     assert np.isfinite(float(res["loss"])) and tr.epoch >= steps
     assert len(tr.replay_memory.memory) == min(steps + env.done_check, env._ring.frames - 1) * 2048 or len(tr.replay_memory.memory) > 0
-    assert float((tr.actor.fc1.weight - w0).abs().max()) > 0 and float((tr.critic_1.fc2.weight - c0).abs().max()) > 0
-    assert float((tr.target_critic_1.fc2.weight - t0w).abs().max()) > 0
+    assert float((tr.actor.fc1.weight.detach() - w0).abs().max()) > 0 and float((tr.critic_1.fc2.weight.detach() - c0).abs().max()) > 0
+    assert float((tr.target_critic_1.fc2.weight.detach() - t0w).abs().max()) > 0
     for net in (tr.actor, tr.critic_1, tr.critic_2, tr.target_critic_1, tr.target_critic_2):
         assert all(torch.isfinite(p).all() for p in net.parameters())
     with pytest.raises(RuntimeError, match="fused"):

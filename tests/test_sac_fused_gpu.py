@@ -95,7 +95,7 @@ def test_gradients_of_both_phases_match_autograd(world):
         mine = pc[k * _lib.SAC_CRITIC_PARAMS:(k + 1) * _lib.SAC_CRITIC_PARAMS]
         assert _rel(mine, g) <= 2e-5, (k, _rel(mine, g))
         assert float((mine - g).abs().max()) <= 2e-5 * float(g.abs().max())
-        assert abs(float(pc[2 * _lib.SAC_CRITIC_PARAMS + k]) - float(loss)) <= 2e-5 * abs(float(loss))
+        assert abs(float(pc[2 * _lib.SAC_CRITIC_PARAMS + k]) - float(loss.detach())) <= 2e-5 * abs(float(loss.detach()))
     # ---- phase B on the SAME critics (no critic step in between here): actor loss, its gradient, sum of log pi
     new_actions, log_prob = ref.actor(states, e_cur)
     actor_loss = torch.mean(ref.log_alpha.exp() * log_prob - torch.min(ref.critic_1(states, new_actions), ref.critic_2(states, new_actions)))
@@ -172,3 +172,73 @@ def test_rejects_what_it_cannot_do(world):
     b = fused.make_batch(flat, ring.action.view(-1), a1.view(-1), ring.reward.view(-1), ring.done.view(-1), idx_s=idx, idx_n=idx + env.N)
     with pytest.raises((UavEnvError, ValueError)):
         fused.learn(b, noise=(torch.zeros((100, 2), device="cuda"), torch.zeros((100, 2), device="cuda")))
+
+
+def _sac_rank_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    from dqn_based_uav_3d_path_planer_amd.sac import FusedSACLearner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    env = make_city26_env(256, uav_per_env=2, obs_dtype="packed")
+    ring = DeviceReplayRing(env, 12 * env.N, discrete=False)
+    ring.reset(seed=5)                                  # every rank builds the SAME ring
+    a1 = torch.zeros((ring.frames, env.N), dtype=torch.float32, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(8):
+        ring.current_action().copy_(torch.rand(env.N, generator=gen, device="cuda") * 2 - 1)
+        a1[ring.head].copy_(torch.rand(env.N, generator=gen, device="cuda") * 2 - 1)
+        ring.step_env(auto_reset=True)
+    torch.manual_seed(0)                                # same initial weights everywhere
+    L = FusedSACLearner(PARAM)
+    g = torch.Generator().manual_seed(7)
+    B = 512
+    draws = torch.stack([torch.randint(0, 7, (B,), generator=g), torch.randint(0, 256, (B,), generator=g)], 1).int()
+    eps = torch.randn((4, 2, B, 2), generator=g)
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    flat = ring.obs.view(-1, ring.obs.shape[-1])
+    b = L.make_batch(flat, ring.action.view(-1), a1.view(-1), ring.reward.view(-1), ring.done.view(-1), valid=ring.valid.view(-1),
+                     draws=draws[sl].contiguous().cuda(), n_agents=env.N, uav_per_env=2, slot=1, frames=ring.frames)
+    losses = []
+    for it in range(4):
+        L.learn(b, noise=(eps[it, 0, sl].contiguous().cuda(), eps[it, 1, sl].contiguous().cuda()))
+        losses.append([float(L.loss), float(L.critic_losses[0]), float(L.critic_losses[1])])
+    torch.cuda.synchronize()
+    torch.save({"actor": L._blocks[0].cpu(), "critics": L._cblocks[:4].cpu(), "log_alpha": float(L.log_alpha), "losses": losses},
+               os.path.join(out_dir, f"sac_w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    env.close()
+
+
+def test_fused_sac_two_ranks_equal_one_process(tmp_path):
+    """The N > 1 branch of FusedSACLearner (uavenv_sac_reduce -> all_reduce(sum) of the column sums -> Adam on that one
+    row with grad_scale = 1 / world), two ranks sharing this GPU over gloo: each takes half of a 512-transition list and
+    half of the rsample() draws; the result must be the update ONE process applies to the whole list."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sac_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_sac_rank_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r0, r1 = torch.load(os.path.join(tmp_path, "sac_w2_r0.pt")), torch.load(os.path.join(tmp_path, "sac_w2_r1.pt"))
+    one = torch.load(os.path.join(tmp_path, "sac_w1_r0.pt"))
+    assert torch.equal(r0["actor"], r1["actor"]) and torch.equal(r0["critics"], r1["critics"])     # ranks in lock-step, bit for bit
+    assert r0["log_alpha"] == r1["log_alpha"] and r0["losses"] == r1["losses"]
+    # vs one process: the same gradient up to the order of the sums; Adam can move an element with a ~0 gradient by a step
+    da = (r0["actor"] - one["actor"]).abs()
+    dc = (r0["critics"] - one["critics"]).abs()
+    assert float(torch.quantile(da, 0.99)) <= 1e-5 and float(da.max()) <= 8e-4
+    assert float(torch.quantile(dc.reshape(-1), 0.99)) <= 1e-4 and float(dc.max()) <= 8e-3
+    assert abs(r0["log_alpha"] - one["log_alpha"]) <= 1e-6
+    assert np.allclose(np.array(r0["losses"]), np.array(one["losses"]), rtol=2e-4, atol=1e-5)
