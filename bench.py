@@ -356,6 +356,31 @@ def run_config4(args, dev):
                         "frac": algo * env.N / (k_use * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": prof.get("k_step_traffic_bytes_per_launch"),
                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": env.N, "kernel_ms": k_use,
                         "kernel_ms_back_to_back": k_ms, "kernel_ms_rocprofv3_committed": k_prof}}
+    if fused:
+        # the two phase kernels of the fused SAC update, back to back between one event pair each (no Adam in between:
+        # the kernels' work does not depend on the weights' values)
+        L, b0 = learners[0], fbatch[0]
+        draw_slot(0)
+        z = torch.randn((2, B, 2), dtype=torch.float32, device=dev)
+        L.epoch += 1
+        ms = []
+        for fn, e in ((L.critic_grad, z[0]), (L.actor_grad, z[1])):
+            fn(b0, e)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn(b0, e)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms.append(e0.elapsed_time(e1) / 20)
+        flops = (169.0e3 + 89.0e3) * B          # as issued on the MFMA (K padded to 104, 16-wide head tiles): DESIGN 3.3
+        tf = flops / (sum(ms) * 1e-3) / 1e12
+        out["roofline_learner"] = {"bound": "mfma", "kernel": "k_sac_critic_grad + k_sac_actor_grad (one SAC update of %d samples)" % B,
+                                   "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                                   "flops_per_sample": 258.0e3, "samples_per_launch": B,
+                                   "kernel_ms": sum(ms), "critic_grad_ms_back_to_back": ms[0], "actor_grad_ms_back_to_back": ms[1],
+                                   "algorithmic_bytes_per_sample": 2 * 80 + 30, "traffic": None}
     print(json.dumps(out))
     env.close()
 
