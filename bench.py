@@ -236,8 +236,10 @@ def run_config4(args, dev):
         learners = [SACLearner(sac_param, device=dev, capturable=graphed) for _ in range(U)]
     B = args.batch
     lib, counter = env.lib, [0]
-    draws = [torch.empty((B, 2), dtype=torch.int32, device=dev) for _ in range(U)]
+    draws_all = torch.empty((U * B, 2), dtype=torch.int32, device=dev)      # one draw launch per pass: U x B distinct (frame, env)
+    draws = [draws_all[j * B:(j + 1) * B] for j in range(U)]
     flat = ring.obs.view(-1, ring.obs.shape[-1])
+    znoise = [None]
     fbatch = [L.make_batch(flat, ring.action.view(-1), a1_plane.view(-1), ring.reward.view(-1), ring.done.view(-1),
                            valid=ring.valid.view(-1), draws=draws[j], n_agents=env.N, uav_per_env=U, slot=j, frames=ring.frames)
               for j, L in enumerate(learners)] if fused else None
@@ -246,7 +248,7 @@ def run_config4(args, dev):
         """gather the drawn transitions of UAV slot j (packed rows -> f32) and take one SAC update"""
         L = learners[j]
         if fused:                              # csrc/sac.hip reads the drawn rows in place: four launches
-            L.learn(fbatch[j])
+            L.learn(fbatch[j], noise=(znoise[0][j, 0], znoise[0][j, 1]))
             return
         f, e = draws[j][:, 0].long(), draws[j][:, 1].long()
         slot = f * env.N + e * U + j
@@ -256,15 +258,26 @@ def run_config4(args, dev):
                      rewards=ring.reward.view(-1)[slot], dones=ring.done.view(-1)[slot].float())
         L.learn(batch, is_weights=ring.valid.view(-1)[slot].float())
 
+    one_draw = fused and (ring.frames - 1) * envs >= U * B
+
     def draw_slot(j):
+        if one_draw:
+            if j == 0:
+                _lib.check(lib.uavenv_replay_draw(ring.frames, envs, ring.head, ring.filled, U * B, 7, counter[0],
+                                                  draws_all.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
+            return
         _lib.check(lib.uavenv_replay_draw(ring.frames, envs, ring.head, ring.filled, B, 7 + j, counter[0], draws[j].data_ptr(),
                                           torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
 
     def act_and_step():
         t = ring.head
         if fused:                              # one launch per slot: actor forward on the packed rows of the current frame
+            # every N(0,1) draw of the pass (the U get_action's and the 2 U rsample()'s of the updates) in ONE launch
+            z = torch.randn(U * (2 * envs + 4 * B), dtype=torch.float32, device=dev)
+            znoise[0] = z[U * 2 * envs:].view(U, 2, B, 2)
+            za = z[:U * 2 * envs].view(U, envs, 2)
             for j, L in enumerate(learners):
-                L.act_rows(flat, t * env.N + j, U, envs, ring.action.view(-1), a1_plane.view(-1))
+                L.act_rows(flat, t * env.N + j, U, envs, ring.action.view(-1), a1_plane.view(-1), eps=za[j])
             ring.step_env(auto_reset=True)
             return
         obs = env.unpack(ring.current_obs()).view(envs, U, 100)
