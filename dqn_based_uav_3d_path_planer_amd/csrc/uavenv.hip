@@ -1560,7 +1560,10 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     // (see k_step_coop).  MEASURED (us per launch, k_step -> k_step_coop): 4 096 envs 10.6 -> 7.8; 16 384: 11.7 -> 8.7;
     // 32 768: 14.6 -> 10.1; 49 152: 16.1 -> 12.3; 65 536: 16.6 -> 19.5 (k_step kept from there on).
     static const int coop_env = env_int("UAVENV_COOP", -1);
-    const bool coop = !(a.flags & UAVENV_STEP_ONE_WAVE) && (coop_env >= 0 ? coop_env != 0 : e->N <= 49152);
+    // (APF on: k_apf_adjust + k_step at every size -- the cooperative kernel adjusts the sub-goals per lane: 105 / 119 us
+    // against 35 / 41 us for 8 192 / 32 768 agents -- unless the per-lane path is asked for)
+    const bool apf_split_ok = apf && !(a.flags & UAVENV_STEP_APF_LANE) && kApfAgentsPerBlock * a.K <= 65536;
+    const bool coop = !(a.flags & UAVENV_STEP_ONE_WAVE) && (coop_env >= 0 ? coop_env != 0 : (e->N <= 49152 && !apf_split_ok));
 #define UAV_LAUNCH(KERNEL, GRID, BLOCK, LDS)                                                                        \
     do {                                                                                                            \
         if (apf) {                                                                                                  \
@@ -1587,7 +1590,7 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
         UAV_LAUNCH(k_step_coop, cgrid, 256, clds);
         return;
     }
-    if (apf && !(a.flags & UAVENV_STEP_APF_LANE) && kApfAgentsPerBlock * a.K <= 65536) {       // the lists first, in their own kernel (16-bit offsets)
+    if (apf_split_ok) {                                                   // the lists first, in their own kernel (16-bit offsets)
         a.apf_split = 1;
         const int agents_per_block = kApfAgentsPerBlock;
         const size_t albs = ((size_t)((e->nb > 0 ? e->nb : 1) * sizeof(BldApf) + 31) & ~(size_t)31) + 4 * sizeof(ApfSortLds);

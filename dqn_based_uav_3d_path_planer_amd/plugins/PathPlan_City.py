@@ -160,7 +160,10 @@ class PathPlan_City:
             ring = self._ring
             self._info = torch.zeros((ring.frames, N), dtype=torch.uint8, device=d)
             self._a1 = torch.zeros((ring.frames, N), dtype=torch.float32, device=d)          # second action component (:444-448)
-            self._draws = [torch.empty((u.Trainer.Batch_Size, 2), dtype=torch.int32, device=d) for u in self.Agents]
+            bs = [u.Trainer.Batch_Size for u in self.Agents]
+            self._draws_all = torch.empty((sum(bs), 2), dtype=torch.int32, device=d)       # one draw launch per step for all slots
+            offs = np.cumsum([0] + bs)
+            self._draws = [self._draws_all[offs[j]:offs[j + 1]] for j in range(self.num_UAV)]
             flat = ring.obs.view(-1, ring.obs.shape[-1])
             self._flat = flat
             self._sac_batches = [u.Trainer.learner.make_batch(flat, ring.action.view(-1), self._a1.view(-1), ring.reward.view(-1),
@@ -418,21 +421,36 @@ class PathPlan_City:
         n_steps, ended = 0, False
         while not ended:
             t0 = ring.head
+            nb = self._draws_all.shape[0]
             for _ in range(k):
                 t = ring.head
+                # every N(0,1) draw of the step (U get_action's, 2 rsample()'s per update) in one launch
+                z = torch.randn(U * 2 * self.num_envs + 4 * nb, dtype=torch.float32, device=dev)
+                za = z[:U * 2 * self.num_envs].view(U, self.num_envs, 2)
+                zl = z[U * 2 * self.num_envs:].view(2, nb, 2)
                 for j, uav in enumerate(self.Agents):
-                    uav.Trainer.learner.act_rows(self._flat, t * N + j, U, self.num_envs, act0, act1)
+                    uav.Trainer.learner.act_rows(self._flat, t * N + j, U, self.num_envs, act0, act1, eps=za[j])
                 ring.step_env(auto_reset=False, skip_done=True, info=self._info)
                 self._sac_counter += 1
+                learn = [uav.Trainer.Is_Train and ring.filled * self.num_envs > uav.Trainer.Batch_Size for uav in self.Agents]   # :383-385
+                if any(learn):      # distinct (frame, env) pairs for all slots at once (each slot reads its own rows of them)
+                    nd = nb if ring.filled * self.num_envs >= nb else 0
+                    if nd:
+                        _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, nd, self.seed + 7,
+                                                          self._sac_counter, self._draws_all.data_ptr(),
+                                                          torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
+                o = 0
                 for j, uav in enumerate(self.Agents):
                     tr = uav.Trainer
-                    if tr.Is_Train and ring.filled * self.num_envs > tr.Batch_Size:            # :383-385
-                        _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, tr.Batch_Size,
-                                                          self.seed + 7 + j, self._sac_counter, self._draws[j].data_ptr(),
-                                                          torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
-                        tr.learner.learn(self._sac_batches[j])
+                    if learn[j]:
+                        if not nd:  # the ring does not hold sum(Batch_Size) transitions yet: one draw per slot
+                            _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, tr.Batch_Size,
+                                                              self.seed + 7 + j, self._sac_counter, self._draws[j].data_ptr(),
+                                                              torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
+                        tr.learner.learn(self._sac_batches[j], noise=(zl[0, o:o + tr.Batch_Size], zl[1, o:o + tr.Batch_Size]))
                     else:
                         tr.learner.epoch += 1                                                   # :322-333
+                    o += tr.Batch_Size
             fr = (t0 + torch.arange(k, device=dev)) % ring.frames
             v = ring.valid[fr].bool()
             inf = self._info[fr]
