@@ -370,6 +370,10 @@ def run_config4(args, dev):
                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": env.N, "kernel_ms": k_use,
                         "kernel_ms_back_to_back": k_ms, "kernel_ms_rocprofv3_committed": k_prof}}
     if fused:
+        L0 = learners[0]
+        out["config"]["slot0_after_run"] = {"updates": L0.epoch, "actor_loss": float(L0.loss), "critic_losses": [float(x) for x in L0.critic_losses],
+                                            "log_alpha": float(L0.log_alpha),
+                                            "finite": bool(all(torch.isfinite(b).all() for L in learners for b in (L._blocks, L._cblocks)))}
         # the two phase kernels of the fused SAC update, back to back between one event pair each (no Adam in between:
         # the kernels' work does not depend on the weights' values)
         L, b0 = learners[0], fbatch[0]
