@@ -1247,6 +1247,248 @@ __global__ void __launch_bounds__(256) k_dqn_grad_h(Grad2Args ga)
     grad_write_partials<NMAX>(g, ga.stride, L.red, A);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The f16 kernel with EIGHT wavefronts per workgroup (two per SIMD), for at most 4 layer-2 outputs -- same division of
+// labour as k_dqn_grad_packed8: wavefronts 0..3 own the s rows, q_local(s) and the backward pass of strip w & 3,
+// wavefronts 4..7 the s' rows and the bootstrap value (q_target(s'), and q_local(s') for double DQN), handed over as one
+// float per sample; both groups stage weights (group 0 the local fc1 / fc2, group 1 the target's) and split the
+// weight-gradient products (group 0: k-column tiles 0, 2, 4, 6; group 1: 1, 3, 5 and dW2^T).  With the matrix work down to
+// ~1 k cycles per tile, a 4-wave workgroup is one serial VALU / LDS chain per SIMD (phase stamps at batch 65 536: row
+// commit 8 k, the two forwards + heads 8.4 k, TD / dL/dH 2.8 k, products 1.3 k cycles per tile); here the two halves of that
+// chain run on the two wavefronts of each SIMD.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wh_commit_half(_Float16 *dst, floatx4 (&v)[kStageIters], float bias, int t256)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int c = it * 256 + t256;
+        if (c < kStageChunks) {
+            const int row = c / 25, q = c - row * 25;
+            *reinterpret_cast<half4 *>(dst + row * kLdH + 4 * q) =
+                half4{(_Float16)v[it][0], (_Float16)v[it][1], (_Float16)v[it][2], (_Float16)v[it][3]};
+        }
+    }
+    if (t256 < kHid) {
+        _Float16 *row = dst + t256 * kLdH;
+        *reinterpret_cast<half4 *>(row + 100) = half4{(_Float16)bias, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<half8 *>(row + 104 + 8 * k) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+struct TileLoads8 {
+    floatx4 vX[kXIters];             // group 0: the s rows of this wavefront's strip, group 1: the s' rows
+    int p_act;
+    float p_rew, p_done, p_valid;
+};
+
+template <int KIND>
+__device__ __forceinline__ void tile_issue8(const GradArgs &g, int tile, int grp, int strip, TileLoads8 &T)
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15;
+    const int smp = tile * kTile + strip * 16 + r;
+    int f, agent;
+    if (g.explicit_idx) {
+        f = g.explicit_idx[2 * smp];
+        agent = g.explicit_idx[2 * smp + 1];
+    } else {
+        replay_slot_to_frame(g.perm, replay_perm_apply(g.perm, (uint32_t)smp), g.head, g.ring.frames, f, agent);
+    }
+    int fn = f + 1;
+    if (fn >= g.ring.frames) fn = 0;
+    const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    xh_issue<KIND>(T.vX, g.ring.obs, grp == 0 ? row_s : row_n);
+    T.p_act = 0; T.p_rew = 0.0f; T.p_done = 0.0f; T.p_valid = 1.0f;
+    if (grp == 0) {
+        T.p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
+        T.p_rew = g.ring.reward[row_s];
+        T.p_done = (float)g.ring.done[row_s];
+        T.p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    }
+}
+
+template <int KIND, bool FIRST>
+__device__ __forceinline__ void grad_tile_h8(const GradArgs &g, const GradLdsH &L, float *qn_lds, int tile, int next_tile, bool more,
+                                             TileLoads8 &T, GradAcc8 &A)
+{
+    constexpr int NMAX = 4;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int r = lane & 15, gq = lane >> 4, t256 = tid & 255;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    _Float16 *x_strip = (grp == 0 ? L.Xs : L.Xn) + strip * 16 * kLdH;
+    const float *net = grp == 0 ? g.local : g.target;
+    floatx4 vW[kStageIters];
+    float pb1 = 0.0f, pw[4] = {0, 0, 0, 0}, pb2 = 0.0f;
+    if (FIRST) {                              // group 0 stages q_local's weights, group 1 q_target's
+        w_issue_half(vW, net, t256);
+        const NetDev nv = net_view(net, n2);
+        pb1 = nv.b1[t256 < kHid ? t256 : kHid - 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[k] = nv.W2[t256 + 256 * k < n2 * kHid ? t256 + 256 * k : 0];
+        pb2 = nv.b2[t256 < n2 ? t256 : 0];
+        tile_issue8<KIND>(g, tile, grp, strip, T);
+    }
+    const int p_act = T.p_act;
+    const float p_rew = T.p_rew, p_done = T.p_done, p_valid = T.p_valid;
+    uint32_t *stage = L.stage + wv * kStageW;
+    if (FIRST) {
+        wh_commit_half(grp == 0 ? L.W1l : L.W1t, vW, pb1, t256);
+        float *W2 = grp == 0 ? L.W2l : L.W2t, *b2 = grp == 0 ? L.b2l : L.b2t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t256 + 256 * k < n2 * kHid) W2[t256 + 256 * k] = pw[k];
+        if (t256 < n2) b2[t256] = pb2;
+        if (grp == 1)
+            for (int k = t256; k < 16 * kLdT / 2; k += 256) reinterpret_cast<uint32_t *>(L.doutT)[k] = 0u;     // rows >= n2 stay zero
+    }
+    L_STAMP(6);
+    xh_commit<KIND>(x_strip, T.vX, stage, grp == 0 ? L.XsT + strip * 16 : nullptr);
+    if (FIRST) __syncthreads();               // both weight sets staged
+    else wave_lds_sync();
+    L_STAMP(7);
+    if (more) tile_issue8<KIND>(g, next_tile, grp, strip, T);         // the next tile's HBM round trip starts here
+    L_STAMP(1);
+    floatx4 hl[4];
+    W2Frag<NMAX> Fl;
+    float ql[NMAX];
+    if (grp == 0) {
+        fwd_strip_h(L.W1l, x_strip, hl);
+        w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+        q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+    } else {
+        int best = 0;
+        floatx4 ht[4];
+        if (g.kind == 1) {                    // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
+            fwd_strip_h(L.W1l, x_strip, ht);
+            W2Frag<NMAX> F;
+            w2_load<NMAX>(F, L.W2l, L.b2l, n2);
+            float qn_l[NMAX];
+            q_strip<NMAX>(ht, F, n2, g.n_actions, g.dueling, qn_l);
+            float bq = qn_l[0];
+#pragma unroll
+            for (int a = 1; a < NMAX; ++a)
+                if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }
+        }
+        fwd_strip_h(L.W1t, x_strip, ht);
+        W2Frag<NMAX> Ft;
+        w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
+        float qt[NMAX];
+        q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+        if (gq == 0) qn_lds[strip * 16 + r] = pick_qn<NMAX>(g, qt, best);
+    }
+    L_STAMP(2);
+    __syncthreads();                          // bootstrap values handed over; every wave is done with the s' rows
+    L_STAMP(3);
+    if (grp == 0) {
+        GradAcc<NMAX> Tc;                     // td_backward's accumulator interface: only csum is used here
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) Tc.csum[a] = A.csum[a];
+        const int s = strip * 16 + r;
+        td_backward<NMAX, true>(g, L.W2l, hl, Fl, ql, qn_lds[s], p_act, p_rew, p_done, p_valid, Tc,
+                                reinterpret_cast<float *>(L.HT + s), reinterpret_cast<float *>(L.dHT + s),
+                                reinterpret_cast<float *>(L.doutT + s));
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = Tc.csum[a];
+    }
+    __syncthreads();
+    L_STAMP(4);
+    // ---- weight gradients, K = 64 samples = 2 MFMA steps of 32 (hidden units 16 strip + r):
+    //   group 0: dW1^T k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and dW2^T[j][a] += sum_s HT[j][s] doutT[a][s]
+    {
+        const _Float16 *xa = L.XsT + r * kLdT + 8 * gq;
+        const _Float16 *db = L.dHT + (16 * strip + r) * kLdT + 8 * gq;
+        const _Float16 *ha = L.HT + (16 * strip + r) * kLdT + 8 * gq;
+        const _Float16 *ob = L.doutT + r * kLdT + 8 * gq;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half8 bdh = *reinterpret_cast<const half8 *>(db + 32 * kk);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                A.acc[u] = mfma16h(*reinterpret_cast<const half8 *>(xa + 16 * (2 * u + grp) * kLdT + 32 * kk), bdh, A.acc[u]);
+            if (grp == 0) A.acc[3] = mfma16h(*reinterpret_cast<const half8 *>(xa + 16 * 6 * kLdT + 32 * kk), bdh, A.acc[3]);
+            else A.acc[3] = mfma16h(*reinterpret_cast<const half8 *>(ha + 32 * kk), *reinterpret_cast<const half8 *>(ob + 32 * kk), A.acc[3]);
+        }
+    }
+    if (more) __syncthreads();
+}
+
+// the partial-gradient row of an 8-wave workgroup (GradAcc8): dW1 | db1 | dW2 | db2 | loss sum | valid count
+__device__ __forceinline__ void grad_write_partials8(const GradArgs &g, int stride, float *red, const GradAcc8 &A)
+{
+    constexpr int NMAX = 4;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int r = lane & 15, gq = lane >> 4;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    float *out = g.partials + (size_t)blockIdx.x * stride;
+    const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
+    const int j = 16 * strip + r;
+    if (grp == 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<floatx4 *>(out + j * kW + 32 * u + 4 * gq) = A.acc[u];     // tiles 0, 2, 4
+        if (gq == 0) *reinterpret_cast<floatx4 *>(out + j * kW + 96) = A.acc[3];                                // tile 6: columns 96..99
+        else if (gq == 1) out[kHid * kW + j] = A.acc[3][0];                                                      // column 100 -> db1[j]
+    } else {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<floatx4 *>(out + j * kW + 16 + 32 * u + 4 * gq) = A.acc[u]; // tiles 1, 3, 5
+        if (r < n2) *reinterpret_cast<floatx4 *>(out + oW2 + r * kHid + 16 * strip + 4 * gq) = A.acc[3];          // dW2^T
+    }
+    if (grp == 0 && lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NMAX + 2; ++a) red[strip * (kMaxOut + 2) + a] = A.csum[a];
+    }
+    __syncthreads();
+    if (tid < NMAX + 2) {
+        const float s = (red[tid] + red[(kMaxOut + 2) + tid]) + (red[2 * (kMaxOut + 2) + tid] + red[3 * (kMaxOut + 2) + tid]);
+        if (tid < n2) out[ob2 + tid] = s;
+        else if (tid == NMAX) out[g.P] = s;
+        else if (tid == NMAX + 1) out[g.P + 1] = s;
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
+{
+    const GradArgs &g = ga.g;
+    extern __shared__ __align__(16) float lds[];
+    GradLdsH L;
+    _Float16 *hb = reinterpret_cast<_Float16 *>(lds);
+    L.W1l = hb;                              // [64][136]
+    L.W1t = L.W1l + kTile * kLdH;
+    L.Xs = L.W1t + kTile * kLdH;
+    L.Xn = L.Xs + kTile * kLdH;              // [64][136] = 8 704 halfs; later HT [64][72] + dHT [64][72] = 9 216 halfs
+    L.HT = L.Xn;
+    L.dHT = L.HT + kTile * kLdT;
+    L.XsT = L.Xn + 2 * kTile * kLdT;         // [112][72]
+    L.doutT = L.XsT + 112 * kLdT;            // [16][72]
+    L.W2l = reinterpret_cast<float *>(L.doutT + 16 * kLdT);
+    L.W2t = L.W2l + kMaxOut * kHid;
+    L.b2l = L.W2t + kMaxOut * kHid;
+    L.b2t = L.b2l + kMaxOut;
+    L.red = L.b2t + kMaxOut;
+    float *qn_lds = L.red + 4 * (kMaxOut + 2);
+    L.stage = reinterpret_cast<uint32_t *>(qn_lds + kTile);
+    // XsT rows 101..111 feed output rows nobody stores; zeroed once so that no NaN bit pattern ever enters an MFMA
+    for (int k = (int)threadIdx.x; k < 11 * kLdT / 2; k += 512) reinterpret_cast<uint32_t *>(L.XsT + 101 * kLdT)[k] = 0u;
+    GradAcc8 A;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) A.acc[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) A.csum[a] = 0.0f;
+    L_STAMP(0);
+    const int step = (int)gridDim.x;
+    int tile = (int)blockIdx.x;
+    TileLoads8 T;
+    grad_tile_h8<KIND, true>(g, L, qn_lds, tile, tile + step, tile + step < ga.n_tiles, T, A);
+    for (tile += step; tile < ga.n_tiles; tile += step)
+        grad_tile_h8<KIND, false>(g, L, qn_lds, tile, tile + step, tile + step < ga.n_tiles, T, A);
+    L_STAMP(5);
+    grad_write_partials8(g, ga.stride, L.red, A);
+}
+
+constexpr size_t kGradH8Lds = (size_t)(3 * kTile * kLdH + 2 * kTile * kLdT + 112 * kLdT + 16 * kLdT) * 2 +
+                              (size_t)(2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2) + kTile + 8 * kStageW) * 4;
+
 constexpr size_t kGradHLds = (size_t)(3 * kTile * kLdH + 2 * kTile * kLdT + 112 * kLdT + 16 * kLdT) * 2 +
                              (size_t)(2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2) + 4 * kStageW) * 4;
 
@@ -1660,6 +1902,20 @@ static int launch_grad_h(const Grad2Args &ga, int grid, hipStream_t s)
 }
 
 template <int KIND>
+static int launch_grad_h8(const Grad2Args &ga, int grid, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_h8<KIND>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradH8Lds) != hipSuccess)
+            return UAVENV_EHIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_dqn_grad_h8<KIND>), dim3(grid), dim3(512), kGradH8Lds, s, ga);
+    return UAVENV_OK;
+}
+
+template <int KIND>
 static int launch_act_h(const ActArgs &g, int grid, hipStream_t s)
 {
     hipLaunchKernelGGL((k_dqn_act_h<KIND, 4>), dim3(grid), dim3(256), kActHLds, s, g);        // 44 KB: no attribute needed
@@ -1778,7 +2034,11 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
     int rc;
     if (net->mfma_dtype == UAVENV_MFMA_F16) {         // f16 operands, f32 accumulate: f16 / packed rings, <= 4 layer-2 outputs
         if (!small || ring->obs_dtype == UAVENV_OBS_F32) return UAVENV_EINVAL;
-        rc = ring->obs_dtype == UAVENV_OBS_PACKED ? launch_grad_h<OBS_KIND_PACKED>(ga, grid, s) : launch_grad_h<OBS_KIND_F16>(ga, grid, s);
+        static const bool four_waves_h = getenv("UAVENV_GRAD_4WAVES") != nullptr;    // A/B knob
+        if (four_waves_h)
+            rc = ring->obs_dtype == UAVENV_OBS_PACKED ? launch_grad_h<OBS_KIND_PACKED>(ga, grid, s) : launch_grad_h<OBS_KIND_F16>(ga, grid, s);
+        else
+            rc = ring->obs_dtype == UAVENV_OBS_PACKED ? launch_grad_h8<OBS_KIND_PACKED>(ga, grid, s) : launch_grad_h8<OBS_KIND_F16>(ga, grid, s);
     } else if (ring->obs_dtype == UAVENV_OBS_F32)
         rc = small ? launch_grad<float, 4>(ga, grid, s) : launch_grad<float, kMaxOut - 2>(ga, grid, s);
     else if (ring->obs_dtype == UAVENV_OBS_PACKED) {
