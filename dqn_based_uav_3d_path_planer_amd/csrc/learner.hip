@@ -1796,7 +1796,30 @@ __global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
     }
 }
 
-// f16 MFMA forward (UavDqnNet.mfma_dtype = 1) on f16 or packed observations
+// f16 MFMA forward (UavDqnNet.mfma_dtype = 1) on f16 or packed observations.  Workgroups are persistent over tiles (the
+// grid is capped at 512): fc1 is staged and converted once per workgroup, not once per 64 agents, and the next tile's rows
+// are requested before the current tile is computed.
+template <int KIND>
+__device__ __forceinline__ void act_rows_issue(const ActArgs &g, int first, floatx4 (&vX)[kXIters])
+{
+    constexpr int per_row = KIND == OBS_KIND_PACKED ? 5 : 25, iters = KIND == OBS_KIND_PACKED ? 2 : kXIters;
+    const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < iters; ++it) {
+        int c = it * 64 + lane;
+        c = c < 16 * per_row ? c : 16 * per_row - 1;
+        const int row = c / per_row, q = c - row * per_row;
+        int i = first + row;
+        i = i < g.n ? i : g.n - 1;
+        if (KIND == OBS_KIND_PACKED) {
+            vX[it] = *reinterpret_cast<const floatx4 *>(reinterpret_cast<const uint32_t *>(g.obs) + (size_t)i * kPackedDwords + 4 * q);
+        } else {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(g.obs) + (size_t)i * kW + 4 * q);
+            vX[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};
+        }
+    }
+}
+
 template <int KIND, int NMAX>
 __global__ void __launch_bounds__(256) k_dqn_act_h(ActArgs g)
 {
@@ -1809,69 +1832,60 @@ __global__ void __launch_bounds__(256) k_dqn_act_h(ActArgs g)
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     const NetDev nl = net_view(g.local, n2);
-    const int first = (int)blockIdx.x * kTile + wv * 16;
+    const int n_tiles = (g.n + kTile - 1) / kTile;
     _Float16 *strip = Xs + wv * 16 * kLdH;
-    floatx4 vX[kXIters], vW[kStageIters];
+    floatx4 vX[kXIters];
+    int tile = (int)blockIdx.x;
+    act_rows_issue<KIND>(g, tile * kTile + wv * 16, vX);
     {
-        constexpr int per_row = KIND == OBS_KIND_PACKED ? 5 : 25, iters = KIND == OBS_KIND_PACKED ? 2 : kXIters;
+        floatx4 vW[kStageIters];
+        w_issue(vW, g.local);
+        const float pb1 = nl.b1[tid < kHid ? tid : kHid - 1];
+        float pw[4];
 #pragma unroll
-        for (int it = 0; it < iters; ++it) {
-            int c = it * 64 + lane;
-            c = c < 16 * per_row ? c : 16 * per_row - 1;
-            const int row = c / per_row, q = c - row * per_row;
-            int i = first + row;
-            i = i < g.n ? i : g.n - 1;
-            if (KIND == OBS_KIND_PACKED) {
-                vX[it] = *reinterpret_cast<const floatx4 *>(reinterpret_cast<const uint32_t *>(g.obs) + (size_t)i * kPackedDwords + 4 * q);
-            } else {
-                const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(g.obs) + (size_t)i * kW + 4 * q);
-                vX[it] = floatx4{__uint_as_float(raw.x), __uint_as_float(raw.y), 0.0f, 0.0f};
-            }
-        }
+        for (int k = 0; k < 4; ++k) pw[k] = nl.W2[tid + 256 * k < n2 * kHid ? tid + 256 * k : 0];
+        const float pb2 = nl.b2[tid < n2 ? tid : 0];
+        wh_commit(W1, vW, pb1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < n2 * kHid) W2[tid + 256 * k] = pw[k];
+        if (tid < n2) b2[tid] = pb2;
     }
-    w_issue(vW, g.local);
-    const int i = first + r;
-    const uint4 rn = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
-                                   make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
-    const float pb1 = nl.b1[tid < kHid ? tid : kHid - 1];
-    float pw[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pw[k] = nl.W2[tid + 256 * k < n2 * kHid ? tid + 256 * k : 0];
-    const float pb2 = nl.b2[tid < n2 ? tid : 0];
-    xh_commit<KIND>(strip, vX, stage + wv * kStageW, nullptr);
-    wh_commit(W1, vW, pb1);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (tid + 256 * k < n2 * kHid) W2[tid + 256 * k] = pw[k];
-    if (tid < n2) b2[tid] = pb2;
     __syncthreads();
-    floatx4 h[4];
-    fwd_strip_h(W1, strip, h);
-    float q[NMAX];
-    {
-        W2Frag<NMAX> F;
-        w2_load<NMAX>(F, W2, b2, n2);
+    W2Frag<NMAX> F;
+    w2_load<NMAX>(F, W2, b2, n2);
+    for (; tile < n_tiles; tile += (int)gridDim.x) {
+        const int i = tile * kTile + wv * 16 + r;
+        xh_commit<KIND>(strip, vX, stage + wv * kStageW, nullptr);
+        wave_lds_sync();
+        if (tile + (int)gridDim.x < n_tiles) act_rows_issue<KIND>(g, (tile + (int)gridDim.x) * kTile + wv * 16, vX);
+        const uint4 rn = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
+                                       make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
+        floatx4 h[4];
+        fwd_strip_h(W1, strip, h);
+        float q[NMAX];
         q_strip<NMAX>(h, F, n2, g.n_actions, g.dueling, q);
-    }
-    if (lane < 16 && i < g.n) {
-        if (g.q_out) {
+        if (lane < 16 && i < g.n) {
+            if (g.q_out) {
 #pragma unroll
-            for (int a = 0; a < NMAX; ++a)
-                if (a < g.n_actions) g.q_out[(size_t)i * g.n_actions + a] = q[a];
-        }
-        const float sample = (float)(rn.x >> 8) * (1.0f / 16777216.0f);
-        int a;
-        if (sample > g.eps) {
-            a = 0;
-            float bq = q[0];
+                for (int a = 0; a < NMAX; ++a)
+                    if (a < g.n_actions) g.q_out[(size_t)i * g.n_actions + a] = q[a];
+            }
+            const float sample = (float)(rn.x >> 8) * (1.0f / 16777216.0f);
+            int a;
+            if (sample > g.eps) {
+                a = 0;
+                float bq = q[0];
 #pragma unroll
-            for (int k = 1; k < NMAX; ++k)
-                if (k < g.n_actions && q[k] > bq) { bq = q[k]; a = k; }
-        } else {
-            a = (int)(((uint64_t)rn.y * (uint64_t)g.n_actions) >> 32);
+                for (int k = 1; k < NMAX; ++k)
+                    if (k < g.n_actions && q[k] > bq) { bq = q[k]; a = k; }
+            } else {
+                a = (int)(((uint64_t)rn.y * (uint64_t)g.n_actions) >> 32);
+            }
+            if (g.index_out) g.index_out[i] = a;
+            if (g.steer_out) g.steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(g.n_actions - 1));
         }
-        if (g.index_out) g.index_out[i] = a;
-        if (g.steer_out) g.steer_out[i] = (float)(-1.0 + 2.0 * (double)a / (double)(g.n_actions - 1));
+        wave_lds_sync();                      // the strip is rewritten by the next tile's commit
     }
 }
 
@@ -1918,7 +1932,7 @@ static int launch_grad_h8(const Grad2Args &ga, int grid, hipStream_t s)
 template <int KIND>
 static int launch_act_h(const ActArgs &g, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_dqn_act_h<KIND, 4>), dim3(grid), dim3(256), kActHLds, s, g);        // 44 KB: no attribute needed
+    hipLaunchKernelGGL((k_dqn_act_h<KIND, 4>), dim3(grid < 512 ? grid : 512), dim3(256), kActHLds, s, g);   // 44 KB: no attribute needed
     return UAVENV_OK;
 }
 
