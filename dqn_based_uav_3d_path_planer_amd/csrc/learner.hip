@@ -1308,111 +1308,6 @@ __device__ __forceinline__ void tile_issue8(const GradArgs &g, int tile, int grp
     }
 }
 
-template <int KIND, bool FIRST>
-__device__ __forceinline__ void grad_tile_h8(const GradArgs &g, const GradLdsH &L, float *qn_lds, int tile, int next_tile, bool more,
-                                             TileLoads8 &T, GradAcc8 &A)
-{
-    constexpr int NMAX = 4;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
-    const int r = lane & 15, gq = lane >> 4, t256 = tid & 255;
-    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
-    _Float16 *x_strip = (grp == 0 ? L.Xs : L.Xn) + strip * 16 * kLdH;
-    const float *net = grp == 0 ? g.local : g.target;
-    floatx4 vW[kStageIters];
-    float pb1 = 0.0f, pw[4] = {0, 0, 0, 0}, pb2 = 0.0f;
-    if (FIRST) {                              // group 0 stages q_local's weights, group 1 q_target's
-        w_issue_half(vW, net, t256);
-        const NetDev nv = net_view(net, n2);
-        pb1 = nv.b1[t256 < kHid ? t256 : kHid - 1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pw[k] = nv.W2[t256 + 256 * k < n2 * kHid ? t256 + 256 * k : 0];
-        pb2 = nv.b2[t256 < n2 ? t256 : 0];
-        tile_issue8<KIND>(g, tile, grp, strip, T);
-    }
-    const int p_act = T.p_act;
-    const float p_rew = T.p_rew, p_done = T.p_done, p_valid = T.p_valid;
-    uint32_t *stage = L.stage + wv * kStageW;
-    if (FIRST) {
-        wh_commit_half(grp == 0 ? L.W1l : L.W1t, vW, pb1, t256);
-        float *W2 = grp == 0 ? L.W2l : L.W2t, *b2 = grp == 0 ? L.b2l : L.b2t;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (t256 + 256 * k < n2 * kHid) W2[t256 + 256 * k] = pw[k];
-        if (t256 < n2) b2[t256] = pb2;
-        if (grp == 1)
-            for (int k = t256; k < 16 * kLdT / 2; k += 256) reinterpret_cast<uint32_t *>(L.doutT)[k] = 0u;     // rows >= n2 stay zero
-    }
-    L_STAMP(6);
-    xh_commit<KIND>(x_strip, T.vX, stage, grp == 0 ? L.XsT + strip * 16 : nullptr);
-    if (FIRST) __syncthreads();               // both weight sets staged
-    else wave_lds_sync();
-    L_STAMP(7);
-    if (more) tile_issue8<KIND>(g, next_tile, grp, strip, T);         // the next tile's HBM round trip starts here
-    L_STAMP(1);
-    floatx4 hl[4];
-    W2Frag<NMAX> Fl;
-    float ql[NMAX];
-    if (grp == 0) {
-        fwd_strip_h(L.W1l, x_strip, hl);
-        w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
-        q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
-    } else {
-        int best = 0;
-        floatx4 ht[4];
-        if (g.kind == 1) {                    // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
-            fwd_strip_h(L.W1l, x_strip, ht);
-            W2Frag<NMAX> F;
-            w2_load<NMAX>(F, L.W2l, L.b2l, n2);
-            float qn_l[NMAX];
-            q_strip<NMAX>(ht, F, n2, g.n_actions, g.dueling, qn_l);
-            float bq = qn_l[0];
-#pragma unroll
-            for (int a = 1; a < NMAX; ++a)
-                if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }
-        }
-        fwd_strip_h(L.W1t, x_strip, ht);
-        W2Frag<NMAX> Ft;
-        w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
-        float qt[NMAX];
-        q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
-        if (gq == 0) qn_lds[strip * 16 + r] = pick_qn<NMAX>(g, qt, best);
-    }
-    L_STAMP(2);
-    __syncthreads();                          // bootstrap values handed over; every wave is done with the s' rows
-    L_STAMP(3);
-    if (grp == 0) {
-        GradAcc<NMAX> Tc;                     // td_backward's accumulator interface: only csum is used here
-#pragma unroll
-        for (int a = 0; a < NMAX + 2; ++a) Tc.csum[a] = A.csum[a];
-        const int s = strip * 16 + r;
-        td_backward<NMAX, true>(g, L.W2l, hl, Fl, ql, qn_lds[s], p_act, p_rew, p_done, p_valid, Tc,
-                                reinterpret_cast<float *>(L.HT + s), reinterpret_cast<float *>(L.dHT + s),
-                                reinterpret_cast<float *>(L.doutT + s));
-#pragma unroll
-        for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = Tc.csum[a];
-    }
-    __syncthreads();
-    L_STAMP(4);
-    // ---- weight gradients, K = 64 samples = 2 MFMA steps of 32 (hidden units 16 strip + r):
-    //   group 0: dW1^T k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and dW2^T[j][a] += sum_s HT[j][s] doutT[a][s]
-    {
-        const _Float16 *xa = L.XsT + r * kLdT + 8 * gq;
-        const _Float16 *db = L.dHT + (16 * strip + r) * kLdT + 8 * gq;
-        const _Float16 *ha = L.HT + (16 * strip + r) * kLdT + 8 * gq;
-        const _Float16 *ob = L.doutT + r * kLdT + 8 * gq;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const half8 bdh = *reinterpret_cast<const half8 *>(db + 32 * kk);
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                A.acc[u] = mfma16h(*reinterpret_cast<const half8 *>(xa + 16 * (2 * u + grp) * kLdT + 32 * kk), bdh, A.acc[u]);
-            if (grp == 0) A.acc[3] = mfma16h(*reinterpret_cast<const half8 *>(xa + 16 * 6 * kLdT + 32 * kk), bdh, A.acc[3]);
-            else A.acc[3] = mfma16h(*reinterpret_cast<const half8 *>(ha + 32 * kk), *reinterpret_cast<const half8 *>(ob + 32 * kk), A.acc[3]);
-        }
-    }
-    if (more) __syncthreads();
-}
-
 // the partial-gradient row of an 8-wave workgroup (GradAcc8): dW1 | db1 | dW2 | db2 | loss sum | valid count
 __device__ __forceinline__ void grad_write_partials8(const GradArgs &g, int stride, float *red, const GradAcc8 &A)
 {
@@ -1446,30 +1341,43 @@ __device__ __forceinline__ void grad_write_partials8(const GradArgs &g, int stri
     }
 }
 
+// Schedule.  Group 1 runs ONE TILE AHEAD of group 0: while group 0 turns tile i's bootstrap values into dL/dH (TD) and
+// then commits + forwards the s rows of tile i + 1, group 1 commits the s' rows of tile i + 1 and computes its bootstrap
+// values -- so the TD never waits for the (longer, two forwards with double DQN) chain of group 1.  Two barriers per tile
+// bracket the weight-gradient products, which both groups share.  Double buffers: the bootstrap values and the
+// transposed X tile (tile i + 1's is written while tile i's still feeds the products); HT / dHT have their own space.
 template <int KIND>
 __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
 {
+    constexpr int NMAX = 4;
     const GradArgs &g = ga.g;
     extern __shared__ __align__(16) float lds[];
-    GradLdsH L;
     _Float16 *hb = reinterpret_cast<_Float16 *>(lds);
-    L.W1l = hb;                              // [64][136]
-    L.W1t = L.W1l + kTile * kLdH;
-    L.Xs = L.W1t + kTile * kLdH;
-    L.Xn = L.Xs + kTile * kLdH;              // [64][136] = 8 704 halfs; later HT [64][72] + dHT [64][72] = 9 216 halfs
-    L.HT = L.Xn;
-    L.dHT = L.HT + kTile * kLdT;
-    L.XsT = L.Xn + 2 * kTile * kLdT;         // [112][72]
-    L.doutT = L.XsT + 112 * kLdT;            // [16][72]
-    L.W2l = reinterpret_cast<float *>(L.doutT + 16 * kLdT);
-    L.W2t = L.W2l + kMaxOut * kHid;
-    L.b2l = L.W2t + kMaxOut * kHid;
-    L.b2t = L.b2l + kMaxOut;
-    L.red = L.b2t + kMaxOut;
-    float *qn_lds = L.red + 4 * (kMaxOut + 2);
-    L.stage = reinterpret_cast<uint32_t *>(qn_lds + kTile);
-    // XsT rows 101..111 feed output rows nobody stores; zeroed once so that no NaN bit pattern ever enters an MFMA
-    for (int k = (int)threadIdx.x; k < 11 * kLdT / 2; k += 512) reinterpret_cast<uint32_t *>(L.XsT + 101 * kLdT)[k] = 0u;
+    _Float16 *W1l = hb;                                  // [64][136]
+    _Float16 *W1t = W1l + kTile * kLdH;
+    _Float16 *Xs = W1t + kTile * kLdH;                   // s rows (group 0), s' rows (group 1)
+    _Float16 *Xn = Xs + kTile * kLdH;
+    _Float16 *HT = Xn + kTile * kLdH;                    // [64][72] each
+    _Float16 *dHT = HT + kTile * kLdT;
+    _Float16 *XsT = dHT + kTile * kLdT;                  // 2 x [112][72]
+    _Float16 *doutT = XsT + 2 * 112 * kLdT;              // [16][72]
+    float *W2l = reinterpret_cast<float *>(doutT + 16 * kLdT);
+    float *W2t = W2l + kMaxOut * kHid;
+    float *b2l = W2t + kMaxOut * kHid;
+    float *b2t = b2l + kMaxOut;
+    float *red = b2t + kMaxOut;
+    float *qn_lds = red + 4 * (kMaxOut + 2);             // [2][64]
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(qn_lds + 2 * kTile);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int r = lane & 15, gq = lane >> 4, t256 = tid & 255;
+    const int n2 = g.n_actions + (g.dueling ? 1 : 0);
+    _Float16 *x_strip = (grp == 0 ? Xs : Xn) + strip * 16 * kLdH;
+    uint32_t *stage = stage_all + wv * kStageW;
+    // XsT rows 101..111 (both buffers) feed output rows nobody stores; zeroed once so that no NaN bit pattern enters an MFMA
+    for (int k = tid; k < 11 * kLdT / 2; k += 512) {
+        reinterpret_cast<uint32_t *>(XsT + 101 * kLdT)[k] = 0u;
+        reinterpret_cast<uint32_t *>(XsT + (112 + 101) * kLdT)[k] = 0u;
+    }
     GradAcc8 A;
 #pragma unroll
     for (int u = 0; u < 4; ++u) A.acc[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1477,17 +1385,115 @@ __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
     for (int a = 0; a < 6; ++a) A.csum[a] = 0.0f;
     L_STAMP(0);
     const int step = (int)gridDim.x;
-    int tile = (int)blockIdx.x;
+    const int n_my = ((int)ga.n_tiles - (int)blockIdx.x + step - 1) / step;      // tiles blockIdx.x + i * step, i < n_my
+    auto tile_of = [&](int i) { return (int)blockIdx.x + i * step; };
     TileLoads8 T;
-    grad_tile_h8<KIND, true>(g, L, qn_lds, tile, tile + step, tile + step < ga.n_tiles, T, A);
-    for (tile += step; tile < ga.n_tiles; tile += step)
-        grad_tile_h8<KIND, false>(g, L, qn_lds, tile, tile + step, tile + step < ga.n_tiles, T, A);
+    {   // ---- weights: group 0 stages q_local's, group 1 q_target's; the first tile's rows are in flight meanwhile
+        const float *net = grp == 0 ? g.local : g.target;
+        floatx4 vW[kStageIters];
+        w_issue_half(vW, net, t256);
+        const NetDev nv = net_view(net, n2);
+        const float pb1 = nv.b1[t256 < kHid ? t256 : kHid - 1];
+        float pw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[k] = nv.W2[t256 + 256 * k < n2 * kHid ? t256 + 256 * k : 0];
+        const float pb2 = nv.b2[t256 < n2 ? t256 : 0];
+        tile_issue8<KIND>(g, tile_of(0), grp, strip, T);
+        wh_commit_half(grp == 0 ? W1l : W1t, vW, pb1, t256);
+        float *W2 = grp == 0 ? W2l : W2t, *b2 = grp == 0 ? b2l : b2t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t256 + 256 * k < n2 * kHid) W2[t256 + 256 * k] = pw[k];
+        if (t256 < n2) b2[t256] = pb2;
+        if (grp == 1)
+            for (int k = t256; k < 16 * kLdT / 2; k += 256) reinterpret_cast<uint32_t *>(doutT)[k] = 0u;     // rows >= n2 stay zero
+    }
+    __syncthreads();
+    L_STAMP(1);
+    floatx4 hl[4];                                        // group 0: pre-activations / Q of the tile whose TD comes next
+    float ql[NMAX];
+    int p_act = 0;
+    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f;
+    // (the fc2 fragments are re-read from LDS where they are used: two of them live across the whole loop spill)
+    // commit this wavefront's rows of tile i, request tile i + 1's, and (group 0) Q_local(s) / (group 1) the bootstrap values
+    auto front = [&](int i) {
+        if (grp == 0) { p_act = T.p_act; p_rew = T.p_rew; p_done = T.p_done; p_valid = T.p_valid; }
+        xh_commit<KIND>(x_strip, T.vX, stage, grp == 0 ? XsT + (i & 1) * 112 * kLdT + strip * 16 : nullptr);
+        wave_lds_sync();
+        if (i + 1 < n_my) tile_issue8<KIND>(g, tile_of(i + 1), grp, strip, T);
+        if (grp == 0) {
+            fwd_strip_h(W1l, x_strip, hl);
+            W2Frag<NMAX> Fl;
+            w2_load<NMAX>(Fl, W2l, b2l, n2);
+            q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+        } else {
+            int best = 0;
+            floatx4 ht[4];
+            if (g.kind == 1) {                // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
+                fwd_strip_h(W1l, x_strip, ht);
+                W2Frag<NMAX> Fl;
+                w2_load<NMAX>(Fl, W2l, b2l, n2);
+                float qn_l[NMAX];
+                q_strip<NMAX>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
+                float bq = qn_l[0];
+#pragma unroll
+                for (int a = 1; a < NMAX; ++a)
+                    if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }
+            }
+            fwd_strip_h(W1t, x_strip, ht);
+            W2Frag<NMAX> Ft;
+            w2_load<NMAX>(Ft, W2t, b2t, n2);
+            float qt[NMAX];
+            q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+            if (gq == 0) qn_lds[(i & 1) * kTile + strip * 16 + r] = pick_qn<NMAX>(g, qt, best);
+            wave_lds_sync();                  // (the strip is rewritten by this wavefront's next commit)
+        }
+    };
+    front(0);
+    __syncthreads();                          // tile 0's bootstrap values handed over
+    L_STAMP(2);
+    for (int i = 0; i < n_my; ++i) {
+        if (grp == 0) {
+            GradAcc<NMAX> Tc;                 // td_backward's accumulator interface: only csum is used here
+#pragma unroll
+            for (int a = 0; a < NMAX + 2; ++a) Tc.csum[a] = A.csum[a];
+            const int s = strip * 16 + r;
+            W2Frag<NMAX> Fl;
+            w2_load<NMAX>(Fl, W2l, b2l, n2);
+            td_backward<NMAX, true>(g, W2l, hl, Fl, ql, qn_lds[(i & 1) * kTile + s], p_act, p_rew, p_done, p_valid, Tc,
+                                    reinterpret_cast<float *>(HT + s), reinterpret_cast<float *>(dHT + s),
+                                    reinterpret_cast<float *>(doutT + s));
+#pragma unroll
+            for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = Tc.csum[a];
+        }
+        if (i + 1 < n_my) front(i + 1);       // both groups, one tile ahead of the products below
+        __syncthreads();                      // HT / dHT / doutT of tile i complete (and tile i + 1's bootstrap values)
+        if (i == n_my - 1) L_STAMP(3);
+        // ---- weight gradients of tile i, K = 64 samples = 2 MFMA steps of 32 (hidden units 16 strip + r):
+        //   group 0: dW1^T k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and dW2^T[j][a] += sum_s HT[j][s] doutT[a][s]
+        {
+            const _Float16 *xa = XsT + (i & 1) * 112 * kLdT + r * kLdT + 8 * gq;
+            const _Float16 *db = dHT + (16 * strip + r) * kLdT + 8 * gq;
+            const _Float16 *ha = HT + (16 * strip + r) * kLdT + 8 * gq;
+            const _Float16 *ob = doutT + r * kLdT + 8 * gq;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const half8 bdh = *reinterpret_cast<const half8 *>(db + 32 * kk);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    A.acc[u] = mfma16h(*reinterpret_cast<const half8 *>(xa + 16 * (2 * u + grp) * kLdT + 32 * kk), bdh, A.acc[u]);
+                if (grp == 0) A.acc[3] = mfma16h(*reinterpret_cast<const half8 *>(xa + 16 * 6 * kLdT + 32 * kk), bdh, A.acc[3]);
+                else A.acc[3] = mfma16h(*reinterpret_cast<const half8 *>(ha + 32 * kk), *reinterpret_cast<const half8 *>(ob + 32 * kk), A.acc[3]);
+            }
+        }
+        if (i + 1 < n_my) __syncthreads();    // the next TD overwrites HT / dHT / doutT
+    }
     L_STAMP(5);
-    grad_write_partials8(g, ga.stride, L.red, A);
+    grad_write_partials8(g, ga.stride, red, A);
 }
 
-constexpr size_t kGradH8Lds = (size_t)(3 * kTile * kLdH + 2 * kTile * kLdT + 112 * kLdT + 16 * kLdT) * 2 +
-                              (size_t)(2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2) + kTile + 8 * kStageW) * 4;
+constexpr size_t kGradH8Lds = (size_t)(4 * kTile * kLdH + 2 * kTile * kLdT + 2 * 112 * kLdT + 16 * kLdT) * 2 +
+                              (size_t)(2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2) + 2 * kTile + 8 * kStageW) * 4;
 
 constexpr size_t kGradHLds = (size_t)(3 * kTile * kLdH + 2 * kTile * kLdT + 112 * kLdT + 16 * kLdT) * 2 +
                              (size_t)(2 * kMaxOut * kHid + 2 * kMaxOut + 4 * (kMaxOut + 2) + 4 * kStageW) * 4;
