@@ -342,4 +342,29 @@ def test_f16_mfma_learner_against_the_f32_mfma_learner(obs, kind, net):
         lb = float(B.learn_from_ring(ring, 2048, 5, it))
         assert abs(la - lb) <= 2e-2 * abs(la), (it, la, lb)
     assert torch.isfinite(B.flat).all()
+    # Several tiles per workgroup, unevenly (640 tiles on 256 workgroups: three for some, two for the others): the
+    # eight-wavefront f16 kernel pipelines its two wavefront groups ACROSS tiles (group 1 one tile ahead), the f32 kernels
+    # walk tiles with persistent accumulators.  Same bars on a 40 960-transition list (with repeats; the ring holds 10 240).
+    B.flat.copy_(A.flat)
+    w0 = A.flat.clone()
+    big = 40960
+    g = torch.Generator().manual_seed(9)
+    idx = torch.stack([torch.randint(0, 5, (big,), generator=g), torch.randint(0, n, (big,), generator=g)], 1).int().cuda()
+    la = float(A.learn_from_ring(ring, big, 5, 100, explicit_idx=idx))
+    lb = float(B.learn_from_ring(ring, big, 5, 100, explicit_idx=idx))
+    assert abs(la - lb) <= 3e-3 * abs(la), (la, lb)
+    ga, gb = A.raw[:A.P].double(), B.raw[:B.P].double()
+    rel = float((ga - gb).norm() / ga.norm())
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert rel <= 1e-2 and cos >= 0.9999, (rel, cos)
+    assert float(A.raw[A.P + 1]) == float(B.raw[B.P + 1])
+    # ... and the multi-tile launch equals the sum of single-tile-per-workgroup launches over the same list (f16 learner)
+    parts = torch.zeros_like(B.raw)
+    for k in range(0, big, 8192):
+        B.flat.copy_(w0)
+        B.learn_from_ring(ring, 8192, 5, 100, explicit_idx=idx[k:k + 8192].contiguous())
+        parts[:B.P] += B.raw[:B.P]
+        parts[B.P + 1] += B.raw[B.P + 1]
+    relp = float((parts[:B.P].double() - gb).norm() / gb.norm())
+    assert relp <= 1e-5 and float(parts[B.P + 1]) == float(A.raw[A.P + 1]), relp
     env.close()
