@@ -89,9 +89,9 @@ __device__ __forceinline__ WSet wset_at(float *p)
 }
 constexpr int kPsLd = 28;                          // dwords per sample of the packed-row tile: 20 + {1, a0, a1, 0} + pad (rows
                                                    // 4 apart are 48 banks apart)
-// LDS maps (floats).  Critic phase, stage I: actor fc1 | target 1 | target 2; stage II: critic | Ps | H1 H2 dH1 dH2 | dq | red;
+// LDS maps (floats).  Critic phase, stage I: actor fc1 | target 1 | target 2; stage II: critic | X | H1 H2 dH1 dH2 | dq | red;
 // the td targets of the workgroup's tiles live behind both.  Actor phase: actor fc1 | critic 1 | critic 2 | Ps | H dH | dq | red.
-constexpr int kCritStage2F = kWSetF + kTile * kPsLd + 4 * kTile * kLh + kTile * 4 + 64;
+constexpr int kCritStage2F = kWSetF + kTileF + 4 * kTile * kLh + kTile * 4 + 64;     // (the critic phase keeps an f32 X tile)
 constexpr int kCritTdOff = kCritStage2F > kTileF + 2 * kWSetF ? kCritStage2F : kTileF + 2 * kWSetF;
 constexpr size_t kSacCriticLds = (size_t)(kCritTdOff + kTMax * kTile * 2) * 4;
 constexpr size_t kSacActorLds = (size_t)(kTileF + 2 * kWSetF + kTile * kPsLd + 2 * kTile * kLh + kTile * 4 + 64) * 4;
@@ -344,6 +344,39 @@ __device__ __forceinline__ void wgrad_x(const float *As, const uint32_t *Ps, flo
             }
     }
 }
+// this strip's 16 rows of an f32 X tile [64][kLd] (columns 0..103; 100 = 1, 101 / 102 = the action) from the lanes' packed rows
+__device__ __forceinline__ void x_strip_store(float *Xs, const PRow &R, float a0, float a1)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const uint32_t slice = prow_slice(R, g);
+    float *dst = Xs + (16 * wv + r) * kLd + 26 * g;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) *reinterpret_cast<float2 *>(dst + 2 * i) = prow_pair<true>(R, slice, g == 0, g == 3, i, a0, a1);
+}
+// dW1 with B read from that tile: no decode between the MFMAs (the VALU of a wavefront does not overlap its own MFMAs: the
+// packed-row decode made this product 7.5 k cycles per tile against 3.6 k of MFMA issue; the actor phase has no LDS for an
+// f32 tile next to its three resident nets and keeps wgrad_x)
+__device__ __forceinline__ void wgrad_xf(const float *As, const float *Xs, floatx4 (&acc)[7])
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const float *ap = As + 4 * g * kLh + 16 * wv + r;
+    const float *bp = Xs + 4 * g * kLd + r;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        float a[4], b[4][7];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int s = kk + 16 * kc;
+            a[kk] = ap[s * kLh];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) b[kk][u] = bp[s * kLd + 16 * u];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int u = 0; u < 7; ++u) acc[u] = mfma16(a[kk], b[kk][u], acc[u]);
+    }
+}
 // the critic's other products in one sweep: dW2 = dH2^T H1 (4 tiles), dWout^T = H2^T dq, db2 = column sums of dH2
 __device__ __forceinline__ void wgrad_critic_rest(const float *dH2s, const float *H1s, const float *H2s, const float *dqs,
                                                   floatx4 (&aw2)[4], floatx4 &awo, floatx4 &ab2)
@@ -496,8 +529,8 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
     S_STAMP(2);
     // ---- stage II: Q1 / Q2 (s, a): loss, backward, weight gradients
     const WSet S = wset_at(lds);
-    uint32_t *Ps = reinterpret_cast<uint32_t *>(lds + kWSetF);
-    float *H1s = lds + kWSetF + kTile * kPsLd, *H2s = H1s + kTile * kLh, *dH1s = H2s + kTile * kLh, *dH2s = dH1s + kTile * kLh;
+    float *Xs = lds + kWSetF;
+    float *H1s = Xs + kTileF, *H2s = H1s + kTile * kLh, *dH1s = H2s + kTile * kLh, *dH2s = dH1s + kTile * kLh;
     float *dqs = dH2s + kTile * kLh, *red = dqs + kTile * 4;
     for (int c = 0; c < 2; ++c) {
         const float *flat = c ? g.c2 : g.c1;
@@ -532,13 +565,11 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
             h_strip_store(H2s, h2);
             h_strip_store(dH1s, dh1);
             h_strip_store(dH2s, dh2);
-            if (gq == 0) {
-                ps_store(Ps, 16 * wv + r, T.R, T.a0, T.a1);
-                dqs[(16 * wv + r) * 4] = dq0; dqs[(16 * wv + r) * 4 + 1] = dq1;
-            }
+            x_strip_store(Xs, T.R, T.a0, T.a1);
+            if (gq == 0) { dqs[(16 * wv + r) * 4] = dq0; dqs[(16 * wv + r) * 4 + 1] = dq1; }
             __syncthreads();
             if (j == 0) S_STAMP(4 + 6 * c);
-            wgrad_x<true>(dH1s, Ps, aw1);              // dW1 (+ db1 as column 100)
+            wgrad_xf(dH1s, Xs, aw1);                   // dW1 (+ db1 as column 100)
             if (j == 0) S_STAMP(5 + 6 * c);
             wgrad_critic_rest(dH2s, H1s, H2s, dqs, aw2, awo, ab2);     // dW2, dWout^T, db2
             __syncthreads();
