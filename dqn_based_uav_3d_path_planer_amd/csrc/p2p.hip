@@ -5,9 +5,9 @@
 // costs a host round trip plus 20-40 us of ring latency for a message this small.  Here every rank owns a receive area
 // in uncached device memory that its peers map through HIP IPC:
 //     push   (tail of the gradient reduction) each workgroup stores its 32 column sums straight into slot [my rank] of
-//            EVERY rank's receive area (its own included); a one-wavefront launch behind it raises flag [my rank] = seq
-//            at every rank (system-scope release);
-//     pull   (head of the Adam kernel) one thread per workgroup waits until all `world` flags of its own rank show
+//            EVERY rank's receive area (its own included);
+//     pull   (head of the Adam kernel, the next launch on the stream) raises flag [my rank] = seq at every rank
+//            (system-scope release), then one thread per workgroup waits until all `world` flags of its own rank show
 //            seq (system-scope loads of local memory), then every thread adds the `world` slots IN RANK ORDER -- all
 //            ranks therefore apply bit-identical updates -- and Adam runs as in k_dqn_adam.
 // Two alternating slots per rank (seq parity): a rank can be at most one update ahead of a peer, because its next push
@@ -100,17 +100,6 @@ __global__ void __launch_bounds__(256) k_p2p_reduce_push(const float *__restrict
     __threadfence_system();                                                      // this workgroup's stores are out
 }
 
-// Raise flag [rank] = seq at every rank.  Its own (tiny) launch right behind k_p2p_reduce_push: the kernel boundary orders
-// it after every workgroup's stores.  (Counting the 213 workgroups out with a device-scope ticket instead -- "the last one
-// publishes" -- serialises 213 atomics across the 8 XCDs' L2s: measured ~140 ns each with a 256-workgroup arrival counter,
-// DESIGN 3.4, i.e. most of what the exchange added to a pass.)
-__global__ void k_p2p_publish(P2PDev d)
-{
-    const int r = (int)threadIdx.x;
-    __threadfence_system();
-    if (r < d.world) __hip_atomic_store(flag_of(d.peer[r], d.rank), d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // wait for the `world` flags, add the slots in rank order, Adam (k_dqn_adam's arithmetic)
 __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restrict__ local, float *__restrict__ target,
                                                        float *__restrict__ m, float *__restrict__ v, float *__restrict__ raw_out,
@@ -118,6 +107,14 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
                                                        float bc2_sqrt, int hard_update, float *__restrict__ loss)
 {
     unsigned char *mine = d.peer[d.rank];
+    // Raise flag [rank] = seq at every rank first: this kernel is launched behind k_p2p_reduce_push on the stream, so the
+    // kernel boundary orders the flags after every push workgroup's stores.  (Counting the 213 push workgroups out with a
+    // device-scope ticket instead -- "the last one publishes" -- serialises 213 atomics across the 8 XCDs' L2s, ~140 ns
+    // each, DESIGN 3.4: most of what the exchange added to a pass.)
+    if (blockIdx.x == 0 && (int)threadIdx.x < d.world) {
+        __threadfence_system();
+        __hip_atomic_store(flag_of(d.peer[threadIdx.x], d.rank), d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (threadIdx.x == 0) {
         for (int r = 0; r < d.world; ++r) {
             uint32_t spins = 0;
@@ -248,7 +245,6 @@ int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials, int32_t n
     c->seq += 1;
     hipLaunchKernelGGL(k_p2p_reduce_push, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials, P,
                        uavenv_dqn_partial_stride(net), dev_view(c));
-    hipLaunchKernelGGL(k_p2p_publish, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_view(c));
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 
