@@ -10,12 +10,20 @@ Multi-GPU is weak scaling: every rank owns its own 16 384-env shard + ring; the 
 gradient bucket per update.
 
 A bench "step" (--steps K) is PASSES_PER_STEP = 128 such passes, enqueued back to back by csrc/loop.hip (one C call per
-bench step, four kernel launches per pass): one pass lasts ~40 us, so that the timed region stays >= 50 ms whatever K
+bench step, three kernel launches per pass): one pass lasts ~35 us, so that the timed region stays >= 50 ms whatever K
 the driver picks (20 steps = 2 560 passes).  `ms_per_step` is per bench step, `ms_per_pass` per pass.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (re-executes this file under
+torch.distributed.run, one rank per GPU); launched by torch.distributed.run it just joins.  At N > 1 the line also carries
+`ranks_bit_identical` (a checksum of every rank's weights after the timed region), the exchange actually used, its error
+counters, and `ms_per_pass_no_exchange` from a short in-run leg without the exchange.
+
 Prints ONE JSON line (rank 0).  `value` = whole-job env-steps/s of the full loop (inputs resident in HBM);
-`roofline` is for the env kernel k_step (HBM-bound by design), `roofline_learner` for k_dqn_grad (the largest share of
-the pass, MFMA); `cpu_baseline` times the CPU oracle port on the host cores (1 core and all cores).
+`roofline` is for the env kernel the loop launches (k_step_coop<policy>: get_action + update_PathPlan + state_PathPlan +
+replay write; HBM-bound by design), `roofline_learner` for k_dqn_grad (the largest share of the pass, MFMA);
+`cpu_baseline` times the CPU oracle port on the host cores (1 core and all cores); `other_configs` (N = 1, default
+command only) carries BASELINE.json configs[2..4] and the env-only 65 536 / 262 144-agent points, each run as a child
+process of this one for >= 50 ms of timed region.
 """
 from __future__ import annotations
 
@@ -86,10 +94,17 @@ def parse():
     p.add_argument("--sync", default="grad", choices=["grad", "fedavg"],
                    help="N > 1: all-reduce the gradient bucket every update (default), or average the weights every "
                         "FL_Loop = 3 updates (the reference's federated mode as all-reduce(avg))")
-    p.add_argument("--exchange", default="p2p", choices=["p2p", "rccl", "none"],
-                   help="N > 1, --sync grad: p2p = one-shot sum over HIP-IPC-mapped peer memory on the stream (falls back "
-                        "to rccl if it cannot be set up); rccl = torch.distributed all_reduce per update; none = diagnostic: "
-                        "no exchange at all (the ranks drift apart) -- the baseline the exchange's cost is measured against")
+    p.add_argument("--exchange", default="p2p", choices=["p2p", "coll", "rccl", "none"],
+                   help="N > 1, --sync grad: p2p = one-shot sum over HIP-IPC-mapped peer memory on the stream (csrc/p2p.hip; "
+                        "falls back to coll, then rccl, if it cannot be set up or raises its sticky error); coll = RCCL "
+                        "all-reduce enqueued from C inside the loop (csrc/coll.hip); rccl = torch.distributed all_reduce per "
+                        "update from Python; none = diagnostic: no exchange at all (the ranks drift apart)")
+    p.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the short in-run leg without the exchange")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="N = 1, default command: do not run BASELINE configs[2..4] + the env-only points as child processes")
+    p.add_argument("--inject-p2p-fault", type=int, default=-1,
+                   help="test: rank R raises the peer exchange's sticky error before the timed region (exercises the fallback)")
+    p.add_argument("--p2p-check-every", type=int, default=256, help="N > 1: on-device weight checksum compare every that many updates")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) | gloo (test: several ranks on one GPU)")
     p.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
     p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
@@ -99,6 +114,7 @@ def parse():
     p.add_argument("--learner", default="fused", choices=["fused", "torch"],
                    help="fused = hand-written HIP kernels (csrc/learner.hip); torch = PyTorch-ROCm ops")
     a = p.parse_args()
+    a.explicit = {k for k in ("envs", "batch", "trainer", "mfma", "obs_dtype") if any(x.startswith("--" + k.replace("_", "-")) for x in sys.argv[1:])}
     if a.config == 3:
         a.envs, a.batch, a.trainer, a.mfma = 65536, 65536, "dueling", "f16"
         a.obs_dtype = a.obs_dtype or "f16"
@@ -186,15 +202,29 @@ def cpu_learner_baseline(batch: int = 16384, seconds: float = 4.0):
             "kind": "port", "sample": f"{n} updates of {batch} resident samples in {dt:.1f} s, PyTorch CPU"}
 
 
+def csrc_sha() -> str:
+    """Hash of every kernel source (csrc/*, include/uavenv.h): scripts/summarize_profile.py stamps profiles/summary.json
+    with it, so that counters taken from a committed profile can be told apart from counters of the code that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dqn_based_uav_3d_path_planer_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "uavenv.h")]:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def committed_profile(args) -> dict:
     """The rocprofv3 figures of THIS command line as last committed under profiles/ (kernel-trace averages, PMC
-    traffic, MFMA busy): scripts/summarize_profile.py writes profiles/summary.json keyed by workload."""
+    traffic, MFMA busy): scripts/summarize_profile.py writes profiles/summary.json keyed by workload.  `stale` says
+    whether the kernel sources changed since that profile was taken."""
     path = os.path.join(ROOT, "profiles", "summary.json")
     key = "envs%d_batch%d_%s_%s" % (args.envs, args.batch, args.trainer, args.obs_dtype) + ("_mfma16" if args.mfma == "f16" else "")
     try:
         d = json.load(open(path)).get(key, {})
         if d:
             d["source"] = "profiles/summary.json[%s] <- %s" % (key, d.get("files", "rocprofv3"))
+            d["stale"] = d.get("csrc_sha") != csrc_sha()
         return d
     except Exception:
         return {}
@@ -256,7 +286,7 @@ def run_config4(args, dev):
         batch = dict(states=env.unpack(flat[slot]), next_states=env.unpack(flat[nxt]),
                      actions=torch.stack([ring.action.view(-1)[slot], a1_plane.view(-1)[slot]], 1),
                      rewards=ring.reward.view(-1)[slot], dones=ring.done.view(-1)[slot].float())
-        L.learn(batch, is_weights=ring.valid.view(-1)[slot].float())
+        L.learn(batch, valid=ring.valid.view(-1)[slot].float())
 
     one_draw = fused and (ring.frames - 1) * envs >= U * B
 
@@ -327,7 +357,7 @@ def run_config4(args, dev):
                 update_slot(j)
         counter[0] += 1
 
-    pps = max(1, args.passes_per_step // 16)          # a pass is ~100x longer than config 2's
+    pps = max(1, args.passes_per_step // 8)           # a pass is ~20x longer than config 2's: 16 passes of ~0.7 ms per step
     for _ in range(max(args.warmup, 1) * pps):
         one_pass()
     torch.cuda.synchronize(dev)
@@ -367,6 +397,7 @@ def run_config4(args, dev):
            "roofline": {"bound": "hbm", "kernel": "k_step<APF> (update_PathPlan + Adjust_subgoal + cal_force + state_PathPlan + replay write)",
                         "achieved": algo * env.N / (k_use * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo * env.N / (k_use * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": prof.get("k_step_traffic_bytes_per_launch"),
+                        "traffic_stale": prof.get("stale"),
                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": env.N, "kernel_ms": k_use,
                         "kernel_ms_back_to_back": k_ms, "kernel_ms_rocprofv3_committed": k_prof}}
     if fused:
@@ -398,35 +429,77 @@ def run_config4(args, dev):
                                    "flops_per_sample": 258.0e3, "samples_per_launch": B,
                                    "kernel_ms": sum(ms), "critic_grad_ms_back_to_back": ms[0], "actor_grad_ms_back_to_back": ms[1],
                                    "algorithmic_bytes_per_sample": 2 * 80 + 30, "traffic": None}
-    print(json.dumps(out))
     env.close()
+    return out
 
 
-def main():
-    args = parse()
-    if args.config == 4:
-        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-            raise SystemExit("--config 4 is a single-GPU workload")
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X: the env hot path has no CPU fallback")
-        torch.cuda.set_device(0)
-        return run_config4(args, torch.device("cuda", 0))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the env hot path has no CPU fallback")
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world_size > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with no rank environment: start the N ranks here -- this file re-executed under
+    torch.distributed.run, one process per GPU of this node, rendezvous on 127.0.0.1 -- and pass rank 0's line through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not args.same_device and n_dev < args.gpus:
+        raise SystemExit("--gpus %d asked for, %d visible (test several ranks on one GPU with --same-device --dist-backend gloo)"
+                         % (args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: HIP IPC handles / RCCL across processes need it here
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def run_child(extra, timeout=600):
+    """One more configuration as a child process (its own HIP context: a fault there cannot take the headline line down).
+    Returns the child's JSON line as a dict, or {'error': ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs"] + extra
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+        if res.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (res.returncode, (res.stderr or res.stdout)[-300:])}
+        return json.loads(lines[-1])
+    except Exception as ex:                                   # noqa: BLE001 -- reported in the line, never fatal
+        return {"error": repr(ex)[:300]}
+
+
+def other_configs(args):
+    """BASELINE.json configs[2], [3], [4] (at one GPU's share) and the env-only 65 536 / 262 144-agent points, each
+    >= 50 ms of timed region, summarised for the headline line."""
+    runs = [("configs[2]", ["--config", "3", "--steps", "10", "--warmup", "3"]),
+            ("configs[3]", ["--config", "4", "--steps", "6", "--warmup", "2"]),
+            ("configs[4] (one GPU's 32768-env share of the 8-GPU run)", ["--config", "5", "--steps", "12", "--warmup", "3"]),
+            ("env-only 65536 agents/launch", ["--env-only", "--envs", "65536", "--steps", "40"]),
+            ("env-only 262144 agents/launch", ["--env-only", "--envs", "262144", "--steps", "20"])]
+    out = []
+    for name, extra in runs:
+        t0 = time.perf_counter()
+        d = run_child(extra)
+        row = {"baseline_config": name, "command": "bench.py " + " ".join(extra), "wall_s": round(time.perf_counter() - t0, 1)}
+        if "error" in d:
+            row["error"] = d["error"]
+        elif d.get("mode") == "env-only":
+            row.update({"workload": "k_step alone, %d agents per launch, %s rows, random actions, auto-reset" % (d["envs"], d["obs_dtype"]),
+                        "value": d["env_steps_per_s"], "unit": "env-steps/s", "timed_region_ms": d.get("timed_region_ms"),
+                        "roofline": {"kernel": "k_step", "kernel_ms": d["k_step_ms_back_to_back"], "achieved": d["achieved_GBs"],
+                                     "unit": "GB/s", "frac": d["frac_of_8TBs"]}})
         else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
+            r, rl = d.get("roofline", {}), d.get("roofline_learner", {})
+            row.update({"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                        "ms_per_pass": d.get("ms_per_pass"), "timed_region_ms": d.get("timed_region_ms"),
+                        "learner_updates_per_s": d.get("learner_updates_per_s"),
+                        "roofline": {k: r.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "agents_per_launch")},
+                        "roofline_learner": {k: rl.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "peak")}})
+        out.append(row)
+    return out
 
+
+def run_dqn(args, world_size, rank, dev):
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
     from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
     from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing, select_actions
@@ -469,11 +542,11 @@ def main():
         ms = e0.elapsed_time(e1) / iters
         algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
         gbs = algo * env.N / (ms * 1e-3) / 1e9
-        print(json.dumps({"mode": "env-only", "envs": env.N, "k_step_ms_back_to_back": ms,
-                          "env_steps_per_s": env.N / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS,
-                          "obs_dtype": args.obs_dtype, "replay_frames": ring.frames}))
+        out = {"mode": "env-only", "envs": env.N, "k_step_ms_back_to_back": ms, "timed_region_ms": ms * iters,
+               "env_steps_per_s": env.N / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS,
+               "obs_dtype": args.obs_dtype, "replay_frames": ring.frames}
         env.close()
-        return
+        return out
     net = "VAnet2" if args.trainer == "dueling" else "Qnet2"
     torch.manual_seed(42)               # same initial weights on every rank
     net_param = {"NetWork": net, "w": "100", "hiden_dim": "64", "output": "3"}
@@ -486,24 +559,45 @@ def main():
     learner.sync = args.sync
     seed = 7 + rank
     pps = args.passes_per_step
-    # N > 1: the gradient bucket is summed over peer-mapped HBM (csrc/p2p.hip, verified against an RCCL all-reduce at
-    # start-up) so that the loop can stay in C; --exchange rccl (or a failed set-up) keeps torch.distributed per update
-    p2p = False
-    if fused and world_size > 1 and args.sync == "grad" and args.exchange == "p2p":
-        p2p = learner.enable_p2p()
-        if rank == 0 and not p2p:
-            print("p2p exchange unavailable: falling back to RCCL all-reduce per update", file=sys.stderr)
-    if args.exchange == "none" and world_size > 1:
-        learner.sync = "fedavg"
-        learner.fl_loop = 1 << 30
-    use_c = fused and args.host_loop == "c" and (world_size == 1 or p2p or args.exchange == "none")
+    multi = world_size > 1
+
+    # ---- N > 1: which exchange carries the gradient bucket.  p2p (csrc/p2p.hip, verified against an RCCL all-reduce at
+    # start-up) and coll (RCCL enqueued from C, csrc/coll.hip) keep the loop in C; rccl = torch.distributed per update.
+    exchange = {"asked": args.exchange if multi and args.sync == "grad" else None, "used": None, "fallbacks": []}
+
+    def choose_exchange(allow_p2p=True):
+        if not (fused and multi and args.sync == "grad"):
+            return "fedavg (weights, every %d updates)" % learner.fl_loop if multi and args.sync == "fedavg" else None
+        if args.exchange == "none":
+            learner.sync = "fedavg"
+            learner.fl_loop = 1 << 30
+            return "none"
+        if args.exchange == "p2p" and allow_p2p:
+            if learner.enable_p2p(check_every=args.p2p_check_every):
+                return "p2p"
+            exchange["fallbacks"].append("p2p set-up or self-test failed")
+        if args.exchange in ("p2p", "coll"):
+            if args.dist_backend == "nccl" and learner.enable_coll():
+                return "coll"
+            exchange["fallbacks"].append("coll unavailable (needs the nccl backend and one GPU per rank)")
+        return "rccl"
+
+    exchange["used"] = choose_exchange()
     counter = [0]
     py_events = []
     ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "8"))
-    hot = None
-    if use_c:
-        from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
-        hot = HotLoop(ring, learner, args.batch, seed, eps=args.eps, time_every=ev_every)
+    state = {"hot": None, "use_c": False}
+
+    def build_loop():
+        if state["hot"] is not None:
+            state["hot"].close()
+            state["hot"] = None
+        state["use_c"] = fused and args.host_loop == "c" and (not multi or exchange["used"] in ("p2p", "coll", "none"))
+        if state["use_c"]:
+            from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+            state["hot"] = HotLoop(ring, learner, args.batch, seed, eps=args.eps, counter=counter[0], time_every=ev_every)
+
+    build_loop()
 
     def one_pass(record=False):
         record = record and counter[0] % ev_every == 0
@@ -528,36 +622,110 @@ def main():
 
     def one_step(record=False):
         """One bench step = pps passes of act -> env step (+ replay write) -> learner update."""
+        hot = state["hot"]
         if hot is not None:
             hot.run(pps)
+            counter[0] = hot.counter
         else:
             for _ in range(pps):
                 one_pass(record)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world_size > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def any_rank(flag: bool) -> bool:
+        if not multi:
+            return flag
+        t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item())
+
+    def timed(n_steps, record=True):
+        """n_steps bench steps between two fences; (seconds, host enqueue seconds, exchange failed on some rank)."""
+        from dqn_based_uav_3d_path_planer_amd.loop import P2PExchangeError
+        failed = False
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            try:
+                one_step(record=record)
+            except P2PExchangeError:
+                failed = True
+                break
+        t_enq = time.perf_counter() - t0
+        fence()
+        dt = time.perf_counter() - t0
+        if exchange["used"] == "p2p" and not failed:
+            failed = learner.p2p_status()["code"] != 0
+        return dt, t_enq, any_rank(failed)
+
+    def recover_from_p2p():
+        """The peer exchange raised its sticky error on some rank: every rank drops it, joins the collective, takes rank
+        0's weights and Adam moments, and the loop is rebuilt."""
+        exchange["fallbacks"].append("p2p raised its sticky error during the run: %s" % learner.p2p_status())
+        torch.cuda.synchronize(dev)
+        learner.disable_p2p()
+        exchange["used"] = choose_exchange(allow_p2p=False)
+        learner.broadcast_weights(0)
+        ep = torch.tensor([learner.epoch], device=dev, dtype=torch.int64)
+        dist.broadcast(ep, src=0)
+        learner.epoch = int(ep.item())
+        build_loop()
+
     # untimed: experience in the ring + warm-up of every kernel / allocator path
-    for _ in range(max(args.warmup, 1)):
-        one_step()
-    if hot is not None:
-        hot.step_times_ms()                   # drop the warm-up's event pairs
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(record=True)
-    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (the loop is GPU-bound if < dt)
-    fence()
-    dt = time.perf_counter() - t0
-    if world_size > 1:
+    _, _, bad = timed(max(args.warmup, 1), record=False)
+    if bad:
+        recover_from_p2p()
+    if args.inject_p2p_fault == rank and exchange["used"] == "p2p":
+        from dqn_based_uav_3d_path_planer_amd import _lib as _l
+        _l.check(learner.lib.uavenv_p2p_inject_fault(learner._p2p, _l.P2P_ERR_TIMEOUT), "uavenv_p2p_inject_fault")
+    if state["hot"] is not None:
+        state["hot"].step_times_ms()          # drop the warm-up's event pairs
+    dt, t_enq, bad = timed(args.steps)
+    if bad:                                   # the timed region ran (partly) on a failed exchange: recover, time it again
+        recover_from_p2p()
+        timed(1, record=False)
+        if state["hot"] is not None:
+            state["hot"].step_times_ms()
+        dt, t_enq, bad = timed(args.steps)
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_pass = args.steps * pps
-    # ---- k_step, three ways (no correction terms):
+    hot, use_c = state["hot"], state["use_c"]
+
+    # ---- N > 1: are the ranks still bit-identical?  (they must be under any per-update exchange of the gradient sums)
+    multi_report = {}
+    if multi and fused:
+        st = learner.p2p_status() if exchange["used"] == "p2p" else {"code": 0, "timeouts": 0, "mismatches": 0, "checks": 0}
+        gathered = [None] * world_size
+        dist.all_gather_object(gathered, (learner.weights_checksum(), st["code"], st["timeouts"], st["mismatches"], st["checks"]))
+        allcs = [g[0] for g in gathered]
+        allst = [g[1:] for g in gathered]
+        multi_report = {"ranks_bit_identical": all(c == allcs[0] for c in allcs),
+                        "exchange": exchange["used"], "exchange_asked": exchange["asked"], "exchange_fallbacks": exchange["fallbacks"],
+                        "p2p_error_code_max": max(int(x[0]) for x in allst), "p2p_timeouts": sum(int(x[1]) for x in allst),
+                        "p2p_checksum_mismatches": sum(int(x[2]) for x in allst), "p2p_checksums_compared": int(allst[0][3]),
+                        "bad_after_recovery": bool(bad)}
+        # the same loop without any exchange (the ranks drift apart from here on: last thing this run does with them)
+        if not args.no_exchange_leg and exchange["used"] in ("p2p", "coll", "rccl") and args.host_loop == "c":
+            saved = (getattr(learner, "_p2p", None), getattr(learner, "_coll", None), exchange["used"])
+            learner._p2p, learner._coll, exchange["used"] = None, None, "none"
+            build_loop()
+            timed(1, record=False)
+            d0, _, _ = timed(max(2, min(args.steps, 8)), record=False)
+            t = torch.tensor([d0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            multi_report["ms_per_pass_no_exchange"] = float(t.item()) / (max(2, min(args.steps, 8)) * pps) * 1e3
+            learner._p2p, learner._coll, exchange["used"] = saved
+            build_loop()
+            hot, use_c = state["hot"], state["use_c"]
+
+    # ---- the step kernel, three ways (no correction terms):
     # (a) HIP event pairs around the launch inside the timed loop, on the launch stream (every ev_every-th pass).  A
     #     pair brackets the kernel PLUS the two marker packets: for a ~9 us kernel it reads 2-3 us above rocprofv3.
     if hot is not None:
@@ -567,18 +735,22 @@ def main():
         k_pair_ms = float(np.mean([a.elapsed_time(b) for a, b in py_events])) if py_events else float("nan")
     # host cost of enqueueing a pass, measured on a burst short enough not to hit the queue-depth back-pressure (the
     # enqueue time of the whole timed region above tracks the GPU once the HIP queue is full)
-    t1 = time.perf_counter()
-    if hot is not None:
-        hot.run(16)
-    else:
-        for _ in range(16):
-            one_pass()
-    t_burst = (time.perf_counter() - t1) / 16
-    torch.cuda.synchronize(dev)
-    if hot is not None:
-        hot.step_times_ms()               # drop the burst's event pairs
+    t_burst = None
+    if not multi:
+        t1 = time.perf_counter()
+        if hot is not None:
+            hot.run(16)
+            counter[0] = hot.counter
+        else:
+            for _ in range(16):
+                one_pass()
+        t_burst = (time.perf_counter() - t1) / 16
+        torch.cuda.synchronize(dev)
+        if hot is not None:
+            hot.step_times_ms()               # drop the burst's event pairs
 
-    # (b) back-to-back k_step launches between ONE event pair (each launch includes its ~1.5 us dispatch boundary)
+    # (b) back-to-back launches between ONE event pair (each launch includes its ~1.5 us dispatch boundary): the kernel
+    #     the loop launches -- k_step_coop<policy> = get_action + step, when this env / net can take it -- and k_step alone
     it = args.env_only_iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
@@ -588,10 +760,21 @@ def main():
     e1.record()
     torch.cuda.synchronize(dev)
     k_b2b_ms = e0.elapsed_time(e1) / it
+    kp_b2b_ms = None
+    if fused and use_c and os.environ.get("UAVENV_NO_FUSED_ACT") is None and ring.step_policy(learner, args.eps, seed, 1 << 40):
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for i in range(it):
+            ring.step_policy(learner, args.eps, seed, (1 << 40) + 1 + i)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        kp_b2b_ms = e0.elapsed_time(e1) / it
     # (c) the rocprofv3 --kernel-trace average of this same command, from the committed profile (cannot be taken in-process)
     prof = committed_profile(args)
     k_prof_ms = prof.get("k_step_ms")
-    k_ms = max(k_b2b_ms, k_prof_ms or 0.0)    # the roofline fraction is quoted on the LARGER of (b) and (c)
+    kp_prof_ms = prof.get("k_step_policy_ms")
+    k_ms = max(k_b2b_ms, k_prof_ms or 0.0)    # every roofline fraction is quoted on the LARGER of (b) and (c)
+    kp_ms = max(kp_b2b_ms, kp_prof_ms or 0.0) if kp_b2b_ms is not None else None
 
     # ---- k_dqn_grad back to back (fused learner): same ring, same batch, fresh draws per launch
     g_b2b_ms = None
@@ -632,6 +815,7 @@ def main():
         copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
 
+    out = None
     if rank == 0:
         n_agents = env.N
         value = n_pass * n_agents * world_size / dt
@@ -639,9 +823,22 @@ def main():
         # packed rows are a lossless image of the f32 row, so they are priced as f32 and simply move fewer bytes
         algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
         stored = algo - (200 if args.obs_dtype == "f16" else 400) + ring.obs.shape[-1] * ring.obs.element_size()
-        achieved = algo * n_agents / (k_ms * 1e-3) / 1e9
-        traffic = prof.get("k_step_traffic_bytes_per_launch")
+        in_loop_policy = kp_ms is not None               # the loop's launch is k_step_coop<policy>; else act + k_step
+        r_ms = kp_ms if in_loop_policy else k_ms
+        achieved = algo * n_agents / (r_ms * 1e-3) / 1e9
+        traffic = prof.get("k_step_policy_traffic_bytes_per_launch" if in_loop_policy else "k_step_traffic_bytes_per_launch")
         ldt = args.mfma if fused else "f32"
+        launches = (3 if in_loop_policy else 4) + (1 if exchange["used"] == "coll" else 0)
+        if not multi:
+            par = "one GPU (env shard x1, no exchange)"
+        elif args.sync == "fedavg":
+            par = "env-shard x%d + weight averaging every %d updates (all-reduce avg)" % (world_size, learner.fl_loop)
+        else:
+            par = "env-shard x%d + flat-bucket gradient sum per update: %s" % (world_size, {
+                "p2p": "peer-to-peer over IPC-mapped HBM on the stream (csrc/p2p.hip)",
+                "coll": "RCCL all-reduce enqueued from C on the stream (csrc/coll.hip)",
+                "rccl": "torch.distributed all_reduce (RCCL) per update from Python",
+                "none": "NO exchange (diagnostic: the ranks drift apart)"}.get(exchange["used"], str(exchange["used"])))
         out = {
             "metric": "env-steps/sec + learner updates/sec, PathPlan_City DQN",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -649,7 +846,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "passes_per_step": pps, "ms_per_pass": dt / n_pass * 1e3, "timed_region_ms": dt * 1e3,
             "learner_updates_per_s": n_pass / dt,
-            "host_enqueue_ms_per_pass": 1e3 * t_burst,
+            "host_enqueue_ms_per_pass": None if t_burst is None else 1e3 * t_burst,
             "host_enqueue_ms_per_pass_timed_region": 1e3 * t_enq / n_pass,
             "learner_samples_per_s": n_pass * args.batch * world_size / dt,
             "env_only_steps_per_s": n_agents / (k_b2b_ms * 1e-3),
@@ -659,35 +856,36 @@ def main():
                        "step_definition": "1 bench step = %d passes of (act -> env step + replay write -> sample + "
                                           "learner update) over the whole env batch" % pps,
                        "envs_per_gpu": args.envs, "learn_batch_per_gpu": args.batch, "obs_dtype": args.obs_dtype,
-                       "host_loop": "csrc/loop.hip (C, 4 launches per pass)" if use_c else "python (ctypes per launch)",
+                       "host_loop": ("csrc/loop.hip (C, %d launches per pass%s)" % (launches, ": act+step, grad, reduce+Adam" if launches == 3 else ""))
+                       if use_c else "python (ctypes per launch)",
                        "learner": "fused HIP kernels (%s MFMA)" % ldt if fused else "PyTorch-ROCm ops",
                        "learner_dtype": ldt if fused else ("f32" if args.obs_dtype == "f32" else "f16 autocast"),
                        "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
                                       % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
-                       "epsilon": args.eps, "parallelism": "env-shard x%d + %s" % (
-                           world_size, ("flat-bucket gradient sum, " + ("peer-to-peer over IPC-mapped HBM (csrc/p2p.hip)" if p2p
-                                                                          else "RCCL all-reduce")) if args.sync == "grad"
-                           else "weight averaging every 3 updates"),
-                       "p2p_timeouts": learner.p2p_timeouts() if (fused and p2p) else None},
-            "roofline": {"bound": "hbm", "kernel": "k_step (update_PathPlan + state_PathPlan + replay write)",
+                       "epsilon": args.eps, "parallelism": par},
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_step_coop<policy> -- the launch the timed loop issues: get_action (Q(s) + epsilon-greedy) + "
+                                    "update_PathPlan + state_PathPlan + replay write") if in_loop_policy
+                         else "k_step (update_PathPlan + state_PathPlan + replay write; get_action is a separate launch here)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_stale": prof.get("stale") if traffic else None,
                          "traffic_source": prof.get("source") if traffic else None,
                          "algorithmic_bytes_per_agent_step": algo, "stored_bytes_per_agent_step": stored,
                          "agents_per_launch": n_agents,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                         "kernel_ms": k_ms,
+                         "kernel_ms": r_ms,
                          "kernel_ms_definition": "max(back-to-back launches between one HIP event pair in this run, "
                                                  "rocprofv3 --kernel-trace average of the committed profile of this command)",
-                         "kernel_ms_back_to_back": k_b2b_ms, "kernel_ms_rocprofv3_committed": k_prof_ms,
-                         # inside the loop the C loop launches the step kernel WITH the policy (Q(s) + epsilon-greedy) in
-                         # its prologue (uavenv_step_policy): that launch replaces k_dqn_act + k_step
-                         "in_loop_kernel": "k_step_coop<policy> (k_dqn_act's forward + k_step)" if (use_c and args.obs_dtype == "packed"
-                                                                                                   and args.mfma == "f32") else "k_step",
-                         "in_loop_kernel_ms_event_pair": k_pair_ms,
-                         "in_loop_kernel_ms_rocprofv3_committed": prof.get("k_step_policy_ms")},
+                         "kernel_ms_back_to_back": kp_b2b_ms if in_loop_policy else k_b2b_ms,
+                         "kernel_ms_rocprofv3_committed": kp_prof_ms if in_loop_policy else k_prof_ms,
+                         "kernel_ms_event_pair_in_loop": k_pair_ms,
+                         # secondary: the step kernel WITHOUT the policy in its prologue (not what the loop runs)
+                         "k_step_alone": {"kernel_ms": k_ms, "kernel_ms_back_to_back": k_b2b_ms, "kernel_ms_rocprofv3_committed": k_prof_ms,
+                                          "achieved": algo * n_agents / (k_ms * 1e-3) / 1e9,
+                                          "frac": algo * n_agents / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
+        out.update(multi_report)
         if g_b2b_ms is not None:
             fl = learner_flops_per_sample(args.trainer)
             g_prof_ms = prof.get("k_dqn_grad_ms")
@@ -700,18 +898,55 @@ def main():
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "flops_per_sample": fl, "samples_per_launch": args.batch,
                 "kernel_ms": g_ms, "kernel_ms_back_to_back": g_b2b_ms, "kernel_ms_rocprofv3_committed": g_prof_ms,
+                "reduce_adam_ms_rocprofv3_committed": prof.get("k_dqn_reduce_adam_ms"),
                 "hbm_GBs": row * args.batch / (g_ms * 1e-3) / 1e9, "algorithmic_bytes_per_sample": row,
                 "mfma_busy_frac_pmc": prof.get("k_dqn_grad_mfma_busy_frac"),
-                "traffic": prof.get("k_dqn_grad_traffic_bytes_per_launch")}
-        if not args.no_cpu_baseline and world_size == 1:
-            out["cpu_baseline"] = cpu_baseline(args.envs, args.cpu_seconds)
-        print(json.dumps(out))
+                "traffic": prof.get("k_dqn_grad_traffic_bytes_per_launch"),
+                "counters_stale": prof.get("stale") if prof.get("k_dqn_grad_traffic_bytes_per_launch") else None}
     if hot is not None:
         hot.close()
+    if fused and multi:
+        learner.disable_p2p()
+    env.close()
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the env hot path has no CPU fallback")
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.config == 4:
+        if world_size != 1:
+            raise SystemExit("--config 4 is a single-GPU workload")
+        torch.cuda.set_device(0)
+        print(json.dumps(run_config4(args, torch.device("cuda", 0))))
+        return
+    if args.same_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
+    out = run_dqn(args, world_size, rank, dev)
+    if rank == 0 and out is not None:
+        headline = args.config == 2 and world_size == 1 and not args.env_only and not args.explicit
+        if headline and not args.no_other_configs:
+            out["other_configs"] = other_configs(args)
+        if not args.no_cpu_baseline and world_size == 1 and not args.env_only:
+            out["cpu_baseline"] = cpu_baseline(args.envs, args.cpu_seconds)
+        print(json.dumps(out))
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
-    env.close()
 
 
 if __name__ == "__main__":

@@ -8,9 +8,11 @@ from . import _build
 
 OBS_DIM = 100
 MAX_BUILDINGS = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
-OK, EINVAL, ENOMEM, EHIP, ENODEV = 0, -22, -12, -5, -19
+OK, EINVAL, ENOMEM, EHIP, ENODEV, EP2P = 0, -22, -12, -5, -19, -70
+P2P_ERR_TIMEOUT, P2P_ERR_DIVERGED = 1, 2
+COLL_ID_BYTES = 128
 INFO_NORMAL, INFO_SUCCESS, INFO_LOSE, INFO_SKIPPED = 0, 1, 2, 3
 INFO_NAMES = ("normal", "success", "lose", "skipped")
 ACT_STEER_F32, ACT_STEER_F64, ACT_INDEX_I32 = 0, 1, 2
@@ -28,6 +30,8 @@ SYMBOLS = (
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
+    "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_inject_fault",
+    "uavenv_coll_last_error", "uavenv_coll_unique_id", "uavenv_coll_create", "uavenv_coll_destroy", "uavenv_coll_allreduce_sum",
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
@@ -74,7 +78,7 @@ class UavLoopConfig(C.Structure):
                 ("eps", C.c_float), ("gamma", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("adam_eps", C.c_float), ("step_flags", C.c_uint32), ("partials_dev", C.c_void_p),
                 ("loss_dev", C.c_void_p), ("info_dev", C.c_void_p), ("p2p", C.c_void_p), ("time_every", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("reserved0", C.c_int32), ("coll", C.c_void_p), ("raw_dev", C.c_void_p)]
 
 
 class UavLoopCursor(C.Structure):
@@ -173,6 +177,21 @@ def load() -> C.CDLL:
     lib.uavenv_p2p_destroy.argtypes = [vp]
     lib.uavenv_p2p_errors.restype = C.c_int
     lib.uavenv_p2p_errors.argtypes = [vp, C.POINTER(i32)]
+    lib.uavenv_p2p_configure.restype = C.c_int
+    lib.uavenv_p2p_configure.argtypes = [vp, i32, i32]
+    lib.uavenv_p2p_status.restype = C.c_int
+    lib.uavenv_p2p_status.argtypes = [vp, i32, C.POINTER(i32)]
+    lib.uavenv_p2p_inject_fault.restype = C.c_int
+    lib.uavenv_p2p_inject_fault.argtypes = [vp, i32]
+    lib.uavenv_coll_last_error.restype = C.c_char_p
+    lib.uavenv_coll_unique_id.restype = C.c_int
+    lib.uavenv_coll_unique_id.argtypes = [C.c_char_p, vp]
+    lib.uavenv_coll_create.restype = C.c_int
+    lib.uavenv_coll_create.argtypes = [C.c_char_p, i32, i32, vp, C.POINTER(vp)]
+    lib.uavenv_coll_destroy.restype = C.c_int
+    lib.uavenv_coll_destroy.argtypes = [vp]
+    lib.uavenv_coll_allreduce_sum.restype = C.c_int
+    lib.uavenv_coll_allreduce_sum.argtypes = [vp, vp, i64, vp]
     lib.uavenv_dqn_reduce_p2p.restype = C.c_int
     lib.uavenv_dqn_reduce_p2p.argtypes = [C.POINTER(UavDqnNet), vp, i32, vp, vp]
     lib.uavenv_dqn_adam_p2p.restype = C.c_int
@@ -244,6 +263,13 @@ def load() -> C.CDLL:
         raise UavEnvError(f"libuavenv ABI {lib.uavenv_abi_version()} != binding {ABI_VERSION}")
     _LIB = lib
     return lib
+
+
+def rccl_path() -> bytes:
+    """PyTorch's own librccl.so (so that csrc/coll.hip shares the instance torch.distributed already mapped)."""
+    import torch
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p.encode() if os.path.exists(p) else b""
 
 
 def check(rc: int, what: str = "") -> None:

@@ -44,6 +44,7 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
                                                                         !cfg->net.m || !cfg->net.v)))
         return UAVENV_EINVAL;
     if (cfg->update_loop <= 0 || cfg->epoch < 0) return UAVENV_EINVAL;
+    if (!cfg->p2p && cfg->coll && !cfg->raw_dev) return UAVENV_EINVAL;
     UavLoop *l = new (std::nothrow) UavLoop();
     if (!l) return UAVENV_ENOMEM;
     l->c = *cfg;
@@ -108,6 +109,10 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
     const UavReplayRing &R = c.ring;
     const size_t n = (size_t)R.n_agents;
     hipStream_t s = (hipStream_t)stream;
+    if (c.p2p) {                              // the exchange's sticky error: stop enqueueing on frozen weights
+        int32_t st[4];
+        if (uavenv_p2p_status(c.p2p, 0, st) == UAVENV_OK && st[0] != 0) return UAVENV_EP2P;
+    }
     for (int k = 0; k < n_steps; ++k) {
         const int t = l->head, nxt = t + 1 == R.frames ? 0 : t + 1;
         unsigned char *obs_t = (unsigned char *)R.obs + (size_t)t * l->obs_row_bytes;
@@ -160,8 +165,19 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
             const int hard = l->epoch % c.update_loop == 0 ? 1 : 0;
             if (c.p2p) {                      // multi-GPU: every rank's column sums to every rank, then the same Adam step
                 rc = uavenv_dqn_reduce_p2p(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.p2p, s);
-                if (rc != UAVENV_OK) return rc;
+                if (rc != UAVENV_OK) {        // (EP2P: nothing was enqueued for this update; the step itself is in the ring)
+                    l->epoch -= 1;
+                    l->counter += 1;
+                    return rc;
+                }
                 rc = uavenv_dqn_adam_p2p(&c.net, c.p2p, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);
+                if (rc == UAVENV_EP2P) l->counter += 1;   // enqueued, but the kernel keeps the weights frozen
+            } else if (c.coll) {              // the same bucket through an RCCL all-reduce enqueued from here (csrc/coll.hip)
+                rc = uavenv_dqn_reduce(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.raw_dev, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_coll_allreduce_sum(c.coll, c.raw_dev, (int64_t)uavenv_dqn_num_params(&c.net) + 2, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_dqn_adam(&c.net, c.raw_dev, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, s);
             } else {
                 rc = uavenv_dqn_reduce_adam(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2,
                                             c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);

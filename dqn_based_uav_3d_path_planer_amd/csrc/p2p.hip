@@ -12,7 +12,15 @@
 //            ranks therefore apply bit-identical updates -- and Adam runs as in k_dqn_adam.
 // Two alternating slots per rank (seq parity): a rank can be at most one update ahead of a peer, because its next push
 // is enqueued behind its own pull of the current one.  xGMI is point to point: 7 peers x 26 KB out and in per rank and
-// update, one hop, no ring.  Every wait is bounded; a timeout is counted (uavenv_p2p_errors) instead of hanging.
+// update, one hop, no ring.
+//
+// Failure handling.  Every wait is bounded.  A timeout sets a STICKY error word (host-mapped, so the host reads it
+// without synchronising): the pull that timed out and every later one skip the Adam step -- the rank's weights freeze
+// instead of being stepped with stale or half-written slots -- and uavenv_dqn_reduce_p2p / uavenv_dqn_adam_p2p /
+// uavenv_loop_run return UAVENV_EP2P from then on, so the caller can fall back to the collective (csrc/coll.hip) and
+// re-broadcast the weights.  Every `check_every` updates the Adam kernels fold a 64-bit checksum of the new weights'
+// bit patterns into the next bucket; a rank whose peers report a different checksum raises the same sticky error
+// (code UAVENV_P2P_ERR_DIVERGED): the ranks are bit-identical by construction and this is how a violation shows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -23,7 +31,7 @@
 
 namespace {
 constexpr int kMaxWorld = 16;
-constexpr uint32_t kSpinLimit = 1u << 22;            // x ~0.25 us per poll: about a second
+constexpr uint32_t kSpinLimit = 1u << 22;            // x ~0.25 us per poll: about a second (uavenv_p2p_configure changes it)
 }
 
 struct UavP2P {
@@ -32,9 +40,16 @@ struct UavP2P {
     unsigned char *local = nullptr;                   // [flags: kMaxWorld x 64 B][recv: world x 2 x bucket_pad floats]
     unsigned char *peer[kMaxWorld] = {nullptr};       // peer[r] = rank r's area as mapped here (peer[rank] = local)
     bool opened[kMaxWorld] = {false};
-    uint32_t *counter = nullptr;                      // [2] workgroup tickets (ordinary device memory)
-    uint32_t *errors = nullptr;                       // timeouts seen by this rank's pulls
+    unsigned long long *wsum = nullptr;               // [2] weight checksums (device memory), by parity of the check index
+    uint32_t *errors = nullptr;                       // device: [0] timeouts, [1] sticky error code, [2] checksum mismatches
+    volatile uint32_t *host_code = nullptr;           // host-mapped copy of the sticky code (polled without synchronising)
+    uint32_t *host_code_dev = nullptr;                // its device address
     uint32_t seq = 0;
+    uint32_t spin_limit = kSpinLimit;
+    int carry_cur = -1, pending_idx = 0;
+    uint32_t check_every = 256;                       // 0 = never
+    uint32_t n_checks = 0;                            // checksums folded so far
+    bool check_pending = false;                       // the last Adam folded a checksum: the next push carries it
     bool connected = false;
 };
 
@@ -44,7 +59,11 @@ struct P2PDev {
     unsigned char *peer[kMaxWorld];
     int world, rank, bucket_pad;
     uint32_t seq;
-    uint32_t *counter, *errors;
+    unsigned long long *wsum;                         // [2]
+    uint32_t *errors;                                 // [0] timeouts, [1] sticky code, [2] mismatches
+    uint32_t *host_code;                              // host-mapped copy of [1]
+    uint32_t spin_limit;
+    int carry, fold;                                  // push: carry wsum[carry] (or -1); pull: fold into wsum[fold] (or -1)
 };
 
 __device__ __forceinline__ float *recv_slot(unsigned char *area, int from, uint32_t seq, int bucket_pad)
@@ -97,6 +116,21 @@ __global__ void __launch_bounds__(256) k_p2p_reduce_push(const float *__restrict
         for (int r = 0; r < d.world; ++r)                                        // 128 B per workgroup and peer
             __hip_atomic_store(recv_slot(d.peer[r], d.rank, d.seq, d.bucket_pad) + p, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // words P + 2, P + 3 of the bucket: the checksum of the weights the previous Adam left (its bit pattern, never
+    // touched by arithmetic), or zeros; the accumulator the NEXT fold will use is cleared here (its last reader was the
+    // push before this one)
+    if (blockIdx.x == 0 && tid == 32) {
+        unsigned long long w = 0ull;
+        if (d.carry >= 0) {
+            w = __hip_atomic_load(d.wsum + d.carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.wsum + (d.carry ^ 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int r = 0; r < d.world; ++r) {
+            uint32_t *slot = reinterpret_cast<uint32_t *>(recv_slot(d.peer[r], d.rank, d.seq, d.bucket_pad));
+            __hip_atomic_store(slot + P + 2, (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(slot + P + 3, (uint32_t)(w >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     __threadfence_system();                                                      // this workgroup's stores are out
 }
 
@@ -115,20 +149,45 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
         __threadfence_system();
         __hip_atomic_store(flag_of(d.peer[threadIdx.x], d.rank), d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __shared__ uint32_t s_bad;
+    __shared__ unsigned long long s_sum;
     if (threadIdx.x == 0) {
-        for (int r = 0; r < d.world; ++r) {
+        uint32_t bad = __hip_atomic_load(d.errors + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky
+        for (int r = 0; r < d.world && !bad; ++r) {
             uint32_t spins = 0;
             while ((int32_t)(__hip_atomic_load(flag_of(mine, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.seq) < 0) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > kSpinLimit) {
-                    atomicAdd(d.errors, 1u);
+                if (++spins > d.spin_limit) {
+                    __hip_atomic_fetch_add(d.errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    bad = UAVENV_P2P_ERR_TIMEOUT;
                     break;
                 }
             }
         }
         __threadfence_system();
+        if (!bad && d.carry >= 0) {              // every rank folded a checksum of its weights into this bucket: all equal?
+            const uint32_t *s0 = reinterpret_cast<const uint32_t *>(recv_slot(mine, 0, d.seq, d.bucket_pad));
+            const uint32_t lo = __hip_atomic_load(s0 + P + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t hi = __hip_atomic_load(s0 + P + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int r = 1; r < d.world; ++r) {
+                const uint32_t *sr = reinterpret_cast<const uint32_t *>(recv_slot(mine, r, d.seq, d.bucket_pad));
+                if (__hip_atomic_load(sr + P + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != lo ||
+                    __hip_atomic_load(sr + P + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != hi)
+                    bad = UAVENV_P2P_ERR_DIVERGED;
+            }
+            if (bad && blockIdx.x == 0) {
+                __hip_atomic_fetch_add(d.errors + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_DIVERGED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_DIVERGED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        s_bad = bad;
+        s_sum = 0ull;
     }
     __syncthreads();
+    const bool frozen = s_bad != 0;              // the sums below may be stale: report them, never step with them
     const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     float cnt = 0.0f, lsum = 0.0f;
     for (int r = 0; r < d.world; ++r) {
@@ -137,30 +196,48 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
         lsum += __hip_atomic_load(slot + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const float inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
-    if (p == 0 && loss) *loss = lsum * inv;
+    if (p == 0 && loss && !frozen) *loss = lsum * inv;
     if (p == 0 && raw_out) { raw_out[P] = lsum; raw_out[P + 1] = cnt; }
-    if (p >= P) return;
-    float gsum = 0.0f;
-    for (int r = 0; r < d.world; ++r)
-        gsum += __hip_atomic_load(recv_slot(mine, r, d.seq, d.bucket_pad) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (raw_out) raw_out[p] = gsum;
-    if (!local) return;                                                          // sum only (self-test)
-    const float gp = gsum * inv;
-    const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);
-    const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;
-    m[p] = mp;
-    v[p] = vp;
-    const float np = local[p] - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
-    local[p] = np;
-    if (hard_update) target[p] = np;
+    float np = 0.0f;
+    if (p < P) {
+        float gsum = 0.0f;
+        for (int r = 0; r < d.world; ++r)
+            gsum += __hip_atomic_load(recv_slot(mine, r, d.seq, d.bucket_pad) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (raw_out) raw_out[p] = gsum;
+        if (local) {                                                             // (NULL: sum only, self-test)
+            np = local[p];
+            if (!frozen) {
+                const float gp = gsum * inv;
+                const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);
+                const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;
+                m[p] = mp;
+                v[p] = vp;
+                np = np - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
+                local[p] = np;
+                if (hard_update) target[p] = np;
+            }
+        }
+    }
+    if (d.fold >= 0 && local) {                  // checksum of the weights after this step: sum over p of mix(bits, p)
+        unsigned long long h = 0ull;
+        if (p < P) {
+            unsigned long long x = ((unsigned long long)__float_as_uint(np) << 20) ^ (unsigned long long)(p + 1) * 0x9E3779B97F4A7C15ull;
+            x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+            h = x;
+        }
+        atomicAdd(&s_sum, h);                    // LDS
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(d.wsum + d.fold, s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-P2PDev dev_view(const UavP2P *c)
+P2PDev dev_view(const UavP2P *c, int carry, int fold)
 {
     P2PDev d;
     for (int r = 0; r < kMaxWorld; ++r) d.peer[r] = c->peer[r];
     d.world = c->world; d.rank = c->rank; d.bucket_pad = c->bucket_pad; d.seq = c->seq;
-    d.counter = c->counter; d.errors = c->errors;
+    d.wsum = c->wsum; d.errors = c->errors; d.host_code = c->host_code_dev; d.spin_limit = c->spin_limit;
+    d.carry = carry; d.fold = fold;
     return d;
 }
 
@@ -174,18 +251,35 @@ int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P
     UavP2P *c = new (std::nothrow) UavP2P();
     if (!c) return UAVENV_ENOMEM;
     c->world = world; c->rank = rank; c->bucket = bucket_floats;
-    c->bucket_pad = (bucket_floats + 63) & ~63;
+    c->bucket_pad = (bucket_floats + 2 + 63) & ~63;           // + the two checksum words
     c->bytes = (size_t)kMaxWorld * 64 + (size_t)world * 2 * c->bucket_pad * sizeof(float);
     // uncached: peers write it while this device reads it inside running kernels
     if (hipExtMallocWithFlags((void **)&c->local, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return UAVENV_ENOMEM; }
-    if (hipMalloc((void **)&c->counter, 3 * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(c->local); delete c; return UAVENV_ENOMEM; }
-    c->errors = c->counter + 2;
+    if (hipMalloc((void **)&c->wsum, 2 * sizeof(unsigned long long) + 4 * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(c->local); delete c; return UAVENV_ENOMEM;
+    }
+    c->errors = reinterpret_cast<uint32_t *>(c->wsum + 2);
+    // the sticky error code also lands in host-mapped memory: the host polls it without synchronising
+    if (hipHostMalloc((void **)&c->host_code, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->host_code_dev, (void *)c->host_code, 0) != hipSuccess) {
+        if (c->host_code) (void)hipHostFree((void *)c->host_code);
+        (void)hipFree(c->local); (void)hipFree(c->wsum); delete c; return UAVENV_ENOMEM;
+    }
+    *c->host_code = 0;
     (void)hipMemset(c->local, 0, c->bytes);
-    (void)hipMemset(c->counter, 0, 3 * sizeof(uint32_t));
+    (void)hipMemset(c->wsum, 0, 2 * sizeof(unsigned long long) + 4 * sizeof(uint32_t));
     (void)hipDeviceSynchronize();
     c->peer[rank] = c->local;
     c->connected = world == 1;
     *out = c;
+    return UAVENV_OK;
+}
+
+int uavenv_p2p_configure(UavP2P *c, int32_t check_every, int32_t spin_limit)
+{
+    if (!c || check_every < 0 || spin_limit < 0) return UAVENV_EINVAL;
+    c->check_every = (uint32_t)check_every;
+    if (spin_limit > 0) c->spin_limit = (uint32_t)spin_limit;
     return UAVENV_OK;
 }
 
@@ -223,7 +317,8 @@ int uavenv_p2p_destroy(UavP2P *c)
     for (int r = 0; r < c->world; ++r)
         if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
     (void)hipFree(c->local);
-    (void)hipFree(c->counter);
+    (void)hipFree(c->wsum);
+    if (c->host_code) (void)hipHostFree((void *)c->host_code);
     delete c;
     return UAVENV_OK;
 }
@@ -237,15 +332,45 @@ int uavenv_p2p_errors(UavP2P *c, int32_t *timeouts_out)
     return UAVENV_OK;
 }
 
+int uavenv_p2p_status(UavP2P *c, int32_t synchronise, int32_t *out4)
+{
+    if (!c || !out4) return UAVENV_EINVAL;
+    out4[0] = (int32_t)*c->host_code;                          // sticky code as the host sees it right now
+    out4[1] = out4[2] = -1;
+    out4[3] = (int32_t)c->n_checks;
+    if (synchronise) {
+        uint32_t e[3] = {0, 0, 0};
+        if (hipMemcpy(e, c->errors, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return UAVENV_EHIP;
+        out4[0] = (int32_t)e[1]; out4[1] = (int32_t)e[0]; out4[2] = (int32_t)e[2];
+    }
+    return UAVENV_OK;
+}
+
+int uavenv_p2p_inject_fault(UavP2P *c, int32_t code)
+{
+    if (!c || code < 0) return UAVENV_EINVAL;
+    const uint32_t v = (uint32_t)code;
+    if (hipMemcpy(c->errors + 1, &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) return UAVENV_EHIP;
+    *c->host_code = v;
+    return UAVENV_OK;
+}
+
 int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials, int32_t n_partials, UavP2P *c, void *stream)
 {
     if (!net || !partials || n_partials <= 0 || !c || !c->connected) return UAVENV_EINVAL;
     const int P = uavenv_dqn_num_params(net);
     if (P <= 0 || P + 2 > c->bucket) return UAVENV_EINVAL;
+    if (*c->host_code) return UAVENV_EP2P;                     // sticky: this rank no longer steps (see the header comment)
     c->seq += 1;
+    c->carry_cur = c->check_pending ? c->pending_idx : -1;
     hipLaunchKernelGGL(k_p2p_reduce_push, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials, P,
-                       uavenv_dqn_partial_stride(net), dev_view(c));
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+                       uavenv_dqn_partial_stride(net), dev_view(c, c->carry_cur, -1));
+    if (hipGetLastError() != hipSuccess) {
+        c->seq -= 1;                                           // nothing was enqueued: the sequence number is not used up
+        return UAVENV_EHIP;
+    }
+    c->check_pending = false;
+    return UAVENV_OK;
 }
 
 int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *c, float lr, float beta1, float beta2, float eps, int32_t step_t,
@@ -259,10 +384,18 @@ int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *c, float lr, float beta1, 
     if (!apply && !raw_out) return UAVENV_EINVAL;
     const float bc1 = apply ? 1.0f - powf(beta1, (float)step_t) : 1.0f;
     const float bc2 = apply ? 1.0f - powf(beta2, (float)step_t) : 1.0f;
-    hipLaunchKernelGGL(k_p2p_pull_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_view(c),
+    const bool fold = apply && c->check_every > 0 && c->seq % c->check_every == 0;
+    const int fold_idx = fold ? (int)(c->n_checks & 1u) : -1;
+    hipLaunchKernelGGL(k_p2p_pull_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_view(c, c->carry_cur, fold_idx),
                        apply ? net->local : (float *)nullptr, net->target, net->m, net->v, raw_out, P, lr, beta1, beta2, eps,
                        bc1, sqrtf(bc2), hard_update, loss_out);
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+    if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
+    if (fold) {
+        c->check_pending = true;
+        c->pending_idx = fold_idx;
+        c->n_checks += 1;
+    }
+    return *c->host_code ? UAVENV_EP2P : UAVENV_OK;
 }
 
 }  // extern "C"

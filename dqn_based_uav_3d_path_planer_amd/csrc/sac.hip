@@ -463,8 +463,10 @@ __device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
     T.w = 1.0f;
     if (CRITIC) {
         if (NEXT) { T.rew = g.reward[rs]; T.nd = 1.0f - (float)g.done[rs]; }
-        else { T.a0 = g.act0[rs]; T.a1 = g.act1[rs]; T.w = g.valid ? (float)g.valid[rs] : 1.0f; }
+        else { T.a0 = g.act0[rs]; T.a1 = g.act1[rs]; }
     }
+    // rows of agents that were only waiting for their team-mates (valid = 0) are not replay memory: weight 0 in every loss
+    if (!NEXT) T.w = g.valid ? (float)g.valid[rs] : 1.0f;
     if (NEXT || !CRITIC) { T.e0 = g.eps[2 * smp]; T.e1 = g.eps[2 * smp + 1]; } else { T.e0 = T.e1 = 0.0f; }
 }
 
@@ -546,7 +548,7 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
         for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) aw2[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-        float s_bo0 = 0.0f, s_bo1 = 0.0f, s_loss = 0.0f;
+        float s_bo0 = 0.0f, s_bo1 = 0.0f, s_loss = 0.0f, s_cnt = 0.0f;
         for (int j = 0; j < nt; ++j) {
             TileIn Tn = T;
             if (j + 1 < nt) tile_in<false, true>(g, t0 + j + 1, Tn);
@@ -556,7 +558,7 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
             critic_fwd(S, T.R, T.a0, T.a1, Fo, acc1, acc2, q);
             const float e0 = q[0] - td[0], e1 = q[1] - td[1];
             const float dq0 = T.w * e0 * inv_b, dq1 = T.w * e1 * inv_b;  // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
-            if (gq == 0) { s_loss += T.w * (e0 * e0 + e1 * e1); s_bo0 += dq0; s_bo1 += dq1; }
+            if (gq == 0) { s_loss += T.w * (e0 * e0 + e1 * e1); s_bo0 += dq0; s_bo1 += dq1; s_cnt += T.w; }
             floatx4 dh1[4], dh2[4], h1[4], h2[4];
             critic_bwd(S, Fo, acc1, acc2, dq0, dq1, dh1, dh2);
             relu4(acc1, h1);
@@ -588,17 +590,19 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
             if (r < 2) out[kCoWo + r * kHid + 16 * wv + 4 * gq + reg] = awo[reg];
             if (r == 0) out[kCob2 + 16 * wv + 4 * gq + reg] = ab2[reg];
         }
-        s_bo0 = wave_sum(s_bo0); s_bo1 = wave_sum(s_bo1); s_loss = wave_sum(s_loss);
-        if (lane == 0) { red[wv * 4] = s_bo0; red[wv * 4 + 1] = s_bo1; red[wv * 4 + 2] = s_loss; }
+        s_bo0 = wave_sum(s_bo0); s_bo1 = wave_sum(s_bo1); s_loss = wave_sum(s_loss); s_cnt = wave_sum(s_cnt);
+        if (lane == 0) { red[wv * 4] = s_bo0; red[wv * 4 + 1] = s_bo1; red[wv * 4 + 2] = s_loss; red[wv * 4 + 3] = s_cnt; }
         __syncthreads();
-        if (tid < 3) {
+        if (tid < 4) {
             const float s = (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]);
             if (tid < 2) out[kCobo + tid] = s;
-            else g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + c] = s * 0.5f * inv_b;      // mean over [B, 2]
-        }
-        if (tid == 3 && c == 0) {
-            g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + 2] = 0.0f;
-            g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + 3] = 0.0f;
+            else if (tid == 2) g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + c] = s * 0.5f * inv_b;      // mean over [B, 2]
+            else if (c == 0) {
+                // the valid FRACTION of the batch this workgroup saw (column sum = sum of valid / B, summed over the ranks
+                // after an all-reduce): the Adam kernel divides every column by it -> means over the valid samples
+                g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + 2] = s * inv_b;
+                g.partials[(size_t)blockIdx.x * kStrideC + 2 * kPc + 3] = 0.0f;
+            }
         }
         __syncthreads();
         S_STAMP(8 + 6 * c);
@@ -641,10 +645,11 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
     floatx4 aw1[7], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-    float s_b[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s_lp = 0.0f, s_loss = 0.0f;
+    float s_b[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s_lp = 0.0f, s_loss = 0.0f, s_cnt = 0.0f;
     for (int j = 0; j < nt; ++j) {
         TileIn Tn = T;
         if (j + 1 < nt) tile_in<false, false>(g, t0 + j + 1, Tn);
+        const float w_lp = g_lp * T.w, w_2b = inv_2b * T.w;               // this sample's weight in the two loss terms
         // a~, log pi(a~ | s)
         floatx4 acc[4];
         fwd_strip_packed(Wa, T.R, acc);
@@ -660,15 +665,16 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
         critic_fwd(S2, T.R, a0, a1, Fo2, c2a, c2b, q2);
         const bool m0 = q2[0] < q1[0], m1 = q2[1] < q1[1];
         if (gq == 0) {
-            s_lp += A.lp[0] + A.lp[1];
-            s_loss += alpha * (A.lp[0] + A.lp[1]) - ((m0 ? q2[0] : q1[0]) + (m1 ? q2[1] : q1[1]));       // :364-365
+            s_lp += T.w * (A.lp[0] + A.lp[1]);
+            s_loss += T.w * (alpha * (A.lp[0] + A.lp[1]) - ((m0 ? q2[0] : q1[0]) + (m1 ? q2[1] : q1[1])));       // :364-365
+            s_cnt += T.w;
         }
         float da0 = 0.0f, da1 = 0.0f;
         {
             floatx4 dh1[4], dh2[4];
-            critic_bwd(S2, Fo2, c2a, c2b, m0 ? -inv_2b : 0.0f, m1 ? -inv_2b : 0.0f, dh1, dh2);
+            critic_bwd(S2, Fo2, c2a, c2b, m0 ? -w_2b : 0.0f, m1 ? -w_2b : 0.0f, dh1, dh2);
             action_grad_part(S2, dh1, da0, da1);
-            critic_bwd(S1, Fo1, c1a, c1b, m0 ? 0.0f : -inv_2b, m1 ? 0.0f : -inv_2b, dh1, dh2);
+            critic_bwd(S1, Fo1, c1a, c1b, m0 ? 0.0f : -w_2b, m1 ? 0.0f : -w_2b, dh1, dh2);
             action_grad_part(S1, dh1, da0, da1);
         }
         da0 = group_sum4(da0);
@@ -680,9 +686,9 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
         for (int d = 0; d < 2; ++d) {
             const float th = tanhf(A.act[d]);
             const float u = 1.0f - th * th + 1e-7f;
-            const float dact = g_lp * (2.0f * th * (1.0f - th * th) / u) + g.bound * dav[d];
+            const float dact = w_lp * (2.0f * th * (1.0f - th * th) / u) + g.bound * dav[d];
             const float dns = dact * (1.0f - A.act[d] * A.act[d]);
-            const float dsd = dns * ev[d] - g_lp / A.sd[d];
+            const float dsd = dns * ev[d] - w_lp / A.sd[d];
             const float s = A.spre[d];
             const float sig = s > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-s));
             dout[d] = dns * (1.0f - A.mu[d] * A.mu[d]);                       // fc_mu pre-activation
@@ -720,20 +726,23 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
     for (int a = 0; a < 4; ++a) s_b[a] = wave_sum(s_b[a]);
     s_lp = wave_sum(s_lp);
     s_loss = wave_sum(s_loss);
+    s_cnt = wave_sum(s_cnt);
     if (lane == 0) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) red[wv * 8 + a] = s_b[a];
         red[wv * 8 + 4] = s_loss;
         red[wv * 8 + 5] = s_lp;
+        red[wv * 8 + 6] = s_cnt;
     }
     __syncthreads();
-    if (tid < 6) {
+    if (tid < 7) {
         const float s = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
         if (tid < 4) out[kAob2 + tid] = s;
         else if (tid == 4) out[kPa] = s * inv_2b;
-        else out[kPa + 1] = s;
+        else if (tid == 5) out[kPa + 1] = s;
+        else out[kPa + 2] = s * 2.0f * inv_2b;               // valid fraction of the batch (see k_sac_critic_grad)
     }
-    if (tid == 6) { out[kPa + 2] = 0.0f; out[kPa + 3] = 0.0f; }
+    if (tid == 7) out[kPa + 3] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -799,6 +808,8 @@ struct AdamArgs {
     // log_alpha step (actor phase): extras column 1 holds sum log pi over [B, 2]
     float *log_alpha, *alpha_mv;             // nullable; alpha_mv = {exp_avg, exp_avg_sq}
     float alpha_lr, target_entropy, inv_2b;
+    int frac_col;                            // column holding the valid fraction of the batch (-1: scale by grad_scale instead)
+    int n_loss;                              // the first n_loss extras are loss means
 };
 
 __device__ __forceinline__ float adam_step(float p, float g, float &m, float &v, const AdamArgs &a, float lr)
@@ -813,21 +824,24 @@ __device__ __forceinline__ float adam_step(float p, float g, float &m, float &v,
 __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgs a)
 {
     __shared__ float part[4][64];
+    __shared__ float fpart[4];
     const int cl = (int)threadIdx.x & 63, rg = (int)threadIdx.x >> 6;
     const int col = (int)blockIdx.x * 64 + cl;
     const int total = a.seg[0].n + (a.nseg > 1 ? a.seg[1].n : 0) + a.extras;
     const float *src = a.partials + (col < total ? col : total - 1);
-    float s = 0.0f;
+    const float *fsrc = a.partials + (a.frac_col >= 0 ? a.frac_col : 0);      // the valid-fraction column (every lane: same address)
+    float s = 0.0f, f = 0.0f;
     int b = rg;
     for (; b + 28 < a.rows; b += 32) {
-        float t[8];
+        float t[8], u[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = src[(size_t)(b + 4 * k) * a.stride];
+        for (int k = 0; k < 8; ++k) { t[k] = src[(size_t)(b + 4 * k) * a.stride]; u[k] = fsrc[(size_t)(b + 4 * k) * a.stride]; }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += t[k];
+        for (int k = 0; k < 8; ++k) { s += t[k]; f += u[k]; }
     }
-    for (; b < a.rows; b += 4) s += src[(size_t)b * a.stride];
+    for (; b < a.rows; b += 4) { s += src[(size_t)b * a.stride]; f += fsrc[(size_t)b * a.stride]; }
     part[rg][cl] = s;
+    if (cl == 0) fpart[rg] = f;
     __syncthreads();
     if (rg != 0 || col >= total) return;
     s = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
@@ -835,24 +849,28 @@ __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgs a)
         a.raw_out[col] = s;
         return;
     }
-    s *= a.grad_scale;
+    // every column was accumulated as sum_i w_i (...) / B per rank; frac = sum of the ranks' (valid / B): dividing by it
+    // gives the mean over the valid samples of all ranks (all valid: 1 / world size)
+    const float frac = (fpart[0] + fpart[1]) + (fpart[2] + fpart[3]);
+    const float norm = a.frac_col >= 0 ? (frac > 0.0f ? 1.0f / frac : 0.0f) : a.grad_scale;
     int c = col;
     for (int k = 0; k < a.nseg; ++k) {
         const AdamSeg &sg = a.seg[k];
         if (c < sg.n) {
             float m = sg.m[c], v = sg.v[c];
-            const float np = adam_step(sg.p[c], s, m, v, a, sg.lr);
+            const float np = adam_step(sg.p[c], s * norm, m, v, a, sg.lr);
             sg.m[c] = m; sg.v[c] = v; sg.p[c] = np;
             if (sg.tgt) sg.tgt[c] = sg.tgt[c] * (1.0f - a.tau) + np * a.tau;
             return;
         }
         c -= sg.n;
     }
-    if (a.scalars_out) a.scalars_out[c] = s;
+    // extras: losses (means: normalised like the gradients), then raw sums (sum log pi; the valid fraction)
+    if (a.scalars_out) a.scalars_out[c] = c < a.n_loss ? s * norm : s;
     if (c == 1 && a.log_alpha) {
-        // alpha_loss = mean((entropy - target_entropy).detach() * exp(log_alpha))   (:372-375)
+        // alpha_loss = mean((entropy - target_entropy).detach() * exp(log_alpha))   (:372-375), over the valid samples
         const float la = *a.log_alpha;
-        const float gl = expf(la) * (-s * a.inv_2b - a.target_entropy);
+        const float gl = expf(la) * (-s * a.inv_2b * norm - a.target_entropy);
         float m = a.alpha_mv[0], v = a.alpha_mv[1];
         const float nla = adam_step(la, gl, m, v, a, a.alpha_lr);
         a.alpha_mv[0] = m; a.alpha_mv[1] = v;
@@ -972,6 +990,7 @@ int uavenv_sac_reduce(const float *partials, int32_t rows, int32_t stride, float
     a.partials = partials; a.rows = rows; a.stride = stride; a.nseg = 1; a.extras = 0;
     a.seg[0].n = stride;
     a.raw_out = raw;
+    a.frac_col = -1;
     hipLaunchKernelGGL(k_sac_reduce_adam, dim3((stride + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_reduce: launch failed");
 }
@@ -986,7 +1005,9 @@ int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_
     a.seg[1] = AdamSeg{nets->critic2, m2, v2, nets->target2, kPc, h->lr};
     a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
     a.tau = h->tau;
-    a.grad_scale = h->grad_scale > 0.0f ? h->grad_scale : 1.0f;
+    a.grad_scale = 1.0f;
+    a.frac_col = 2 * kPc + 2;
+    a.n_loss = 2;
     a.scalars_out = losses_out;
     const int total = 2 * kPc + 4;
     hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
@@ -1004,7 +1025,9 @@ int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t
     a.seg[0] = AdamSeg{nets->actor, m, v, nullptr, kPa, h->lr};
     a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
     a.tau = 0.0f;
-    a.grad_scale = h->grad_scale > 0.0f ? h->grad_scale : 1.0f;
+    a.grad_scale = 1.0f;
+    a.frac_col = kPa + 2;
+    a.n_loss = 1;
     a.scalars_out = scalars_out;
     a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
     a.inv_2b = 0.5f / (float)batch;

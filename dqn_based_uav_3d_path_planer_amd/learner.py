@@ -348,11 +348,13 @@ class FusedDQNLearner:
         return self.learn_from_ring(r, bp, 0, 0, explicit_idx=buf["idx"])
 
     # -- multi-GPU: the gradient bucket summed over peer-mapped HBM instead of a collective call -------------------
-    def enable_p2p(self, verify: bool = True) -> bool:
+    def enable_p2p(self, verify: bool = True, check_every: int = 256, spin_limit: int = 0) -> bool:
         """Set up csrc/p2p.hip between the ranks of the initialised process group (one rank per GPU of ONE node): every
         rank maps every other rank's receive area through HIP IPC.  With verify, one all-reduce of a known vector is
         compared with torch.distributed's result on every rank; on any failure (IPC not available, timeout, mismatch)
-        the learner keeps the RCCL path.  Returns whether the peer-to-peer path is active on ALL ranks."""
+        the learner keeps the RCCL path.  Returns whether the peer-to-peer path is active on ALL ranks.
+        check_every: the ranks compare a checksum of their weights on the device every that many updates (0 = never);
+        spin_limit: polls before a flag wait gives up (0 = the library's default, about a second)."""
         C, _lib = self._C, self._lib_mod
         self._p2p = None
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -361,6 +363,7 @@ class FusedDQNLearner:
         ok, h = True, C.c_void_p()
         try:
             _lib.check(self.lib.uavenv_p2p_create(world, rank, self.P + 2, C.byref(h)), "uavenv_p2p_create")
+            _lib.check(self.lib.uavenv_p2p_configure(h, int(check_every), int(spin_limit)), "uavenv_p2p_configure")
             mine = (C.c_ubyte * _lib.P2P_HANDLE_BYTES)()
             _lib.check(self.lib.uavenv_p2p_handle(h, mine), "uavenv_p2p_handle")
         except Exception:
@@ -404,6 +407,73 @@ class FusedDQNLearner:
         err = self._C.c_int32(0)
         self.lib.uavenv_p2p_errors(self._p2p, self._C.byref(err))
         return int(err.value)
+
+    def p2p_status(self, synchronise: bool = True) -> dict:
+        """{'code': sticky error (0 healthy, 1 timeout, 2 ranks diverged), 'timeouts', 'mismatches', 'checks'} of the
+        peer exchange; synchronise=False reads only the host-mapped code (no device round trip)."""
+        if getattr(self, "_p2p", None) is None:
+            return {"code": 0, "timeouts": 0, "mismatches": 0, "checks": 0}
+        out = (self._C.c_int32 * 4)()
+        self._lib_mod.check(self.lib.uavenv_p2p_status(self._p2p, 1 if synchronise else 0, out), "uavenv_p2p_status")
+        return {"code": int(out[0]), "timeouts": int(out[1]), "mismatches": int(out[2]), "checks": int(out[3])}
+
+    def disable_p2p(self):
+        if getattr(self, "_p2p", None) is not None:
+            self.lib.uavenv_p2p_destroy(self._p2p)
+            self._p2p = None
+
+    def enable_coll(self) -> bool:
+        """The RCCL fallback of the peer exchange, enqueued from C (csrc/coll.hip): rank 0 draws the communicator id,
+        it travels over the process group, every rank joins.  With it the C loop (csrc/loop.hip) keeps driving the
+        pass at N > 1 when csrc/p2p.hip is unavailable.  Returns whether the communicator is up on ALL ranks."""
+        C, _lib = self._C, self._lib_mod
+        self._coll = None
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return False
+        world, rank = dist.get_world_size(), dist.get_rank()
+        path = _lib.rccl_path()
+        buf = (C.c_ubyte * _lib.COLL_ID_BYTES)()
+        ok = True
+        if rank == 0:
+            ok = self.lib.uavenv_coll_unique_id(path, buf) == 0
+        box = [(ok, bytes(buf))]
+        dist.broadcast_object_list(box, src=0)
+        ok, idb = box[0]
+        h = C.c_void_p()
+        if ok:
+            torch.cuda.set_device(self.device)
+            ok = self.lib.uavenv_coll_create(path, world, rank, C.create_string_buffer(idb, len(idb)), C.byref(h)) == 0
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if not all(flags):
+            if h.value:
+                self.lib.uavenv_coll_destroy(h)
+            return False
+        # one exchange of a known vector against torch.distributed's result
+        t = torch.arange(self.P + 2, device=self.device, dtype=torch.float32) * 1e-3 + (rank + 1)
+        want = t.clone()
+        dist.all_reduce(want, op=dist.ReduceOp.SUM)
+        rc = self.lib.uavenv_coll_allreduce_sum(h, t.data_ptr(), self.P + 2, self._stream())
+        torch.cuda.synchronize(self.device)
+        ok = rc == 0 and bool(torch.allclose(t, want, rtol=1e-6, atol=1e-6))
+        dist.all_gather_object(flags, ok)
+        if not all(flags):
+            self.lib.uavenv_coll_destroy(h)
+            return False
+        self._coll = h
+        return True
+
+    def broadcast_weights(self, src: int = 0):
+        """All four flat blocks (q_local, q_target, Adam's moments) of rank `src` to every rank: the recovery step after
+        the peer exchange raised its sticky error (the ranks may have diverged by then)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self._flat_pad, src=src)
+
+    def weights_checksum(self) -> int:
+        """64-bit sum of the weight blocks' bit patterns (q_local + q_target): equal on every rank iff they are bit-identical."""
+        w = self._flat_pad[:2].contiguous().view(torch.int32).to(torch.int64)
+        idx = torch.arange(1, w.numel() + 1, device=w.device, dtype=torch.int64)
+        return int(((w.view(-1) & 0xFFFFFFFF) * idx).sum().item())
 
     def act(self, obs: torch.Tensor, eps: float, seed: int, counter: int, index_out: torch.Tensor = None,
             steer_out: torch.Tensor = None, q_out: torch.Tensor = None):
@@ -453,7 +523,10 @@ class FusedDQNLearner:
         _lib.check(rc, "uavenv_dqn_reduce")
         # one ~26 KB bucket over RCCL / xGMI: gradient SUMS + loss sum + valid count, so the update is the mean over
         # the valid samples of all ranks (== single-GPU on the concatenated batch)
-        if multi:
+        if multi and getattr(self, "_coll", None) is not None:    # RCCL enqueued from C on the same stream (csrc/coll.hip)
+            _lib.check(self.lib.uavenv_coll_allreduce_sum(self._coll, self.raw.data_ptr(), self.P + 2, s),
+                       "uavenv_coll_allreduce_sum")
+        elif multi:
             dist.all_reduce(self.raw, op=dist.ReduceOp.SUM)
         rc = self.lib.uavenv_dqn_adam(C.byref(self.net), self.raw.data_ptr(), self.lr, self.betas[0], self.betas[1],
                                       self.eps, self.epoch, hard, self.loss.data_ptr(), s)

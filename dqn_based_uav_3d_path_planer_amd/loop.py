@@ -15,6 +15,10 @@ from .learner import FusedDQNLearner
 from .replay import DeviceReplayRing
 
 
+class P2PExchangeError(_lib.UavEnvError):
+    """uavenv_loop_run returned UAVENV_EP2P (csrc/p2p.hip: timeout or diverged ranks)."""
+
+
 class HotLoop:
     def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
                  counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
@@ -54,6 +58,9 @@ class HotLoop:
         self._info = info
         if getattr(learner, "_p2p", None) is not None:      # multi-GPU: the gradient sum goes through csrc/p2p.hip
             cfg.p2p = learner._p2p
+        elif getattr(learner, "_coll", None) is not None:   # ... or through an RCCL all-reduce enqueued from C
+            cfg.coll = learner._coll
+            cfg.raw_dev = learner.raw.data_ptr()
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_loop_create")
         self.counter = int(counter)
@@ -75,7 +82,16 @@ class HotLoop:
     def run(self, n_steps: int):
         """Enqueue n_steps of act -> step -> learn on the current torch stream (asynchronous)."""
         s = torch.cuda.current_stream(self.ring.env.device).cuda_stream
-        _lib.check(self.lib.uavenv_loop_run(self._h, int(n_steps), s), "uavenv_loop_run")
+        rc = self.lib.uavenv_loop_run(self._h, int(n_steps), s)
+        if rc == _lib.EP2P:
+            self._sync_cursor()
+            raise P2PExchangeError("the peer-to-peer gradient exchange raised its sticky error "
+                                   f"({self.learner.p2p_status()}): this rank's weights are frozen; fall back to the "
+                                   "collective (FusedDQNLearner.enable_coll) and re-broadcast the weights")
+        _lib.check(rc, "uavenv_loop_run")
+        self._sync_cursor()
+
+    def _sync_cursor(self):
         cur = _lib.UavLoopCursor()
         _lib.check(self.lib.uavenv_loop_get(self._h, C.byref(cur)), "uavenv_loop_get")
         self.ring.head, self.ring.filled = cur.head, cur.filled

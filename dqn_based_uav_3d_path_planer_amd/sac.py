@@ -59,27 +59,39 @@ class SACLearner:
                 p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
 
-    def learn(self, batch: dict, noise=None, is_weights=None):
+    def learn(self, batch: dict, noise=None, is_weights=None, valid=None):
         """One SAC_Trainer.update (continuous branch).  batch: states [B,100], actions [B,2], rewards, next_states,
         dones.  noise = (eps_next, eps_cur) optionally pins the two rsample() draws.  is_weights [B] (prioritised
         replay, IsPriority_Replay == 1): the critic losses become mean_i w_i * err_i^2 and self.abs_errors holds
         |min(Q1, Q2) - td_target| for ReplayTree.batch_update (SAC_Trainer.py:346-352; the reference's own
-        `is_weights * critic_loss` there is a vector and its backward() raises)."""
+        `is_weights * critic_loss` there is a vector and its backward() raises).  valid [B] (0 / 1): rows that are not
+        replay memory in the reference (a finished agent waiting for its team-mates, PathPlan_City.py:365-366, re-emitted
+        by the vectorised step) -- they carry weight 0 in EVERY loss (critics, actor, log_alpha) and every mean is over the
+        valid rows, so the update equals the reference's on the valid rows alone."""
         self.epoch += 1
         states, next_states = batch["states"].float(), batch["next_states"].float()
         actions = batch["actions"].float().reshape(len(states), -1)
         rewards, dones = batch["rewards"].float().view(-1, 1), batch["dones"].float().view(-1, 1)
         e_next, e_cur = noise if noise is not None else (None, None)
+        if valid is not None:
+            vm = valid.to(states.dtype).view(-1, 1)
+            inv_n = 1.0 / vm.sum().clamp_min(1.0)
+
+            def mean(x):                                       # mean over the valid rows (and the 2 output columns)
+                return (vm * x).sum() * inv_n / x.shape[1]
+        else:
+            mean = torch.mean
         td_target = self.calc_target(rewards, next_states, dones, e_next)
         q1, q2 = self.critic_1(states, actions), self.critic_2(states, actions)
         if is_weights is None:
-            critic_1_loss = torch.mean(F.mse_loss(q1, td_target.detach()))
-            critic_2_loss = torch.mean(F.mse_loss(q2, td_target.detach()))
+            critic_1_loss = mean((q1 - td_target.detach()) ** 2)
+            critic_2_loss = mean((q2 - td_target.detach()) ** 2)
         else:
             w = is_weights.to(q1.dtype).view(-1, 1)
-            critic_1_loss = torch.mean(w * (q1 - td_target.detach()) ** 2)
-            critic_2_loss = torch.mean(w * (q2 - td_target.detach()) ** 2)
+            critic_1_loss = mean(w * (q1 - td_target.detach()) ** 2)
+            critic_2_loss = mean(w * (q2 - td_target.detach()) ** 2)
             self.abs_errors = torch.abs(torch.min(q1, q2) - td_target).detach()[:, 0]      # :351 .squeeze() of [B,2] rows
+        self.critic_losses = (critic_1_loss.detach(), critic_2_loss.detach())
         for opt, loss, net in ((self.critic_1_optimizer, critic_1_loss, self.critic_1),
                                (self.critic_2_optimizer, critic_2_loss, self.critic_2)):
             opt.zero_grad()
@@ -88,13 +100,13 @@ class SACLearner:
             opt.step()
         new_actions, log_prob = self.actor(states, e_cur)
         entropy = -log_prob
-        actor_loss = torch.mean(-self.log_alpha.exp() * entropy -
-                                torch.min(self.critic_1(states, new_actions), self.critic_2(states, new_actions)))
+        actor_loss = mean(-self.log_alpha.exp() * entropy -
+                          torch.min(self.critic_1(states, new_actions), self.critic_2(states, new_actions)))
         self.actor_optimizer.zero_grad()
         actor_loss.backward()
         self._sync_grads(list(self.actor.parameters()))
         self.actor_optimizer.step()
-        alpha_loss = torch.mean((entropy - self.target_entropy).detach() * self.log_alpha.exp())
+        alpha_loss = mean((entropy - self.target_entropy).detach() * self.log_alpha.exp())
         self.log_alpha_optimizer.zero_grad()
         alpha_loss.backward()
         self._sync_grads([self.log_alpha])
@@ -219,7 +231,7 @@ class FusedSACLearner:
         raw = self._raw.setdefault(stride, torch.empty(stride, dtype=torch.float32, device=self.device))
         self._check(self.lib.uavenv_sac_reduce(partials.data_ptr(), rows, stride, raw.data_ptr(), self._stream()), "uavenv_sac_reduce")
         dist.all_reduce(raw, op=dist.ReduceOp.SUM)
-        return raw, 1, 1.0 / world
+        return raw, 1, 0.0        # (the valid-fraction column, summed over the ranks, normalises: 1 / world when all valid)
 
     # the four launches, separately (tests drive them one by one)
     def critic_grad(self, batch, eps_next: torch.Tensor):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 2
+#define UAVENV_ABI_VERSION 3
 #define UAVENV_OBS_DIM 100          /* Agents/UAV.py:517  state_map = zeros(1,1,1,100) */
 #define UAVENV_MAX_BUILDINGS 64     /* broad-phase masks are 64-bit */
 
@@ -37,6 +37,8 @@ extern "C" {
 #define UAVENV_ENOMEM (-12)
 #define UAVENV_EHIP (-5)            /* a HIP runtime call failed; see uavenv_last_error() */
 #define UAVENV_ENODEV (-19)         /* no gfx950 device visible -- there is no CPU fallback */
+#define UAVENV_EP2P (-70)           /* the peer-to-peer gradient exchange raised its sticky error (uavenv_p2p_status): this
+                                       rank's weights are frozen; fall back to the collective and re-broadcast the weights */
 
 /* info codes written by uavenv_step (Agents/UAV.py:406,465,483,495,509,513) */
 #define UAVENV_INFO_NORMAL 0
@@ -298,19 +300,46 @@ int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype,
  * replaces uavenv_dqn_reduce -> RCCL all-reduce -> uavenv_dqn_adam: the column sums are stored straight into every
  * rank's receive area (xGMI), flags tell the readers, every rank adds the `world` contributions in rank order (bit-
  * identical updates) and takes the Adam step -- all on the stream, no host round trip.  Waits are bounded: a timeout
- * is counted (uavenv_p2p_errors, synchronising) instead of hanging. */
+ * raises a sticky error (uavenv_p2p_status) instead of hanging; see there. */
 #define UAVENV_P2P_HANDLE_BYTES 64
+#define UAVENV_P2P_ERR_TIMEOUT 1    /* a peer's flag did not arrive within the spin limit */
+#define UAVENV_P2P_ERR_DIVERGED 2   /* the ranks' weight checksums differ */
 typedef struct UavP2P UavP2P;
 int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P **out);
 int uavenv_p2p_handle(UavP2P *p2p, void *handle_out_host);
 int uavenv_p2p_connect(UavP2P *p2p, const void *all_handles_host);
 int uavenv_p2p_destroy(UavP2P *p2p);
-int uavenv_p2p_errors(UavP2P *p2p, int32_t *timeouts_out);
+/* check_every: every that many updates the Adam kernel folds a 64-bit checksum of the new weights into the next bucket
+ * and every rank compares the `world` checksums (0 = never; default 256).  spin_limit: polls before a wait gives up
+ * (0 = keep; default 2^22, about a second).  Must be the same on every rank. */
+int uavenv_p2p_configure(UavP2P *p2p, int32_t check_every, int32_t spin_limit);
+int uavenv_p2p_errors(UavP2P *p2p, int32_t *timeouts_out);        /* synchronises */
+/* out4 = {sticky error code (0 = healthy, UAVENV_P2P_ERR_*), timeouts, checksum mismatches, checksums folded so far}.
+ * synchronise == 0: only the code, read from host-mapped memory without touching the device (timeouts / mismatches = -1).
+ * Once the code is non-zero the rank's Adam steps are skipped (its weights freeze rather than absorb stale or partial
+ * sums) and uavenv_dqn_reduce_p2p / uavenv_dqn_adam_p2p / uavenv_loop_run return UAVENV_EP2P. */
+int uavenv_p2p_status(UavP2P *p2p, int32_t synchronise, int32_t *out4);
+/* Tests: raise the sticky error as a timeout / a mismatch would (code 0 clears it). */
+int uavenv_p2p_inject_fault(UavP2P *p2p, int32_t code);
 int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, UavP2P *p2p, void *stream);
 /* step_t == 0: only the rank-ordered sum, into raw_out_dev[num_params + 2] (self-test); otherwise Adam as uavenv_dqn_adam
  * (raw_out_dev nullable). */
 int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *p2p, float lr, float beta1, float beta2, float eps, int32_t step_t,
                         int32_t hard_update, float *loss_out_dev, float *raw_out_dev, void *stream);
+
+/* ---- multi-GPU fallback: the same bucket through an RCCL all-reduce enqueued from C (csrc/coll.hip) ------------------ */
+/* RCCL is dlopen'ed (rccl_path first -- e.g. PyTorch's own librccl.so --, then the loader's search path); the library
+ * has no link-time dependency on it.  Rank 0: uavenv_coll_unique_id -> the UAVENV_COLL_ID_BYTES travel to every rank
+ * (any channel) -> every rank: uavenv_coll_create with its HIP device current.  Per update, on the stream:
+ *     uavenv_dqn_grad -> uavenv_dqn_reduce(raw) -> uavenv_coll_allreduce_sum(raw) -> uavenv_dqn_adam(raw)
+ * which is what uavenv_loop_run issues when UavLoopConfig.coll is set.  All ranks receive bit-identical sums. */
+#define UAVENV_COLL_ID_BYTES 128
+typedef struct UavColl UavColl;
+const char *uavenv_coll_last_error(void);
+int uavenv_coll_unique_id(const char *rccl_path, void *id_out_host);
+int uavenv_coll_create(const char *rccl_path, int32_t world, int32_t rank, const void *id_host, UavColl **out);
+int uavenv_coll_destroy(UavColl *coll);
+int uavenv_coll_allreduce_sum(UavColl *coll, float *buf_dev, int64_t n, void *stream);
 
 /* ---- the whole off-policy loop, enqueued from C ------------------------------------------------------------------ */
 /* PathPlan_City.run_thread_OffPolicy (Envs/PathPlan_City.py:364-385) for every env of the shard at once, K times:
@@ -318,8 +347,9 @@ int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *p2p, float lr, float beta1
  *     step    update_PathPlan + state_PathPlan -> ring frame head / head+1   (Move_Agent + Push_Replay, :371-379)
  *     learn   learn_off_policy(): sample, TD target, loss, Adam, hard copy   (:380-383; skipped while the ring holds
  *             fewer than `learn_start` transitions or when batch == 0)
- * One call enqueues all 4 K launches on the stream; the host does nothing per step but four kernel launches from
- * C (no interpreter, no per-step allocation).  The cursor (head, filled, counter, epoch) lives in the UavLoop and is
+ * One call enqueues all 3 K launches on the stream (act rides in the step kernel's prologue when it can: uavenv_step_policy;
+ * 4 K otherwise, + 1 K with the RCCL exchange); the host does nothing per step but those launches from C (no
+ * interpreter, no per-step allocation).  The cursor (head, filled, counter, epoch) lives in the UavLoop and is
  * advanced by uavenv_loop_run; read it back with uavenv_loop_get. */
 typedef struct UavLoop UavLoop;
 typedef struct UavLoopConfig {
@@ -342,6 +372,8 @@ typedef struct UavLoopConfig {
     UavP2P *p2p;                 /* nullable: multi-GPU -- gradients are summed over the ranks through csrc/p2p.hip */
     int32_t time_every;          /* > 0: bracket the step kernel of every time_every-th step with HIP events */
     int32_t reserved0;
+    UavColl *coll;               /* nullable (used when p2p is NULL): multi-GPU -- RCCL all-reduce of raw_dev from C */
+    float *raw_dev;              /* num_params + 2 floats of scratch for the coll path */
 } UavLoopConfig;
 typedef struct UavLoopCursor {
     int32_t head, filled, epoch, reserved0;
@@ -367,7 +399,7 @@ int uavenv_loop_step_times(UavLoop *loop, float *ms_out, int32_t max_n, int32_t 
  *   actor : fc1.weight 64x100 | fc1.bias 64 | fc_mu.weight 2x64 | fc_std.weight 2x64 | fc_mu.bias 2 | fc_std.bias 2
  *   critic: fc1.weight 64x102 | fc1.bias 64 | fc2.weight 64x64 | fc2.bias 64 | fc_out.weight 2x64 | fc_out.bias 2
  * A partial-gradient row (one per workgroup, uavenv_sac_partial_rows(batch) of them) has the same layout:
- *   critic rows: critic 1 | critic 2 | loss 1 | loss 2 | 0 | 0        actor rows: actor | actor loss | sum log pi | 0 | 0 */
+ *   critic rows: critic 1 | critic 2 | loss 1 | loss 2 | valid / B | 0     actor rows: actor | actor loss | sum log pi | valid / B | 0 */
 #define UAVENV_SAC_CRITIC_IN 102
 #define UAVENV_SAC_ACTOR_PARAMS 6724
 #define UAVENV_SAC_CRITIC_PARAMS 10882
@@ -387,14 +419,17 @@ typedef struct UavSacBatch {
     const int32_t *draws;                /* nullable: batch x (frame, env) */
     int32_t n_agents, uav_per_env, slot, frames;
     const float *act0, *act1, *reward;   /* the two action components (:444-448), the reward */
-    const uint8_t *done, *valid;         /* valid nullable: sample weight of the critic losses (0 / 1) */
+    const uint8_t *done, *valid;         /* valid nullable (= all 1): rows with 0 (agents that only waited for their team-mates:
+                                            not replay memory in the reference) carry weight 0 in EVERY loss -- critics, actor,
+                                            log_alpha -- and all means are over the valid samples */
     const float *eps;                    /* batch x 2 N(0,1) draws standing for Normal.rsample() of this phase */
     int32_t batch, reserved0;            /* batch: a multiple of 64 */
 } UavSacBatch;
 typedef struct UavSacAdam {
     float lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt;   /* 1 - beta1^t, sqrt(1 - beta2^t) */
     float tau;                           /* soft target update (critic_adam only) */
-    float grad_scale;                    /* gradient = column sum x grad_scale; 0 = 1 (1 / world size after an all-reduce SUM) */
+    float grad_scale;                    /* ignored since ABI 3: every column is divided by the summed valid-fraction column of the
+                                            partial rows (1 / world size after an all-reduce SUM of all-valid batches) */
 } UavSacAdam;
 /* get_action (SAC_Trainer.py:444-448) for `count` agents whose packed rows are first_row + i * row_stride: the two
  * action components land in act0[row] / act1[row].  eps: count x 2 N(0,1) draws (Normal.rsample()). */
@@ -412,7 +447,8 @@ int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, flo
 int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
                            const UavSacAdam *h, float *losses_out, void *stream);
 /* Multi-GPU: column sums of the partial rows only -> raw[stride] (stride = one of the two UAVENV_SAC_*_STRIDE); all-reduce
- * raw over the ranks, then call the *_adam entry point with partials = raw, rows = 1 and grad_scale = 1 / world size. */
+ * (sum) raw over the ranks, then call the *_adam entry point with partials = raw, rows = 1: the valid-fraction column, summed
+ * over the ranks, makes the update the mean over the valid samples of ALL ranks. */
 int uavenv_sac_reduce(const float *partials, int32_t rows, int32_t stride, float *raw, void *stream);
 /* eps = the draws of actor(states).  partials: rows x UAVENV_SAC_ACTOR_STRIDE floats. */
 int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, float action_bound, float *partials, void *stream);

@@ -1,0 +1,203 @@
+"""Row e (multi-GPU) on ONE GPU: the hardened peer exchange (csrc/p2p.hip: sticky error, frozen weights, on-device weight
+checksums), the RCCL-from-C fallback's plumbing (csrc/coll.hip, world size 1) and bench.py's own rank spawning with its
+self-check line.  Two ranks share cuda:0 here; a real xGMI run is the driver's SCALE measurement."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PARAM = {"NetWork": "Qnet2", "w": "100", "hiden_dim": "64", "output": "3"}
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, scenario):
+    import torch.distributed as dist
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop, P2PExchangeError
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    n = 1024
+    env = make_city26_env(n)
+    ring = DeviceReplayRing(env, 6 * n, discrete=True)
+    ring.reset(seed=4 + rank)
+    torch.manual_seed(0)
+    L = FusedDQNLearner(PARAM, "dqn", device="cuda:0")
+    assert L.enable_p2p(check_every=1, spin_limit=1 << 18), "peer-to-peer exchange could not be set up"
+    hot = HotLoop(ring, L, 256, seed=3 + rank, eps=0.3)
+    res = {}
+    hot.run(6)
+    torch.cuda.synchronize()
+    res["healthy"] = L.p2p_status()
+    res["sum_healthy"] = L.weights_checksum()
+    if scenario == "diverge":
+        # rank 1's weights are nudged behind the exchange's back: the next checksum compare must catch it on BOTH ranks
+        if rank == 1:
+            L.flat[0][5] += 1e-3
+        torch.cuda.synchronize()
+        dist.barrier()
+        raised = False
+        try:
+            for _ in range(4):
+                hot.run(2)
+                torch.cuda.synchronize()
+        except P2PExchangeError:
+            raised = True
+        res["raised"] = raised
+        res["after"] = L.p2p_status()
+        w = L.flat[0].clone()
+        # frozen: further updates through the plain entry points return EP2P and leave the weights alone
+        rc = L.lib.uavenv_dqn_reduce_p2p(C.byref(L.net), hot._partials.data_ptr(), L.lib.uavenv_dqn_partial_rows(256), L._p2p,
+                                         torch.cuda.current_stream().cuda_stream)
+        res["rc_after"] = rc
+        torch.cuda.synchronize()
+        res["frozen"] = bool(torch.equal(w, L.flat[0]))
+    elif scenario == "timeout":
+        # rank 1 stops taking part: rank 0's next pull must give up after the spin limit, freeze, and report a timeout
+        dist.barrier()
+        if rank == 0:
+            w = L.flat[0].clone()
+            raised = False
+            try:
+                hot.run(1)
+                torch.cuda.synchronize()
+                hot.run(1)
+            except P2PExchangeError:
+                raised = True
+            torch.cuda.synchronize()
+            res["raised"] = raised
+            res["after"] = L.p2p_status()
+            res["frozen"] = bool(torch.equal(w, L.flat[0]))
+        dist.barrier()
+    torch.save(res, os.path.join(out_dir, f"{scenario}_r{rank}.pt"))
+    hot.close()
+    dist.barrier()
+    L.disable_p2p()
+    dist.destroy_process_group()
+    env.close()
+
+
+@pytest.mark.parametrize("scenario", ["diverge", "timeout"])
+def test_peer_exchange_raises_a_sticky_error_and_freezes(scenario, tmp_path):
+    import torch.multiprocessing as mp
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    mp.spawn(_worker, args=(2, _port(), str(tmp_path), scenario), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, f"{scenario}_r0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, f"{scenario}_r1.pt"))
+    for r in (r0, r1):                      # six healthy updates, a checksum compared at every one from the second on
+        assert r["healthy"]["code"] == 0 and r["healthy"]["timeouts"] == 0 and r["healthy"]["mismatches"] == 0
+        assert r["healthy"]["checks"] >= 5
+    assert r0["sum_healthy"] == r1["sum_healthy"]            # lock-step, bit for bit
+    if scenario == "diverge":
+        for r in (r0, r1):
+            assert r["raised"] and r["after"]["code"] == _lib.P2P_ERR_DIVERGED and r["after"]["mismatches"] >= 1
+            assert r["rc_after"] == _lib.EP2P and r["frozen"]
+    else:
+        assert r0["raised"] and r0["after"]["code"] == _lib.P2P_ERR_TIMEOUT and r0["after"]["timeouts"] >= 1
+        assert r0["frozen"]
+
+
+def test_rccl_from_c_world_size_one():
+    """csrc/coll.hip end to end with a one-rank communicator: dlopen of PyTorch's librccl.so, ncclCommInitRank,
+    ncclAllReduce on the caller's stream (identity at world size 1), and the C loop taking its coll branch
+    (uavenv_dqn_reduce -> all-reduce -> uavenv_dqn_adam) with the same result as the fused single-GPU launch."""
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    lib = _lib.load()
+    path = _lib.rccl_path()
+    idb = (C.c_ubyte * _lib.COLL_ID_BYTES)()
+    rc = lib.uavenv_coll_unique_id(path, idb)
+    assert rc == 0, lib.uavenv_coll_last_error()
+    h = C.c_void_p()
+    rc = lib.uavenv_coll_create(path, 1, 0, idb, C.byref(h))
+    assert rc == 0, lib.uavenv_coll_last_error()
+    x = torch.arange(6661, device="cuda", dtype=torch.float32) * 0.5
+    want = x.clone()
+    assert lib.uavenv_coll_allreduce_sum(h, x.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    out = []
+    for use_coll in (False, True):
+        n = 1024
+        env = make_city26_env(n)
+        ring = DeviceReplayRing(env, 6 * n, discrete=True)
+        ring.reset(seed=4)
+        torch.manual_seed(0)
+        L = FusedDQNLearner(PARAM, "dqn", device="cuda:0")
+        if use_coll:
+            L._coll = h
+        hot = HotLoop(ring, L, 256, seed=3, eps=0.3)
+        hot.run(6)
+        torch.cuda.synchronize()
+        out.append((L.flat.clone(), float(L.loss)))
+        hot.close()
+        env.close()
+    # k_dqn_reduce + k_dqn_adam against the one-launch k_dqn_reduce_adam: same sums in a different association
+    assert (out[0][0][:2] - out[1][0][:2]).abs().max().item() <= 2e-6
+    assert abs(out[0][1] - out[1][1]) <= 1e-5 * abs(out[0][1])
+    assert lib.uavenv_coll_destroy(h) == 0
+
+
+def _bench(*extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-other-configs", "--envs", "2048", "--batch", "2048", "--replay", "16384", "--env-only-iters", "5",
+                          *extra], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_and_checks_them():
+    """`python bench.py --gpus 2` (no torchrun around it) starts two ranks, rank 0 prints ONE line with n_gpus == 2, the
+    ranks' weights are bit-identical after the timed region, the peer exchange reports no timeout / mismatch, and the
+    line carries the in-run no-exchange leg."""
+    d = _bench("--gpus", "2", "--same-device", "--dist-backend", "gloo", "--p2p-check-every", "16")
+    assert d["n_gpus"] == 2 and d["exchange"] == "p2p" and d["ranks_bit_identical"] is True
+    assert d["p2p_timeouts"] == 0 and d["p2p_checksum_mismatches"] == 0 and d["p2p_error_code_max"] == 0
+    assert d["p2p_checksums_compared"] >= 10
+    assert d["ms_per_pass_no_exchange"] > 0 and "peer-to-peer" in d["config"]["parallelism"]
+    assert d["config"]["host_loop"].startswith("csrc/loop.hip")
+
+
+def test_bench_recovers_when_the_peer_exchange_fails_mid_run():
+    """Rank 1's exchange raises its sticky error before the timed region: every rank must notice, drop to the collective
+    (torch.distributed here: RCCL refuses two ranks on one device), take rank 0's weights, and finish bit-identical."""
+    d = _bench("--gpus", "2", "--same-device", "--dist-backend", "gloo", "--inject-p2p-fault", "1", "--no-exchange-leg")
+    assert d["n_gpus"] == 2 and d["exchange"] == "rccl" and d["ranks_bit_identical"] is True
+    assert any("sticky" in f for f in d["exchange_fallbacks"]) and d["bad_after_recovery"] is False
+
+
+def test_bench_one_gpu_line_has_the_in_loop_roofline():
+    d = _bench()
+    assert d["n_gpus"] == 1 and "k_step_coop<policy>" in d["roofline"]["kernel"]
+    assert d["roofline"]["kernel_ms_back_to_back"] > d["roofline"]["k_step_alone"]["kernel_ms_back_to_back"] * 0.9
+    assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline_learner"]["frac"] < 1
+    assert "3 launches" in d["config"]["host_loop"]

@@ -98,14 +98,20 @@ def test_gradients_of_both_phases_match_autograd(world):
         assert abs(float(pc[2 * _lib.SAC_CRITIC_PARAMS + k]) - float(loss.detach())) <= 2e-5 * abs(float(loss.detach()))
     # ---- phase B on the SAME critics (no critic step in between here): actor loss, its gradient, sum of log pi
     new_actions, log_prob = ref.actor(states, e_cur)
-    actor_loss = torch.mean(ref.log_alpha.exp() * log_prob - torch.min(ref.critic_1(states, new_actions), ref.critic_2(states, new_actions)))
+    # rows with valid = 0 carry weight 0 in the actor loss and in sum log pi too (the kernels keep the 1 / B of a plain mean;
+    # the Adam kernel divides by the valid fraction)
+    actor_loss = torch.mean(w.view(-1, 1) * (ref.log_alpha.exp() * log_prob -
+                                             torch.min(ref.critic_1(states, new_actions), ref.critic_2(states, new_actions))))
     params = dict(ref.actor.named_parameters())
     g = _flat(torch.autograd.grad(actor_loss, [params[n] for n in A_NAMES]))
     pa = fused.actor_grad(b, e_cur).sum(0)
     mine = pa[:_lib.SAC_ACTOR_PARAMS]
     assert _rel(mine, g) <= 5e-5, _rel(mine, g)
     assert abs(float(pa[_lib.SAC_ACTOR_PARAMS]) - float(actor_loss)) <= 2e-5 * max(1.0, abs(float(actor_loss)))
-    assert abs(float(pa[_lib.SAC_ACTOR_PARAMS + 1]) - float(log_prob.sum())) <= 2e-5 * abs(float(log_prob.sum()))
+    lp_sum = float((w.view(-1, 1) * log_prob).sum())
+    assert abs(float(pa[_lib.SAC_ACTOR_PARAMS + 1]) - lp_sum) <= 2e-5 * abs(lp_sum)
+    assert abs(float(pa[_lib.SAC_ACTOR_PARAMS + 2]) - float(w.mean())) <= 1e-6            # the valid fraction of the batch
+    assert abs(float(pc[2 * _lib.SAC_CRITIC_PARAMS + 2]) - float(w.mean())) <= 1e-6
 
 
 @pytest.mark.parametrize("B", [64, 4096, 20480])
@@ -114,7 +120,7 @@ def test_whole_updates_track_the_torch_learner(world, B):
     fused, ref = _pair(seed=B)
     for it in range(4):
         b, td, w, noise = _batch(world, fused, B, seed=100 + it, slot=it & 1)
-        ref.learn(td, noise=noise, is_weights=w)
+        ref.learn(td, noise=noise, valid=w)
         fused.learn(b, noise=noise)
         torch.cuda.synchronize()
         # losses of this update (computed before the steps)
