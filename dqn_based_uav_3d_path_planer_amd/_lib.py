@@ -28,13 +28,13 @@ SYMBOLS = (
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
-    "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
+    "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
     "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_inject_fault",
     "uavenv_coll_last_error", "uavenv_coll_unique_id", "uavenv_coll_create", "uavenv_coll_destroy", "uavenv_coll_allreduce_sum",
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
-    "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_step_times",
-    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill",
+    "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_get_per", "uavenv_loop_step_times",
+    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
     "uavenv_sac_actor_adam",
 )
@@ -78,7 +78,11 @@ class UavLoopConfig(C.Structure):
                 ("eps", C.c_float), ("gamma", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("adam_eps", C.c_float), ("step_flags", C.c_uint32), ("partials_dev", C.c_void_p),
                 ("loss_dev", C.c_void_p), ("info_dev", C.c_void_p), ("p2p", C.c_void_p), ("time_every", C.c_int32),
-                ("reserved0", C.c_int32), ("coll", C.c_void_p), ("raw_dev", C.c_void_p)]
+                ("reserved0", C.c_int32), ("coll", C.c_void_p), ("raw_dev", C.c_void_p),
+                ("per", UavPer), ("per_alpha", C.c_double), ("per_beta", C.c_double), ("per_beta_inc", C.c_double),
+                ("per_eps", C.c_double), ("per_clip", C.c_double),
+                ("per_slots_dev", C.c_void_p), ("per_prio_dev", C.c_void_p), ("per_w_dev", C.c_void_p),
+                ("per_abs_dev", C.c_void_p), ("per_idx_dev", C.c_void_p)]
 
 
 class UavLoopCursor(C.Structure):
@@ -238,6 +242,8 @@ def load() -> C.CDLL:
     lib.uavenv_dqn_set_debug_buffer.argtypes = [vp]
     lib.uavenv_dqn_grad.restype = C.c_int
     lib.uavenv_dqn_grad.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, net, i32, f32, i32, vp, vp]
+    lib.uavenv_dqn_grad_w.restype = C.c_int
+    lib.uavenv_dqn_grad_w.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, net, i32, f32, i32, vp, vp, vp, vp]
     lib.uavenv_dqn_reduce.restype = C.c_int
     lib.uavenv_dqn_reduce.argtypes = [net, vp, i32, vp, vp]
     lib.uavenv_dqn_adam.restype = C.c_int
@@ -257,6 +263,12 @@ def load() -> C.CDLL:
     lib.uavenv_per_sample.argtypes = [per, i32, vp, u64, u64, vp, vp, vp]
     lib.uavenv_per_set.restype = C.c_int
     lib.uavenv_per_set.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
+    lib.uavenv_per_set_f32.restype = C.c_int
+    lib.uavenv_per_set_f32.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
+    lib.uavenv_per_weights.restype = C.c_int
+    lib.uavenv_per_weights.argtypes = [per, vp, vp, i32, i64, f64, i32, vp, vp, vp]
+    lib.uavenv_loop_get_per.restype = C.c_int
+    lib.uavenv_loop_get_per.argtypes = [vp, C.POINTER(C.c_double)]
     lib.uavenv_per_fill.restype = C.c_int
     lib.uavenv_per_fill.argtypes = [per, i64, i64, f64, vp, vp]
     if lib.uavenv_abi_version() != ABI_VERSION:

@@ -44,6 +44,10 @@ struct GradArgs {
     float *partials;                 // [gridDim.x][stride]: parameter layout, then loss sum and valid count
     int P;
     unsigned long long *dbg;         // diagnostics build: 8 s_memtime stamps per workgroup
+    // prioritised replay (nullable): importance-sampling weight of sample s in the loss (mean_s w_s loss_s); |TD error| of
+    // sample s out (ReplayTree.batch_update's input)
+    const float *is_w;
+    float *abs_td;
 };
 
 #ifdef UAVENV_PHASE_PROFILE
@@ -199,8 +203,8 @@ __device__ __forceinline__ float pick_qn(const GradArgs &g, const float (&qt)[NM
 template <int NMAX, bool HALF_T = false>
 __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l, const floatx4 (&hl)[4], const W2Frag<NMAX> &Fl,
                                             const float (&ql)[NMAX], float qn, int p_act, float p_rew,
-                                            float p_done, float p_valid, GradAcc<NMAX> &A, float *hrow, float *drow,
-                                            float *dout_row)
+                                            float p_done, float p_valid, float p_w, int smp, GradAcc<NMAX> &A, float *hrow,
+                                            float *drow, float *dout_row)
 {
     constexpr bool kKeepW2 = NMAX <= 4;
     const int gq = ((int)threadIdx.x & 63) >> 4;
@@ -223,6 +227,8 @@ __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l,
         dq = 2.0f * delta;
     }
     dq *= p_valid;
+    dq *= p_w;                                        // (x 1 without prioritised replay: bit-identical)
+    if (g.abs_td && gq == 0) g.abs_td[smp] = fabsf(delta);
     float dv[NMAX + 2];
     const float inv_a = 1.0f / (float)g.n_actions;
 #pragma unroll
@@ -236,7 +242,7 @@ __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l,
         }
         dv[a] = d;
     }
-    dv[NMAX] = per * p_valid;                         // loss and valid count ride along as two more columns
+    dv[NMAX] = per * p_valid * p_w;                   // loss and valid count ride along as two more columns
     dv[NMAX + 1] = p_valid;
     // column sums over the strip's 16 samples (db2, loss sum, valid count): four DPP row rotations each
 #pragma unroll
@@ -338,6 +344,7 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
     const float p_rew = g.ring.reward[row_s];
     const float p_done = (float)g.ring.done[row_s];
     const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    const float p_w = g.is_w ? g.is_w[smp] : 1.0f;
     x_issue<ObsT>(vXn, obs, row_n);
     if (FIRST) w_issue(vWt, g.target);
 
@@ -392,7 +399,7 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
     }
     L_STAMP(3);
     // H of sample r of this strip goes where its s' rows were (dead now)
-    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, A, xn_strip + r * kLh,
+    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, p_w, smp, A, xn_strip + r * kLh,
                       L.dHs + (wv * 16 + r) * kLh, L.douts + (wv * 16 + r) * kMaxOut);
     __syncthreads();                                  // H, dH, dout of all 64 samples visible
     L_STAMP(4);
@@ -522,6 +529,7 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     const float p_rew = g.ring.reward[row_s];
     const float p_done = (float)g.ring.done[row_s];
     const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    const float p_w = g.is_w ? g.is_w[smp] : 1.0f;
     prow_load(Rn, obs + (size_t)row_n * kPackedDwords);
     if (FIRST) w_issue(vWt, g.target);
 
@@ -569,7 +577,7 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
         q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
     }
     L_STAMP(3);
-    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, A, L.Hs + (wv * 16 + r) * kLh,
+    td_backward<NMAX>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, p_w, smp, A, L.Hs + (wv * 16 + r) * kLh,
                       L.dHs + (wv * 16 + r) * kLh, L.douts + (wv * 16 + r) * kMaxOut);
     __syncthreads();                                  // H, dH, dout and the packed s rows of all 64 samples visible
     L_STAMP(4);
@@ -746,12 +754,13 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     PRow R;
     prow_load(R, obs + (size_t)(grp == 0 ? row_s : row_n) * kPackedDwords);
     int p_act = 0;
-    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f;
+    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f, p_w = 1.0f;
     if (grp == 0) {
         p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
         p_rew = g.ring.reward[row_s];
         p_done = (float)g.ring.done[row_s];
         p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+        p_w = g.is_w ? g.is_w[smp] : 1.0f;
     }
     if (FIRST) {
         w_commit_half(grp == 0 ? L.W1l : L.W1t, vW, pb1, t256);
@@ -801,7 +810,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
         GradAcc<NMAX> T;                              // td_backward's accumulator interface: only csum is used here
 #pragma unroll
         for (int a = 0; a < NMAX + 2; ++a) T.csum[a] = A.csum[a];
-        td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qn_lds[strip * 16 + r], p_act, p_rew, p_done, p_valid, T,
+        td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qn_lds[strip * 16 + r], p_act, p_rew, p_done, p_valid, p_w, smp, T,
                           L.Hs + (strip * 16 + r) * kLh, L.dHs + (strip * 16 + r) * kLh, L.douts + (strip * 16 + r) * kMaxOut);
 #pragma unroll
         for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = T.csum[a];
@@ -1076,8 +1085,8 @@ struct GradLdsH {
 // what a tile needs from HBM: its 2 x 16 observation rows per wavefront and each lane's transition scalars
 struct TileLoads {
     floatx4 vXs[kXIters], vXn[kXIters];
-    int p_act;
-    float p_rew, p_done, p_valid;
+    int p_act, smp;
+    float p_rew, p_done, p_valid, p_w;
 };
 
 template <int KIND>
@@ -1101,6 +1110,8 @@ __device__ __forceinline__ void tile_issue(const GradArgs &g, int tile, TileLoad
     T.p_rew = g.ring.reward[row_s];
     T.p_done = (float)g.ring.done[row_s];
     T.p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    T.p_w = g.is_w ? g.is_w[smp] : 1.0f;
+    T.smp = smp;
     xh_issue<KIND>(T.vXn, g.ring.obs, row_n);
 }
 
@@ -1131,8 +1142,8 @@ __device__ __forceinline__ void grad_tile_h(const GradArgs &g, const GradLdsH &L
         tile_issue<KIND>(g, tile, T);
         w_issue(vWt, g.target);
     }
-    const int p_act = T.p_act;
-    const float p_rew = T.p_rew, p_done = T.p_done, p_valid = T.p_valid;
+    const int p_act = T.p_act, smp = T.smp;
+    const float p_rew = T.p_rew, p_done = T.p_done, p_valid = T.p_valid, p_w = T.p_w;
 
     uint32_t *stage = L.stage + wv * kStageW;
     if (FIRST) wh_commit(L.W1l, vWl, pb1);
@@ -1182,7 +1193,7 @@ __device__ __forceinline__ void grad_tile_h(const GradArgs &g, const GradLdsH &L
     L_STAMP(3);
     __syncthreads();                                  // every wave is done with its s' rows: HT / dHT overwrite that tile
     const int s = wv * 16 + r;
-    td_backward<NMAX, true>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, A,
+    td_backward<NMAX, true>(g, L.W2l, hl, Fl, ql, pick_qn<NMAX>(g, qt, best), p_act, p_rew, p_done, p_valid, p_w, smp, A,
                             reinterpret_cast<float *>(L.HT + s), reinterpret_cast<float *>(L.dHT + s),
                             reinterpret_cast<float *>(L.doutT + s));
     __syncthreads();
@@ -1278,8 +1289,8 @@ __device__ __forceinline__ void wh_commit_half(_Float16 *dst, floatx4 (&v)[kStag
 
 struct TileLoads8 {
     floatx4 vX[kXIters];             // group 0: the s rows of this wavefront's strip, group 1: the s' rows
-    int p_act;
-    float p_rew, p_done, p_valid;
+    int p_act, smp;
+    float p_rew, p_done, p_valid, p_w;
 };
 
 template <int KIND>
@@ -1299,12 +1310,13 @@ __device__ __forceinline__ void tile_issue8(const GradArgs &g, int tile, int grp
     const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
     const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
     xh_issue<KIND>(T.vX, g.ring.obs, grp == 0 ? row_s : row_n);
-    T.p_act = 0; T.p_rew = 0.0f; T.p_done = 0.0f; T.p_valid = 1.0f;
+    T.p_act = 0; T.p_rew = 0.0f; T.p_done = 0.0f; T.p_valid = 1.0f; T.p_w = 1.0f; T.smp = smp;
     if (grp == 0) {
         T.p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
         T.p_rew = g.ring.reward[row_s];
         T.p_done = (float)g.ring.done[row_s];
         T.p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+        T.p_w = g.is_w ? g.is_w[smp] : 1.0f;
     }
 }
 
@@ -1412,12 +1424,12 @@ __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
     L_STAMP(1);
     floatx4 hl[4];                                        // group 0: pre-activations / Q of the tile whose TD comes next
     float ql[NMAX];
-    int p_act = 0;
-    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f;
+    int p_act = 0, smp = 0;
+    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f, p_w = 1.0f;
     // (the fc2 fragments are re-read from LDS where they are used: two of them live across the whole loop spill)
     // commit this wavefront's rows of tile i, request tile i + 1's, and (group 0) Q_local(s) / (group 1) the bootstrap values
     auto front = [&](int i) {
-        if (grp == 0) { p_act = T.p_act; p_rew = T.p_rew; p_done = T.p_done; p_valid = T.p_valid; }
+        if (grp == 0) { p_act = T.p_act; p_rew = T.p_rew; p_done = T.p_done; p_valid = T.p_valid; p_w = T.p_w; smp = T.smp; }
         xh_commit<KIND>(x_strip, T.vX, stage, grp == 0 ? XsT + (i & 1) * 112 * kLdT + strip * 16 : nullptr);
         wave_lds_sync();
         if (i + 1 < n_my) tile_issue8<KIND>(g, tile_of(i + 1), grp, strip, T);
@@ -1460,7 +1472,7 @@ __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
             const int s = strip * 16 + r;
             W2Frag<NMAX> Fl;
             w2_load<NMAX>(Fl, W2l, b2l, n2);
-            td_backward<NMAX, true>(g, W2l, hl, Fl, ql, qn_lds[(i & 1) * kTile + s], p_act, p_rew, p_done, p_valid, Tc,
+            td_backward<NMAX, true>(g, W2l, hl, Fl, ql, qn_lds[(i & 1) * kTile + s], p_act, p_rew, p_done, p_valid, p_w, smp, Tc,
                                     reinterpret_cast<float *>(HT + s), reinterpret_cast<float *>(dHT + s),
                                     reinterpret_cast<float *>(doutT + s));
 #pragma unroll
@@ -2026,6 +2038,14 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
                     uint64_t counter, const int32_t *explicit_idx, const UavDqnNet *net, int32_t kind, float gamma,
                     int32_t huber, float *partials, void *stream)
 {
+    return uavenv_dqn_grad_w(ring, head, filled, batch, seed, counter, explicit_idx, net, kind, gamma, huber, nullptr, nullptr,
+                             partials, stream);
+}
+
+int uavenv_dqn_grad_w(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                      uint64_t counter, const int32_t *explicit_idx, const UavDqnNet *net, int32_t kind, float gamma,
+                      int32_t huber, const float *is_weights, float *abs_td_out, float *partials, void *stream)
+{
     if (!ring || !ring->obs || !ring->action || !ring->reward || !ring->done || !partials || !net_ok(net) || !net->target)
         return UAVENV_EINVAL;
     if (batch <= 0 || batch % kTile != 0 || ring->frames < 2 || head < 0 || head >= ring->frames) return UAVENV_EINVAL;
@@ -2046,6 +2066,8 @@ int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int
     g.partials = partials;
     g.P = uavenv_dqn_num_params(net);
     g.dbg = g_learner_dbg;
+    g.is_w = is_weights;
+    g.abs_td = abs_td_out;
     ga.n_tiles = batch / kTile;
     ga.stride = uavenv_dqn_partial_stride(net);
     const int grid = uavenv_dqn_partial_rows(batch);

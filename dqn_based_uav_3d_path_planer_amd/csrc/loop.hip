@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <new>
 #include <vector>
 
@@ -25,6 +26,8 @@ struct UavLoop {
     uint64_t counter;
     size_t obs_row_bytes;
     bool fuse_act = true;            // act in the step kernel's prologue (uavenv_step_policy) until it says it cannot
+    bool per = false;                // prioritised replay on (c.per.prio != NULL)
+    double per_beta = 0.4;
     std::vector<hipEvent_t> ev;      // pairs (start, stop), recorded so far
     std::vector<hipEvent_t> pool;    // idle events
 };
@@ -45,6 +48,11 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
         return UAVENV_EINVAL;
     if (cfg->update_loop <= 0 || cfg->epoch < 0) return UAVENV_EINVAL;
     if (!cfg->p2p && cfg->coll && !cfg->raw_dev) return UAVENV_EINVAL;
+    if (cfg->per.prio) {
+        if (cfg->per.capacity != (int64_t)cfg->ring.frames * cfg->ring.n_agents || cfg->batch <= 0 || !cfg->per_slots_dev ||
+            !cfg->per_prio_dev || !cfg->per_w_dev || !cfg->per_abs_dev || !cfg->per_idx_dev || !cfg->ring.valid)
+            return UAVENV_EINVAL;
+    }
     UavLoop *l = new (std::nothrow) UavLoop();
     if (!l) return UAVENV_ENOMEM;
     l->c = *cfg;
@@ -52,6 +60,8 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
     l->filled = cfg->filled;
     l->epoch = cfg->epoch;
     l->counter = cfg->counter;
+    l->per = cfg->per.prio != nullptr;
+    l->per_beta = cfg->per_beta;
     l->fuse_act = getenv("UAVENV_NO_FUSED_ACT") == nullptr;
     l->prof = getenv("UAVENV_LOOP_PROFILE") != nullptr;
     l->obs_row_bytes = (size_t)cfg->ring.n_agents * (cfg->ring.obs_dtype == UAVENV_OBS_PACKED ? UAVENV_OBS_PACKED_DWORDS * 4
@@ -76,6 +86,13 @@ int uavenv_loop_set_eps(UavLoop *l, float eps)
 {
     if (!l) return UAVENV_EINVAL;
     l->c.eps = eps;
+    return UAVENV_OK;
+}
+
+int uavenv_loop_get_per(const UavLoop *l, double *beta_out)
+{
+    if (!l || !beta_out) return UAVENV_EINVAL;
+    *beta_out = l->per_beta;
     return UAVENV_OK;
 }
 
@@ -156,9 +173,29 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
         if (l->prof) tp1 = std::chrono::steady_clock::now();
         l->head = nxt;
         if (l->filled < R.frames - 1) l->filled += 1;
+        if (l->per) {                     // ReplayTree.push(error 0) for the frame just written; the new head's rows are retired
+            rc = uavenv_per_fill(&c.per, (int64_t)t * (int64_t)n, (int64_t)n, pow(0.0 + (double)c.per_eps, (double)c.per_alpha),
+                                 R.valid + (size_t)t * n, s);
+            if (rc != UAVENV_OK) return rc;
+            rc = uavenv_per_fill(&c.per, (int64_t)nxt * (int64_t)n, (int64_t)n, 0.0, nullptr, s);
+            if (rc != UAVENV_OK) return rc;
+        }
         if (c.batch > 0 && (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch)) {
-            rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
-                                 c.huber, c.partials_dev, s);
+            if (l->per) {                 // ReplayTree.sample: beta first (:155), selection, importance weights
+                l->per_beta = l->per_beta + (double)c.per_beta_inc < 1.0 ? l->per_beta + (double)c.per_beta_inc : 1.0;
+                rc = uavenv_per_rebuild(&c.per, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_per_sample(&c.per, c.batch, nullptr, c.seed, l->counter, c.per_slots_dev, c.per_prio_dev, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_per_weights(&c.per, c.per_slots_dev, c.per_prio_dev, c.batch, (int64_t)l->filled * (int64_t)n,
+                                        l->per_beta, R.n_agents, c.per_w_dev, c.per_idx_dev, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_dqn_grad_w(&R, l->head, l->filled, c.batch, c.seed, l->counter, c.per_idx_dev, &c.net, c.kind, c.gamma,
+                                       c.huber, c.per_w_dev, c.per_abs_dev, c.partials_dev, s);
+            } else {
+                rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
+                                     c.huber, c.partials_dev, s);
+            }
             if (rc != UAVENV_OK) return rc;
             if (l->prof) tp2 = std::chrono::steady_clock::now();
             l->epoch += 1;
@@ -183,6 +220,11 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                                             c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);
             }
             if (rc != UAVENV_OK) return rc;
+            if (l->per) {                 // ReplayTree.batch_update (:215-222)
+                rc = uavenv_per_set_f32(&c.per, c.per_slots_dev, c.per_abs_dev, c.batch, (double)c.per_eps, (double)c.per_alpha,
+                                        (double)c.per_clip, s);
+                if (rc != UAVENV_OK) return rc;
+            }
             if (l->prof) {
                 tp3 = std::chrono::steady_clock::now();
                 l->t_host[0] += std::chrono::duration<double>(tp1 - tp0).count();

@@ -179,6 +179,54 @@ __global__ void k_per_set(UavPer p, const int64_t *__restrict__ slots, const dou
     p.prio[s] = pow(e, alpha);
 }
 
+__global__ void k_per_set_f32(UavPer p, const int64_t *__restrict__ slots, const float *__restrict__ abs_err, int n,
+                              double epsilon, double alpha, double clip)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int64_t s = slots[i];
+    if (s < 0 || s >= p.capacity) return;
+    double e = fabs((double)abs_err[i]) + epsilon;
+    if (clip > 0.0 && e > clip) e = clip;
+    p.prio[s] = pow(e, alpha);
+}
+
+// ReplayTree.sample's importance weights (:175-178) for a whole batch in ONE workgroup: w_i = (n p_i / int(total)) ** -beta,
+// then / max_i w_i; the maximum through a fixed-order LDS tree (deterministic).
+__global__ void __launch_bounds__(1024) k_per_weights(UavPer p, int n_chunks, const int64_t *__restrict__ slots,
+                                                      const double *__restrict__ prio, int batch, double n_entries, double beta,
+                                                      int n_agents, float *__restrict__ w_out, int32_t *__restrict__ fa_out)
+{
+    __shared__ double red[1024];
+    double total = floor(p.chunk_prefix[n_chunks]);
+    total = total < 1.0 ? 1.0 : total;
+    double mx = 0.0;
+    for (int i = (int)threadIdx.x; i < batch; i += 1024) {
+        const double pi = prio[i];
+        const double w = pi > 0.0 ? pow(n_entries * (pi / total), -beta) : 0.0;
+        mx = w > mx ? w : mx;
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + k] ? red[threadIdx.x] : red[threadIdx.x + k];
+        __syncthreads();
+    }
+    mx = red[0];
+    mx = mx > 2.2250738585072014e-308 ? mx : 2.2250738585072014e-308;
+    for (int i = (int)threadIdx.x; i < batch; i += 1024) {
+        const double pi = prio[i];
+        const double w = pi > 0.0 ? pow(n_entries * (pi / total), -beta) : 0.0;
+        w_out[i] = (float)(w / mx);
+        if (fa_out) {
+            const int64_t s = slots[i];
+            const int64_t f = s / n_agents;
+            fa_out[2 * i] = (int32_t)f;
+            fa_out[2 * i + 1] = (int32_t)(s - f * n_agents);
+        }
+    }
+}
+
 __global__ void k_per_fill(UavPer p, int64_t first, int64_t count, double value, const uint8_t *__restrict__ valid)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,6 +280,27 @@ int uavenv_per_set(const UavPer *p, const int64_t *slots_dev, const double *abs_
     if (n == 0) return UAVENV_OK;
     hipLaunchKernelGGL(k_per_set, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, slots_dev, abs_err_dev, n,
                        epsilon, alpha, clip);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_per_set_f32(const UavPer *p, const int64_t *slots_dev, const float *abs_err_dev, int32_t n, double epsilon,
+                       double alpha, double clip, void *stream)
+{
+    if (!per_ok(p) || !slots_dev || !abs_err_dev || n < 0) return UAVENV_EINVAL;
+    if (n == 0) return UAVENV_OK;
+    hipLaunchKernelGGL(k_per_set_f32, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, slots_dev, abs_err_dev, n,
+                       epsilon, alpha, clip);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_per_weights(const UavPer *p, const int64_t *slots_dev, const double *prio_dev, int32_t batch, int64_t n_entries,
+                       double beta, int32_t n_agents, float *is_weights_out_dev, int32_t *frame_agent_out_dev, void *stream)
+{
+    if (!per_ok(p) || !slots_dev || !prio_dev || !is_weights_out_dev || batch <= 0 || n_entries < 0) return UAVENV_EINVAL;
+    if (frame_agent_out_dev && n_agents <= 0) return UAVENV_EINVAL;
+    hipLaunchKernelGGL(k_per_weights, dim3(1), dim3(1024), 0, (hipStream_t)stream, *p, uavenv_per_num_chunks(p->capacity),
+                       slots_dev, prio_dev, batch, (double)n_entries, beta, n_agents > 0 ? n_agents : 1, is_weights_out_dev,
+                       frame_agent_out_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

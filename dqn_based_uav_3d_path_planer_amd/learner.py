@@ -345,7 +345,26 @@ class FusedDQNLearner:
             pass
         r = _R()
         r._c, r.head, r.filled = buf["c"], 1, 1
-        return self.learn_from_ring(r, bp, 0, 0, explicit_idx=buf["idx"])
+        w = batch.get("is_weights")
+        if w is None:
+            return self.learn_from_ring(r, bp, 0, 0, explicit_idx=buf["idx"])
+        if "isw" not in buf:
+            buf["isw"] = torch.zeros(bp, dtype=torch.float32, device=self.device)
+            buf["abs"] = torch.zeros(bp, dtype=torch.float32, device=self.device)
+        buf["isw"].zero_()
+        buf["isw"][:b].copy_(w.reshape(-1).to(self.device, torch.float32))
+        loss = self.learn_from_ring(r, bp, 0, 0, explicit_idx=buf["idx"], is_weights=buf["isw"], abs_td_out=buf["abs"])
+        self.abs_errors = buf["abs"][:b]
+        return loss
+
+    def learn_weighted(self, batch: dict, is_weights: torch.Tensor):
+        """DQNLearner.learn_weighted on the fused kernels (uavenv_dqn_grad_w): loss = mean_i w_i * per_i over the batch
+        rows, returns (loss, |TD error| per row)."""
+        b = dict(batch)
+        b["is_weights"] = is_weights
+        b.pop("valid", None)
+        loss = self.learn(b)
+        return loss, self.abs_errors.clone()
 
     # -- multi-GPU: the gradient bucket summed over peer-mapped HBM instead of a collective call -------------------
     def enable_p2p(self, verify: bool = True, check_every: int = 256, spin_limit: int = 0) -> bool:
@@ -486,8 +505,11 @@ class FusedDQNLearner:
                                      None if q_out is None else q_out.data_ptr(), self._stream())
         _lib.check(rc, "uavenv_dqn_act")
 
-    def learn_from_ring(self, ring, batch: int, seed: int, counter: int, explicit_idx: torch.Tensor = None):
-        """One learn_off_policy() on `batch` transitions drawn from the device ring (same draws as ring.sample)."""
+    def learn_from_ring(self, ring, batch: int, seed: int, counter: int, explicit_idx: torch.Tensor = None,
+                        is_weights: torch.Tensor = None, abs_td_out: torch.Tensor = None):
+        """One learn_off_policy() on `batch` transitions drawn from the device ring (same draws as ring.sample).
+        is_weights / abs_td_out (f32 [batch], prioritised replay): importance-sampling weights of the samples in the loss and
+        the per-sample |TD error| coming back (uavenv_dqn_grad_w)."""
         C, _lib = self._C, self._lib_mod
         if batch % 64:
             raise ValueError("fused learner needs batch % 64 == 0")
@@ -497,10 +519,12 @@ class FusedDQNLearner:
         self.epoch += 1
         s = self._stream()
         kind = 0 if self.kind == "dqn" else 1
-        rc = self.lib.uavenv_dqn_grad(C.byref(ring._c), ring.head, ring.filled, batch, int(seed), int(counter),
-                                      None if explicit_idx is None else explicit_idx.data_ptr(), C.byref(self.net),
-                                      kind, self.gamma, self.huber, self._partials.data_ptr(), s)
-        _lib.check(rc, "uavenv_dqn_grad")
+        rc = self.lib.uavenv_dqn_grad_w(C.byref(ring._c), ring.head, ring.filled, batch, int(seed), int(counter),
+                                        None if explicit_idx is None else explicit_idx.data_ptr(), C.byref(self.net),
+                                        kind, self.gamma, self.huber,
+                                        None if is_weights is None else is_weights.data_ptr(),
+                                        None if abs_td_out is None else abs_td_out.data_ptr(), self._partials.data_ptr(), s)
+        _lib.check(rc, "uavenv_dqn_grad_w")
         hard = 1 if self.epoch % self.update_loop == 0 else 0
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         fed = multi and self.sync == "fedavg"

@@ -22,7 +22,10 @@ class P2PExchangeError(_lib.UavEnvError):
 class HotLoop:
     def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
                  counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
-                 time_every: int = 0, info: torch.Tensor = None):
+                 time_every: int = 0, info: torch.Tensor = None, per=None):
+        """per: a replay.DevicePER over the ring's frames * N slots -- prioritised replay (IsPriority_Replay = 1) inside the C
+        loop: new-frame priorities, rebuild, ReplayTree.sample, importance weights, the weighted update and batch_update are
+        enqueued per pass (csrc/loop.hip); per.beta / per.n_entries are kept in step."""
         if not ring.discrete:
             raise ValueError("HotLoop drives the discrete (DQN-family) path")
         if batch % 64:
@@ -61,6 +64,19 @@ class HotLoop:
         elif getattr(learner, "_coll", None) is not None:   # ... or through an RCCL all-reduce enqueued from C
             cfg.coll = learner._coll
             cfg.raw_dev = learner.raw.data_ptr()
+        self._per = per
+        if per is not None:
+            if per.capacity != ring.frames * env.N or per._c.rot != 0:
+                raise ValueError("the DevicePER must cover the ring's frames * N slots in slot order (tree_order=False)")
+            d, b = env.device, max(int(batch), 64)
+            self._per_bufs = (torch.zeros(b, dtype=torch.int64, device=d), torch.zeros(b, dtype=torch.float64, device=d),
+                              torch.zeros(b, dtype=torch.float32, device=d), torch.zeros(b, dtype=torch.float32, device=d),
+                              torch.zeros((b, 2), dtype=torch.int32, device=d))
+            cfg.per = per._c
+            cfg.per_alpha, cfg.per_beta, cfg.per_beta_inc = per.alpha, per.beta, per.beta_inc
+            cfg.per_eps, cfg.per_clip = per.epsilon, per.clip
+            cfg.per_slots_dev, cfg.per_prio_dev, cfg.per_w_dev, cfg.per_abs_dev, cfg.per_idx_dev = \
+                (t.data_ptr() for t in self._per_bufs)
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_loop_create")
         self.counter = int(counter)
@@ -97,6 +113,12 @@ class HotLoop:
         self.ring.head, self.ring.filled = cur.head, cur.filled
         self.learner.epoch = cur.epoch
         self.counter = int(cur.counter)
+        if self._per is not None:
+            beta = C.c_double(0.0)
+            _lib.check(self.lib.uavenv_loop_get_per(self._h, C.byref(beta)), "uavenv_loop_get_per")
+            self._per.beta = float(beta.value)
+            self._per.n_entries = self.ring.filled * self.ring.env.N
+            self._per._dirty = True
 
     def step_times_ms(self, max_n: int = 4096) -> np.ndarray:
         """Durations of the event-bracketed step kernels since the last call (synchronises on them)."""

@@ -87,7 +87,7 @@ class PathPlan_City:
         # the fused path keeps observations packed (15 scalars + 80 flag bits per row); decided before the backend exists
         self._want_fast = (int(None2Value(param.get("fast_path"), 1)) != 0 and self.num_UAV == 1 and
                            (tcfg.get("Trainer_Type") in ("DQN_Trainer", "DDQN_Trainer", "DuelingDQN_Trainer")) and
-                           int(None2Value(tcfg.get("IsPriority_Replay"), 0)) == 0 and param.get("obs_dtype") is None and
+                           param.get("obs_dtype") is None and
                            int(None2Value(tcfg.get("Batch_Size"), 128)) % 64 == 0 and
                            int(None2Value(tcfg.get("fused"), 1)) != 0 and torch.cuda.is_available())
         # ... and so does the SAC fast path (any number of UAVs per env: one fused trainer per UAV slot, csrc/sac.hip)
@@ -144,6 +144,12 @@ class PathPlan_City:
             self._ring = DeviceReplayRing(self.backend, max(tr0.replay_size, 2 * self.backend.N), discrete=True)
             self._info = torch.zeros((self._ring.frames, self.backend.N), dtype=torch.uint8, device=self.backend.device)
             tr0.replay_memory = _RingMemoryView(self._ring)
+            self._per = None
+            if getattr(tr0, "IsPriority_Replay", 0) == 1:
+                # IsPriority_Replay = 1 stays on the fused path: one priority per ring slot (frame * N + agent), ReplayTree's
+                # hyper-parameters, sampled / updated inside the C loop (csrc/loop.hip, csrc/per.hip)
+                from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+                self._per = DevicePER(self._ring.frames * self.backend.N, device=self.backend.device, tree_order=False)
         self.fast_sac = bool(self._want_fast_sac and getattr(self.backend, "packed", False) and
                              all(getattr(u.Trainer, "fused", False) for u in self.Agents))
         if self._want_fast_sac and not self.fast_sac:
@@ -362,7 +368,8 @@ class PathPlan_City:
         self._paths, self._path_done = [[] for _ in range(self.num_UAV)], [False] * self.num_UAV
         if self._hot is None:
             self._hot = HotLoop(ring, tr.learner, tr.Batch_Size if tr.Is_Train else 0, seed=self.seed, eps=eps_rate,
-                                learn_start=tr.Batch_Size + 1, auto_reset=False, skip_done=True, info=self._info)
+                                learn_start=tr.Batch_Size + 1, auto_reset=False, skip_done=True, info=self._info,
+                                per=getattr(self, "_per", None))
         self._hot.set_eps(eps_rate if tr.Is_Train else 0.0)
         k = 1 if self.record_path else min(self.done_check, ring.frames - 2)
         n_steps, ended = 0, False

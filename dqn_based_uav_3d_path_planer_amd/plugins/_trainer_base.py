@@ -149,7 +149,7 @@ class BaseDQNTrainer:
         n2 = self.output + (1 if self.KIND == "dueling" else 0)
         want = param.get("fused")
         fusable = (self.device.type == "cuda" and torch.cuda.is_available() and self.w == 100 and hid == 64 and
-                   self.output >= 2 and n2 + 2 <= 16 and self.IsPriority_Replay == 0)
+                   self.output >= 2 and n2 + 2 <= 16)
         self.fused = fusable and (want is None or int(want) != 0)
         loss_kind = param.get("loss") or "mse"
         if self.fused:

@@ -246,6 +246,16 @@ int uavenv_per_set(const UavPer *per, const int64_t *slots_dev, const double *ab
  * ring frame k_step has just written. */
 int uavenv_per_fill(const UavPer *per, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
                     void *stream);
+/* uavenv_per_set with f32 errors (what uavenv_dqn_grad_w / uavenv_sac_critic_grad write). */
+int uavenv_per_set_f32(const UavPer *per, const int64_t *slots_dev, const float *abs_err_dev, int32_t n, double epsilon,
+                       double alpha, double clip, void *stream);
+/* ReplayTree.sample (:163-178), the part after the selection: is_weights[i] = (n_entries * p_i / int(total)) ** -beta,
+ * divided by their maximum (f32 out); a zero priority gets weight 0; int(total) < 1 counts as 1.  Also splits each slot
+ * into the (frame, agent) pair uavenv_dqn_grad takes (frame_agent_out_dev nullable, batch x 2 int32; slot = frame *
+ * n_agents + agent).  One workgroup; needs the rebuild uavenv_per_sample used. */
+int uavenv_per_weights(const UavPer *per, const int64_t *slots_dev, const double *prio_dev, int32_t batch,
+                       int64_t n_entries, double beta, int32_t n_agents, float *is_weights_out_dev,
+                       int32_t *frame_agent_out_dev, void *stream);
 
 /* ---- fused DQN-family learner for the reference's Q-MLPs (BaseClass/BaseCNN.py:93-139, w=100, hid=64) ---------- */
 /* Flat f32 parameter blocks in HBM (16-byte aligned), layout [W1 hid*w][b1 hid][W2 n2*hid][b2 n2] with n2 = n_actions
@@ -277,6 +287,13 @@ int uavenv_dqn_partial_rows(int32_t batch);
 int uavenv_dqn_grad(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
                     uint64_t counter, const int32_t *explicit_idx_dev, const UavDqnNet *net, int32_t kind, float gamma,
                     int32_t huber, float *partials_dev, void *stream);
+/* The same with prioritised replay (BaseClass/replay_buffer.py:146-223, Trainer/SAC_Trainer.py:336-352 applied to the
+ * DQN family): is_weights_dev (nullable, batch f32) = the importance-sampling weight of sample s -- the loss becomes
+ * mean_s w_s loss_s --, abs_td_out_dev (nullable, batch f32) receives |Q(s, a) - y| of sample s for ReplayTree.batch_update.
+ * With both NULL this IS uavenv_dqn_grad (bit for bit). */
+int uavenv_dqn_grad_w(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                      uint64_t counter, const int32_t *explicit_idx_dev, const UavDqnNet *net, int32_t kind, float gamma,
+                      int32_t huber, const float *is_weights_dev, float *abs_td_out_dev, float *partials_dev, void *stream);
 /* n_partials = uavenv_dqn_partial_rows(batch).  Sum the partial rows -> raw_out_dev[num_params + 2] = gradient sums, loss sum, valid-sample count.  This flat vector
  * is the RCCL all-reduce(sum) payload for multi-GPU (the mean is then over the valid samples of all ranks). */
 int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, float *raw_out_dev,
@@ -374,6 +391,18 @@ typedef struct UavLoopConfig {
     int32_t reserved0;
     UavColl *coll;               /* nullable (used when p2p is NULL): multi-GPU -- RCCL all-reduce of raw_dev from C */
     float *raw_dev;              /* num_params + 2 floats of scratch for the coll path */
+    /* prioritised replay (per.prio != NULL; capacity = frames * N, slot = frame * N + agent): per pass, after the step,
+     * the frame just completed gets the new-transition priority (|0| + per_eps) ** per_alpha where valid and the ring's
+     * new head frame gets 0; the update then is rebuild -> uavenv_per_sample (Philox(seed, counter)) -> uavenv_per_weights
+     * -> uavenv_dqn_grad_w -> reduce + Adam -> uavenv_per_set_f32, all stream-ordered.  beta advances by per_beta_inc per
+     * update (capped at 1) and is read back through uavenv_loop_get_per. */
+    UavPer per;
+    double per_alpha, per_beta, per_beta_inc, per_eps, per_clip;
+    int64_t *per_slots_dev;      /* batch */
+    double *per_prio_dev;        /* batch */
+    float *per_w_dev;            /* batch */
+    float *per_abs_dev;          /* batch */
+    int32_t *per_idx_dev;        /* batch x 2 */
 } UavLoopConfig;
 typedef struct UavLoopCursor {
     int32_t head, filled, epoch, reserved0;
@@ -386,6 +415,8 @@ int uavenv_loop_set_eps(UavLoop *loop, float eps);
 /* Enqueue n_steps iterations on `stream`; never synchronises. */
 int uavenv_loop_run(UavLoop *loop, int32_t n_steps, void *stream);
 int uavenv_loop_get(const UavLoop *loop, UavLoopCursor *out);
+/* Prioritised replay: the current beta. */
+int uavenv_loop_get_per(const UavLoop *loop, double *beta_out);
 /* Synchronises the recorded events; writes up to max_n step-kernel durations (ms) and returns their number in *n_out;
  * clears the record. */
 int uavenv_loop_step_times(UavLoop *loop, float *ms_out, int32_t max_n, int32_t *n_out);

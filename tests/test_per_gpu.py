@@ -140,3 +140,126 @@ def test_zero_priority_leaves_are_never_picked_and_weights_stay_finite():
     per2.set_priorities(q, n_entries=10)
     _, w2, _ = per2.sample(32, seed=1, counter=0)
     assert torch.isfinite(w2).all() and float(w2.max()) == 1.0
+
+
+PARAM = {"NetWork": "Qnet2", "w": "100", "hiden_dim": "64", "output": "3"}
+
+
+def test_weights_kernel_matches_the_reference_weights():
+    """uavenv_per_weights (the in-loop form of ReplayTree.sample's importance weights, :175-178) on the reference's own
+    draws: equal to the golden weights at f32 resolution, and the (frame, agent) split of the slots is exact."""
+    import ctypes as C
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+    g = load_golden("per.npz")
+    for ci in range(4):
+        pre = f"c{ci}_"
+        cap, batch = int(g[pre + "capacity"]), int(g[pre + "batch"])
+        per = DevicePER(cap)
+        per.set_priorities(torch.tensor(g[pre + "prio"]), n_entries=int(g[pre + "n_entries"]))
+        slots, w, p = per.sample(batch, draws=torch.tensor(g[pre + "r0_draws"]))
+        w32 = torch.zeros(batch, dtype=torch.float32, device="cuda")
+        fa = torch.zeros((batch, 2), dtype=torch.int32, device="cuda")
+        n_agents = 7
+        rc = per.lib.uavenv_per_weights(C.byref(per._c), slots.data_ptr(), p.data_ptr(), batch, per.n_entries, per.beta, n_agents,
+                                        w32.data_ptr(), fa.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.allclose(w32.cpu().numpy(), g[pre + "r0_weights"].astype(np.float32), rtol=2e-7, atol=0)
+        assert torch.equal(fa[:, 0].long() * n_agents + fa[:, 1].long(), slots)
+
+
+def _ring(n=1024, frames=8, seed=4):
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    env = make_city26_env(n)
+    ring = DeviceReplayRing(env, (frames - 1) * n, discrete=True)
+    ring.reset(seed=seed)
+    return env, ring
+
+
+@pytest.mark.parametrize("kind,net,huber", [("dqn", "Qnet2", False), ("dueling", "VAnet2", True)])
+def test_weighted_fused_update_matches_the_torch_learner(kind, net, huber):
+    """uavenv_dqn_grad_w: importance weights in the loss and |TD error| out, against DQNLearner.learn_weighted (the
+    PyTorch statement of Trainer/SAC_Trainer.py:346-352 for the DQN family) on the same transitions."""
+    from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner, FusedDQNLearner
+    env, ring = _ring()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(5):
+        ring.current_action().copy_(torch.randint(0, 3, (env.N,), generator=gen, device="cuda", dtype=torch.int32))
+        ring.step_env(auto_reset=True)
+    param = dict(PARAM, NetWork=net)
+    torch.manual_seed(0)
+    T = DQNLearner(param, kind, device="cuda:0", loss="huber" if huber else "mse")
+    F = FusedDQNLearner(param, kind, device="cuda:0", loss="huber" if huber else "mse")
+    F.q_local.load_state_dict(T.q_local.state_dict())
+    F.q_target.load_state_dict(T.q_target.state_dict())
+    B = 2048
+    for it in range(3):
+        f = torch.randint(0, ring.filled, (B,), generator=gen, device="cuda")
+        f = (ring.head - 1 - f) % ring.frames
+        a = torch.randint(0, env.N, (B,), generator=gen, device="cuda")
+        idx = torch.stack([f, a], 1).int().contiguous()
+        w = torch.rand(B, generator=gen, device="cuda") * 0.9 + 0.1
+        batch = ring.gather(f * env.N + a)
+        lt, abs_t = T.learn_weighted(batch, w)
+        abs_f = torch.zeros(B, device="cuda")
+        lf = F.learn_from_ring(ring, B, 0, 0, explicit_idx=idx, is_weights=w.contiguous(), abs_td_out=abs_f)
+        torch.cuda.synchronize()
+        assert abs(float(lt) - float(lf)) <= 3e-5 * abs(float(lt)), (it, float(lt), float(lf))
+        assert float((abs_f - abs_t).abs().max()) <= 2e-5 * max(1.0, float(abs_t.max()))
+    for (k, x), (_, y) in zip(T.q_local.state_dict().items(), F.q_local.state_dict().items()):
+        assert (x - y).abs().max().item() <= 3e-5, k
+    # and the batch-dict entry point the trainer plugins use
+    batch = ring.gather(f * env.N + a)
+    lt, abs_t = T.learn_weighted(batch, w)
+    lf, abs_f = F.learn_weighted(batch, w)
+    assert abs(float(lt) - float(lf)) <= 3e-5 * abs(float(lt))
+    assert float((abs_f - abs_t).abs().max()) <= 2e-5 * max(1.0, float(abs_t.max()))
+    env.close()
+
+
+def test_prioritised_replay_inside_the_c_loop_equals_the_stepwise_path():
+    """IsPriority_Replay = 1 as a PATH: HotLoop(per=...) -- per pass new-frame priorities, rebuild, ReplayTree.sample,
+    importance weights, the weighted fused update, batch_update, all enqueued from C -- against the same sequence issued
+    call by call from Python through DevicePER (itself pinned to the executed reference's ReplayTree above): identical
+    slots, priorities, beta, and weights after K passes."""
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+    K, B, seed = 12, 512, 9
+    out = []
+    for mode in ("c", "py"):
+        env, ring = _ring(n=1024, frames=6, seed=4)          # 12 passes wrap the 6-frame ring: retired frames are exercised
+        torch.manual_seed(0)
+        L = FusedDQNLearner(PARAM, "dqn", device="cuda:0")
+        per = DevicePER(ring.frames * env.N, tree_order=False)
+        if mode == "c":
+            hot = HotLoop(ring, L, B, seed=seed, eps=0.2, per=per)
+            hot.run(K)
+            torch.cuda.synchronize()
+            last_slots = hot._per_bufs[0].clone()
+            hot.close()
+        else:
+            abs_f = torch.zeros(B, device="cuda")
+            for t in range(K):
+                L.act(ring.current_obs(), 0.2, seed, t, index_out=ring.current_action())
+                ring.step_env(auto_reset=True)
+                per.on_frame(ring)
+                if ring.filled * env.N >= B:
+                    slots, w, _ = per.sample(B, seed=seed, counter=t)
+                    idx = torch.stack([slots // env.N, slots % env.N], 1).int().contiguous()
+                    L.learn_from_ring(ring, B, seed, t, explicit_idx=idx, is_weights=w.float().contiguous(), abs_td_out=abs_f)
+                    per.update(slots, abs_f)
+                    last_slots = slots.clone()
+            torch.cuda.synchronize()
+        out.append((per.prio.clone(), per.beta, per.n_entries, L.flat.clone(), last_slots, L.epoch))
+        env.close()
+    (pc, bc, nc, wc, sc, ec), (pp, bp, npy, wp, sp, ep) = out
+    assert ec == ep and ec >= K - 1 and nc == npy and abs(bc - bp) <= 1e-6
+    assert torch.equal(sc, sp)                                     # the same transitions were drawn at the last update
+    assert float((pc - pp).abs().max()) <= 1e-9                    # priorities (f64 pow of an f32 |TD error|)
+    assert float((wc[:2] - wp[:2]).abs().max()) <= 1e-6            # weights
+    live = pc > 0
+    fresh = (0.0 + 0.01) ** 0.6
+    assert 0 < int(live.sum()) <= (6 - 1) * 1024 and float(((pc[live] - fresh).abs() > 1e-9).float().mean()) > 0.05

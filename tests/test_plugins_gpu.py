@@ -220,14 +220,37 @@ def test_fused_trainer_checkpoint_roundtrip(tmp_path, monkeypatch):
     assert torch.equal(tr2.learner.flat, tr.learner.flat)
 
 
+def test_prioritised_replay_stays_on_the_fused_path(tmp_path, monkeypatch):
+    """IsPriority_Replay = 1 with a DQN-family trainer: run_eposide keeps the fused path (HotLoop with a DevicePER over the
+    ring's slots: sampling, importance weights, the weighted update and batch_update are enqueued from C)."""
+    from dqn_based_uav_3d_path_planer_amd import driver
+    monkeypatch.chdir(tmp_path)
+    xml = driver.make_config_dir(str(tmp_path), "DuelingDQN", num_envs=512)
+    _set_xml(tmp_path / "config" / "Trainer.xml", IsPriority_Replay=1, Batch_Size=256)
+    env = driver.simulator(xml).env
+    tr = env.Agents[0].Trainer
+    assert env.fast and tr.fused and env._per is not None
+    res = env.run_eposide(0.3)
+    assert env._hot is not None and env._hot._per is env._per
+    assert env.Check_uav_Done() and np.isfinite(float(res["loss"])) and tr.epoch > 100
+    per, ring = env._per, env._ring
+    prio = per.prio.view(ring.frames, -1)
+    assert float(prio[ring.head].abs().max()) == 0.0                       # the frame under construction is retired
+    live = prio[prio > 0]
+    fresh = (0.0 + per.epsilon) ** per.alpha
+    assert live.numel() > 0 and ((live - fresh).abs() > 1e-9).float().mean().item() > 0.05      # re-prioritised by batch_update
+    assert live.max().item() <= 1.0 + 1e-9 and per.beta > 0.4 and torch.isfinite(tr.learner.flat).all()
+
+
 @pytest.mark.parametrize("trainer", ["DuelingDQN", "SAC"])
 def test_prioritised_replay_through_the_plugins(trainer, tmp_path, monkeypatch):
-    """IsPriority_Replay = 1 (BaseClass/replay_buffer.py:121-223, Trainer/SAC_Trainer.py:336-352): the trainer plugins
-    sample through DevicePER with importance weights and feed |TD error| back into the priorities."""
+    """IsPriority_Replay = 1 (BaseClass/replay_buffer.py:121-223, Trainer/SAC_Trainer.py:336-352) on the general per-step
+    path (<fused>0</fused>): the trainer plugins sample through DevicePER with importance weights and feed |TD error| back
+    into the priorities."""
     from dqn_based_uav_3d_path_planer_amd import driver
     monkeypatch.chdir(tmp_path)
     xml = driver.make_config_dir(str(tmp_path), trainer, num_envs=64)
-    _set_xml(tmp_path / "config" / "Trainer.xml", IsPriority_Replay=1)
+    _set_xml(tmp_path / "config" / "Trainer.xml", IsPriority_Replay=1, fused=0)
     env = driver.simulator(xml).env
     tr = env.Agents[0].Trainer
     assert not env.fast and tr.replay_memory.per is not None
