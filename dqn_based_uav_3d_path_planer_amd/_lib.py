@@ -26,7 +26,7 @@ STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE, STEP_APF_LANE = 1, 
 SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
-    "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs",
+    "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs", "uavenv_geometry",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
@@ -163,6 +163,8 @@ def load() -> C.CDLL:
     lib.uavenv_observe.argtypes = [vp, vp, vp]
     lib.uavenv_threaten_rate.restype = C.c_int
     lib.uavenv_threaten_rate.argtypes = [vp, vp, vp, i64, vp]
+    lib.uavenv_geometry.restype = C.c_int
+    lib.uavenv_geometry.argtypes = [vp, vp, vp, i64, vp]
     lib.uavenv_threaten_rate_allpairs.restype = C.c_int
     lib.uavenv_threaten_rate_allpairs.argtypes = [vp, vp, vp, i64, vp]
     lib.uavenv_replay_sample.restype = C.c_int

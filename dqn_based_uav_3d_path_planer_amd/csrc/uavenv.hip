@@ -1348,6 +1348,17 @@ __global__ void __launch_bounds__(256) k_observe(StepArgs a)
     }
 }
 
+// BaseClass/CalMod.py:89-102 calculate_angle and :64-65 Eu_Loc_distance for n point pairs, with the device functions the
+// step kernels use (calc_angle / dist3): the direct known-answer check of the geometry layer.
+__global__ void k_geometry(const double *__restrict__ ab, double *__restrict__ angle_out, double *__restrict__ dist_out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ax = ab[6 * i], ay = ab[6 * i + 1], az = ab[6 * i + 2], bx = ab[6 * i + 3], by = ab[6 * i + 4], bz = ab[6 * i + 5];
+    if (angle_out) angle_out[i] = calc_angle(bx - ax, by - ay);
+    if (dist_out) dist_out[i] = dist3(ax, ay, az, bx, by, bz);
+}
+
 template <typename MaskT, bool ALLPAIRS>
 __global__ void k_threaten(StepArgs a, const double *__restrict__ xyz, uint8_t *__restrict__ out, int64_t n)
 {
@@ -2114,6 +2125,14 @@ static int threaten_impl(UavEnv *e, const double *xyz, uint8_t *out, int64_t n, 
     }
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
+}
+
+int uavenv_geometry(const double *ab, double *angle_out, double *dist_out, int64_t n, void *stream)
+{
+    if (!ab || n < 0 || (!angle_out && !dist_out)) return UAVENV_EINVAL;
+    if (n == 0) return UAVENV_OK;
+    hipLaunchKernelGGL(k_geometry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ab, angle_out, dist_out, n);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 
 int uavenv_threaten_rate(UavEnv *e, const double *xyz, uint8_t *out, int64_t n, void *stream)

@@ -175,6 +175,10 @@ int uavenv_set_debug_buffer(UavEnv *env, unsigned long long *dev_buf);
 int uavenv_observe(UavEnv *env, void *obs_dev, void *stream);
 /* PathPlan_City.Threaten_rate (PathPlan_City.py:215-223) for n points: xyz_dev n x 3 doubles -> out_dev n bytes. */
 int uavenv_threaten_rate(UavEnv *env, const double *xyz_dev, uint8_t *out_dev, int64_t n, void *stream);
+/* BaseClass/CalMod.py:89-102 calculate_angle(a, b) (atan2 -> degrees -> (x + 360) % 360 -> radians, in [0, 2 pi)) and
+ * :64-65 Eu_Loc_distance(a, b) for n point pairs, computed by the device functions the step kernels use.
+ * ab_dev: n x 6 doubles (ax, ay, az, bx, by, bz); either output nullable. */
+int uavenv_geometry(const double *ab_dev, double *angle_out_dev, double *dist_out_dev, int64_t n, void *stream);
 /* Same, bypassing the broad-phase grid (all-pairs); used to prove the culling is exact. */
 int uavenv_threaten_rate_allpairs(UavEnv *env, const double *xyz_dev, uint8_t *out_dev, int64_t n, void *stream);
 

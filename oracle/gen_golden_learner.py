@@ -87,6 +87,7 @@ def main():
         gen(s, "DDQN_Trainer", "Qnet2")
         gen(s, "DuelingDQN_Trainer", "VAnet2")
         gen_sac(s)
+        gen_sac_packed(s)
         # epsilon schedule, simulator.py:141-145
         sim = s.sim
         eps = []
@@ -164,8 +165,81 @@ def gen_sac(s):
     print("SAC_Trainer losses", losses, "log_alpha", alphas, "act", act)
 
 
+# The same update on PACKED-REPRESENTABLE observations: rows the reference's own state_PathPlan produced (tests/golden/
+# episodes.npz, generated by gen_golden.py from executed episodes) -- 80 of their 100 columns are 0/1 flags, 5 are zeros,
+# 15 are scalars -- so that csrc/sac.hip, which reads 80-byte packed rows, can be run on EXACTLY the inputs the executed
+# SAC_Trainer.update saw (tests/test_sac_fused_gpu.py::test_fused_sac_against_the_executed_reference).
+def gen_sac_packed(s):
+    from FactoryClass.TrainerFactory import TrainerFactory
+    B = 128                                                       # two 64-sample tiles of the fused kernels
+    param = {"Trainer_Type": "SAC_Trainer", "Is_Train": "1", "IsPriority_Replay": "0",
+             "actor": {"NetWork": "PolicyNetContinuous_SAC", "h": "1", "w": "100", "channel": "1", "action_bound": "1",
+                       "hiden_dim": "64", "output": "2", "lr": "0.0001"},
+             "critic": {"NetWork": "QValueNetContinuous_SAC", "h": "1", "w": "100", "channel": "1", "hiden_dim": "64",
+                        "action_dim": "2", "lr": "0.001"},
+             "SAC_param": {"IS_Continuous": "1", "alpha_lr": "0.0001", "target_entropy": "1", "gamma": "0.99", "tau": "0.05"},
+             "Priority_Replay": "0", "replay_size": "10000", "LEARNING_RATE": "0.0005", "Batch_Size": str(B),
+             "max_epoch": "100", "save_loop": str(10 ** 9), "name": "golden"}
+    tr = TrainerFactory().Create_Trainer(param)
+    assert tr is not None
+    tr.save = lambda *a, **k: None
+    g = torch.Generator().manual_seed(8642)
+    nets = {"actor": tr.actor, "critic_1": tr.critic_1, "critic_2": tr.critic_2}
+    for net in nets.values():
+        with torch.no_grad():
+            for p in net.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    with torch.no_grad():                                         # targets away from the critics (as after some training)
+        for tgt, src in ((tr.target_critic_1, tr.critic_1), (tr.target_critic_2, tr.critic_2)):
+            for pt, p in zip(tgt.parameters(), src.parameters()):
+                pt.copy_(p + 0.01 * torch.randn(p.shape, generator=g))
+    out = {}
+    for name, net in {**nets, "target_critic_1": tr.target_critic_1, "target_critic_2": tr.target_critic_2}.items():
+        for k, v in sd_to_np(net.state_dict()).items():
+            out[f"{name}0_{k}"] = v
+    ep = np.load(os.path.join(OUT, "episodes.npz"))
+    obs, outs, off = ep["obs"], ep["outs"], ep["offsets"]
+    rng = np.random.default_rng(11)
+    ok = np.ones(len(obs), bool)
+    ok[off[1:] - 1] = False                                        # s' must be the next record of the same episode
+    pick = rng.choice(np.nonzero(ok)[0], B, replace=False)
+    states = obs[pick].astype(np.float32)
+    next_states = obs[pick + 1].astype(np.float32)
+    actions = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+    rewards = outs[pick, 0].astype(np.float32)
+    dones = (rng.random(B) < 0.2).astype(np.float32)
+    for i in range(B):
+        tr.replay_memory.push((0, 0, 0, 0, 0), 0)     # update() only checks len(memory) >= Batch_Size (:333)
+    td = {"states": states.tolist(), "actions": actions.tolist(), "rewards": rewards.tolist(),
+          "next_states": next_states.tolist(), "dones": dones.tolist()}
+    SEED, K = 2000, 5
+    losses, alphas, noise = [], [], []
+    for k in range(K):
+        torch.manual_seed(SEED + k)
+        n1, n2 = torch.randn(B, 2), torch.randn(B, 2)
+        noise.append(np.stack([n1.numpy(), n2.numpy()]))
+        torch.manual_seed(SEED + k)
+        res = tr.update(td)
+        losses.append(float(res["loss"]))
+        alphas.append(float(tr.log_alpha))
+    out.update(states=states, next_states=next_states, actions=actions, rewards=rewards, dones=dones,
+               losses=np.array(losses), log_alpha=np.array(alphas), noise=np.array(noise), seed=SEED, epoch=int(tr.epoch),
+               episode_rows=pick)
+    for name, net in {**nets, "target_critic_1": tr.target_critic_1, "target_critic_2": tr.target_critic_2}.items():
+        for k, v in sd_to_np(net.state_dict()).items():
+            out[f"{name}1_{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "learner_SAC_Trainer_packed.npz"), **out)
+    print("SAC_Trainer (packed-representable rows) losses", losses, "log_alpha", alphas)
+
+
 if __name__ == "__main__":
-    if "--sac" in sys.argv:
+    if "--sac-packed" in sys.argv:
+        _s = RefSession()
+        try:
+            gen_sac_packed(_s)
+        finally:
+            _s.close()
+    elif "--sac" in sys.argv:
         _s = RefSession()
         try:
             gen_sac(_s)

@@ -56,6 +56,28 @@ def test_sac_updates_match_reference_with_injected_noise():
     _check(L, g, 2e-6)
 
 
+def _load_all(L, g):
+    for name in ("actor", "critic_1", "critic_2", "target_critic_1", "target_critic_2"):
+        getattr(L, name).load_state_dict({k[len(name) + 2:]: torch.tensor(v) for k, v in g.items() if k.startswith(f"{name}0_")})
+
+
+def test_sac_updates_match_reference_on_packed_representable_rows():
+    """The second SAC golden (oracle/gen_golden_learner.py::gen_sac_packed): observations the reference's own
+    state_PathPlan produced, targets away from the critics, batch 128 -- the vectors the fused HIP update is checked
+    against on the GPU (tests/test_sac_fused_gpu.py); here they pin the PyTorch learner too."""
+    from dqn_based_uav_3d_path_planer_amd.sac import SACLearner
+    g = load_golden("learner_SAC_Trainer_packed.npz")
+    L = SACLearner(PARAM, device="cpu")
+    _load_all(L, g)
+    batch = {k: torch.tensor(g[k]) for k in ("states", "actions", "rewards", "next_states", "dones")}
+    for k in range(len(g["losses"])):
+        n = torch.tensor(g["noise"][k])
+        loss = float(L.learn(batch, noise=(n[0], n[1])))
+        assert abs(loss - g["losses"][k]) <= 2e-5 * max(1.0, abs(g["losses"][k])), k
+        assert abs(float(L.log_alpha) - g["log_alpha"][k]) <= 1e-6
+    _check(L, g, 2e-6)
+
+
 def test_sac_trainer_plugin_surface(tmp_path):
     from dqn_based_uav_3d_path_planer_amd import factories
     g = load_golden("learner_SAC_Trainer.npz")
