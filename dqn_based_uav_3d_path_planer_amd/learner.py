@@ -319,7 +319,9 @@ class FusedDQNLearner:
         buf = self._adhoc.get(bp)
         if buf is None:
             d = self.device
-            buf = dict(obs=torch.zeros((2, bp, _lib.OBS_DIM), dtype=torch.float32, device=d),
+            # (the f16-MFMA kernels take f16 / packed rings: an arbitrary batch is rounded to f16 rows for them)
+            odt, ocode = (torch.float16, _lib.OBS_F16) if self.mfma == "f16" else (torch.float32, _lib.OBS_F32)
+            buf = dict(obs=torch.zeros((2, bp, _lib.OBS_DIM), dtype=odt, device=d),
                        action=torch.zeros((2, bp), dtype=torch.int32, device=d),
                        reward=torch.zeros((2, bp), dtype=torch.float32, device=d),
                        done=torch.zeros((2, bp), dtype=torch.uint8, device=d),
@@ -327,7 +329,7 @@ class FusedDQNLearner:
                        idx=torch.stack([torch.zeros(bp, dtype=torch.int32), torch.arange(bp, dtype=torch.int32)], 1)
                        .contiguous().to(d))
             buf["c"] = _lib.UavReplayRing(buf["obs"].data_ptr(), buf["action"].data_ptr(), buf["reward"].data_ptr(),
-                                          buf["done"].data_ptr(), buf["valid"].data_ptr(), 2, bp, _lib.OBS_F32, 1)
+                                          buf["done"].data_ptr(), buf["valid"].data_ptr(), 2, bp, ocode, 1)
             self._adhoc[bp] = buf
         buf["obs"][0, :b].copy_(st)
         buf["obs"][1, :b].copy_(batch["next_states"].to(self.device, torch.float32).reshape(-1, _lib.OBS_DIM))

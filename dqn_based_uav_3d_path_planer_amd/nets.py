@@ -60,13 +60,17 @@ class _SplitKLinearFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = gy @ w if ctx.needs_input_grad[0] else None
-        n = x.shape[0]
-        c = 512
-        if n >= 8 * c and n % c == 0:
-            gw = torch.bmm(gy.view(n // c, c, -1).transpose(1, 2), x.view(n // c, c, -1)).sum(0)
-        else:
-            gw = gy.t() @ x
-        return gx, gw, gy.sum(0)
+        gw = gb = None
+        if ctx.needs_input_grad[1]:          # (the critics are only passed through in the actor loss: no dW needed there)
+            n = x.shape[0]
+            c = 512
+            if n >= 8 * c and n % c == 0:    # reshape, not view: an upstream gradient may arrive transposed / strided
+                gw = torch.bmm(gy.reshape(n // c, c, -1).transpose(1, 2), x.reshape(n // c, c, -1)).sum(0)
+            else:
+                gw = gy.t() @ x
+        if ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
 
 
 class SplitKLinear(torch.nn.Linear):

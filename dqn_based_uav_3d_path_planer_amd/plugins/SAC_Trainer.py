@@ -65,10 +65,32 @@ class SAC_Trainer:
     def get_action_batch(self, states, eps):
         return self.learner.act(states)
 
+    def downgrade(self):
+        """Fused -> PyTorch learner, in place, keeping weights, targets, log_alpha, the Adam moments and the update counts.
+        The fused update lives on PathPlan_City's packed replay ring; whoever cannot offer that (an env off the fast path:
+        f16 / f32 observation rows, <fast_path>0</fast_path>; a caller of update(transition_dict) with arbitrary f32 states)
+        gets the same trainer on PyTorch-ROCm ops instead of an error."""
+        if not self.fused:
+            return
+        F = self.learner
+        T = SACLearner(self.param, self.device)
+        for name in ("actor", "critic_1", "critic_2", "target_critic_1", "target_critic_2"):
+            getattr(T, name).load_state_dict(getattr(F, name).state_dict())
+        for opt, sd in zip((T.actor_optimizer, T.critic_1_optimizer, T.critic_2_optimizer), F.optimizer_state_dicts()):
+            if F.adam_steps > 0:
+                opt.load_state_dict(sd)
+        with torch.no_grad():
+            T.log_alpha.copy_(F.log_alpha)
+        if F.adam_steps > 0:
+            T.log_alpha_optimizer.state[T.log_alpha] = {"step": torch.tensor(float(F.adam_steps)),
+                                                        "exp_avg": F._alpha_mv[0].detach().clone().reshape(()),
+                                                        "exp_avg_sq": F._alpha_mv[1].detach().clone().reshape(())}
+        T.epoch = F.epoch
+        self.learner, self.fused = T, False
+
     def update(self, transition_dict):
-        if self.fused:
-            raise RuntimeError("this SAC_Trainer runs the fused update on PathPlan_City's replay ring (run_eposide); for "
-                               "trainer.update(transition_dict) set <fused>0</fused> in Trainer.xml")
+        if self.fused:           # arbitrary f32 states: not rows of the packed ring -> the PyTorch learner takes over
+            self.downgrade()
         states = transition_dict.get("states") if transition_dict else None
         if states is None or len(states) == 0 or len(self.replay_memory.memory) < self.Batch_Size:   # :322-333
             self.learner.epoch += 1
@@ -101,10 +123,8 @@ class SAC_Trainer:
 
     def _optim_states(self):
         L = self.learner
-        if self.fused:           # Adam moments live in the learner's flat blocks; same keys as torch.optim.Adam's state dict
-            mk = lambda m, v: {"fused_adam": True, "step": L.epoch, "exp_avg": m.detach().cpu().clone(),   # noqa: E731
-                               "exp_avg_sq": v.detach().cpu().clone()}
-            return (mk(L._blocks[1], L._blocks[2]), mk(L._cblocks[4], L._cblocks[5]), mk(L._cblocks[6], L._cblocks[7]))
+        if self.fused:           # the kernels' flat Adam moments, in torch.optim.Adam's own state-dict format
+            return L.optimizer_state_dicts()
         return (L.actor_optimizer.state_dict(), L.critic_1_optimizer.state_dict(), L.critic_2_optimizer.state_dict())
 
     def save(self, directory=None):
@@ -115,28 +135,47 @@ class SAC_Trainer:
             torch.save({"model": cpu(net.state_dict()), "optimizer": opt, "epoch": self.epoch}, self._path(role, directory))
 
     def Load_Mod(self, Mod=None):
+        """Trainer/SAC_Trainer.py:98-111.  All three files are read and checked before any net is touched, so a bad
+        checkpoint cannot leave a half-loaded model; fused and PyTorch trainers read each other's files (both write
+        torch.optim.Adam state dicts)."""
         L = self.learner
         paths = [self._path(r) for r in ("actor", "critic_1", "critic_2")]
-        if all(os.path.exists(p) for p in paths):
+        if not all(os.path.exists(p) for p in paths):
+            return
+        try:
+            cks = [torch.load(p, map_location=self.device) for p in paths]
+            nets = (L.actor, L.critic_1, L.critic_2)
+            for ck, net in zip(cks, nets):                       # validate first
+                want = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+                got = {k: tuple(v.shape) for k, v in ck["model"].items()}
+                if want != got:
+                    raise ValueError("checkpoint does not fit the network: %s" % sorted(set(want.items()) ^ set(got.items()))[:4])
+            opts = [ck["optimizer"] for ck in cks]
+            legacy = [isinstance(o, dict) and o.get("fused_adam") for o in opts]    # round-2 fused checkpoints
+            backup = [{k: v.clone() for k, v in net.state_dict().items()} for net in nets]
             try:
+                for ck, net in zip(cks, nets):
+                    net.load_state_dict(ck["model"])             # (fused: parameters are views of the flat blocks: copies in place)
                 if self.fused:
-                    slots = ((L._blocks[1], L._blocks[2]), (L._cblocks[4], L._cblocks[5]), (L._cblocks[6], L._cblocks[7]))
-                    for p, net, (m, v) in zip(paths, (L.actor, L.critic_1, L.critic_2), slots):
-                        ck = torch.load(p, map_location=self.device)
-                        net.load_state_dict(ck["model"])             # parameters are views of the flat blocks: copies in place
-                        o = ck["optimizer"]
-                        if o.get("fused_adam"):
+                    if all(legacy):
+                        slots = ((L._blocks[1], L._blocks[2]), (L._cblocks[4], L._cblocks[5]), (L._cblocks[6], L._cblocks[7]))
+                        for o, (m, v) in zip(opts, slots):
                             m.copy_(o["exp_avg"].to(self.device))
                             v.copy_(o["exp_avg_sq"].to(self.device))
-                        self.epoch = ck["epoch"]
+                        L.adam_steps = int(opts[0].get("step", 0))
+                    else:
+                        L.load_optimizer_state_dicts(opts)
                 else:
-                    for p, net, opt in zip(paths, (L.actor, L.critic_1, L.critic_2),
-                                           (L.actor_optimizer, L.critic_1_optimizer, L.critic_2_optimizer)):
-                        ck = torch.load(p, map_location=self.device)
-                        net.load_state_dict(ck["model"])
-                        opt.load_state_dict(ck["optimizer"])
-                        self.epoch = ck["epoch"]
-                L.target_critic_1.load_state_dict(L.critic_1.state_dict())
-                L.target_critic_2.load_state_dict(L.critic_2.state_dict())
-            except Exception as e:
-                print(e.args)
+                    if any(legacy):
+                        raise ValueError("this checkpoint holds a round-2 fused-Adam blob; load it with <fused>1</fused> once and save again")
+                    for o, opt in zip(opts, (L.actor_optimizer, L.critic_1_optimizer, L.critic_2_optimizer)):
+                        opt.load_state_dict(o)
+            except Exception:
+                for net, sd in zip(nets, backup):                # leave the model as it was
+                    net.load_state_dict(sd)
+                raise
+            self.epoch = cks[0]["epoch"]
+            L.target_critic_1.load_state_dict(L.critic_1.state_dict())
+            L.target_critic_2.load_state_dict(L.critic_2.state_dict())
+        except Exception as e:
+            print(e.args)

@@ -162,7 +162,8 @@ class FusedSACLearner:
         self.gamma, self.tau = float(sp.get("gamma")), float(sp.get("tau"))
         self.action_bound = float(ap.get("action_bound"))
         self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-8                           # torch.optim.Adam defaults
-        self.epoch = 0
+        self.epoch = 0                 # SAC_Trainer.update calls (incl. the warm-up / Is_Train = 0 no-ops, as the reference counts)
+        self.adam_steps = 0            # updates actually taken: torch.optim.Adam's own `step` (bias correction)
         self._scalars = torch.zeros(8, dtype=torch.float32, device=d)                      # critic losses [0:4], actor [4:8]
         self._partials = {}
         self._raw = {}
@@ -217,7 +218,7 @@ class FusedSACLearner:
         return b
 
     def _adam(self, lr, tau=0.0, scale=0.0):
-        t = self.epoch
+        t = max(self.adam_steps, 1)
         return self._lib.UavSacAdam(lr, self.beta1, self.beta2, self.adam_eps, 1.0 - self.beta1 ** t,
                                     float(np.sqrt(1.0 - self.beta2 ** t)), tau, scale)
 
@@ -280,12 +281,55 @@ class FusedSACLearner:
         e_next, e_cur = (t.contiguous() for t in noise)
         assert e_next.shape == (n, 2) and e_next.dtype == torch.float32
         self.epoch += 1
+        self.adam_steps += 1
         self.critic_grad(batch, e_next)
         self.critic_step(n)
         self.actor_grad(batch, e_cur)
         self.actor_step(n)
         batch._noise = (e_next, e_cur)
         return self._scalars[4]
+
+    # -- checkpoints: torch.optim.Adam's state-dict format around the kernels' flat moment blocks (as FusedDQNLearner) ----
+    def _opt_slots(self):
+        return ((self.actor, self._blocks[0], self._blocks[1], self._blocks[2], self.actor_lr),
+                (self.critic_1, self._cblocks[0], self._cblocks[4], self._cblocks[5], self.critic_lr),
+                (self.critic_2, self._cblocks[1], self._cblocks[6], self._cblocks[7], self.critic_lr))
+
+    def _opt_view(self, net, pblock, m, v, lr):
+        opt = torch.optim.Adam(net.parameters(), lr=lr, betas=(self.beta1, self.beta2), eps=self.adam_eps)
+        base = pblock.data_ptr()
+        for p in net.parameters():
+            off, n = (p.data_ptr() - base) // 4, p.numel()
+            opt.state[p] = {"step": torch.tensor(float(self.adam_steps)), "exp_avg": m[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": v[off:off + n].view_as(p).clone()}
+        return opt
+
+    def optimizer_state_dicts(self):
+        """(actor, critic_1, critic_2) optimizer state dicts in torch.optim.Adam's own format: interchangeable with
+        SACLearner / the reference's {'model', 'optimizer', 'epoch'} checkpoints (Trainer/SAC_Trainer.py:98-119)."""
+        return tuple(self._opt_view(*slot).state_dict() for slot in self._opt_slots())
+
+    def load_optimizer_state_dicts(self, sds):
+        """The inverse; validates all three before touching any moment block."""
+        views = []
+        for slot, sd in zip(self._opt_slots(), sds):
+            opt = self._opt_view(*slot)
+            opt.load_state_dict(sd)
+            views.append(opt)
+        steps = []
+        with torch.no_grad():
+            for (net, pblock, m, v, _), opt in zip(self._opt_slots(), views):
+                base = pblock.data_ptr()
+                for p in net.parameters():
+                    st = opt.state.get(p)
+                    if not st:
+                        continue
+                    off, n = (p.data_ptr() - base) // 4, p.numel()
+                    m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.append(int(float(st["step"])))
+        if steps:
+            self.adam_steps = max(steps)
 
     @property
     def loss(self):

@@ -107,10 +107,10 @@ def test_config4_fused_sac_episode_path(tmp_path, monkeypatch):
     assert float((tr.target_critic_1.fc2.weight.detach() - t0w).abs().max()) > 0
     for net in (tr.actor, tr.critic_1, tr.critic_2, tr.target_critic_1, tr.target_critic_2):
         assert all(torch.isfinite(p).all() for p in net.parameters())
-    with pytest.raises(RuntimeError, match="fused"):
-        tr.update({"states": [1]})
-    # checkpoint round trip (model + Adam moments)
+    # checkpoint round trip (model + Adam moments, torch.optim.Adam's own format)
     tr.save()
+    ck = torch.load(tr._path("critic_1"))
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and float(ck["optimizer"]["state"][0]["step"]) == tr.learner.adam_steps
     m_saved = tr.learner._blocks[1].clone()
     a_saved = tr.actor.fc1.weight.detach().clone()
     with torch.no_grad():
@@ -118,6 +118,15 @@ def test_config4_fused_sac_episode_path(tmp_path, monkeypatch):
         tr.learner._blocks[1].zero_()
     tr.Load_Mod()
     assert torch.equal(tr.actor.fc1.weight, a_saved) and torch.equal(tr.learner._blocks[1], m_saved)
+    # ... and a PyTorch-learner trainer (<fused>0</fused>) reads the same files: weights, Adam moments, step count
+    from dqn_based_uav_3d_path_planer_amd import factories
+    p2 = dict(tr.param, fused="0", model_dir=tr.model_dir)
+    tr2 = factories.TrainerFactory().Create_Trainer(p2)
+    assert not tr2.fused and torch.equal(tr2.actor.fc1.weight.detach(), a_saved) and tr2.epoch == tr.epoch
+    st = tr2.learner.actor_optimizer.state[tr2.actor.fc1.weight]
+    assert float(st["step"]) == tr.learner.adam_steps
+    off = 0
+    assert torch.equal(st["exp_avg"].reshape(-1), m_saved[off:off + st["exp_avg"].numel()])
     # speed: a second episode, timed
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -126,6 +135,20 @@ def test_config4_fused_sac_episode_path(tmp_path, monkeypatch):
     per_step = (time.perf_counter() - t0) / env.steps_last_episode
     print(f"fused SAC plugin episode: {env.steps_last_episode} steps, {per_step * 1e6:.0f} us/step (4 slots x (act + draw + 4-launch update))")
     assert per_step <= 2.5e-3
+    # trainer.update(transition_dict) on arbitrary f32 states: the trainer moves itself to the PyTorch learner (same weights,
+    # same Adam state) instead of raising
+    a_now, steps_now = tr.actor.fc1.weight.detach().clone(), tr.learner.adam_steps
+    out = tr.update({"states": []})
+    assert not tr.fused and type(tr.learner).__name__ == "SACLearner" and "sum_epoch" in out
+    assert torch.equal(tr.actor.fc1.weight.detach(), a_now)
+    assert float(tr.learner.actor_optimizer.state[tr.actor.fc1.weight]["step"]) == steps_now
+    rng = np.random.default_rng(0)
+    td = {"states": rng.normal(0, 1, (64, 100)).astype(np.float32), "actions": rng.uniform(-1, 1, (64, 2)).astype(np.float32),
+          "rewards": rng.normal(0, 1, 64).astype(np.float32), "next_states": rng.normal(0, 1, (64, 100)).astype(np.float32),
+          "dones": np.zeros(64, np.float32)}
+    tr.update(td)
+    assert float(tr.learner.actor_optimizer.state[tr.actor.fc1.weight]["step"]) == steps_now + 1
+    assert not torch.equal(tr.actor.fc1.weight.detach(), a_now) and np.isfinite(float(tr.loss))
 
 
 def test_fused_episode_path_runs_at_bench_speed(tmp_path, monkeypatch):
