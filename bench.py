@@ -102,6 +102,10 @@ def parse():
     p.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the short in-run leg without the exchange")
     p.add_argument("--no-other-configs", action="store_true",
                    help="N = 1, default command: do not run BASELINE configs[2..4] + the env-only points as child processes")
+    p.add_argument("--sample-lag", type=int, default=0, choices=[0, 1],
+                   help="0 = the reference's strictly serial act -> step -> learn (the benchmark line).  1 = EXPERIMENT (a stated "
+                        "deviation): update t samples the transitions stored before step t, so its gradient kernel runs on a "
+                        "second stream beside step t (csrc/loop.hip)")
     p.add_argument("--inject-p2p-fault", type=int, default=-1,
                    help="test: rank R raises the peer exchange's sticky error before the timed region (exercises the fallback)")
     p.add_argument("--p2p-check-every", type=int, default=256, help="N > 1: on-device weight checksum compare every that many updates")
@@ -474,6 +478,8 @@ def other_configs(args):
     runs = [("configs[2]", ["--config", "3", "--steps", "10", "--warmup", "3"]),
             ("configs[3]", ["--config", "4", "--steps", "6", "--warmup", "2"]),
             ("configs[4] (one GPU's 32768-env share of the 8-GPU run)", ["--config", "5", "--steps", "12", "--warmup", "3"]),
+            ("EXPERIMENT on configs[1] (not the benchmark's semantics): sample_lag = 1 -- update t samples transitions <= t - 1, "
+             "its gradient kernel on a second stream beside step t", ["--sample-lag", "1", "--steps", "20", "--warmup", "4"]),
             ("env-only 65536 agents/launch", ["--env-only", "--envs", "65536", "--steps", "40"]),
             ("env-only 262144 agents/launch", ["--env-only", "--envs", "262144", "--steps", "20"])]
     out = []
@@ -595,7 +601,8 @@ def run_dqn(args, world_size, rank, dev):
         state["use_c"] = fused and args.host_loop == "c" and (not multi or exchange["used"] in ("p2p", "coll", "none"))
         if state["use_c"]:
             from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
-            state["hot"] = HotLoop(ring, learner, args.batch, seed, eps=args.eps, counter=counter[0], time_every=ev_every)
+            state["hot"] = HotLoop(ring, learner, args.batch, seed, eps=args.eps, counter=counter[0], time_every=ev_every,
+                                   sample_lag=args.sample_lag)
 
     build_loop()
 
@@ -863,7 +870,8 @@ def run_dqn(args, world_size, rank, dev):
                        "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
                                       % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
-                       "epsilon": args.eps, "parallelism": par},
+                       "epsilon": args.eps, "parallelism": par,
+                       "sample_lag": args.sample_lag},
             "roofline": {"bound": "hbm",
                          "kernel": ("k_step_coop<policy> -- the launch the timed loop issues: get_action (Q(s) + epsilon-greedy) + "
                                     "update_PathPlan + state_PathPlan + replay write") if in_loop_policy
@@ -938,7 +946,7 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
     out = run_dqn(args, world_size, rank, dev)
     if rank == 0 and out is not None:
-        headline = args.config == 2 and world_size == 1 and not args.env_only and not args.explicit
+        headline = args.config == 2 and world_size == 1 and not args.env_only and not args.explicit and args.sample_lag == 0
         if headline and not args.no_other_configs:
             out["other_configs"] = other_configs(args)
         if not args.no_cpu_baseline and world_size == 1 and not args.env_only:

@@ -78,7 +78,7 @@ class UavLoopConfig(C.Structure):
                 ("eps", C.c_float), ("gamma", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("adam_eps", C.c_float), ("step_flags", C.c_uint32), ("partials_dev", C.c_void_p),
                 ("loss_dev", C.c_void_p), ("info_dev", C.c_void_p), ("p2p", C.c_void_p), ("time_every", C.c_int32),
-                ("reserved0", C.c_int32), ("coll", C.c_void_p), ("raw_dev", C.c_void_p),
+                ("sample_lag", C.c_int32), ("coll", C.c_void_p), ("raw_dev", C.c_void_p),
                 ("per", UavPer), ("per_alpha", C.c_double), ("per_beta", C.c_double), ("per_beta_inc", C.c_double),
                 ("per_eps", C.c_double), ("per_clip", C.c_double),
                 ("per_slots_dev", C.c_void_p), ("per_prio_dev", C.c_void_p), ("per_w_dev", C.c_void_p),

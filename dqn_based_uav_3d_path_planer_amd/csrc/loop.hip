@@ -28,6 +28,9 @@ struct UavLoop {
     bool fuse_act = true;            // act in the step kernel's prologue (uavenv_step_policy) until it says it cannot
     bool per = false;                // prioritised replay on (c.per.prio != NULL)
     double per_beta = 0.4;
+    // sample_lag = 1 (experiment): the gradient kernel of pass t runs on a second stream beside the step kernel of pass t
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_grad = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev;      // pairs (start, stop), recorded so far
     std::vector<hipEvent_t> pool;    // idle events
 };
@@ -62,6 +65,15 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
     l->counter = cfg->counter;
     l->per = cfg->per.prio != nullptr;
     l->per_beta = cfg->per_beta;
+    if (cfg->sample_lag != 0) {
+        if (cfg->sample_lag != 1 || l->per) { delete l; return UAVENV_EINVAL; }
+        if (hipStreamCreateWithFlags(&l->aux, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&l->ev_grad, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess) {
+            uavenv_loop_destroy(l);
+            return UAVENV_EHIP;
+        }
+    }
     l->fuse_act = getenv("UAVENV_NO_FUSED_ACT") == nullptr;
     l->prof = getenv("UAVENV_LOOP_PROFILE") != nullptr;
     l->obs_row_bytes = (size_t)cfg->ring.n_agents * (cfg->ring.obs_dtype == UAVENV_OBS_PACKED ? UAVENV_OBS_PACKED_DWORDS * 4
@@ -78,6 +90,8 @@ int uavenv_loop_destroy(UavLoop *l)
                 1e6 * l->t_host[1] / l->t_host[3], 1e6 * l->t_host[2] / l->t_host[3], l->t_host[3]);
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : l->pool) (void)hipEventDestroy(e);
+    if (l->aux) { (void)hipStreamSynchronize(l->aux); (void)hipStreamDestroy(l->aux); }
+    for (hipEvent_t e : {l->ev_grad, l->ev_join}) if (e) (void)hipEventDestroy(e);
     delete l;
     return UAVENV_OK;
 }
@@ -130,8 +144,24 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
         int32_t st[4];
         if (uavenv_p2p_status(c.p2p, 0, st) == UAVENV_OK && st[0] != 0) return UAVENV_EP2P;
     }
+    const bool lag = l->aux != nullptr;
     for (int k = 0; k < n_steps; ++k) {
         const int t = l->head, nxt = t + 1 == R.frames ? 0 : t + 1;
+        bool lag_update = false;
+        if (lag && c.batch > 0 && l->filled > 0 &&
+            (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch)) {
+            // update t samples the transitions stored BEFORE step t (frames <= t - 1: the cursor as it stands), so its
+            // gradient depends on adam(t - 1) only, like step t -- the two run side by side
+            // (the second stream starts behind the main stream's tail: Adam t - 1, or step t - 1 when that pass had no update)
+            if (hipEventRecord(l->ev_join, s) != hipSuccess || hipStreamWaitEvent(l->aux, l->ev_join, 0) != hipSuccess) return UAVENV_EHIP;
+            // (a full ring's oldest frame is the one step t is overwriting: it is left out -- one frame less replay in this mode)
+            const int filled_lag = l->filled < R.frames - 2 ? l->filled : R.frames - 2;
+            int rcg = uavenv_dqn_grad(&R, l->head, filled_lag, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
+                                      c.huber, c.partials_dev, l->aux);
+            if (rcg != UAVENV_OK) return rcg;
+            if (hipEventRecord(l->ev_grad, l->aux) != hipSuccess) return UAVENV_EHIP;
+            lag_update = true;
+        }
         unsigned char *obs_t = (unsigned char *)R.obs + (size_t)t * l->obs_row_bytes;
         unsigned char *obs_n = (unsigned char *)R.obs + (size_t)nxt * l->obs_row_bytes;
         int32_t *act_t = (int32_t *)R.action + (size_t)t * n;
@@ -180,8 +210,12 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
             rc = uavenv_per_fill(&c.per, (int64_t)nxt * (int64_t)n, (int64_t)n, 0.0, nullptr, s);
             if (rc != UAVENV_OK) return rc;
         }
-        if (c.batch > 0 && (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch)) {
-            if (l->per) {                 // ReplayTree.sample: beta first (:155), selection, importance weights
+        if (lag ? lag_update
+                : (c.batch > 0 && (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch))) {
+            if (lag) {                    // the gradient is already in flight on the second stream: join it in front of Adam
+                if (hipStreamWaitEvent(s, l->ev_grad, 0) != hipSuccess) return UAVENV_EHIP;
+                rc = UAVENV_OK;
+            } else if (l->per) {          // ReplayTree.sample: beta first (:155), selection, importance weights
                 l->per_beta = l->per_beta + (double)c.per_beta_inc < 1.0 ? l->per_beta + (double)c.per_beta_inc : 1.0;
                 rc = uavenv_per_rebuild(&c.per, s);
                 if (rc != UAVENV_OK) return rc;

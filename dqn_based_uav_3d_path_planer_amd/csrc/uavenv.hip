@@ -986,6 +986,9 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
             const unsigned long long gm = (a.U >= 64) ? ~0ull : (((1ull << a.U) - 1ull) << g0);
             did_reset = active && ((dm & gm) == gm);
             if (APF && a.apf_split) reset_agents_wave(a, i - lane, ii, g, did_reset);
+            // (Tried in round 3 and dropped: requesting the reset candidate's bank rows speculatively before update_PathPlan
+            // for every agent that CAN finish this step, as k_step_coop's helper wavefront does -- the draw + 13 extra loads
+            // per candidate lane cost more than the hidden round trip saved: 65 536 agents 12.7 -> 13.2 us, 98 304: 14.9 -> 15.3.)
             else if (did_reset) reset_agent<APF>(a, ii, g);
         }
 
@@ -1558,7 +1561,11 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
     const int obs = e->cfg.obs_dtype;
     const bool apf = e->cfg.apf_enabled == 1;
     static const int tile_env = env_int("UAVENV_TILE_STORE", -1);
-    const bool tile_store = tile_env >= 0 ? tile_env != 0 : e->N > 32768;
+    // the wave-cooperative tile store pays once a SIMD holds several wavefronts (MEASURED, round 3, us per launch with /
+    // without it -- packed rows: 65 536 agents 13.8 / 12.7, 131 072: 16.9 / 16.4, 262 144: 25.8 / 26.4; f16 rows: 65 536:
+    // 16.2 / 15.0, 131 072: 21.2 / 22.0, 262 144: 34.7 / 38.3; f32 rows keep the round-1 threshold)
+    const int tile_from = obs == UAVENV_OBS_PACKED ? 196608 : (obs == UAVENV_OBS_F16 ? 131072 : 32769);
+    const bool tile_store = tile_env >= 0 ? tile_env != 0 : e->N >= tile_from;
     const int nw = block / 64;
     a.obsq_off = (e->world_bytes + 15) & ~15;
     int slot = (int)sizeof(ObsWaveLds);            // per-wave LDS slot: the work queue, then (same bytes) the tile

@@ -22,7 +22,7 @@ class P2PExchangeError(_lib.UavEnvError):
 class HotLoop:
     def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
                  counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
-                 time_every: int = 0, info: torch.Tensor = None, per=None):
+                 time_every: int = 0, info: torch.Tensor = None, per=None, sample_lag: int = 0):
         """per: a replay.DevicePER over the ring's frames * N slots -- prioritised replay (IsPriority_Replay = 1) inside the C
         loop: new-frame priorities, rebuild, ReplayTree.sample, importance weights, the weighted update and batch_update are
         enqueued per pass (csrc/loop.hip); per.beta / per.n_entries are kept in step."""
@@ -55,6 +55,7 @@ class HotLoop:
         cfg.partials_dev = self._partials.data_ptr()
         cfg.loss_dev = learner.loss.data_ptr()
         cfg.time_every = int(time_every)
+        cfg.sample_lag = int(sample_lag)     # 1: experiment -- update t samples transitions <= t - 1, gradient beside the step
         if info is not None:        # [frames, N] uint8: the info code of every transition (episode statistics)
             assert info.dtype == torch.uint8 and tuple(info.shape) == (ring.frames, env.N) and info.is_contiguous()
             cfg.info_dev = info.data_ptr()

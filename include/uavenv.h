@@ -392,7 +392,11 @@ typedef struct UavLoopConfig {
     uint8_t *info_dev;           /* nullable: frames x N plane receiving uavenv_step's info codes (frame-major like reward) */
     UavP2P *p2p;                 /* nullable: multi-GPU -- gradients are summed over the ranks through csrc/p2p.hip */
     int32_t time_every;          /* > 0: bracket the step kernel of every time_every-th step with HIP events */
-    int32_t reserved0;
+    int32_t sample_lag;          /* 0 = the reference's order (update t samples transitions <= t: act -> step -> learn, strictly
+                                    serial).  1 = EXPERIMENT, a stated deviation from Envs/PathPlan_City.py:374-385: update t samples
+                                    the transitions stored before step t (<= t - 1), so its gradient kernel depends on the
+                                    previous Adam step only and runs on a second stream BESIDE step t; Adam t joins both.  Not
+                                    with prioritised replay. */
     UavColl *coll;               /* nullable (used when p2p is NULL): multi-GPU -- RCCL all-reduce of raw_dev from C */
     float *raw_dev;              /* num_params + 2 floats of scratch for the coll path */
     /* prioritised replay (per.prio != NULL; capacity = frames * N, slot = frame * N + agent): per pass, after the step,

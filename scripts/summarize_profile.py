@@ -40,7 +40,7 @@ for line in open(pmc):
     m = re.match(r"\S+ (\S+) (\S+) n=(\d+) mean=([0-9.eE+-]+)", line)
     if m:
         c[(m.group(1), m.group(2))] = float(m.group(4))
-for k in ("k_step", "k_dqn_grad"):
+for k in ("k_step", "k_step_policy", "k_dqn_grad", "k_dqn_reduce_adam"):
     f, w = c.get((k, "FETCH_SIZE")), c.get((k, "WRITE_SIZE"))
     if f is not None and w is not None:
         # gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; KB units
@@ -62,6 +62,17 @@ for name in ("SQ_INSTS_VALU_MFMA_F32", "SQ_INSTS_VALU_MFMA_F16", "SQ_INSTS_VALU_
     v = c.get(("k_dqn_grad", name))
     if v is not None:
         entry["k_dqn_grad_" + name] = v
+# which kernel sources these counters belong to: bench.py compares this with the sources it runs (traffic_stale)
+sys.path.insert(0, ROOT)
+try:
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_sha", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    entry["csrc_sha"] = mod.csrc_sha()
+except Exception as ex:      # noqa: BLE001
+    entry["csrc_sha"] = None
+    print("csrc_sha unavailable:", ex)
 path = os.path.join(dst, "summary.json")
 allv = json.load(open(path)) if os.path.exists(path) else {}
 allv[key] = entry

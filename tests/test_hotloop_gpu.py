@@ -75,3 +75,48 @@ def test_rollout_only_and_learn_start():
     assert L.epoch == 3 and torch.equal(L.flat[0], w1) and ring.filled == 12
     roll.close()
     env.close()
+
+
+def test_sample_lag_experiment_equals_its_serial_statement():
+    """sample_lag = 1 (csrc/loop.hip, an EXPERIMENT and a stated deviation from PathPlan_City.py:374-385): update t samples
+    the transitions stored before step t, so the gradient kernel runs on a second stream beside the step kernel.  The
+    two-stream schedule must compute exactly what the same semantics computes when issued serially from Python: act with
+    theta_t, step t, then the update from the PRE-step cursor -- ring, weights, Adam moments bit for bit (any missing
+    dependency between the streams would show as a difference)."""
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    n, batch, steps = 2048, 2048, 40
+
+    def build():
+        env = make_city26_env(n, obs_dtype="packed")
+        ring = DeviceReplayRing(env, 8 * n, discrete=True)
+        ring.reset(seed=12)
+        torch.manual_seed(1)
+        return env, ring, FusedDQNLearner(dict(PARAM, NetWork="Qnet2"), "dqn", device="cuda:0")
+
+    class Pre:            # the ring as the update of pass t sees it: the cursor before step t
+        pass
+
+    env_a, ring_a, La = build()
+    for c in range(steps):
+        La.act(ring_a.current_obs(), 0.2, 9, c, index_out=ring_a.current_action())
+        pre = Pre()
+        pre._c, pre.head, pre.filled = ring_a._c, ring_a.head, min(ring_a.filled, ring_a.frames - 2)   # (the frame step t overwrites is out)
+        ring_a.step_env(auto_reset=True)
+        if pre.filled > 0 and pre.filled * n >= batch:
+            La.learn_from_ring(pre, batch, 9, c)
+    env_b, ring_b, Lb = build()
+    loop = HotLoop(ring_b, Lb, batch, seed=9, eps=0.2, sample_lag=1)
+    loop.run(7)
+    loop.run(steps - 7)
+    torch.cuda.synchronize()
+    assert (ring_b.head, ring_b.filled, Lb.epoch, loop.counter) == (ring_a.head, ring_a.filled, La.epoch, steps)
+    assert La.epoch == steps - 1
+    for name in ("obs", "action", "reward", "done", "valid"):
+        assert torch.equal(getattr(ring_a, name), getattr(ring_b, name)), name
+    assert torch.equal(La.flat, Lb.flat) and float(La.loss) == float(Lb.loss)
+    loop.close()
+    env_a.close()
+    env_b.close()
