@@ -102,6 +102,9 @@ def parse():
     p.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the short in-run leg without the exchange")
     p.add_argument("--no-other-configs", action="store_true",
                    help="N = 1, default command: do not run BASELINE configs[2..4] + the env-only points as child processes")
+    p.add_argument("--per", action="store_true",
+                   help="prioritised replay (IsPriority_Replay = 1; BaseClass/replay_buffer.py:121-223) inside the C loop: per pass "
+                        "new-frame priorities, rebuild, ReplayTree.sample, importance weights, the weighted update, batch_update")
     p.add_argument("--sample-lag", type=int, default=0, choices=[0, 1],
                    help="0 = the reference's strictly serial act -> step -> learn (the benchmark line).  1 = EXPERIMENT (a stated "
                         "deviation): update t samples the transitions stored before step t, so its gradient kernel runs on a "
@@ -478,6 +481,7 @@ def other_configs(args):
     runs = [("configs[2]", ["--config", "3", "--steps", "10", "--warmup", "3"]),
             ("configs[3]", ["--config", "4", "--steps", "6", "--warmup", "2"]),
             ("configs[4] (one GPU's 32768-env share of the 8-GPU run)", ["--config", "5", "--steps", "12", "--warmup", "3"]),
+            ("configs[1] with prioritised replay (IsPriority_Replay = 1) on the fused path", ["--per", "--steps", "12", "--warmup", "3"]),
             ("EXPERIMENT on configs[1] (not the benchmark's semantics): sample_lag = 1 -- update t samples transitions <= t - 1, "
              "its gradient kernel on a second stream beside step t", ["--sample-lag", "1", "--steps", "20", "--warmup", "4"]),
             ("env-only 65536 agents/launch", ["--env-only", "--envs", "65536", "--steps", "40"]),
@@ -599,10 +603,15 @@ def run_dqn(args, world_size, rank, dev):
             state["hot"].close()
             state["hot"] = None
         state["use_c"] = fused and args.host_loop == "c" and (not multi or exchange["used"] in ("p2p", "coll", "none"))
+        if args.per and not state["use_c"]:
+            raise SystemExit("--per runs inside the C loop (fused learner, --host-loop c)")
         if state["use_c"]:
             from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+            if args.per and state.get("per") is None:
+                from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+                state["per"] = DevicePER(ring.frames * env.N, device=dev, tree_order=False)
             state["hot"] = HotLoop(ring, learner, args.batch, seed, eps=args.eps, counter=counter[0], time_every=ev_every,
-                                   sample_lag=args.sample_lag)
+                                   sample_lag=args.sample_lag, per=state.get("per"))
 
     build_loop()
 
@@ -871,7 +880,9 @@ def run_dqn(args, world_size, rank, dev):
                                       % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
                        "epsilon": args.eps, "parallelism": par,
-                       "sample_lag": args.sample_lag},
+                       "sample_lag": args.sample_lag,
+                       "replay": ("prioritised (ReplayTree semantics, alpha 0.6, beta 0.4 + 0.001 per update, epsilon 0.01, clip 1) -- "
+                                  "10 launches per pass from C") if args.per else "uniform without replacement"},
             "roofline": {"bound": "hbm",
                          "kernel": ("k_step_coop<policy> -- the launch the timed loop issues: get_action (Q(s) + epsilon-greedy) + "
                                     "update_PathPlan + state_PathPlan + replay write") if in_loop_policy
@@ -914,6 +925,8 @@ def run_dqn(args, world_size, rank, dev):
     if hot is not None:
         hot.close()
     if fused and multi:
+        torch.cuda.synchronize(dev)
+        dist.barrier()                       # no rank unmaps its peers while one of them may still be running a pull
         learner.disable_p2p()
     env.close()
     return out
@@ -946,7 +959,8 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
     out = run_dqn(args, world_size, rank, dev)
     if rank == 0 and out is not None:
-        headline = args.config == 2 and world_size == 1 and not args.env_only and not args.explicit and args.sample_lag == 0
+        headline = (args.config == 2 and world_size == 1 and not args.env_only and not args.explicit and args.sample_lag == 0
+                    and not args.per)
         if headline and not args.no_other_configs:
             out["other_configs"] = other_configs(args)
         if not args.no_cpu_baseline and world_size == 1 and not args.env_only:

@@ -30,7 +30,7 @@ SYMBOLS = (
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
-    "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_inject_fault",
+    "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_inject_fault", "uavenv_p2p_can_reach",
     "uavenv_coll_last_error", "uavenv_coll_unique_id", "uavenv_coll_create", "uavenv_coll_destroy", "uavenv_coll_allreduce_sum",
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_get_per", "uavenv_loop_step_times",
@@ -187,6 +187,8 @@ def load() -> C.CDLL:
     lib.uavenv_p2p_configure.argtypes = [vp, i32, i32]
     lib.uavenv_p2p_status.restype = C.c_int
     lib.uavenv_p2p_status.argtypes = [vp, i32, C.POINTER(i32)]
+    lib.uavenv_p2p_can_reach.restype = C.c_int
+    lib.uavenv_p2p_can_reach.argtypes = [i32, i32]
     lib.uavenv_p2p_inject_fault.restype = C.c_int
     lib.uavenv_p2p_inject_fault.argtypes = [vp, i32]
     lib.uavenv_coll_last_error.restype = C.c_char_p

@@ -31,7 +31,7 @@
 
 namespace {
 constexpr int kMaxWorld = 16;
-constexpr uint32_t kSpinLimit = 1u << 22;            // x ~0.25 us per poll: about a second (uavenv_p2p_configure changes it)
+constexpr uint32_t kSpinLimit = 1u << 24;            // x ~0.25 us per poll: about four seconds (uavenv_p2p_configure changes it)
 }
 
 struct UavP2P {
@@ -292,6 +292,14 @@ int uavenv_p2p_handle(UavP2P *c, void *handle_out)
     memset(handle_out, 0, UAVENV_P2P_HANDLE_BYTES);
     memcpy(handle_out, &h, sizeof(h));
     return UAVENV_OK;
+}
+
+int uavenv_p2p_can_reach(int32_t device, int32_t peer_device)
+{
+    if (device == peer_device) return 1;
+    int ok = 0;
+    if (hipDeviceCanAccessPeer(&ok, device, peer_device) != hipSuccess) return 0;
+    return ok ? 1 : 0;
 }
 
 int uavenv_p2p_connect(UavP2P *c, const void *all_handles)

@@ -390,10 +390,16 @@ class FusedDQNLearner:
         except Exception:
             ok, mine = False, (C.c_ubyte * _lib.P2P_HANDLE_BYTES)()
         allh = [None] * world
-        dist.all_gather_object(allh, (ok, bytes(mine)))
-        ok = all(o for o, _ in allh)
+        my_dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        dist.all_gather_object(allh, (ok, bytes(mine), my_dev))
+        ok = all(o for o, _, _ in allh)
+        if ok:      # nothing is mapped unless this device may address every peer's memory (xGMI / PCIe peer access)
+            ok = all(self.lib.uavenv_p2p_can_reach(my_dev, d) == 1 for _, _, d in allh)
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        ok = all(flags)
         if ok:
-            blob = b"".join(b for _, b in allh)
+            blob = b"".join(b for _, b, _ in allh)
             ok = self.lib.uavenv_p2p_connect(h, C.create_string_buffer(blob, len(blob))) == 0
         flags = [None] * world
         dist.all_gather_object(flags, ok)

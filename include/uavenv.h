@@ -328,11 +328,14 @@ int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype,
 typedef struct UavP2P UavP2P;
 int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P **out);
 int uavenv_p2p_handle(UavP2P *p2p, void *handle_out_host);
+/* 1 when kernels on `device` may address memory of `peer_device` (hipDeviceCanAccessPeer; a device reaches itself): the
+ * check to run on every rank before uavenv_p2p_connect maps anything. */
+int uavenv_p2p_can_reach(int32_t device, int32_t peer_device);
 int uavenv_p2p_connect(UavP2P *p2p, const void *all_handles_host);
 int uavenv_p2p_destroy(UavP2P *p2p);
 /* check_every: every that many updates the Adam kernel folds a 64-bit checksum of the new weights into the next bucket
  * and every rank compares the `world` checksums (0 = never; default 256).  spin_limit: polls before a wait gives up
- * (0 = keep; default 2^22, about a second).  Must be the same on every rank. */
+ * (0 = keep; default 2^24, about four seconds).  Must be the same on every rank. */
 int uavenv_p2p_configure(UavP2P *p2p, int32_t check_every, int32_t spin_limit);
 int uavenv_p2p_errors(UavP2P *p2p, int32_t *timeouts_out);        /* synchronises */
 /* out4 = {sticky error code (0 = healthy, UAVENV_P2P_ERR_*), timeouts, checksum mismatches, checksums folded so far}.

@@ -6,13 +6,13 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --env-only-iters 50 $*"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --env-only-iters 50 $*"
 rm -rf /tmp/prof_$TAG
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS) > $OUT/${TAG}_stats.log 2>&1
 find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
 tail -1 $OUT/${TAG}_stats.log > $OUT/${TAG}_bench_under_rocprof.json
 head -12 $OUT/${TAG}_kernel_stats.csv
-PARGS="--steps 1 --warmup 1 --no-cpu-baseline --env-only-iters 20 $*"
+PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --env-only-iters 20 $*"
 : > $OUT/${TAG}_pmc.txt
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
