@@ -652,12 +652,21 @@ def run_dqn(args, world_size, rank, dev):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(x: float) -> float:
+        """(through all_gather_object: a gloo all_reduce of a CUDA tensor leaves this process's later GPU work 2-3x slower --
+        measured with two ranks on one GPU, round 3 -- and the backend-neutral object gather costs nothing here)"""
+        if not multi:
+            return x
+        got = [None] * world_size
+        dist.all_gather_object(got, float(x))
+        return max(got)
+
     def any_rank(flag: bool) -> bool:
         if not multi:
             return flag
-        t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return bool(t.item())
+        got = [None] * world_size
+        dist.all_gather_object(got, bool(flag))
+        return any(got)
 
     def timed(n_steps, record=True):
         """n_steps bench steps between two fences; (seconds, host enqueue seconds, exchange failed on some rank)."""
@@ -707,10 +716,7 @@ def run_dqn(args, world_size, rank, dev):
         if state["hot"] is not None:
             state["hot"].step_times_ms()
         dt, t_enq, bad = timed(args.steps)
-    if multi:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
     n_pass = args.steps * pps
     hot, use_c = state["hot"], state["use_c"]
 
@@ -734,9 +740,7 @@ def run_dqn(args, world_size, rank, dev):
             build_loop()
             timed(1, record=False)
             d0, _, _ = timed(max(2, min(args.steps, 8)), record=False)
-            t = torch.tensor([d0], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            multi_report["ms_per_pass_no_exchange"] = float(t.item()) / (max(2, min(args.steps, 8)) * pps) * 1e3
+            multi_report["ms_per_pass_no_exchange"] = max_over_ranks(d0) / (max(2, min(args.steps, 8)) * pps) * 1e3
             learner._p2p, learner._coll, exchange["used"] = saved
             build_loop()
             hot, use_c = state["hot"], state["use_c"]
