@@ -67,7 +67,7 @@ class UavDqnNet(C.Structure):
 
 class UavPer(C.Structure):
     _fields_ = [("prio", C.c_void_p), ("chunk_sum", C.c_void_p), ("chunk_prefix", C.c_void_p),
-                ("capacity", C.c_int64), ("rot", C.c_int64)]
+                ("capacity", C.c_int64), ("rot", C.c_int64), ("group_sum", C.c_void_p)]
 
 
 class UavLoopConfig(C.Structure):

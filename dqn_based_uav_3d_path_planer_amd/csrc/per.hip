@@ -38,15 +38,26 @@ __device__ __forceinline__ int64_t slot_of(const UavPer &p, int64_t q)
 __global__ void __launch_bounds__(256) k_per_chunk_sum(UavPer p)
 {
     __shared__ double red[256];
+    __shared__ double leaf[kChunk];
     const int64_t q0 = (int64_t)blockIdx.x * kChunk + (int64_t)threadIdx.x * 4;
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t q = q0 + j;
-        if (q < p.capacity) s += p.prio[slot_of(p, q)];
+        const double v = q < p.capacity ? p.prio[slot_of(p, q)] : 0.0;
+        leaf[threadIdx.x * 4 + j] = v;
+        s += v;
     }
     red[threadIdx.x] = s;
     __syncthreads();
+    // the chunk's 64 group sums: 16 consecutive in-order leaves each, added in leaf order from 0.0 -- exactly the sum a lane
+    // of k_per_sample forms over its 16 leaves, so the sampler can read one double per lane instead of sixteen
+    if (p.group_sum && threadIdx.x < 64) {
+        double g = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g += leaf[threadIdx.x * 16 + j];
+        p.group_sum[(int64_t)blockIdx.x * 64 + threadIdx.x] = g;
+    }
     for (int w = 128; w > 0; w >>= 1) {            // fixed pairing: the sum does not depend on scheduling
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
@@ -115,11 +126,16 @@ __global__ void __launch_bounds__(256) k_per_sample(UavPer p, int n_chunks, int 
     const int64_t q0 = (int64_t)b * kChunk + (int64_t)lane * 16;
     double pv[16];
     double s = 0.0;
+    const bool grouped = p.group_sum != nullptr;
+    if (grouped) {                           // one double per lane (the rebuild summed the lane's 16 leaves in this order)
+        s = p.group_sum[(int64_t)b * 64 + lane];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int64_t q = q0 + j;
-        pv[j] = q < p.capacity ? p.prio[slot_of(p, q)] : 0.0;
-        s += pv[j];
+        for (int j = 0; j < 16; ++j) {
+            const int64_t q = q0 + j;
+            pv[j] = q < p.capacity ? p.prio[slot_of(p, q)] : 0.0;
+            s += pv[j];
+        }
     }
     double incl = s;
 #pragma unroll
@@ -133,6 +149,13 @@ __global__ void __launch_bounds__(256) k_per_sample(UavPer p, int n_chunks, int 
     int64_t q = -1;
     double pq = 0.0;
     bool found = false;
+    if (grouped) {                           // only the lane that owns the pick reads its 16 leaves
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t q = q0 + j;
+            pv[j] = (hit && lane == owner && q < p.capacity) ? p.prio[slot_of(p, q)] : 0.0;
+        }
+    }
     if (hit && lane == owner) {
         double run = excl;
 #pragma unroll
@@ -142,6 +165,13 @@ __global__ void __launch_bounds__(256) k_per_sample(UavPer p, int n_chunks, int 
         }
     }
     if (__ballot(found) == 0) {
+        if (grouped) {                       // (rare) the fall-back looks at every leaf of the chunk
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int64_t q = q0 + j;
+                pv[j] = q < p.capacity ? p.prio[slot_of(p, q)] : 0.0;
+            }
+        }
         // Rounding can leave r above the chunk's fresh sum (or on a zero-priority leaf): take the chunk's LAST leaf with
         // p > 0 -- never a retired / invalid slot (priority 0), whose importance weight pow(0, -beta) would be inf.
         // Only a chunk that is all zero falls through to its last leaf with priority 0 (the caller masks those).
@@ -191,39 +221,56 @@ __global__ void k_per_set_f32(UavPer p, const int64_t *__restrict__ slots, const
     p.prio[s] = pow(e, alpha);
 }
 
-// ReplayTree.sample's importance weights (:175-178) for a whole batch in ONE workgroup: w_i = (n p_i / int(total)) ** -beta,
-// then / max_i w_i; the maximum through a fixed-order LDS tree (deterministic).
-__global__ void __launch_bounds__(1024) k_per_weights(UavPer p, int n_chunks, const int64_t *__restrict__ slots,
-                                                      const double *__restrict__ prio, int batch, double n_entries, double beta,
-                                                      int n_agents, float *__restrict__ w_out, int32_t *__restrict__ fa_out)
+// ReplayTree.sample's importance weights (:175-178): w_i = (n p_i / int(total)) ** -beta, then / max_i w_i.  Two launches:
+// the powers (one f64 pow per thread) with one maximum per workgroup, then the division by the maximum of those maxima
+// (fixed-order LDS trees: deterministic).  `w64` holds the unnormalised weights in between (it may alias the priorities),
+// `wg_max` one double per workgroup of the first launch.
+__global__ void __launch_bounds__(256) k_per_weights_pow(UavPer p, int n_chunks, const double *__restrict__ prio, int batch,
+                                                         double n_entries, double beta, double *__restrict__ w64,
+                                                         double *__restrict__ wg_max)
 {
-    __shared__ double red[1024];
+    __shared__ double red[256];
     double total = floor(p.chunk_prefix[n_chunks]);
     total = total < 1.0 ? 1.0 : total;
-    double mx = 0.0;
-    for (int i = (int)threadIdx.x; i < batch; i += 1024) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    double w = 0.0;
+    if (i < batch) {
         const double pi = prio[i];
-        const double w = pi > 0.0 ? pow(n_entries * (pi / total), -beta) : 0.0;
-        mx = w > mx ? w : mx;
+        w = pi > 0.0 ? pow(n_entries * (pi / total), -beta) : 0.0;
+        w64[i] = w;
     }
+    red[threadIdx.x] = w;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + k] ? red[threadIdx.x] : red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wg_max[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_per_weights_norm(const int64_t *__restrict__ slots, const double *__restrict__ w64,
+                                                          const double *__restrict__ wg_max, int n_wg, int batch, int n_agents,
+                                                          float *__restrict__ w_out, int32_t *__restrict__ fa_out)
+{
+    __shared__ double red[256];
+    double mx = 0.0;
+    for (int k = (int)threadIdx.x; k < n_wg; k += 256) mx = wg_max[k] > mx ? wg_max[k] : mx;
     red[threadIdx.x] = mx;
     __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) {
+    for (int k = 128; k > 0; k >>= 1) {
         if ((int)threadIdx.x < k) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + k] ? red[threadIdx.x] : red[threadIdx.x + k];
         __syncthreads();
     }
     mx = red[0];
     mx = mx > 2.2250738585072014e-308 ? mx : 2.2250738585072014e-308;
-    for (int i = (int)threadIdx.x; i < batch; i += 1024) {
-        const double pi = prio[i];
-        const double w = pi > 0.0 ? pow(n_entries * (pi / total), -beta) : 0.0;
-        w_out[i] = (float)(w / mx);
-        if (fa_out) {
-            const int64_t s = slots[i];
-            const int64_t f = s / n_agents;
-            fa_out[2 * i] = (int32_t)f;
-            fa_out[2 * i + 1] = (int32_t)(s - f * n_agents);
-        }
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= batch) return;
+    w_out[i] = (float)(w64[i] / mx);
+    if (fa_out) {
+        const int64_t s = slots[i];
+        const int64_t f = s / n_agents;
+        fa_out[2 * i] = (int32_t)f;
+        fa_out[2 * i + 1] = (int32_t)(s - f * n_agents);
     }
 }
 
@@ -293,14 +340,18 @@ int uavenv_per_set_f32(const UavPer *p, const int64_t *slots_dev, const float *a
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 
-int uavenv_per_weights(const UavPer *p, const int64_t *slots_dev, const double *prio_dev, int32_t batch, int64_t n_entries,
+int uavenv_per_weights(const UavPer *p, const int64_t *slots_dev, double *prio_dev, int32_t batch, int64_t n_entries,
                        double beta, int32_t n_agents, float *is_weights_out_dev, int32_t *frame_agent_out_dev, void *stream)
 {
     if (!per_ok(p) || !slots_dev || !prio_dev || !is_weights_out_dev || batch <= 0 || n_entries < 0) return UAVENV_EINVAL;
     if (frame_agent_out_dev && n_agents <= 0) return UAVENV_EINVAL;
-    hipLaunchKernelGGL(k_per_weights, dim3(1), dim3(1024), 0, (hipStream_t)stream, *p, uavenv_per_num_chunks(p->capacity),
-                       slots_dev, prio_dev, batch, (double)n_entries, beta, n_agents > 0 ? n_agents : 1, is_weights_out_dev,
-                       frame_agent_out_dev);
+    const int n_wg = (batch + 255) / 256;
+    double *wg_max = prio_dev + batch;                         // the scratch tail the caller left behind the priorities
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_per_weights_pow, dim3(n_wg), dim3(256), 0, s, *p, uavenv_per_num_chunks(p->capacity), prio_dev, batch,
+                       (double)n_entries, beta, prio_dev, wg_max);
+    hipLaunchKernelGGL(k_per_weights_norm, dim3(n_wg), dim3(256), 0, s, slots_dev, prio_dev, wg_max, n_wg, batch,
+                       n_agents > 0 ? n_agents : 1, is_weights_out_dev, frame_agent_out_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

@@ -70,7 +70,7 @@ class HotLoop:
             if per.capacity != ring.frames * env.N or per._c.rot != 0:
                 raise ValueError("the DevicePER must cover the ring's frames * N slots in slot order (tree_order=False)")
             d, b = env.device, max(int(batch), 64)
-            self._per_bufs = (torch.zeros(b, dtype=torch.int64, device=d), torch.zeros(b, dtype=torch.float64, device=d),
+            self._per_bufs = (torch.zeros(b, dtype=torch.int64, device=d), torch.zeros(b + (b + 255) // 256, dtype=torch.float64, device=d),
                               torch.zeros(b, dtype=torch.float32, device=d), torch.zeros(b, dtype=torch.float32, device=d),
                               torch.zeros((b, 2), dtype=torch.int32, device=d))
             cfg.per = per._c

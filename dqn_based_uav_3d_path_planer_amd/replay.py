@@ -157,9 +157,10 @@ class DevicePER:
         self.prio = torch.zeros(self.capacity, dtype=torch.float64, device=self.device)
         self._chunk_sum = torch.zeros(nc, dtype=torch.float64, device=self.device)
         self._chunk_prefix = torch.zeros(nc + 1, dtype=torch.float64, device=self.device)
+        self._group_sum = torch.zeros(nc * 64, dtype=torch.float64, device=self.device)     # 16-leaf sums: the sampler's fast path
         rot = self.lib.uavenv_per_rotation(self.capacity) if tree_order else 0
         self._c = _lib.UavPer(self.prio.data_ptr(), self._chunk_sum.data_ptr(), self._chunk_prefix.data_ptr(),
-                              self.capacity, rot)
+                              self.capacity, rot, self._group_sum.data_ptr())
         self.n_entries = 0
         self._dirty = True
 

@@ -232,6 +232,8 @@ typedef struct UavPer {
     double *chunk_prefix;  /* [num_chunks + 1]; the last entry is the total priority */
     int64_t capacity;
     int64_t rot;
+    double *group_sum;     /* nullable [num_chunks * 64]: sums of 16 consecutive in-order leaves, written by the rebuild; with
+                              it a sample reads 64 + 16 doubles instead of 1 024 (same selection, bit for bit) */
 } UavPer;
 
 int uavenv_per_num_chunks(int64_t capacity);
@@ -256,8 +258,9 @@ int uavenv_per_set_f32(const UavPer *per, const int64_t *slots_dev, const float 
 /* ReplayTree.sample (:163-178), the part after the selection: is_weights[i] = (n_entries * p_i / int(total)) ** -beta,
  * divided by their maximum (f32 out); a zero priority gets weight 0; int(total) < 1 counts as 1.  Also splits each slot
  * into the (frame, agent) pair uavenv_dqn_grad takes (frame_agent_out_dev nullable, batch x 2 int32; slot = frame *
- * n_agents + agent).  One workgroup; needs the rebuild uavenv_per_sample used. */
-int uavenv_per_weights(const UavPer *per, const int64_t *slots_dev, const double *prio_dev, int32_t batch,
+ * n_agents + agent).  prio_dev: the batch priorities uavenv_per_sample returned FOLLOWED by (batch + 255) / 256 doubles of
+ * scratch; the call overwrites all of it.  Needs the rebuild uavenv_per_sample used. */
+int uavenv_per_weights(const UavPer *per, const int64_t *slots_dev, double *prio_dev, int32_t batch,
                        int64_t n_entries, double beta, int32_t n_agents, float *is_weights_out_dev,
                        int32_t *frame_agent_out_dev, void *stream);
 
@@ -410,7 +413,7 @@ typedef struct UavLoopConfig {
     UavPer per;
     double per_alpha, per_beta, per_beta_inc, per_eps, per_clip;
     int64_t *per_slots_dev;      /* batch */
-    double *per_prio_dev;        /* batch */
+    double *per_prio_dev;        /* batch + (batch + 255) / 256 (priorities, then uavenv_per_weights' scratch) */
     float *per_w_dev;            /* batch */
     float *per_abs_dev;          /* batch */
     int32_t *per_idx_dev;        /* batch x 2 */

@@ -161,6 +161,7 @@ def test_weights_kernel_matches_the_reference_weights():
         w32 = torch.zeros(batch, dtype=torch.float32, device="cuda")
         fa = torch.zeros((batch, 2), dtype=torch.int32, device="cuda")
         n_agents = 7
+        p = torch.cat([p, torch.zeros((batch + 255) // 256, dtype=torch.float64, device="cuda")])     # + the call's scratch
         rc = per.lib.uavenv_per_weights(C.byref(per._c), slots.data_ptr(), p.data_ptr(), batch, per.n_entries, per.beta, n_agents,
                                         w32.data_ptr(), fa.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0
