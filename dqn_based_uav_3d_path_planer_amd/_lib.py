@@ -99,7 +99,8 @@ class UavSacBatch(C.Structure):
     _fields_ = [("obs_packed", C.c_void_p), ("idx_s", C.c_void_p), ("idx_n", C.c_void_p), ("draws", C.c_void_p),
                 ("n_agents", C.c_int32), ("uav_per_env", C.c_int32), ("slot", C.c_int32), ("frames", C.c_int32),
                 ("act0", C.c_void_p), ("act1", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("valid", C.c_void_p),
-                ("eps", C.c_void_p), ("batch", C.c_int32), ("reserved0", C.c_int32)]
+                ("eps", C.c_void_p), ("batch", C.c_int32), ("reserved0", C.c_int32),
+                ("is_weights", C.c_void_p), ("abs_td_out", C.c_void_p)]
 
 
 class UavSacAdam(C.Structure):

@@ -204,6 +204,9 @@ __global__ void k_per_set(UavPer p, const int64_t *__restrict__ slots, const dou
     if (i >= n) return;
     const int64_t s = slots[i];
     if (s < 0 || s >= p.capacity) return;
+    // batch_update (clip > 0) re-prioritises SAMPLED transitions: a slot whose priority is 0 is an empty leaf (a retired or
+    // never-valid ring row; the sampler only returns one when the whole tree is empty) and stays empty
+    if (clip > 0.0 && p.prio[s] == 0.0) return;
     double e = fabs(abs_err[i]) + epsilon;
     if (clip > 0.0 && e > clip) e = clip;
     p.prio[s] = pow(e, alpha);
@@ -216,6 +219,7 @@ __global__ void k_per_set_f32(UavPer p, const int64_t *__restrict__ slots, const
     if (i >= n) return;
     const int64_t s = slots[i];
     if (s < 0 || s >= p.capacity) return;
+    if (clip > 0.0 && p.prio[s] == 0.0) return;          // (an empty leaf stays empty: see k_per_set)
     double e = fabs((double)abs_err[i]) + epsilon;
     if (clip > 0.0 && e > clip) e = clip;
     p.prio[s] = pow(e, alpha);

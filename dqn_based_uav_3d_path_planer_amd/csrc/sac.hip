@@ -69,6 +69,10 @@ struct SacArgs {
     float gamma, bound;
     float *partials;
     unsigned long long *dbg;              // diagnostics build: 16 s_memtime stamps per workgroup
+    // prioritised replay (Trainer/SAC_Trainer.py:336-352; nullable): importance weight of sample s in the critic losses;
+    // |min(Q1, Q2)(s, a) - td_target|[:, 0] of sample s out (ReplayTree.batch_update's input, :351)
+    const float *is_w;
+    float *abs_td;
 };
 
 #ifdef UAVENV_PHASE_PROFILE
@@ -93,7 +97,7 @@ constexpr int kPsLd = 28;                          // dwords per sample of the p
 // the td targets of the workgroup's tiles live behind both.  Actor phase: actor fc1 | critic 1 | critic 2 | Ps | H dH | dq | red.
 constexpr int kCritStage2F = kWSetF + kTileF + 4 * kTile * kLh + kTile * 4 + 64;     // (the critic phase keeps an f32 X tile)
 constexpr int kCritTdOff = kCritStage2F > kTileF + 2 * kWSetF ? kCritStage2F : kTileF + 2 * kWSetF;
-constexpr size_t kSacCriticLds = (size_t)(kCritTdOff + kTMax * kTile * 2) * 4;
+constexpr size_t kSacCriticLds = (size_t)(kCritTdOff + kTMax * kTile * 3) * 4;      // td targets [.][2] + critic 1's Q[0] per sample
 constexpr size_t kSacActorLds = (size_t)(kTileF + 2 * kWSetF + kTile * kPsLd + 2 * kTile * kLh + kTile * 4 + 64) * 4;
 static_assert(kSacActorLds <= 160 * 1024 && kSacCriticLds <= 160 * 1024, "LDS budget");
 
@@ -449,7 +453,7 @@ __device__ __forceinline__ float wave_sum(float v)
 // what a tile's pass needs from HBM for this lane's sample (requested one tile ahead)
 struct TileIn {
     PRow R;
-    float a0, a1, rew, nd, w, e0, e1;
+    float a0, a1, rew, nd, w, e0, e1, isw;
 };
 template <bool NEXT, bool CRITIC>
 __device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
@@ -461,6 +465,7 @@ __device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
     prow_load(T.R, g.obs + (size_t)(NEXT ? rn : rs) * kPackedDwords);
     T.a0 = T.a1 = T.rew = T.nd = 0.0f;
     T.w = 1.0f;
+    T.isw = (CRITIC && !NEXT && g.is_w) ? g.is_w[smp] : 1.0f;
     if (CRITIC) {
         if (NEXT) { T.rew = g.reward[rs]; T.nd = 1.0f - (float)g.done[rs]; }
         else { T.a0 = g.act0[rs]; T.a1 = g.act1[rs]; }
@@ -483,6 +488,7 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
     const float alpha = expf(*g.log_alpha);
     const float inv_b = 1.0f / (float)g.batch;
     float *tds = lds + kCritTdOff;                     // [tile][sample][2]
+    float *q1s = tds + kTMax * kTile * 2;              // [tile][sample]: critic 1's Q(s, a)[0] (for |TD| of prioritised replay)
     S_STAMP(0);
 
     // ---- stage I: td target = r + gamma (min(Q_t1, Q_t2)(s', a') - alpha log pi(a' | s')) (1 - done)      (:122-131)
@@ -557,8 +563,13 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
             float q[2];
             critic_fwd(S, T.R, T.a0, T.a1, Fo, acc1, acc2, q);
             const float e0 = q[0] - td[0], e1 = q[1] - td[1];
-            const float dq0 = T.w * e0 * inv_b, dq1 = T.w * e1 * inv_b;  // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
-            if (gq == 0) { s_loss += T.w * (e0 * e0 + e1 * e1); s_bo0 += dq0; s_bo1 += dq1; s_cnt += T.w; }
+            const float ww = T.w * T.isw;                                // validity x importance-sampling weight (1 without PER)
+            const float dq0 = ww * e0 * inv_b, dq1 = ww * e1 * inv_b;    // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
+            if (gq == 0) { s_loss += ww * (e0 * e0 + e1 * e1); s_bo0 += dq0; s_bo1 += dq1; s_cnt += T.w; }
+            if (g.abs_td && gq == 0) {                                   // :351 |min(Q1, Q2) - td_target|, column 0
+                if (c == 0) q1s[j * kTile + 16 * wv + r] = q[0];
+                else g.abs_td[(size_t)(t0 + j) * kTile + 16 * wv + r] = fabsf(fminf(q1s[j * kTile + 16 * wv + r], q[0]) - td[0]);
+            }
             floatx4 dh1[4], dh2[4], h1[4], h2[4];
             critic_bwd(S, Fo, acc1, acc2, dq0, dq1, dh1, dh2);
             relu4(acc1, h1);
@@ -899,6 +910,8 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
     g.n_agents = b->n_agents; g.uav = b->uav_per_env; g.slot = b->slot; g.frames = b->frames;
     g.act0 = b->act0; g.act1 = b->act1; g.reward = b->reward; g.done = b->done; g.valid = b->valid;
     g.eps = b->eps;
+    g.is_w = b->is_weights;
+    g.abs_td = b->abs_td_out;
     g.batch = b->batch;
     const int n_tiles = b->batch / kTile;
     int tpw = (n_tiles + 255) / 256;

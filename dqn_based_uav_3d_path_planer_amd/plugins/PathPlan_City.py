@@ -93,8 +93,7 @@ class PathPlan_City:
         # ... and so does the SAC fast path (any number of UAVs per env: one fused trainer per UAV slot, csrc/sac.hip)
         sacp = tcfg.get("SAC_param") or {}
         self._want_fast_sac = (int(None2Value(param.get("fast_path"), 1)) != 0 and tcfg.get("Trainer_Type") == "SAC_Trainer" and
-                               int(None2Value(sacp.get("IS_Continuous"), 0)) == 1 and
-                               int(None2Value(tcfg.get("IsPriority_Replay"), 0)) == 0 and param.get("obs_dtype") is None and
+                               int(None2Value(sacp.get("IS_Continuous"), 0)) == 1 and param.get("obs_dtype") is None and
                                int(None2Value(tcfg.get("Batch_Size"), 128)) % 64 == 0 and
                                int(None2Value(tcfg.get("fused"), 1)) != 0 and torch.cuda.is_available())
         if self._want_fast or self._want_fast_sac:
@@ -171,9 +170,19 @@ class PathPlan_City:
             self._draws = [self._draws_all[offs[j]:offs[j + 1]] for j in range(self.num_UAV)]
             flat = ring.obs.view(-1, ring.obs.shape[-1])
             self._flat = flat
+            # IsPriority_Replay = 1 (the reference's ReplayTree use, Trainer/SAC_Trainer.py:336-352): one priority per stored
+            # transition of each UAV slot (data slot = frame * num_envs + env); the slot's draws then come from its tree
+            self._sac_per, self._sac_per_bufs = [None] * self.num_UAV, [None] * self.num_UAV
+            for j, u in enumerate(self.Agents):
+                if getattr(u.Trainer, "IsPriority_Replay", 0) == 1:
+                    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+                    self._sac_per[j] = DevicePER(ring.frames * self.num_envs, device=d, tree_order=False)
+                    self._sac_per_bufs[j] = self._sac_per[j].make_bufs(u.Trainer.Batch_Size, pairs=self._draws[j])
             self._sac_batches = [u.Trainer.learner.make_batch(flat, ring.action.view(-1), self._a1.view(-1), ring.reward.view(-1),
                                                               ring.done.view(-1), valid=ring.valid.view(-1), draws=self._draws[j],
-                                                              n_agents=N, uav_per_env=self.num_UAV, slot=j, frames=ring.frames)
+                                                              n_agents=N, uav_per_env=self.num_UAV, slot=j, frames=ring.frames,
+                                                              is_weights=None if self._sac_per[j] is None else self._sac_per_bufs[j]["w"],
+                                                              abs_td_out=None if self._sac_per[j] is None else self._sac_per_bufs[j]["abs"])
                                  for j, u in enumerate(self.Agents)]
             self._sac_counter = 0
             for u in self.Agents:
@@ -438,8 +447,15 @@ class PathPlan_City:
                     uav.Trainer.learner.act_rows(self._flat, t * N + j, U, self.num_envs, act0, act1, eps=za[j])
                 ring.step_env(auto_reset=False, skip_done=True, info=self._info)
                 self._sac_counter += 1
+                for j, per in enumerate(self._sac_per):      # ReplayTree.push(error 0) for the slot's rows of the frame just written
+                    if per is not None:
+                        per.fill(t * self.num_envs, self.num_envs, 0.0, valid=ring.valid[t].view(self.num_envs, U)[:, j].contiguous())
+                        per.fill(ring.head * self.num_envs, self.num_envs, zero=True)
+                        per.n_entries = ring.filled * self.num_envs
                 learn = [uav.Trainer.Is_Train and ring.filled * self.num_envs > uav.Trainer.Batch_Size for uav in self.Agents]   # :383-385
-                if any(learn):      # distinct (frame, env) pairs for all slots at once (each slot reads its own rows of them)
+                uniform = [l and self._sac_per[j] is None for j, l in enumerate(learn)]
+                nd = 0
+                if any(uniform):    # distinct (frame, env) pairs for all slots at once (each slot reads its own rows of them)
                     nd = nb if ring.filled * self.num_envs >= nb else 0
                     if nd:
                         _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, nd, self.seed + 7,
@@ -448,7 +464,14 @@ class PathPlan_City:
                 o = 0
                 for j, uav in enumerate(self.Agents):
                     tr = uav.Trainer
-                    if learn[j]:
+                    if learn[j] and self._sac_per[j] is not None:
+                        # ReplayTree.sample -> importance weights -> the fused update (weights in the critic losses, |TD| out) ->
+                        # batch_update, all on the stream (:336-352)
+                        per, pb = self._sac_per[j], self._sac_per_bufs[j]
+                        per.sample_into(tr.Batch_Size, self.seed + 7 + j, self._sac_counter, pb, self.num_envs)
+                        tr.learner.learn(self._sac_batches[j], noise=(zl[0, o:o + tr.Batch_Size], zl[1, o:o + tr.Batch_Size]))
+                        per.update_f32(pb["slots"], pb["abs"])
+                    elif learn[j]:
                         if not nd:  # the ring does not hold sum(Batch_Size) transitions yet: one draw per slot
                             _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, tr.Batch_Size,
                                                               self.seed + 7 + j, self._sac_counter, self._draws[j].data_ptr(),

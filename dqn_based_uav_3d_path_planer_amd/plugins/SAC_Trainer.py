@@ -27,10 +27,10 @@ class SAC_Trainer:
         dev = param.get("device") or ("cuda:0" if torch.cuda.is_available() else "cpu")
         self.device = torch.device(dev)
         # <fused>1</fused> (default): the hand-written HIP update (csrc/sac.hip) when the nets have the reference's shipped
-        # shapes, replay is uniform and a GPU is there -- PathPlan_City then drives it on its packed replay ring.
+        # shapes and a GPU is there -- PathPlan_City then drives it on its packed replay ring (uniform or prioritised replay).
         ap, cp = param.get("actor"), param.get("critic")
         shapes = (int(ap.get("w")), int(ap.get("hiden_dim")), int(ap.get("output")), int(cp.get("hiden_dim")), int(cp.get("action_dim")))
-        self.fused = (int(None2Value(param.get("fused"), 1)) != 0 and self.device.type == "cuda" and self.IsPriority_Replay == 0 and
+        self.fused = (int(None2Value(param.get("fused"), 1)) != 0 and self.device.type == "cuda" and
                       shapes == (100, 64, 2, 64, 2) and self.Batch_Size % 64 == 0)
         self.learner = FusedSACLearner(param, self.device) if self.fused else SACLearner(param, self.device)
         self.w = int(param.get("actor").get("w"))

@@ -209,6 +209,33 @@ class DevicePER:
         _lib.check(rc, "uavenv_per_set")
         self._dirty = True
 
+    def sample_into(self, batch: int, seed: int, counter: int, bufs: dict, n_agents: int):
+        """ReplayTree.sample without a host round trip (the fused learners' form): slots -> bufs['slots'] (int64 [batch]),
+        priorities -> bufs['prio'] (f64 [batch + (batch + 255) // 256]), importance weights -> bufs['w'] (f32 [batch]) and
+        the (frame, agent-of-the-frame) split of every slot -> bufs['pairs'] (int32 [batch, 2]; slot = frame * n_agents +
+        agent).  Four launches on the current stream."""
+        self._rebuild()
+        self.beta = min(1.0, self.beta + self.beta_inc)
+        s = self._stream()
+        _lib.check(self.lib.uavenv_per_sample(C.byref(self._c), int(batch), None, int(seed), int(counter), bufs["slots"].data_ptr(),
+                                              bufs["prio"].data_ptr(), s), "uavenv_per_sample")
+        _lib.check(self.lib.uavenv_per_weights(C.byref(self._c), bufs["slots"].data_ptr(), bufs["prio"].data_ptr(), int(batch),
+                                               int(self.n_entries), float(self.beta), int(n_agents), bufs["w"].data_ptr(),
+                                               bufs["pairs"].data_ptr(), s), "uavenv_per_weights")
+
+    def make_bufs(self, batch: int, pairs: torch.Tensor = None) -> dict:
+        d = self.device
+        return dict(slots=torch.zeros(batch, dtype=torch.int64, device=d),
+                    prio=torch.zeros(batch + (batch + 255) // 256, dtype=torch.float64, device=d),
+                    w=torch.zeros(batch, dtype=torch.float32, device=d), abs=torch.zeros(batch, dtype=torch.float32, device=d),
+                    pairs=pairs if pairs is not None else torch.zeros((batch, 2), dtype=torch.int32, device=d))
+
+    def update_f32(self, slots: torch.Tensor, abs_errors: torch.Tensor):
+        """ReplayTree.batch_update (:215-222) from f32 |TD errors| already on the device."""
+        _lib.check(self.lib.uavenv_per_set_f32(C.byref(self._c), slots.data_ptr(), abs_errors.data_ptr(), slots.numel(),
+                                               self.epsilon, self.alpha, self.clip, self._stream()), "uavenv_per_set_f32")
+        self._dirty = True
+
     def sample(self, batch: int, seed: int = 0, counter: int = 0, draws: torch.Tensor = None):
         """ReplayTree.sample (:146-180) -> (slots int64 [batch], is_weights float64 [batch], priorities)."""
         self._rebuild()

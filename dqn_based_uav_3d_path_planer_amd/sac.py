@@ -201,9 +201,13 @@ class FusedSACLearner:
             raise self._lib.UavEnvError(f"{what} failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()}")
 
     def make_batch(self, obs_packed: torch.Tensor, act0, act1, reward, done, *, valid=None, idx_s=None, idx_n=None,
-                   draws=None, n_agents=0, uav_per_env=1, slot=0, frames=0):
-        """Describe the sampled transitions in place (see UavSacBatch in include/uavenv.h).  Keeps the tensors alive."""
-        keep = (obs_packed, act0, act1, reward, done, valid, idx_s, idx_n, draws)
+                   draws=None, n_agents=0, uav_per_env=1, slot=0, frames=0, is_weights=None, abs_td_out=None):
+        """Describe the sampled transitions in place (see UavSacBatch in include/uavenv.h).  Keeps the tensors alive.
+        is_weights / abs_td_out (f32 [batch], prioritised replay): importance weights into the critic losses, and where
+        uavenv_sac_critic_grad leaves |min(Q1, Q2) - td_target| per sample."""
+        keep = (obs_packed, act0, act1, reward, done, valid, idx_s, idx_n, draws, is_weights, abs_td_out)
+        for t in (is_weights, abs_td_out):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
         n = int(draws.shape[0]) if draws is not None else int(idx_s.numel())
         ptr = lambda t: None if t is None else t.data_ptr()      # noqa: E731
         for t, dt in ((act0, torch.float32), (act1, torch.float32), (reward, torch.float32), (done, torch.uint8)):
@@ -213,7 +217,7 @@ class FusedSACLearner:
         assert idx_s is None or (idx_s.dtype == torch.int32 and idx_n.dtype == torch.int32)
         b = self._lib.UavSacBatch(obs_packed.data_ptr(), ptr(idx_s), ptr(idx_n), ptr(draws), int(n_agents), int(uav_per_env),
                                   int(slot), int(frames), act0.data_ptr(), act1.data_ptr(), reward.data_ptr(), done.data_ptr(),
-                                  ptr(valid), None, n, 0)
+                                  ptr(valid), None, n, 0, ptr(is_weights), ptr(abs_td_out))
         b._keep = keep
         return b
 

@@ -245,7 +245,8 @@ int uavenv_per_rebuild(const UavPer *per, void *stream);
  * leaf the tree descent (:99-115) reaches, out_prio_dev[i] (nullable) its priority.  Needs a current rebuild. */
 int uavenv_per_sample(const UavPer *per, int32_t batch, const double *draws_dev, uint64_t seed, uint64_t counter,
                       int64_t *out_slot_dev, double *out_prio_dev, void *stream);
-/* prio[slots[i]] = min(|abs_err[i]| + epsilon, clip) ** alpha   (batch_update :215-222; clip <= 0: no clip = push :143). */
+/* prio[slots[i]] = min(|abs_err[i]| + epsilon, clip) ** alpha   (batch_update :215-222; clip <= 0: no clip = push :143).
+ * With clip > 0 a slot whose priority is 0 -- an empty leaf: a retired or never-valid ring row -- is left at 0. */
 int uavenv_per_set(const UavPer *per, const int64_t *slots_dev, const double *abs_err_dev, int32_t n, double epsilon,
                    double alpha, double clip, void *stream);
 /* prio[first .. first+count) = priority where valid_dev[i] != 0 (or everywhere if NULL), 0 elsewhere: the slots of a
@@ -469,6 +470,11 @@ typedef struct UavSacBatch {
                                             log_alpha -- and all means are over the valid samples */
     const float *eps;                    /* batch x 2 N(0,1) draws standing for Normal.rsample() of this phase */
     int32_t batch, reserved0;            /* batch: a multiple of 64 */
+    /* prioritised replay (Trainer/SAC_Trainer.py:336-352), both nullable: is_weights[s] multiplies sample s in the two critic
+     * losses (mean_s w_s err_s^2: the per-sample form of `is_weights * critic_loss`); abs_td_out[s] receives
+     * |min(Q1, Q2)(s, a) - td_target| of output column 0 (:351) -- written by uavenv_sac_critic_grad. */
+    const float *is_weights;
+    float *abs_td_out;
 } UavSacBatch;
 typedef struct UavSacAdam {
     float lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt;   /* 1 - beta1^t, sqrt(1 - beta2^t) */

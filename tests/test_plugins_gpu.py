@@ -265,6 +265,37 @@ def test_prioritised_replay_stays_on_the_fused_path(tmp_path, monkeypatch):
     assert live.max().item() <= 1.0 + 1e-9 and per.beta > 0.4 and torch.isfinite(tr.learner.flat).all()
 
 
+def test_prioritised_replay_stays_on_the_fused_sac_path(tmp_path, monkeypatch):
+    """The reference's own use of ReplayTree (Trainer/SAC_Trainer.py:336-352) on the fast path: 4 UAVs per env, APF on, one
+    fused SAC trainer + one DevicePER per UAV slot; per step and slot new-frame priorities, ReplayTree.sample, importance
+    weights, the fused update (weights in the critic losses, |TD| out) and batch_update are stream-ordered launches."""
+    monkeypatch.chdir(tmp_path)
+    sim = _config4(tmp_path, 512, Batch_Size=256, replay_size=16384, IsPriority_Replay=1)
+    env = sim.env
+    assert env.fast_sac and all(u.Trainer.fused for u in env.Agents) and all(p is not None for p in env._sac_per)
+    torch.manual_seed(0)
+    res = env.run_eposide(0.1)
+    assert env.Check_uav_Done() and np.isfinite(float(res["loss"]))
+    ring = env._ring
+    reprioritised = 0
+    for j, per in enumerate(env._sac_per):
+        tr = env.Agents[j].Trainer
+        assert tr.epoch > 100 and all(torch.isfinite(p).all() for p in tr.actor.parameters())
+        prio = per.prio.view(ring.frames, -1)
+        assert float(prio[ring.head].abs().max()) == 0.0 and per.beta > 0.4
+        # a retired / never-valid row is an empty leaf: rows of agents that only waited carry no priority -- also at the end of
+        # the episode, when a slot's whole tree is empty and the sampler can only return empty leaves (batch_update skips them)
+        valid_j = ring.valid.view(ring.frames, env.num_envs, env.num_UAV)[:, :, j]
+        off = (valid_j == 0) & (torch.arange(ring.frames, device=prio.device).view(-1, 1) != ring.head)
+        assert float(prio[off].abs().max()) == 0.0
+        live = prio[prio > 0]
+        fresh = (0.0 + per.epsilon) ** per.alpha
+        if live.numel():
+            assert live.max().item() <= 1.0 + 1e-9
+            reprioritised += int(((live - fresh).abs() > 1e-9).sum())
+    assert reprioritised > 0
+
+
 @pytest.mark.parametrize("trainer", ["DuelingDQN", "SAC"])
 def test_prioritised_replay_through_the_plugins(trainer, tmp_path, monkeypatch):
     """IsPriority_Replay = 1 (BaseClass/replay_buffer.py:121-223, Trainer/SAC_Trainer.py:336-352) on the general per-step
