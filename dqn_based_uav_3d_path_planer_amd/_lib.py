@@ -34,6 +34,8 @@ SYMBOLS = (
     "uavenv_coll_last_error", "uavenv_coll_unique_id", "uavenv_coll_create", "uavenv_coll_destroy", "uavenv_coll_allreduce_sum",
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_get_per", "uavenv_loop_step_times",
+    "uavenv_randn", "uavenv_sac_loop_noise_floats", "uavenv_sac_loop_create", "uavenv_sac_loop_destroy", "uavenv_sac_loop_run",
+    "uavenv_sac_loop_get",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
     "uavenv_sac_actor_adam",
@@ -106,6 +108,32 @@ class UavSacBatch(C.Structure):
 class UavSacAdam(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("tau", C.c_float), ("grad_scale", C.c_float)]
+
+
+SAC_LOOP_MAX_SLOTS = 8
+
+
+class UavSacLoopSlot(C.Structure):
+    _fields_ = [("nets", UavSacNets), ("m_actor", C.c_void_p), ("v_actor", C.c_void_p), ("alpha_mv", C.c_void_p),
+                ("m1", C.c_void_p), ("v1", C.c_void_p), ("m2", C.c_void_p), ("v2", C.c_void_p), ("scalars", C.c_void_p),
+                ("epoch", C.c_int32), ("adam_steps", C.c_int32)]
+
+
+class UavSacLoopConfig(C.Structure):
+    _fields_ = [("env", C.c_void_p), ("ring", UavReplayRing), ("act1_plane", C.c_void_p), ("info_dev", C.c_void_p),
+                ("n_slots", C.c_int32), ("batch", C.c_int32), ("head", C.c_int32), ("filled", C.c_int32),
+                ("is_train", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64), ("counter", C.c_uint64),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double),
+                ("gamma", C.c_float), ("tau", C.c_float), ("action_bound", C.c_float), ("actor_lr", C.c_float),
+                ("critic_lr", C.c_float), ("alpha_lr", C.c_float), ("target_entropy", C.c_float), ("reserved1", C.c_float),
+                ("step_flags", C.c_uint32), ("reserved2", C.c_uint32),
+                ("draws_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("partials_critic", C.c_void_p),
+                ("partials_actor", C.c_void_p), ("slot", UavSacLoopSlot * SAC_LOOP_MAX_SLOTS)]
+
+
+class UavSacLoopCursor(C.Structure):
+    _fields_ = [("head", C.c_int32), ("filled", C.c_int32), ("counter", C.c_uint64),
+                ("epoch", C.c_int32 * SAC_LOOP_MAX_SLOTS), ("adam_steps", C.c_int32 * SAC_LOOP_MAX_SLOTS)]
 
 
 class UavEnvError(RuntimeError):
@@ -217,6 +245,18 @@ def load() -> C.CDLL:
     lib.uavenv_loop_get.argtypes = [vp, C.POINTER(UavLoopCursor)]
     lib.uavenv_loop_step_times.restype = C.c_int
     lib.uavenv_loop_step_times.argtypes = [vp, vp, i32, C.POINTER(i32)]
+    lib.uavenv_randn.restype = C.c_int
+    lib.uavenv_randn.argtypes = [u64, u64, i64, vp, vp]
+    lib.uavenv_sac_loop_noise_floats.restype = C.c_int64
+    lib.uavenv_sac_loop_noise_floats.argtypes = [i32, i32, i32]
+    lib.uavenv_sac_loop_create.restype = C.c_int
+    lib.uavenv_sac_loop_create.argtypes = [C.POINTER(UavSacLoopConfig), C.POINTER(vp)]
+    lib.uavenv_sac_loop_destroy.restype = C.c_int
+    lib.uavenv_sac_loop_destroy.argtypes = [vp]
+    lib.uavenv_sac_loop_run.restype = C.c_int
+    lib.uavenv_sac_loop_run.argtypes = [vp, i32, vp]
+    lib.uavenv_sac_loop_get.restype = C.c_int
+    lib.uavenv_sac_loop_get.argtypes = [vp, C.POINTER(UavSacLoopCursor)]
     lib.uavenv_sac_act.restype = C.c_int
     lib.uavenv_sac_act.argtypes = [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp]
     lib.uavenv_sac_reduce.restype = C.c_int

@@ -289,3 +289,197 @@ int uavenv_loop_step_times(UavLoop *l, float *ms_out, int32_t max_n, int32_t *n_
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// The same loop for SAC_Trainer with continuous actions, one trainer per UAV slot (Envs/PathPlan_City.py:59-69, :364-385,
+// BASELINE configs[3]'s shape): per time step
+//     one launch of N(0,1) draws for every rsample() of the step (the U get_action's, the 2 U rsample()'s of the updates)
+//     U x uavenv_sac_act            get_action (SAC_Trainer.py:444-448) of slot j's agents from the packed rows of frame t
+//     uavenv_step                   Move_Agent for every agent (+ k_apf_adjust in front with APF on), replay write included
+//     uavenv_replay_draw            distinct (frame, env) pairs for all slots at once (each slot reads ITS rows of them)
+//     U x (critic_grad, critic_adam, actor_grad, actor_adam)      SAC_Trainer.update (:325-379)
+// Driven from Python this was ~24 ctypes / torch launches per step: 389 us per step at 2 048 envs x 4 UAVs, host-bound.
+// Every launch goes through the library's own entry points, in the order and with the arguments the Python loop of
+// plugins/PathPlan_City._run_eposide_fused_sac uses: K steps from here == K steps from there, bit for bit.
+// =====================================================================================================================
+#include "uavenv_device.hpp"
+
+namespace {
+
+// out[i] ~ N(0, 1), i < n: Philox4x32-10 keyed by seed, counter (step, block of four), Box-Muller on two uniforms each.
+__global__ void __launch_bounds__(256) k_randn(uint64_t seed, uint64_t counter, int64_t n, float *__restrict__ out)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= n) return;
+    const uint4 r = uav::philox4x32_10(make_uint4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)counter, (uint32_t)(counter >> 32) ^ 0x6a55u),
+                                       make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    const float u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+    const float u3 = ((float)(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u4 = (float)(r.w >> 8) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+    float sa, ca, sb, cb;
+    sincosf(6.283185307179586f * u2, &sa, &ca);
+    sincosf(6.283185307179586f * u4, &sb, &cb);
+    const float v[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * q + e < n) out[4 * q + e] = v[e];
+}
+
+}  // namespace
+
+struct UavSacLoop {
+    UavSacLoopConfig c;
+    int32_t head, filled;
+    int32_t epoch[UAVENV_SAC_LOOP_MAX_SLOTS], adam_steps[UAVENV_SAC_LOOP_MAX_SLOTS];
+    uint64_t counter;
+    size_t obs_row_bytes;
+};
+
+extern "C" {
+
+int uavenv_randn(uint64_t seed, uint64_t counter, int64_t n, float *out_dev, void *stream)
+{
+    if (!out_dev || n < 0) return UAVENV_EINVAL;
+    if (n == 0) return UAVENV_OK;
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, counter, n, out_dev);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int64_t uavenv_sac_loop_noise_floats(int32_t n_slots, int32_t n_envs, int32_t batch)
+{
+    return (int64_t)n_slots * 2 * n_envs + 4 * (int64_t)n_slots * batch;
+}
+
+int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out)
+{
+    if (!cfg || !out || !cfg->env || !cfg->ring.obs || !cfg->ring.action || !cfg->ring.reward || !cfg->ring.done || !cfg->ring.valid)
+        return UAVENV_EINVAL;
+    if (cfg->ring.action_is_index || cfg->ring.obs_dtype != UAVENV_OBS_PACKED || cfg->ring.frames < 3 ||
+        cfg->ring.n_agents != uavenv_num_agents(cfg->env))
+        return UAVENV_EINVAL;
+    if (cfg->n_slots < 1 || cfg->n_slots > UAVENV_SAC_LOOP_MAX_SLOTS || cfg->ring.n_agents % cfg->n_slots != 0) return UAVENV_EINVAL;
+    if (cfg->batch <= 0 || cfg->batch % 64 != 0 || !cfg->act1_plane || !cfg->draws_dev || !cfg->noise_dev || !cfg->partials_critic ||
+        !cfg->partials_actor)
+        return UAVENV_EINVAL;
+    if (cfg->head < 0 || cfg->head >= cfg->ring.frames || cfg->filled < 0 || cfg->filled > cfg->ring.frames - 1) return UAVENV_EINVAL;
+    for (int j = 0; j < cfg->n_slots; ++j) {
+        const UavSacLoopSlot &sl = cfg->slot[j];
+        if (!sl.nets.actor || !sl.nets.critic1 || !sl.nets.critic2 || !sl.nets.target1 || !sl.nets.target2 || !sl.nets.log_alpha ||
+            !sl.m_actor || !sl.v_actor || !sl.alpha_mv || !sl.m1 || !sl.v1 || !sl.m2 || !sl.v2 || !sl.scalars || sl.epoch < 0 ||
+            sl.adam_steps < 0)
+            return UAVENV_EINVAL;
+    }
+    UavSacLoop *l = new (std::nothrow) UavSacLoop();
+    if (!l) return UAVENV_ENOMEM;
+    l->c = *cfg;
+    l->head = cfg->head;
+    l->filled = cfg->filled;
+    l->counter = cfg->counter;
+    for (int j = 0; j < cfg->n_slots; ++j) { l->epoch[j] = cfg->slot[j].epoch; l->adam_steps[j] = cfg->slot[j].adam_steps; }
+    l->obs_row_bytes = (size_t)cfg->ring.n_agents * UAVENV_OBS_PACKED_DWORDS * 4;
+    *out = l;
+    return UAVENV_OK;
+}
+
+int uavenv_sac_loop_destroy(UavSacLoop *l)
+{
+    delete l;
+    return UAVENV_OK;
+}
+
+int uavenv_sac_loop_get(const UavSacLoop *l, UavSacLoopCursor *out)
+{
+    if (!l || !out) return UAVENV_EINVAL;
+    out->head = l->head;
+    out->filled = l->filled;
+    out->counter = l->counter;
+    for (int j = 0; j < UAVENV_SAC_LOOP_MAX_SLOTS; ++j) {
+        out->epoch[j] = j < l->c.n_slots ? l->epoch[j] : 0;
+        out->adam_steps[j] = j < l->c.n_slots ? l->adam_steps[j] : 0;
+    }
+    return UAVENV_OK;
+}
+
+int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
+{
+    if (!l || n_steps < 0) return UAVENV_EINVAL;
+    const UavSacLoopConfig &c = l->c;
+    const UavReplayRing &R = c.ring;
+    const int U = c.n_slots, B = c.batch;
+    const size_t n = (size_t)R.n_agents;
+    const int envs = R.n_agents / U;
+    const int64_t nb = (int64_t)U * B;
+    const int64_t n_noise = uavenv_sac_loop_noise_floats(U, envs, B);
+    float *act0 = (float *)R.action;
+    hipStream_t s = (hipStream_t)stream;
+    for (int k = 0; k < n_steps; ++k) {
+        const int t = l->head, nxt = t + 1 == R.frames ? 0 : t + 1;
+        l->counter += 1;                                                  // (the Python loop counts before it draws)
+        int rc = uavenv_randn(c.seed, l->counter, n_noise, c.noise_dev, s);
+        if (rc != UAVENV_OK) return rc;
+        const float *za = c.noise_dev;                                     // [U][envs][2]   get_action
+        const float *zl = c.noise_dev + (size_t)U * 2 * envs;              // [2][U * B][2]  rsample() of calc_target / of the actor phase
+        for (int j = 0; j < U; ++j) {
+            rc = uavenv_sac_act(c.slot[j].nets.actor, R.obs, (int32_t)((size_t)t * n + j), U, envs, za + (size_t)j * 2 * envs,
+                                c.action_bound, act0, c.act1_plane, s);
+            if (rc != UAVENV_OK) return rc;
+        }
+        rc = uavenv_step(c.env, act0 + (size_t)t * n, UAVENV_ACT_STEER_F32, (unsigned char *)R.obs + (size_t)nxt * l->obs_row_bytes, nullptr,
+                         R.reward + (size_t)t * n, R.done + (size_t)t * n, nullptr, c.info_dev ? c.info_dev + (size_t)t * n : nullptr,
+                         R.valid + (size_t)t * n, nullptr, nullptr, c.step_flags, s);
+        if (rc != UAVENV_OK) return rc;
+        l->head = nxt;
+        if (l->filled < R.frames - 1) l->filled += 1;
+        const bool learn = c.is_train && (int64_t)l->filled * envs > (int64_t)B;            // :383-385
+        bool one_draw = false;
+        if (learn && (int64_t)l->filled * envs >= nb) {
+            rc = uavenv_replay_draw(R.frames, envs, l->head, l->filled, (int32_t)nb, c.seed + 7, l->counter, c.draws_dev, s);
+            if (rc != UAVENV_OK) return rc;
+            one_draw = true;
+        }
+        for (int j = 0; j < U; ++j) {
+            l->epoch[j] += 1;                                             // update() is called either way (:322-333)
+            if (!learn) continue;
+            const UavSacLoopSlot &sl = c.slot[j];
+            int32_t *draws = c.draws_dev + (size_t)j * B * 2;
+            if (!one_draw) {          // the ring does not hold U x B transitions yet: one draw per slot
+                rc = uavenv_replay_draw(R.frames, envs, l->head, l->filled, B, c.seed + 7 + (uint64_t)j, l->counter, draws, s);
+                if (rc != UAVENV_OK) return rc;
+            }
+            l->adam_steps[j] += 1;
+            const double tt = (double)l->adam_steps[j];
+            UavSacBatch b = UavSacBatch();
+            b.obs_packed = R.obs;
+            b.draws = draws;
+            b.n_agents = R.n_agents; b.uav_per_env = U; b.slot = j; b.frames = R.frames;
+            b.act0 = act0; b.act1 = c.act1_plane; b.reward = R.reward; b.done = R.done; b.valid = R.valid;
+            b.batch = B;
+            UavSacAdam h;
+            h.beta1 = (float)c.beta1; h.beta2 = (float)c.beta2; h.eps = (float)c.adam_eps;
+            h.bias_correction1 = (float)(1.0 - pow(c.beta1, tt));
+            h.bias_correction2_sqrt = (float)sqrt(1.0 - pow(c.beta2, tt));
+            h.grad_scale = 0.0f;
+            // critics (:340-357), then the actor and log_alpha on the updated critics (:359-377); the soft update (:378-379)
+            // rides in critic_adam
+            b.eps = zl + ((size_t)j * B) * 2;
+            rc = uavenv_sac_critic_grad(&sl.nets, &b, c.gamma, c.action_bound, c.partials_critic, s);
+            if (rc != UAVENV_OK) return rc;
+            h.lr = c.critic_lr; h.tau = c.tau;
+            rc = uavenv_sac_critic_adam(&sl.nets, c.partials_critic, uavenv_sac_partial_rows(B), sl.m1, sl.v1, sl.m2, sl.v2, &h, sl.scalars, s);
+            if (rc != UAVENV_OK) return rc;
+            b.eps = zl + ((size_t)nb + (size_t)j * B) * 2;
+            rc = uavenv_sac_actor_grad(&sl.nets, &b, c.action_bound, c.partials_actor, s);
+            if (rc != UAVENV_OK) return rc;
+            h.lr = c.actor_lr; h.tau = 0.0f;
+            rc = uavenv_sac_actor_adam(&sl.nets, c.partials_actor, uavenv_sac_partial_rows(B), B, sl.m_actor, sl.v_actor, sl.alpha_mv, &h,
+                                       c.alpha_lr, c.target_entropy, sl.scalars + 4, s);
+            if (rc != UAVENV_OK) return rc;
+        }
+    }
+    return UAVENV_OK;
+}
+
+}  // extern "C"

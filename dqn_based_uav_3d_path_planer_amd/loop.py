@@ -127,3 +127,88 @@ class HotLoop:
         n = C.c_int32(0)
         _lib.check(self.lib.uavenv_loop_step_times(self._h, buf.ctypes.data, max_n, C.byref(n)), "uavenv_loop_step_times")
         return buf[:n.value].copy()
+
+
+
+class SACHotLoop:
+    """The off-policy loop with one fused SAC trainer per UAV slot (BASELINE configs[3]'s shape), enqueued by csrc/loop.hip:
+    per step one launch of N(0,1) draws, U x get_action, the env step (replay write included), one draw of (frame, env) pairs
+    and U x the four launches of SAC_Trainer.update -- what PathPlan_City._run_eposide_fused_sac issues from Python, bit for
+    bit, without the interpreter between the launches.  The ring cursor and the learners' update counts live in the C object
+    while the loop exists; `run` writes them back."""
+
+    def __init__(self, ring: DeviceReplayRing, learners, batch: int, seed: int, act1_plane: torch.Tensor, counter: int = 0,
+                 info: torch.Tensor = None, is_train: bool = True, auto_reset: bool = True, skip_done: bool = True):
+        if ring.discrete or not ring.env.packed:
+            raise ValueError("SACHotLoop drives the continuous-action path on a packed ring")
+        env = ring.env
+        U = env.uav_per_env
+        if len(learners) != U or U > _lib.SAC_LOOP_MAX_SLOTS:
+            raise ValueError("one FusedSACLearner per UAV slot (at most %d)" % _lib.SAC_LOOP_MAX_SLOTS)
+        if batch % 64:
+            raise ValueError("batch must be a multiple of 64")
+        self.lib = _lib.load()
+        self.ring, self.learners = ring, list(learners)
+        L0 = self.learners[0]
+        for L in self.learners:      # one Trainer.xml: the slots share their hyper-parameters
+            if (L.gamma, L.tau, L.action_bound, L.actor_lr, L.critic_lr, L.alpha_lr, L.target_entropy) != \
+               (L0.gamma, L0.tau, L0.action_bound, L0.actor_lr, L0.critic_lr, L0.alpha_lr, L0.target_entropy):
+                raise ValueError("the SAC slots must share their hyper-parameters")
+        d = env.device
+        n_envs = env.N // U
+        self._draws = torch.zeros((U * batch, 2), dtype=torch.int32, device=d)
+        self._noise = torch.zeros(int(self.lib.uavenv_sac_loop_noise_floats(U, n_envs, int(batch))), dtype=torch.float32, device=d)
+        rows, pc, pa = L0._scratch(int(batch))
+        cfg = _lib.UavSacLoopConfig()
+        cfg.env = env._h
+        cfg.ring = ring._c
+        assert act1_plane.dtype == torch.float32 and tuple(act1_plane.shape) == (ring.frames, env.N) and act1_plane.is_contiguous()
+        cfg.act1_plane = act1_plane.data_ptr()
+        if info is not None:
+            assert info.dtype == torch.uint8 and tuple(info.shape) == (ring.frames, env.N) and info.is_contiguous()
+            cfg.info_dev = info.data_ptr()
+        cfg.n_slots, cfg.batch = U, int(batch)
+        cfg.head, cfg.filled = ring.head, ring.filled
+        cfg.is_train = 1 if is_train else 0
+        cfg.seed, cfg.counter = int(seed), int(counter)
+        cfg.beta1, cfg.beta2, cfg.adam_eps = L0.beta1, L0.beta2, L0.adam_eps
+        cfg.gamma, cfg.tau, cfg.action_bound = L0.gamma, L0.tau, L0.action_bound
+        cfg.actor_lr, cfg.critic_lr, cfg.alpha_lr, cfg.target_entropy = L0.actor_lr, L0.critic_lr, L0.alpha_lr, L0.target_entropy
+        cfg.step_flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | ring.extra_flags
+        cfg.draws_dev, cfg.noise_dev = self._draws.data_ptr(), self._noise.data_ptr()
+        cfg.partials_critic, cfg.partials_actor = pc.data_ptr(), pa.data_ptr()
+        for j, L in enumerate(self.learners):
+            sl = cfg.slot[j]
+            sl.nets = L._nets
+            sl.m_actor, sl.v_actor, sl.alpha_mv = L._blocks[1].data_ptr(), L._blocks[2].data_ptr(), L._alpha_mv.data_ptr()
+            sl.m1, sl.v1, sl.m2, sl.v2 = (L._cblocks[k].data_ptr() for k in (4, 5, 6, 7))
+            sl.scalars = L._scalars.data_ptr()
+            sl.epoch, sl.adam_steps = L.epoch, L.adam_steps
+        self._keep = (act1_plane, info, pc, pa)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.uavenv_sac_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_sac_loop_create")
+        self.counter = int(counter)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.uavenv_sac_loop_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, n_steps: int):
+        s = torch.cuda.current_stream(self.ring.env.device).cuda_stream
+        rc = self.lib.uavenv_sac_loop_run(self._h, int(n_steps), s)
+        if rc != 0:
+            raise _lib.UavEnvError(f"uavenv_sac_loop_run failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()} / "
+                                   f"{self.lib.uavenv_last_error().decode()}")
+        cur = _lib.UavSacLoopCursor()
+        _lib.check(self.lib.uavenv_sac_loop_get(self._h, C.byref(cur)), "uavenv_sac_loop_get")
+        self.ring.head, self.ring.filled = cur.head, cur.filled
+        self.counter = int(cur.counter)
+        for j, L in enumerate(self.learners):
+            L.epoch, L.adam_steps = int(cur.epoch[j]), int(cur.adam_steps[j])

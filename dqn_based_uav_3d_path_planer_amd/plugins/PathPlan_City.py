@@ -434,19 +434,35 @@ class PathPlan_City:
         lib = self.backend.lib
         act0, act1 = ring.action.view(-1), self._a1.view(-1)
         n_steps, ended = 0, False
+        # the whole step sequence enqueued from C (csrc/loop.hip: uavenv_sac_loop_run) when the slots share one batch size and
+        # replay is uniform; the Python loop below issues the same launches one by one (prioritised replay, mixed settings)
+        trs = [u.Trainer for u in self.Agents]
+        use_c = (all(p is None for p in self._sac_per) and len({t_.Batch_Size for t_ in trs}) == 1 and
+                 len({bool(t_.Is_Train) for t_ in trs}) == 1 and U <= _lib.SAC_LOOP_MAX_SLOTS and
+                 int(None2Value(self.param.get("sac_c_loop"), 1)) != 0)
+        if use_c and getattr(self, "_sac_hot", None) is None:
+            from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
+            self._sac_hot = SACHotLoop(ring, [t_.learner for t_ in trs], trs[0].Batch_Size, seed=self.seed, act1_plane=self._a1,
+                                       counter=self._sac_counter, info=self._info, is_train=bool(trs[0].Is_Train),
+                                       auto_reset=False, skip_done=True)
+        z = getattr(self, "_sac_noise", None)
         while not ended:
             t0 = ring.head
             nb = self._draws_all.shape[0]
-            for _ in range(k):
+            for _ in range(0 if use_c else k):
                 t = ring.head
+                self._sac_counter += 1
                 # every N(0,1) draw of the step (U get_action's, 2 rsample()'s per update) in one launch
-                z = torch.randn(U * 2 * self.num_envs + 4 * nb, dtype=torch.float32, device=dev)
+                n_z = U * 2 * self.num_envs + 4 * nb
+                if z is None or z.numel() != n_z:
+                    z = self._sac_noise = torch.empty(n_z, dtype=torch.float32, device=dev)
+                _lib.check(lib.uavenv_randn(self.seed, self._sac_counter, n_z, z.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                           "uavenv_randn")
                 za = z[:U * 2 * self.num_envs].view(U, self.num_envs, 2)
                 zl = z[U * 2 * self.num_envs:].view(2, nb, 2)
                 for j, uav in enumerate(self.Agents):
                     uav.Trainer.learner.act_rows(self._flat, t * N + j, U, self.num_envs, act0, act1, eps=za[j])
                 ring.step_env(auto_reset=False, skip_done=True, info=self._info)
-                self._sac_counter += 1
                 for j, per in enumerate(self._sac_per):      # ReplayTree.push(error 0) for the slot's rows of the frame just written
                     if per is not None:
                         per.fill(t * self.num_envs, self.num_envs, 0.0, valid=ring.valid[t].view(self.num_envs, U)[:, j].contiguous())
@@ -480,6 +496,9 @@ class PathPlan_City:
                     else:
                         tr.learner.epoch += 1                                                   # :322-333
                     o += tr.Batch_Size
+            if use_c:
+                self._sac_hot.run(k)
+                self._sac_counter = self._sac_hot.counter
             fr = (t0 + torch.arange(k, device=dev)) % ring.frames
             v = ring.valid[fr].bool()
             inf = self._info[fr]

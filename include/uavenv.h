@@ -509,6 +509,54 @@ int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t
                           float *alpha_mv, const UavSacAdam *h, float alpha_lr, float target_entropy, float *scalars_out,
                           void *stream);
 
+/* ---- the off-policy loop for SAC (continuous actions), one trainer per UAV slot, enqueued from C ----------------------
+ * PathPlan_City.run_thread_OffPolicy (Envs/PathPlan_City.py:364-385) with SAC_Trainer for every env at once, K steps per
+ * call.  Per step: one launch of N(0,1) draws (uavenv_randn) for every rsample() of the step, U x uavenv_sac_act, uavenv_step
+ * (replay write included), one uavenv_replay_draw, U x the four launches of the fused update -- the sequence
+ * plugins/PathPlan_City._run_eposide_fused_sac issues from Python, bit for bit (389 us per step there at 2 048 envs x 4
+ * UAVs: host-bound).  Uniform replay; slots with prioritised replay stay on the Python loop. */
+#define UAVENV_SAC_LOOP_MAX_SLOTS 8
+typedef struct UavSacLoopSlot {
+    UavSacNets nets;
+    float *m_actor, *v_actor, *alpha_mv;     /* Adam moments of the actor (UAVENV_SAC_ACTOR_PARAMS each) and of log_alpha (2) */
+    float *m1, *v1, *m2, *v2;                /* Adam moments of the two critics (UAVENV_SAC_CRITIC_PARAMS each) */
+    float *scalars;                          /* 8 floats: critic losses [0:4], actor loss / sum log pi [4:8] of the last update */
+    int32_t epoch, adam_steps;               /* update() calls so far; Adam steps actually taken (bias correction) */
+} UavSacLoopSlot;
+typedef struct UavSacLoopConfig {
+    UavEnv *env;
+    UavReplayRing ring;                      /* packed rows, action_is_index = 0 (action plane = first action component) */
+    float *act1_plane;                       /* frames x N: the second action component (SAC_Trainer.py:444-448) */
+    uint8_t *info_dev;                       /* nullable frames x N */
+    int32_t n_slots;                         /* = uav_per_env: slot j trains on rows e * n_slots + j */
+    int32_t batch;                           /* per slot; multiple of 64 */
+    int32_t head, filled;
+    int32_t is_train, reserved0;
+    uint64_t seed, counter;
+    double beta1, beta2, adam_eps;           /* torch.optim.Adam's (doubles: the bias corrections are formed in double) */
+    float gamma, tau, action_bound, actor_lr, critic_lr, alpha_lr, target_entropy, reserved1;
+    uint32_t step_flags, reserved2;
+    int32_t *draws_dev;                      /* n_slots x batch x 2 */
+    float *noise_dev;                        /* uavenv_sac_loop_noise_floats(n_slots, n_envs, batch) floats */
+    float *partials_critic, *partials_actor; /* uavenv_sac_partial_rows(batch) x UAVENV_SAC_CRITIC_STRIDE / _ACTOR_STRIDE */
+    UavSacLoopSlot slot[UAVENV_SAC_LOOP_MAX_SLOTS];
+} UavSacLoopConfig;
+typedef struct UavSacLoopCursor {
+    int32_t head, filled;
+    uint64_t counter;
+    int32_t epoch[UAVENV_SAC_LOOP_MAX_SLOTS], adam_steps[UAVENV_SAC_LOOP_MAX_SLOTS];
+} UavSacLoopCursor;
+typedef struct UavSacLoop UavSacLoop;
+/* out[i] ~ N(0, 1) for i < n from Philox4x32-10(seed; counter, i / 4) + Box-Muller, one launch. */
+int uavenv_randn(uint64_t seed, uint64_t counter, int64_t n, float *out_dev, void *stream);
+/* Layout of noise_dev: [n_slots][n_envs][2] get_action draws, then [2][n_slots * batch][2] (rsample() of calc_target, of
+ * the actor phase; slot j's rows are j * batch .. (j + 1) * batch of each half). */
+int64_t uavenv_sac_loop_noise_floats(int32_t n_slots, int32_t n_envs, int32_t batch);
+int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out);
+int uavenv_sac_loop_destroy(UavSacLoop *loop);
+int uavenv_sac_loop_run(UavSacLoop *loop, int32_t n_steps, void *stream);
+int uavenv_sac_loop_get(const UavSacLoop *loop, UavSacLoopCursor *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,7 +44,9 @@ def test_every_struct_layout_matches_the_header_as_gcc_sees_it(tmp_path):
     import subprocess
     structs = {"UavEnvConfig": _lib.UavEnvConfig, "UavReplayRing": _lib.UavReplayRing, "UavDqnNet": _lib.UavDqnNet,
                "UavPer": _lib.UavPer, "UavLoopConfig": _lib.UavLoopConfig, "UavLoopCursor": _lib.UavLoopCursor,
-               "UavSacNets": _lib.UavSacNets, "UavSacBatch": _lib.UavSacBatch, "UavSacAdam": _lib.UavSacAdam}
+               "UavSacNets": _lib.UavSacNets, "UavSacBatch": _lib.UavSacBatch, "UavSacAdam": _lib.UavSacAdam,
+               "UavSacLoopSlot": _lib.UavSacLoopSlot, "UavSacLoopConfig": _lib.UavSacLoopConfig,
+               "UavSacLoopCursor": _lib.UavSacLoopCursor}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "uavenv.h"', 'int main(void){']
     for name, ct in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')

@@ -315,3 +315,42 @@ def test_prioritised_replay_through_the_plugins(trainer, tmp_path, monkeypatch):
     fresh = (0.0 + tr.replay_memory.per.epsilon) ** tr.replay_memory.per.alpha
     assert (prio > 0).all() and ((prio - fresh).abs() > 1e-9).float().mean().item() > 0.2     # many were re-prioritised
     assert prio.max().item() <= 1.0 + 1e-9                                                    # clip at 1 (:219-221)
+
+
+def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch):
+    """csrc/loop.hip: uavenv_sac_loop_run -- per step the N(0,1) draws, U x get_action, the env step (APF on), one replay
+    draw and U x the four launches of the fused SAC update, enqueued from C -- against the same sequence issued launch by
+    launch from Python (PathPlan_City._run_eposide_fused_sac with <sac_c_loop>0</sac_c_loop>): ring, every parameter block
+    of every slot (weights, targets, Adam moments, log_alpha), update counts -- bit for bit.  (Speed: both are GPU-bound at
+    this size -- ~375 us per step = ~22 latency-bound launches -- so the C loop removes the interpreter, not time.)"""
+    import time
+    monkeypatch.chdir(tmp_path)
+    out = []
+    for c_loop in ("1", "0"):
+        sim = _config4(tmp_path, 512, Batch_Size=512, replay_size=8192)
+        env = sim.env
+        env.param["sac_c_loop"] = c_loop
+        assert env.fast_sac
+        torch.manual_seed(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = env.run_eposide(0.1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / env.steps_last_episode
+        assert (getattr(env, "_sac_hot", None) is not None) == (c_loop == "1")
+        L = [u.Trainer.learner for u in env.Agents]
+        out.append(dict(ring={k: getattr(env._ring, k).clone() for k in ("obs", "action", "reward", "done", "valid")},
+                        a1=env._a1.clone(), blocks=[torch.cat([x._blocks.reshape(-1), x._cblocks.reshape(-1), x._alpha_mv,
+                                                               x.log_alpha.reshape(1)]) for x in L],
+                        counts=[(x.epoch, x.adam_steps) for x in L], cursor=(env._ring.head, env._ring.filled, env._sac_counter),
+                        steps=env.steps_last_episode, us=dt * 1e6, loss=float(res["loss"])))
+    a, b = out
+    assert a["cursor"] == b["cursor"] and a["counts"] == b["counts"] and a["steps"] == b["steps"] and a["steps"] >= 150
+    for k in a["ring"]:
+        assert torch.equal(a["ring"][k], b["ring"][k]), k
+    assert torch.equal(a["a1"], b["a1"])
+    for j in range(4):
+        assert torch.equal(a["blocks"][j], b["blocks"][j]), j
+    assert a["loss"] == b["loss"]
+    print(f"fused SAC episode, 512 envs x 4 UAVs: C loop {a['us']:.0f} us/step, Python loop {b['us']:.0f} us/step")
+    assert a["us"] < 1.25 * b["us"]
