@@ -201,3 +201,20 @@ def test_bench_one_gpu_line_has_the_in_loop_roofline():
     assert d["roofline"]["kernel_ms_back_to_back"] > 0 and d["roofline"]["k_step_alone"]["kernel_ms_back_to_back"] > 0
     assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline_learner"]["frac"] < 1
     assert "3 launches" in d["config"]["host_loop"]
+
+
+def test_bench_legs_run_small():
+    """The other legs of bench.py at a small size: prioritised replay inside the C loop, the sample_lag experiment, an
+    env-only point and the config 3 / 5 presets' code paths (f16 MFMA learner; explicit sizes keep them small)."""
+    d = _bench("--per")
+    assert "prioritised" in d["config"]["replay"] and d["value"] > 0 and "10 launches" in d["config"]["replay"]
+    d = _bench("--sample-lag", "1")
+    assert d["config"]["sample_lag"] == 1 and d["value"] > 0
+    d = _bench("--trainer", "dueling", "--mfma", "f16", "--obs-dtype", "f16")
+    assert d["config"]["learner_dtype"] == "f16" and d["roofline_learner"]["peak"] == 2500.0
+    env = dict(os.environ)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--env-only", "--envs", "4096", "--steps", "2"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-1000:]
+    e = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert e["mode"] == "env-only" and e["envs"] == 4096 and 0 < e["frac_of_8TBs"] < 1
