@@ -365,12 +365,26 @@ def run_config4(args, dev):
         counter[0] += 1
 
     pps = max(1, args.passes_per_step // 8)           # a pass is ~20x longer than config 2's: 16 passes of ~0.7 ms per step
-    for _ in range(max(args.warmup, 1) * pps):
-        one_pass()
+    hot = None
+    if fused and args.host_loop == "c":
+        # the product's loop: csrc/loop.hip uavenv_sac_loop_run -- per pass one launch of N(0,1) draws, get_action of the four
+        # slots in one launch, the env step, one replay draw, and each phase of the fused update for the four slots in one
+        # launch (8 launches per pass; --host-loop python issues the same work slot by slot from here, ~25 launches)
+        from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
+        hot = SACHotLoop(ring, learners, B, seed=7, act1_plane=a1_plane, auto_reset=True, skip_done=True)
+
+    def run_passes(n_passes):
+        if hot is not None:
+            hot.run(n_passes)
+        else:
+            for _ in range(n_passes):
+                one_pass()
+
+    run_passes(max(args.warmup, 1) * pps)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps * pps):
-        one_pass()
+    for _ in range(args.steps):
+        run_passes(pps)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     n_pass = args.steps * pps
@@ -397,6 +411,9 @@ def run_config4(args, dev):
                       "step_definition": "1 bench step = %d passes of (SAC act x%d -> env step with APF + replay write -> "
                                          "%d x (sample + SAC update))" % (pps, U, U),
                       "envs_per_gpu": envs, "uav_per_env": U, "learn_batch_per_slot": B, "obs_dtype": "packed",
+                      "host_loop": "csrc/loop.hip uavenv_sac_loop_run (C, 8 launches per pass: N(0,1) draws, get_action x4 slots, "
+                                   "k_apf_adjust + k_step, replay draw, 4 update phases x4 slots each)" if hot is not None
+                      else "python (one launch per slot and phase)",
                       "learner": ("fused HIP SAC update (csrc/sac.hip: critic_grad, critic_adam, actor_grad, actor_adam; f32 MFMA)"
                                   if fused else "SAC on PyTorch-ROCm ops (f32)" +
                                   (", each slot's sample + update replayed as one HIP graph" if graphs is not None else ", eager")),

@@ -35,7 +35,8 @@ SYMBOLS = (
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_get_per", "uavenv_loop_step_times",
     "uavenv_randn", "uavenv_sac_loop_noise_floats", "uavenv_sac_loop_create", "uavenv_sac_loop_destroy", "uavenv_sac_loop_run",
-    "uavenv_sac_loop_get",
+    "uavenv_sac_loop_get", "uavenv_sac_act_multi", "uavenv_sac_critic_grad_multi", "uavenv_sac_actor_grad_multi",
+    "uavenv_sac_critic_adam_multi", "uavenv_sac_actor_adam_multi",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
     "uavenv_sac_actor_adam",
@@ -116,6 +117,7 @@ SAC_LOOP_MAX_SLOTS = 8
 class UavSacLoopSlot(C.Structure):
     _fields_ = [("nets", UavSacNets), ("m_actor", C.c_void_p), ("v_actor", C.c_void_p), ("alpha_mv", C.c_void_p),
                 ("m1", C.c_void_p), ("v1", C.c_void_p), ("m2", C.c_void_p), ("v2", C.c_void_p), ("scalars", C.c_void_p),
+                ("partials_critic", C.c_void_p), ("partials_actor", C.c_void_p),
                 ("epoch", C.c_int32), ("adam_steps", C.c_int32)]
 
 
@@ -127,8 +129,7 @@ class UavSacLoopConfig(C.Structure):
                 ("gamma", C.c_float), ("tau", C.c_float), ("action_bound", C.c_float), ("actor_lr", C.c_float),
                 ("critic_lr", C.c_float), ("alpha_lr", C.c_float), ("target_entropy", C.c_float), ("reserved1", C.c_float),
                 ("step_flags", C.c_uint32), ("reserved2", C.c_uint32),
-                ("draws_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("partials_critic", C.c_void_p),
-                ("partials_actor", C.c_void_p), ("slot", UavSacLoopSlot * SAC_LOOP_MAX_SLOTS)]
+                ("draws_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("slot", UavSacLoopSlot * SAC_LOOP_MAX_SLOTS)]
 
 
 class UavSacLoopCursor(C.Structure):
@@ -245,6 +246,9 @@ def load() -> C.CDLL:
     lib.uavenv_loop_get.argtypes = [vp, C.POINTER(UavLoopCursor)]
     lib.uavenv_loop_step_times.restype = C.c_int
     lib.uavenv_loop_step_times.argtypes = [vp, vp, i32, C.POINTER(i32)]
+    for _n in ("uavenv_sac_act_multi", "uavenv_sac_critic_grad_multi", "uavenv_sac_actor_grad_multi",
+               "uavenv_sac_critic_adam_multi", "uavenv_sac_actor_adam_multi"):       # (called from csrc/loop.hip; no Python caller)
+        getattr(lib, _n).restype = C.c_int
     lib.uavenv_randn.restype = C.c_int
     lib.uavenv_randn.argtypes = [u64, u64, i64, vp, vp]
     lib.uavenv_sac_loop_noise_floats.restype = C.c_int64

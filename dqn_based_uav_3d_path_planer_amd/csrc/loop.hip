@@ -361,14 +361,13 @@ int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out)
         cfg->ring.n_agents != uavenv_num_agents(cfg->env))
         return UAVENV_EINVAL;
     if (cfg->n_slots < 1 || cfg->n_slots > UAVENV_SAC_LOOP_MAX_SLOTS || cfg->ring.n_agents % cfg->n_slots != 0) return UAVENV_EINVAL;
-    if (cfg->batch <= 0 || cfg->batch % 64 != 0 || !cfg->act1_plane || !cfg->draws_dev || !cfg->noise_dev || !cfg->partials_critic ||
-        !cfg->partials_actor)
-        return UAVENV_EINVAL;
+    if (cfg->batch <= 0 || cfg->batch % 64 != 0 || !cfg->act1_plane || !cfg->draws_dev || !cfg->noise_dev) return UAVENV_EINVAL;
     if (cfg->head < 0 || cfg->head >= cfg->ring.frames || cfg->filled < 0 || cfg->filled > cfg->ring.frames - 1) return UAVENV_EINVAL;
     for (int j = 0; j < cfg->n_slots; ++j) {
         const UavSacLoopSlot &sl = cfg->slot[j];
         if (!sl.nets.actor || !sl.nets.critic1 || !sl.nets.critic2 || !sl.nets.target1 || !sl.nets.target2 || !sl.nets.log_alpha ||
-            !sl.m_actor || !sl.v_actor || !sl.alpha_mv || !sl.m1 || !sl.v1 || !sl.m2 || !sl.v2 || !sl.scalars || sl.epoch < 0 ||
+            !sl.m_actor || !sl.v_actor || !sl.alpha_mv || !sl.m1 || !sl.v1 || !sl.m2 || !sl.v2 || !sl.scalars || !sl.partials_critic ||
+            !sl.partials_actor || sl.epoch < 0 ||
             sl.adam_steps < 0)
             return UAVENV_EINVAL;
     }
@@ -422,9 +421,15 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         if (rc != UAVENV_OK) return rc;
         const float *za = c.noise_dev;                                     // [U][envs][2]   get_action
         const float *zl = c.noise_dev + (size_t)U * 2 * envs;              // [2][U * B][2]  rsample() of calc_target / of the actor phase
-        for (int j = 0; j < U; ++j) {
-            rc = uavenv_sac_act(c.slot[j].nets.actor, R.obs, (int32_t)((size_t)t * n + j), U, envs, za + (size_t)j * 2 * envs,
-                                c.action_bound, act0, c.act1_plane, s);
+        {                                                                 // get_action of every slot: one launch
+            const float *actors[UAVENV_SAC_LOOP_MAX_SLOTS], *eps[UAVENV_SAC_LOOP_MAX_SLOTS];
+            int32_t first[UAVENV_SAC_LOOP_MAX_SLOTS];
+            for (int j = 0; j < U; ++j) {
+                actors[j] = c.slot[j].nets.actor;
+                eps[j] = za + (size_t)j * 2 * envs;
+                first[j] = (int32_t)((size_t)t * n + j);
+            }
+            rc = uavenv_sac_act_multi(actors, R.obs, first, U, envs, eps, c.action_bound, act0, c.act1_plane, U, s);
             if (rc != UAVENV_OK) return rc;
         }
         rc = uavenv_step(c.env, act0 + (size_t)t * n, UAVENV_ACT_STEER_F32, (unsigned char *)R.obs + (size_t)nxt * l->obs_row_bytes, nullptr,
@@ -440,9 +445,15 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             if (rc != UAVENV_OK) return rc;
             one_draw = true;
         }
+        for (int j = 0; j < U; ++j) l->epoch[j] += 1;                     // update() is called either way (:322-333)
+        if (!learn) continue;
+        UavSacNets nets[UAVENV_SAC_LOOP_MAX_SLOTS];
+        UavSacBatch bt[UAVENV_SAC_LOOP_MAX_SLOTS];
+        UavSacAdam hc[UAVENV_SAC_LOOP_MAX_SLOTS], ha[UAVENV_SAC_LOOP_MAX_SLOTS];
+        float *pc[UAVENV_SAC_LOOP_MAX_SLOTS], *pa[UAVENV_SAC_LOOP_MAX_SLOTS], *m1[UAVENV_SAC_LOOP_MAX_SLOTS], *v1[UAVENV_SAC_LOOP_MAX_SLOTS],
+              *m2[UAVENV_SAC_LOOP_MAX_SLOTS], *v2[UAVENV_SAC_LOOP_MAX_SLOTS], *ma[UAVENV_SAC_LOOP_MAX_SLOTS], *va[UAVENV_SAC_LOOP_MAX_SLOTS],
+              *amv[UAVENV_SAC_LOOP_MAX_SLOTS], *sc_c[UAVENV_SAC_LOOP_MAX_SLOTS], *sc_a[UAVENV_SAC_LOOP_MAX_SLOTS];
         for (int j = 0; j < U; ++j) {
-            l->epoch[j] += 1;                                             // update() is called either way (:322-333)
-            if (!learn) continue;
             const UavSacLoopSlot &sl = c.slot[j];
             int32_t *draws = c.draws_dev + (size_t)j * B * 2;
             if (!one_draw) {          // the ring does not hold U x B transitions yet: one draw per slot
@@ -457,27 +468,34 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             b.n_agents = R.n_agents; b.uav_per_env = U; b.slot = j; b.frames = R.frames;
             b.act0 = act0; b.act1 = c.act1_plane; b.reward = R.reward; b.done = R.done; b.valid = R.valid;
             b.batch = B;
+            b.eps = zl + ((size_t)j * B) * 2;                             // rsample() of calc_target; the actor phase's below
+            bt[j] = b;
+            nets[j] = sl.nets;
             UavSacAdam h;
             h.beta1 = (float)c.beta1; h.beta2 = (float)c.beta2; h.eps = (float)c.adam_eps;
             h.bias_correction1 = (float)(1.0 - pow(c.beta1, tt));
             h.bias_correction2_sqrt = (float)sqrt(1.0 - pow(c.beta2, tt));
             h.grad_scale = 0.0f;
-            // critics (:340-357), then the actor and log_alpha on the updated critics (:359-377); the soft update (:378-379)
-            // rides in critic_adam
-            b.eps = zl + ((size_t)j * B) * 2;
-            rc = uavenv_sac_critic_grad(&sl.nets, &b, c.gamma, c.action_bound, c.partials_critic, s);
-            if (rc != UAVENV_OK) return rc;
             h.lr = c.critic_lr; h.tau = c.tau;
-            rc = uavenv_sac_critic_adam(&sl.nets, c.partials_critic, uavenv_sac_partial_rows(B), sl.m1, sl.v1, sl.m2, sl.v2, &h, sl.scalars, s);
-            if (rc != UAVENV_OK) return rc;
-            b.eps = zl + ((size_t)nb + (size_t)j * B) * 2;
-            rc = uavenv_sac_actor_grad(&sl.nets, &b, c.action_bound, c.partials_actor, s);
-            if (rc != UAVENV_OK) return rc;
+            hc[j] = h;
             h.lr = c.actor_lr; h.tau = 0.0f;
-            rc = uavenv_sac_actor_adam(&sl.nets, c.partials_actor, uavenv_sac_partial_rows(B), B, sl.m_actor, sl.v_actor, sl.alpha_mv, &h,
-                                       c.alpha_lr, c.target_entropy, sl.scalars + 4, s);
-            if (rc != UAVENV_OK) return rc;
+            ha[j] = h;
+            pc[j] = sl.partials_critic; pa[j] = sl.partials_actor;
+            m1[j] = sl.m1; v1[j] = sl.v1; m2[j] = sl.m2; v2[j] = sl.v2; ma[j] = sl.m_actor; va[j] = sl.v_actor; amv[j] = sl.alpha_mv;
+            sc_c[j] = sl.scalars; sc_a[j] = sl.scalars + 4;
         }
+        // critics (:340-357), then the actor and log_alpha on the updated critics (:359-377); the soft update (:378-379) rides
+        // in critic_adam -- every phase for all U slots in one launch
+        const int rows = uavenv_sac_partial_rows(B);
+        rc = uavenv_sac_critic_grad_multi(nets, bt, U, c.gamma, c.action_bound, pc, s);
+        if (rc != UAVENV_OK) return rc;
+        rc = uavenv_sac_critic_adam_multi(nets, pc, rows, m1, v1, m2, v2, hc, sc_c, U, s);
+        if (rc != UAVENV_OK) return rc;
+        for (int j = 0; j < U; ++j) bt[j].eps = zl + ((size_t)nb + (size_t)j * B) * 2;
+        rc = uavenv_sac_actor_grad_multi(nets, bt, U, c.action_bound, pa, s);
+        if (rc != UAVENV_OK) return rc;
+        rc = uavenv_sac_actor_adam_multi(nets, pa, rows, B, ma, va, amv, ha, c.alpha_lr, c.target_entropy, sc_a, U, s);
+        if (rc != UAVENV_OK) return rc;
     }
     return UAVENV_OK;
 }

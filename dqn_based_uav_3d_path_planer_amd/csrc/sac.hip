@@ -23,6 +23,7 @@
 // current tile is computed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -73,6 +74,14 @@ struct SacArgs {
     // |min(Q1, Q2)(s, a) - td_target|[:, 0] of sample s out (ReplayTree.batch_update's input, :351)
     const float *is_w;
     float *abs_td;
+    int grid;                             // workgroups of this slot (a batched launch's grid.x is the maximum over its slots)
+};
+// A launch covers up to kSlots independent SAC trainers (one per UAV slot, Envs/PathPlan_City.py:59-69): blockIdx.y = slot.
+// One trainer at BASELINE configs[3]'s batch fills the chip by itself; small runs (a few tiles per slot) are a chain of
+// latency-bound launches, and four slots side by side cost what one does.
+constexpr int kSlots = UAVENV_SAC_LOOP_MAX_SLOTS;
+struct SacArgsN {
+    SacArgs s[kSlots];
 };
 
 #ifdef UAVENV_PHASE_PROFILE
@@ -478,8 +487,10 @@ __device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
 // ---------------------------------------------------------------------------------------------------------------------
 // phase A: the critics
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
+__global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
 {
+    const SacArgs &g = slots.s[blockIdx.y];
+    if ((int)blockIdx.x >= g.grid) return;
     extern __shared__ __align__(16) float lds[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
     const int n_tiles = g.batch / kTile;
@@ -623,8 +634,10 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgs g)
 // ---------------------------------------------------------------------------------------------------------------------
 // phase B: the actor (critics already updated).  Actor fc1 and both critics stay in LDS; one pass over the tiles.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgs g)
+__global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
 {
+    const SacArgs &g = slots.s[blockIdx.y];
+    if ((int)blockIdx.x >= g.grid) return;
     extern __shared__ __align__(16) float lds[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
     const int n_tiles = g.batch / kTile;
@@ -768,10 +781,14 @@ struct SacActArgs {
     float bound;
     float *act0, *act1;
 };
+struct SacActArgsN {
+    SacActArgs s[kSlots];
+};
 constexpr size_t kSacActLds = (size_t)kTileF * 4;
 
-__global__ void __launch_bounds__(256) k_sac_act(SacActArgs g)
+__global__ void __launch_bounds__(256) k_sac_act(SacActArgsN slots)
 {
+    const SacActArgs &g = slots.s[blockIdx.y];
     extern __shared__ __align__(16) float lds[];
     float *W1s = lds;
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
@@ -832,8 +849,13 @@ __device__ __forceinline__ float adam_step(float p, float g, float &m, float &v,
 
 // 64 columns per workgroup, four row groups (wavefront w sums rows w, w + 4, ...: 8 loads in flight per thread), combined
 // through LDS in a fixed order -- deterministic.
-__global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgs a)
+struct AdamArgsN {
+    AdamArgs s[kSlots];
+};
+
+__global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgsN slots)
 {
+    const AdamArgs &a = slots.s[blockIdx.y];
     __shared__ float part[4][64];
     __shared__ float fpart[4];
     const int cl = (int)threadIdx.x & 63, rg = (int)threadIdx.x >> 6;
@@ -918,6 +940,7 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
     if (tpw > kTMax) tpw = kTMax;
     g.tiles_per_wg = tpw;
     grid = (n_tiles + tpw - 1) / tpw;
+    g.grid = grid;
     g.actor = n->actor; g.c1 = n->critic1; g.c2 = n->critic2; g.t1 = n->target1; g.t2 = n->target2; g.log_alpha = n->log_alpha;
     g.partials = partials;
     g.dbg = g_sac_dbg;
@@ -925,7 +948,7 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
 }
 
 template <typename K>
-int launch_phase(K kernel, bool &attr, size_t lds, const SacArgs &g, int grid, hipStream_t s)
+int launch_phase(K kernel, bool &attr, size_t lds, const SacArgsN &slots, int n, int grid, hipStream_t s)
 {
     if (!attr) {                         // (once per kernel; one process = one device for this library's learners)
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -933,8 +956,74 @@ int launch_phase(K kernel, bool &attr, size_t lds, const SacArgs &g, int grid, h
             return sac_fail(UAVENV_EHIP, "uavenv_sac: cannot raise the dynamic LDS limit");
         attr = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, g);
+    hipLaunchKernelGGL(kernel, dim3(grid, n), dim3(256), lds, s, slots);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac: launch failed");
+}
+
+// the two grad phases for n slots in one launch (n = 1: the single-trainer entry points)
+int grad_phase(bool critic, const UavSacNets *nets, const UavSacBatch *batches, int n, float gamma, float action_bound,
+               float *const *partials, hipStream_t s)
+{
+    if (n < 1 || n > kSlots || !nets || !batches || !partials) return sac_fail(UAVENV_EINVAL, "uavenv_sac: 1 .. 8 slots per launch");
+    SacArgsN slots;
+    memset(&slots, 0, sizeof(slots));
+    int grid = 0;
+    for (int j = 0; j < n; ++j) {
+        int gj = 0;
+        const int rc = fill_args(&nets[j], &batches[j], partials[j], slots.s[j], gj);
+        if (rc != UAVENV_OK) return rc;
+        slots.s[j].gamma = critic ? gamma : 0.0f;
+        slots.s[j].bound = action_bound;
+        grid = gj > grid ? gj : grid;
+    }
+    static bool attr_c = false, attr_a = false;
+    return critic ? launch_phase(k_sac_critic_grad, attr_c, kSacCriticLds, slots, n, grid, s)
+                  : launch_phase(k_sac_actor_grad, attr_a, kSacActorLds, slots, n, grid, s);
+}
+
+int adam_launch(const AdamArgs *args, int n, int total, hipStream_t s, const char *what)
+{
+    AdamArgsN slots;
+    memset(&slots, 0, sizeof(slots));
+    for (int j = 0; j < n; ++j) slots.s[j] = args[j];
+    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 63) / 64, n), dim3(256), 0, s, slots);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, what);
+}
+
+int critic_adam_args(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
+                     const UavSacAdam *h, float *losses_out, AdamArgs &a)
+{
+    if (!nets || !partials || rows <= 0 || !m1 || !v1 || !m2 || !v2 || !h) return sac_fail(UAVENV_EINVAL, "uavenv_sac_critic_adam: null argument");
+    a = AdamArgs();
+    a.partials = partials; a.rows = rows; a.stride = kStrideC; a.nseg = 2; a.extras = 4;
+    a.seg[0] = AdamSeg{nets->critic1, m1, v1, nets->target1, kPc, h->lr};
+    a.seg[1] = AdamSeg{nets->critic2, m2, v2, nets->target2, kPc, h->lr};
+    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
+    a.tau = h->tau;
+    a.grad_scale = 1.0f;
+    a.frac_col = 2 * kPc + 2;
+    a.n_loss = 2;
+    a.scalars_out = losses_out;
+    return UAVENV_OK;
+}
+
+int actor_adam_args(const UavSacNets *nets, const float *partials, int32_t rows, int32_t batch, float *m, float *v, float *alpha_mv,
+                    const UavSacAdam *h, float alpha_lr, float target_entropy, float *scalars_out, AdamArgs &a)
+{
+    if (!nets || !partials || rows <= 0 || batch <= 0 || !m || !v || !alpha_mv || !h)
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac_actor_adam: null argument");
+    a = AdamArgs();
+    a.partials = partials; a.rows = rows; a.stride = kStrideA; a.nseg = 1; a.extras = 4;
+    a.seg[0] = AdamSeg{nets->actor, m, v, nullptr, kPa, h->lr};
+    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
+    a.tau = 0.0f;
+    a.grad_scale = 1.0f;
+    a.frac_col = kPa + 2;
+    a.n_loss = 1;
+    a.scalars_out = scalars_out;
+    a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
+    a.inv_2b = 0.5f / (float)batch;
+    return UAVENV_OK;
 }
 
 }  // namespace
@@ -958,95 +1047,109 @@ int uavenv_sac_partial_rows(int32_t batch)
     return (n_tiles + tpw - 1) / tpw;
 }
 
+int uavenv_sac_act_multi(const float *const *actors, const void *obs_packed, const int32_t *first_rows, int32_t row_stride,
+                         int32_t count, const float *const *eps, float action_bound, float *act0, float *act1, int32_t n, void *stream)
+{
+    if (!actors || !obs_packed || !first_rows || !eps || !act0 || !act1 || count <= 0 || row_stride <= 0 || n < 1 || n > kSlots)
+        return sac_fail(UAVENV_EINVAL, "uavenv_sac_act: bad argument");
+    if (!aligned16(obs_packed)) return sac_fail(UAVENV_EINVAL, "uavenv_sac_act: 16-byte alignment");
+    SacActArgsN slots;
+    memset(&slots, 0, sizeof(slots));
+    for (int j = 0; j < n; ++j) {
+        if (!actors[j] || !eps[j] || first_rows[j] < 0 || !aligned16(actors[j])) return sac_fail(UAVENV_EINVAL, "uavenv_sac_act: bad slot argument");
+        slots.s[j] = SacActArgs{actors[j], reinterpret_cast<const uint32_t *>(obs_packed), first_rows[j], row_stride, count, eps[j],
+                                action_bound, act0, act1};
+    }
+    const int n_tiles = (count + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_sac_act, dim3(n_tiles < 512 ? n_tiles : 512, n), dim3(256), kSacActLds, (hipStream_t)stream, slots);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_act: launch failed");
+}
+
 int uavenv_sac_act(const float *actor, const void *obs_packed, int32_t first_row, int32_t row_stride, int32_t count,
                    const float *eps, float action_bound, float *act0, float *act1, void *stream)
 {
-    if (!actor || !obs_packed || !eps || !act0 || !act1 || count <= 0 || first_row < 0 || row_stride <= 0)
-        return sac_fail(UAVENV_EINVAL, "uavenv_sac_act: bad argument");
-    if (!aligned16(actor) || !aligned16(obs_packed)) return sac_fail(UAVENV_EINVAL, "uavenv_sac_act: 16-byte alignment");
-    SacActArgs g = {actor, reinterpret_cast<const uint32_t *>(obs_packed), first_row, row_stride, count, eps, action_bound, act0, act1};
-    const int n_tiles = (count + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_sac_act, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), kSacActLds, (hipStream_t)stream, g);
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_act: launch failed");
+    return uavenv_sac_act_multi(&actor, obs_packed, &first_row, row_stride, count, &eps, action_bound, act0, act1, 1, stream);
 }
 
 int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, float gamma, float action_bound, float *partials,
                            void *stream)
 {
-    SacArgs g;
-    int grid = 0;
-    const int rc = fill_args(nets, batch, partials, g, grid);
-    if (rc != UAVENV_OK) return rc;
-    g.gamma = gamma;
-    g.bound = action_bound;
-    static bool attr = false;
-    return launch_phase(k_sac_critic_grad, attr, kSacCriticLds, g, grid, (hipStream_t)stream);
+    return grad_phase(true, nets, batch, 1, gamma, action_bound, &partials, (hipStream_t)stream);
 }
 
 int uavenv_sac_actor_grad(const UavSacNets *nets, const UavSacBatch *batch, float action_bound, float *partials, void *stream)
 {
-    SacArgs g;
-    int grid = 0;
-    const int rc = fill_args(nets, batch, partials, g, grid);
-    if (rc != UAVENV_OK) return rc;
-    g.gamma = 0.0f;
-    g.bound = action_bound;
-    static bool attr = false;
-    return launch_phase(k_sac_actor_grad, attr, kSacActorLds, g, grid, (hipStream_t)stream);
+    return grad_phase(false, nets, batch, 1, 0.0f, action_bound, &partials, (hipStream_t)stream);
+}
+
+int uavenv_sac_critic_grad_multi(const UavSacNets *nets, const UavSacBatch *batches, int32_t n, float gamma, float action_bound,
+                                 float *const *partials, void *stream)
+{
+    return grad_phase(true, nets, batches, n, gamma, action_bound, partials, (hipStream_t)stream);
+}
+
+int uavenv_sac_actor_grad_multi(const UavSacNets *nets, const UavSacBatch *batches, int32_t n, float action_bound,
+                                float *const *partials, void *stream)
+{
+    return grad_phase(false, nets, batches, n, 0.0f, action_bound, partials, (hipStream_t)stream);
 }
 
 // multi-GPU: column sums only (rows x stride -> raw[stride]); the caller all-reduces raw and passes it back as ONE row
 int uavenv_sac_reduce(const float *partials, int32_t rows, int32_t stride, float *raw, void *stream)
 {
     if (!partials || !raw || rows <= 0 || (stride != kStrideA && stride != kStrideC)) return sac_fail(UAVENV_EINVAL, "uavenv_sac_reduce: bad argument");
-    AdamArgs a = {};
+    AdamArgs a = AdamArgs();
     a.partials = partials; a.rows = rows; a.stride = stride; a.nseg = 1; a.extras = 0;
     a.seg[0].n = stride;
     a.raw_out = raw;
     a.frac_col = -1;
-    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((stride + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_reduce: launch failed");
+    return adam_launch(&a, 1, stride, (hipStream_t)stream, "uavenv_sac_reduce: launch failed");
 }
 
 int uavenv_sac_critic_adam(const UavSacNets *nets, const float *partials, int32_t rows, float *m1, float *v1, float *m2, float *v2,
                            const UavSacAdam *h, float *losses_out, void *stream)
 {
-    if (!nets || !partials || rows <= 0 || !m1 || !v1 || !m2 || !v2 || !h) return sac_fail(UAVENV_EINVAL, "uavenv_sac_critic_adam: null argument");
-    AdamArgs a = {};
-    a.partials = partials; a.rows = rows; a.stride = kStrideC; a.nseg = 2; a.extras = 4;
-    a.seg[0] = AdamSeg{nets->critic1, m1, v1, nets->target1, kPc, h->lr};
-    a.seg[1] = AdamSeg{nets->critic2, m2, v2, nets->target2, kPc, h->lr};
-    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
-    a.tau = h->tau;
-    a.grad_scale = 1.0f;
-    a.frac_col = 2 * kPc + 2;
-    a.n_loss = 2;
-    a.scalars_out = losses_out;
-    const int total = 2 * kPc + 4;
-    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_critic_adam: launch failed");
+    AdamArgs a;
+    const int rc = critic_adam_args(nets, partials, rows, m1, v1, m2, v2, h, losses_out, a);
+    if (rc != UAVENV_OK) return rc;
+    return adam_launch(&a, 1, 2 * kPc + 4, (hipStream_t)stream, "uavenv_sac_critic_adam: launch failed");
 }
 
 int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t rows, int32_t batch, float *m, float *v,
                           float *alpha_mv, const UavSacAdam *h, float alpha_lr, float target_entropy, float *scalars_out,
                           void *stream)
 {
-    if (!nets || !partials || rows <= 0 || batch <= 0 || !m || !v || !alpha_mv || !h)
-        return sac_fail(UAVENV_EINVAL, "uavenv_sac_actor_adam: null argument");
-    AdamArgs a = {};
-    a.partials = partials; a.rows = rows; a.stride = kStrideA; a.nseg = 1; a.extras = 4;
-    a.seg[0] = AdamSeg{nets->actor, m, v, nullptr, kPa, h->lr};
-    a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.bc1 = h->bias_correction1; a.bc2_sqrt = h->bias_correction2_sqrt;
-    a.tau = 0.0f;
-    a.grad_scale = 1.0f;
-    a.frac_col = kPa + 2;
-    a.n_loss = 1;
-    a.scalars_out = scalars_out;
-    a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
-    a.inv_2b = 0.5f / (float)batch;
-    const int total = kPa + 4;
-    hipLaunchKernelGGL(k_sac_reduce_adam, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_actor_adam: launch failed");
+    AdamArgs a;
+    const int rc = actor_adam_args(nets, partials, rows, batch, m, v, alpha_mv, h, alpha_lr, target_entropy, scalars_out, a);
+    if (rc != UAVENV_OK) return rc;
+    return adam_launch(&a, 1, kPa + 4, (hipStream_t)stream, "uavenv_sac_actor_adam: launch failed");
+}
+
+int uavenv_sac_critic_adam_multi(const UavSacNets *nets, float *const *partials, int32_t rows, float *const *m1, float *const *v1,
+                                 float *const *m2, float *const *v2, const UavSacAdam *h, float *const *losses_out, int32_t n,
+                                 void *stream)
+{
+    if (n < 1 || n > kSlots || !nets || !partials || !m1 || !v1 || !m2 || !v2 || !h) return sac_fail(UAVENV_EINVAL, "uavenv_sac_critic_adam_multi: bad argument");
+    AdamArgs a[kSlots];
+    for (int j = 0; j < n; ++j) {
+        const int rc = critic_adam_args(&nets[j], partials[j], rows, m1[j], v1[j], m2[j], v2[j], &h[j], losses_out ? losses_out[j] : nullptr, a[j]);
+        if (rc != UAVENV_OK) return rc;
+    }
+    return adam_launch(a, n, 2 * kPc + 4, (hipStream_t)stream, "uavenv_sac_critic_adam_multi: launch failed");
+}
+
+int uavenv_sac_actor_adam_multi(const UavSacNets *nets, float *const *partials, int32_t rows, int32_t batch, float *const *m,
+                                float *const *v, float *const *alpha_mv, const UavSacAdam *h, float alpha_lr, float target_entropy,
+                                float *const *scalars_out, int32_t n, void *stream)
+{
+    if (n < 1 || n > kSlots || !nets || !partials || !m || !v || !alpha_mv || !h) return sac_fail(UAVENV_EINVAL, "uavenv_sac_actor_adam_multi: bad argument");
+    AdamArgs a[kSlots];
+    for (int j = 0; j < n; ++j) {
+        const int rc = actor_adam_args(&nets[j], partials[j], rows, batch, m[j], v[j], alpha_mv[j], &h[j], alpha_lr, target_entropy,
+                                       scalars_out ? scalars_out[j] : nullptr, a[j]);
+        if (rc != UAVENV_OK) return rc;
+    }
+    return adam_launch(a, n, kPa + 4, (hipStream_t)stream, "uavenv_sac_actor_adam_multi: launch failed");
 }
 
 }  // extern "C"

@@ -158,7 +158,6 @@ class SACHotLoop:
         n_envs = env.N // U
         self._draws = torch.zeros((U * batch, 2), dtype=torch.int32, device=d)
         self._noise = torch.zeros(int(self.lib.uavenv_sac_loop_noise_floats(U, n_envs, int(batch))), dtype=torch.float32, device=d)
-        rows, pc, pa = L0._scratch(int(batch))
         cfg = _lib.UavSacLoopConfig()
         cfg.env = env._h
         cfg.ring = ring._c
@@ -176,15 +175,16 @@ class SACHotLoop:
         cfg.actor_lr, cfg.critic_lr, cfg.alpha_lr, cfg.target_entropy = L0.actor_lr, L0.critic_lr, L0.alpha_lr, L0.target_entropy
         cfg.step_flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | ring.extra_flags
         cfg.draws_dev, cfg.noise_dev = self._draws.data_ptr(), self._noise.data_ptr()
-        cfg.partials_critic, cfg.partials_actor = pc.data_ptr(), pa.data_ptr()
         for j, L in enumerate(self.learners):
             sl = cfg.slot[j]
+            _, pc, pa = L._scratch(int(batch))           # every slot's own partial rows: the phases run for all slots at once
+            sl.partials_critic, sl.partials_actor = pc.data_ptr(), pa.data_ptr()
             sl.nets = L._nets
             sl.m_actor, sl.v_actor, sl.alpha_mv = L._blocks[1].data_ptr(), L._blocks[2].data_ptr(), L._alpha_mv.data_ptr()
             sl.m1, sl.v1, sl.m2, sl.v2 = (L._cblocks[k].data_ptr() for k in (4, 5, 6, 7))
             sl.scalars = L._scalars.data_ptr()
             sl.epoch, sl.adam_steps = L.epoch, L.adam_steps
-        self._keep = (act1_plane, info, pc, pa)
+        self._keep = (act1_plane, info)
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_sac_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_sac_loop_create")
         self.counter = int(counter)

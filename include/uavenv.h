@@ -490,6 +490,24 @@ int uavenv_sac_partial_rows(int32_t batch);
 const char *uavenv_sac_last_error(void);
 /* Diagnostics (UAVENV_PHASE_PROFILE builds): 16 s_memtime stamps per workgroup of uavenv_sac_critic_grad; NULL disables. */
 int uavenv_sac_set_debug_buffer(unsigned long long *dev_buf);
+/* Batched forms: n <= UAVENV_SAC_LOOP_MAX_SLOTS independent trainers (one per UAV slot, Envs/PathPlan_City.py:59-69) in ONE launch
+ * per phase (grid.y = slot); arrays of n entries each; results are bit-identical to n single launches.  At BASELINE
+ * configs[3]'s batch one trainer fills the chip; in small runs a step is a chain of latency-bound launches and n slots side
+ * by side cost what one does. */
+#define UAVENV_SAC_LOOP_MAX_SLOTS 8
+int uavenv_sac_act_multi(const float *const *actors, const void *obs_packed, const int32_t *first_rows, int32_t row_stride,
+                         int32_t count, const float *const *eps, float action_bound, float *act0, float *act1, int32_t n,
+                         void *stream);
+int uavenv_sac_critic_grad_multi(const UavSacNets *nets, const UavSacBatch *batches, int32_t n, float gamma, float action_bound,
+                                 float *const *partials, void *stream);
+int uavenv_sac_actor_grad_multi(const UavSacNets *nets, const UavSacBatch *batches, int32_t n, float action_bound,
+                                float *const *partials, void *stream);
+int uavenv_sac_critic_adam_multi(const UavSacNets *nets, float *const *partials, int32_t rows, float *const *m1, float *const *v1,
+                                 float *const *m2, float *const *v2, const UavSacAdam *h, float *const *losses_out, int32_t n,
+                                 void *stream);
+int uavenv_sac_actor_adam_multi(const UavSacNets *nets, float *const *partials, int32_t rows, int32_t batch, float *const *m,
+                                float *const *v, float *const *alpha_mv, const UavSacAdam *h, float alpha_lr, float target_entropy,
+                                float *const *scalars_out, int32_t n, void *stream);
 /* eps = the draws of actor(next_states).  partials: rows x UAVENV_SAC_CRITIC_STRIDE floats. */
 int uavenv_sac_critic_grad(const UavSacNets *nets, const UavSacBatch *batch, float gamma, float action_bound, float *partials,
                            void *stream);
@@ -511,16 +529,16 @@ int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t
 
 /* ---- the off-policy loop for SAC (continuous actions), one trainer per UAV slot, enqueued from C ----------------------
  * PathPlan_City.run_thread_OffPolicy (Envs/PathPlan_City.py:364-385) with SAC_Trainer for every env at once, K steps per
- * call.  Per step: one launch of N(0,1) draws (uavenv_randn) for every rsample() of the step, U x uavenv_sac_act, uavenv_step
- * (replay write included), one uavenv_replay_draw, U x the four launches of the fused update -- the sequence
- * plugins/PathPlan_City._run_eposide_fused_sac issues from Python, bit for bit (389 us per step there at 2 048 envs x 4
- * UAVs: host-bound).  Uniform replay; slots with prioritised replay stay on the Python loop. */
-#define UAVENV_SAC_LOOP_MAX_SLOTS 8
+ * call.  Per step: one launch of N(0,1) draws (uavenv_randn) for every rsample() of the step, get_action of all U slots
+ * (uavenv_sac_act_multi), uavenv_step (replay write included), one uavenv_replay_draw, and the four phases of the fused update
+ * for all U slots at once (the *_multi entry points) -- what plugins/PathPlan_City._run_eposide_fused_sac issues from Python slot
+ * by slot (~22 launches per step), bit for bit, in 8.  Uniform replay; slots with prioritised replay stay on the Python loop. */
 typedef struct UavSacLoopSlot {
     UavSacNets nets;
     float *m_actor, *v_actor, *alpha_mv;     /* Adam moments of the actor (UAVENV_SAC_ACTOR_PARAMS each) and of log_alpha (2) */
     float *m1, *v1, *m2, *v2;                /* Adam moments of the two critics (UAVENV_SAC_CRITIC_PARAMS each) */
     float *scalars;                          /* 8 floats: critic losses [0:4], actor loss / sum log pi [4:8] of the last update */
+    float *partials_critic, *partials_actor; /* uavenv_sac_partial_rows(batch) x UAVENV_SAC_CRITIC_STRIDE / _ACTOR_STRIDE, per slot */
     int32_t epoch, adam_steps;               /* update() calls so far; Adam steps actually taken (bias correction) */
 } UavSacLoopSlot;
 typedef struct UavSacLoopConfig {
@@ -538,7 +556,6 @@ typedef struct UavSacLoopConfig {
     uint32_t step_flags, reserved2;
     int32_t *draws_dev;                      /* n_slots x batch x 2 */
     float *noise_dev;                        /* uavenv_sac_loop_noise_floats(n_slots, n_envs, batch) floats */
-    float *partials_critic, *partials_actor; /* uavenv_sac_partial_rows(batch) x UAVENV_SAC_CRITIC_STRIDE / _ACTOR_STRIDE */
     UavSacLoopSlot slot[UAVENV_SAC_LOOP_MAX_SLOTS];
 } UavSacLoopConfig;
 typedef struct UavSacLoopCursor {
