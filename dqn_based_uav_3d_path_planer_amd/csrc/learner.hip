@@ -1641,6 +1641,11 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
 {
     __shared__ float cnt_part[4];
     const int tid = (int)threadIdx.x;
+    const int p = (int)blockIdx.x * 32 + tid;
+    // this parameter's moments and value are requested FIRST: their round trip runs under the partial rows' (behind the
+    // reduction's barriers they were a second, dependent round trip of the launch)
+    float m0 = 0.0f, v0 = 0.0f, w0 = 0.0f;
+    if (tid < 32 && p < P) { m0 = m[p]; v0 = v[p]; w0 = local[p]; }
     float c;
     const float t = reduce_columns(partials, nblk, P, stride, c);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
@@ -1648,16 +1653,15 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
     __syncthreads();
     const float cnt = (cnt_part[0] + cnt_part[1]) + (cnt_part[2] + cnt_part[3]);
     const float inv = 1.0f / (cnt > 1.0f ? cnt : 1.0f);
-    const int p = (int)blockIdx.x * 32 + tid;
     if (tid < 32 && p < P + 2) {
         if (raw) raw[p] = t;
         if (p < P) {
             const float gp = t * inv;
-            const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);
-            const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;
+            const float mp = m0 + (gp - m0) * (1.0f - beta1);
+            const float vp = v0 * beta2 + (1.0f - beta2) * gp * gp;
             m[p] = mp;
             v[p] = vp;
-            const float np = local[p] - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
+            const float np = w0 - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
             local[p] = np;
             if (hard_update) target[p] = np;
         } else if (p == P && loss) {

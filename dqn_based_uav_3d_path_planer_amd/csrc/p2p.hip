@@ -161,6 +161,10 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
     }
     __shared__ uint32_t s_bad;
     __shared__ unsigned long long s_sum;
+    // this parameter's moments and value: requested before the wait, so their round trip runs under it
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    float m0 = 0.0f, v0 = 0.0f, w0 = 0.0f;
+    if (p < P && local) { m0 = m[p]; v0 = v[p]; w0 = local[p]; }
     if (threadIdx.x == 0) {
         uint32_t bad = __hip_atomic_load(d.errors + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky
         for (int r = 0; r < d.world && !bad; ++r) {
@@ -198,7 +202,6 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
     }
     __syncthreads();
     const bool frozen = s_bad != 0;              // the sums below may be stale: report them, never step with them
-    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     float cnt = 0.0f, lsum = 0.0f;
     for (int r = 0; r < d.world; ++r) {
         const float *slot = recv_slot(mine, r, d.seq, d.bucket_pad);
@@ -215,11 +218,11 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
             gsum += __hip_atomic_load(recv_slot(mine, r, d.seq, d.bucket_pad) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (raw_out) raw_out[p] = gsum;
         if (local) {                                                             // (NULL: sum only, self-test)
-            np = local[p];
+            np = w0;
             if (!frozen) {
                 const float gp = gsum * inv;
-                const float mp = m[p] + (gp - m[p]) * (1.0f - beta1);
-                const float vp = v[p] * beta2 + (1.0f - beta2) * gp * gp;
+                const float mp = m0 + (gp - m0) * (1.0f - beta1);
+                const float vp = v0 * beta2 + (1.0f - beta2) * gp * gp;
                 m[p] = mp;
                 v[p] = vp;
                 np = np - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
