@@ -501,6 +501,9 @@ def other_configs(args):
             ("configs[1] with prioritised replay (IsPriority_Replay = 1) on the fused path", ["--per", "--steps", "12", "--warmup", "3"]),
             ("EXPERIMENT on configs[1] (not the benchmark's semantics): sample_lag = 1 -- update t samples transitions <= t - 1, "
              "its gradient kernel on a second stream beside step t", ["--sample-lag", "1", "--steps", "20", "--warmup", "4"]),
+            ("row e on ONE GPU (NOT a multi-GPU measurement): two ranks sharing this device, 16384 envs each, gradient bucket "
+             "summed over HIP-IPC-mapped memory on the stream (csrc/p2p.hip), ranks started by bench.py itself",
+             ["--gpus", "2", "--same-device", "--dist-backend", "gloo", "--steps", "8", "--warmup", "2"]),
             ("env-only 65536 agents/launch", ["--env-only", "--envs", "65536", "--steps", "40"]),
             ("env-only 262144 agents/launch", ["--env-only", "--envs", "262144", "--steps", "20"])]
     out = []
@@ -520,6 +523,8 @@ def other_configs(args):
             row.update({"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                         "ms_per_pass": d.get("ms_per_pass"), "timed_region_ms": d.get("timed_region_ms"),
                         "learner_updates_per_s": d.get("learner_updates_per_s"),
+                        **{k: d[k] for k in ("n_gpus", "ranks_bit_identical", "exchange", "exchange_fallbacks", "p2p_timeouts",
+                                             "p2p_checksum_mismatches", "p2p_checksums_compared", "ms_per_pass_no_exchange") if k in d},
                         "roofline": {k: r.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "agents_per_launch")},
                         "roofline_learner": {k: rl.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "peak")}})
         out.append(row)
