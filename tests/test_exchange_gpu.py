@@ -39,11 +39,12 @@ def _worker(rank, world, port, out_dir, scenario):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     n = 1024
-    env = make_city26_env(n)
+    nine = scenario == "healthy9"      # 9 actions: P + 2 = 7051 = 3 mod 4 -- the two checksum words straddle two storing lanes
+    env = make_city26_env(n, n_actions=9) if nine else make_city26_env(n)
     ring = DeviceReplayRing(env, 6 * n, discrete=True)
     ring.reset(seed=4 + rank)
     torch.manual_seed(0)
-    L = FusedDQNLearner(PARAM, "dqn", device="cuda:0")
+    L = FusedDQNLearner(dict(PARAM, output="9") if nine else PARAM, "dqn", device="cuda:0")
     assert L.enable_p2p(check_every=1, spin_limit=1 << 18), "peer-to-peer exchange could not be set up"
     hot = HotLoop(ring, L, 256, seed=3 + rank, eps=0.3)
     res = {}
@@ -98,7 +99,7 @@ def _worker(rank, world, port, out_dir, scenario):
     env.close()
 
 
-@pytest.mark.parametrize("scenario", ["diverge", "timeout"])
+@pytest.mark.parametrize("scenario", ["diverge", "timeout", "healthy9"])
 def test_peer_exchange_raises_a_sticky_error_and_freezes(scenario, tmp_path):
     import torch.multiprocessing as mp
     from dqn_based_uav_3d_path_planer_amd import _lib
@@ -109,6 +110,8 @@ def test_peer_exchange_raises_a_sticky_error_and_freezes(scenario, tmp_path):
         assert r["healthy"]["code"] == 0 and r["healthy"]["timeouts"] == 0 and r["healthy"]["mismatches"] == 0
         assert r["healthy"]["checks"] >= 5
     assert r0["sum_healthy"] == r1["sum_healthy"]            # lock-step, bit for bit
+    if scenario == "healthy9":
+        return
     if scenario == "diverge":
         for r in (r0, r1):
             assert r["raised"] and r["after"]["code"] == _lib.P2P_ERR_DIVERGED and r["after"]["mismatches"] >= 1
