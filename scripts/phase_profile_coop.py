@@ -7,8 +7,12 @@ from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
 from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-env = make_city26_env(n)
+POLICY = os.environ.get("POLICY") == "1"         # the launch the C loop issues: get_action in the step kernel's prologue
+env = make_city26_env(n, obs_dtype="packed" if POLICY else torch.float32)
 ring = DeviceReplayRing(env, 8 * n)
+if POLICY:
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    L = FusedDQNLearner({"NetWork": "Qnet2", "w": "100", "hiden_dim": "64", "output": "3"}, "dqn")
 ring.reset(seed=1)
 gen = torch.Generator(device="cuda").manual_seed(0)
 for _ in range(300):
@@ -18,9 +22,12 @@ nb = (n + 63) // 64
 buf = torch.zeros(nb * 4 * 8, dtype=torch.int64, device="cuda")
 env.lib.uavenv_set_debug_buffer(env._h, buf.data_ptr())
 rows = []
-for _ in range(20):
-    ring.current_action().copy_(torch.randint(0, 3, (n,), generator=gen, device="cuda", dtype=torch.int32))
-    ring.step_env(auto_reset=True)
+for it in range(20):
+    if POLICY:
+        assert ring.step_policy(L, 0.1, 3, 1000 + it)
+    else:
+        ring.current_action().copy_(torch.randint(0, 3, (n,), generator=gen, device="cuda", dtype=torch.int32))
+        ring.step_env(auto_reset=True)
     torch.cuda.synchronize()
     rows.append(buf.cpu().numpy().reshape(nb, 4, 8).astype(np.float64))
 env.lib.uavenv_set_debug_buffer(env._h, None)
