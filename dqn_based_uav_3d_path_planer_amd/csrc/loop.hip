@@ -204,10 +204,8 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
         l->head = nxt;
         if (l->filled < R.frames - 1) l->filled += 1;
         if (l->per) {                     // ReplayTree.push(error 0) for the frame just written; the new head's rows are retired
-            rc = uavenv_per_fill(&c.per, (int64_t)t * (int64_t)n, (int64_t)n, pow(0.0 + (double)c.per_eps, (double)c.per_alpha),
-                                 R.valid + (size_t)t * n, s);
-            if (rc != UAVENV_OK) return rc;
-            rc = uavenv_per_fill(&c.per, (int64_t)nxt * (int64_t)n, (int64_t)n, 0.0, nullptr, s);
+            rc = uavenv_per_fill_frame(&c.per, (int64_t)t * (int64_t)n, (int64_t)n, pow(0.0 + (double)c.per_eps, (double)c.per_alpha),
+                                       R.valid + (size_t)t * n, (int64_t)nxt * (int64_t)n, s);
             if (rc != UAVENV_OK) return rc;
         }
         if (lag ? lag_update
