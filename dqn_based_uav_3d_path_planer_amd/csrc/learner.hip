@@ -947,15 +947,8 @@ static_assert((2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kH
 // then zeros), rows of kLdT = 72 for the K = 64 (samples) products of the backward, whose operands are TRANSPOSED
 // ([column][sample]: an MFMA lane supplies 8 consecutive K elements of one row).
 // =====================================================================================================================
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-constexpr int kLdH = 136;
+constexpr int kLdH = 136;            // (half8 / half4 / mfma16h: qnet_device.hpp)
 constexpr int kStageW = 16 * kPackedDwords + 4;   // dwords of packed-row staging per wavefront (+ pad: the expansion over-reads 1)
-
-__device__ __forceinline__ floatx4 mfma16h(half8 a, half8 b, floatx4 c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
 
 // four columns 4 q .. 4 q + 3 of the row whose packed image is at pr (LDS)
 __device__ __forceinline__ floatx4 packed_expand4(const uint32_t *pr, int q)

@@ -253,4 +253,155 @@ __device__ __forceinline__ void fwd_strip_packed(const float *W, const PRow &R, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// f16-MFMA policy for ONE wavefront = 64 agents of an f16 ring (the forward of k_dqn_act_h, learner.hip: same operands in
+// the same K positions of the same four v_mfma_f32_16x16x32_f16 per accumulator, so the Q values -- and the actions -- are
+// bit-identical), for the prologue of the one-wave env step kernel (uavenv_step_policy on f16 rings).  Nothing is staged
+// through LDS: a lane's share of the fc1 operand (rows 16 t + r, columns 32 kk + 8 g .. + 7: the whole matrix exactly once
+// per wavefront) and of the four 16-agent strips' observation rows (row r of strip st, the same columns) come straight
+// from memory into registers, all in flight together with the caller's own state loads.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ floatx4 mfma16h(half8 a, half8 b, floatx4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// LDS of a 64-agent policy team: the fc1 tile in f16 (row stride 104 halfs = 52 dwords: the 16 rows of a ds_read_b128 phase
+// start 4 banks apart and cover all 64), the 64 raw observation rows (200 bytes each, as in memory), 64 x 16 bytes of Q values.
+constexpr int kPolLdW = 104;
+constexpr int kPolWBytes = kHid * kPolLdW * 2;            // 13 312
+constexpr int kPolXBytes = 64 * kW * 2;                   // 12 800
+constexpr int kPolBytes = kPolWBytes + kPolXBytes + 64 * 16;
+
+#ifdef UAVENV_PHASE_PROFILE
+#define POL_STAMP(k) do { if (dbg && ((int)threadIdx.x & 63) == 0) dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define POL_STAMP(k) do { } while (0)
+#endif
+
+// One of the TWO policy wavefronts (p = 0, 1) of a 64-agent team (first .. first + 63; the third wavefront of the workgroup
+// is the agents themselves): Q(s) of agents 32 p .. 32 p + 31 into qs[agent] -- the forward of k_dqn_act_h, same operands in
+// the same K positions of the same four v_mfma_f32_16x16x32_f16 per accumulator, so the Q values (and the actions the agent
+// wavefront picks from them) are bit-identical.  flat: q_local's parameter block; obs: [N][100] halfs of the CURRENT frame
+// (16-byte aligned; first is a multiple of 64, so the rows start on a 16-byte boundary); lds: kPolBytes owned by the team.
+// Everything comes in as full 1 KiB runs (64 lanes x 16 consecutive bytes): each wavefront converts half of fc1 and copies
+// its 32 rows; the MFMA lanes take their operands from LDS.  Calls __syncthreads() twice -- the agent wavefront's staging
+// barrier and the hand-over of the Q values -- and so must every other wavefront of the workgroup.
+// History (65 536 agents, cycles of the agent wavefront until it has its action, 4.3 k without a policy): the agent
+// wavefront running the policy itself 19 k; one policy wavefront with its operand pieces loaded straight into registers
+// (59 scattered loads per lane) 14.7 k, through LDS 15.1 k -- a single wavefront's dependent instruction stream (four strips x
+// (16 MFMAs + ~135 VALU of layer 2), ~10 cycles per instruction) is the cost, so it is split over two.
+__device__ __forceinline__ void polh_wave(int p, const float *flat, int n_actions, int dueling, const void *obs, int first,
+                                          int N, unsigned char *lds, unsigned long long *dbg = nullptr)
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int n2 = n_actions + (dueling ? 1 : 0);
+    const NetDev nl = net_view(flat, n2);
+    _Float16 *Wt = reinterpret_cast<_Float16 *>(lds);
+    unsigned char *xs = lds + kPolWBytes + p * (32 * kW * 2);               // this wavefront's 32 rows
+    floatx4 *qs = reinterpret_cast<floatx4 *>(lds + kPolWBytes + kPolXBytes) + 32 * p;
+    POL_STAMP(0);
+    {
+        floatx4 vw[13];
+        uintx4 vx[7];
+        int rows = N - (first + 32 * p);
+        rows = rows < 0 ? 0 : (rows < 32 ? rows : 32);
+        const int nx = rows * (kW * 2) / 16;                                  // whole 16-byte chunks inside the frame
+        const uintx4 *xsrc = reinterpret_cast<const uintx4 *>(reinterpret_cast<const unsigned char *>(obs) +
+                                                              (size_t)(rows > 0 ? first + 32 * p : first) * (kW * 2));
+#pragma unroll
+        for (int it = 0; it < 13; ++it) {
+            const int c = it * 128 + p * 64 + lane;
+            vw[it] = *reinterpret_cast<const floatx4 *>(nl.W1 + 4 * (c < kStageChunks ? c : kStageChunks - 1));
+        }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int c = it * 64 + lane;
+            vx[it] = xsrc[c < nx ? c : 0];
+        }
+        const float pb1 = nl.b1[lane];
+        POL_STAMP(1);
+#pragma unroll
+        for (int it = 0; it < 13; ++it) {
+            const int c = it * 128 + p * 64 + lane, row = c / 25, q = c - row * 25;
+            if (c < kStageChunks)
+                *reinterpret_cast<half4 *>(Wt + row * kPolLdW + 4 * q) =
+                    half4{(_Float16)vw[it][0], (_Float16)vw[it][1], (_Float16)vw[it][2], (_Float16)vw[it][3]};
+        }
+        if (p == 0)                                                             // column 100 = b1, 101..103 = 0
+            *reinterpret_cast<half4 *>(Wt + lane * kPolLdW + kW) = half4{(_Float16)pb1, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int c = it * 64 + lane;
+            if (c < 400) reinterpret_cast<uintx4 *>(xs)[c] = vx[it];
+        }
+    }
+    W2Frag<4> F;
+    w2_load<4>(F, nl.W2, nl.b2, n2);             // fc2 fragments straight from memory (16-byte aligned: 6 464 floats in)
+    __syncthreads();                             // fc1 tile complete (both halves); the agent wavefront: world staged
+    POL_STAMP(2);
+    const _Float16 z = (_Float16)0.0f;
+    floatx4 acc[2][4];
+    half8 b[2][4];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const unsigned char *xr = xs + (16 * st + r) * (kW * 2);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(xr + 64 * kk + 16 * g), hi = *reinterpret_cast<const uint2 *>(xr + 64 * kk + 16 * g + 8);
+            const uintx4 raw = uintx4{lo.x, lo.y, hi.x, hi.y};
+            b[st][kk] = *reinterpret_cast<const half8 *>(&raw);
+        }
+        const uint2 lo = *reinterpret_cast<const uint2 *>(xr + 192);
+        const uintx4 raw = uintx4{lo.x, lo.y, 0x3c00u, 0u};                              // column 100 = 1.0 (f16 0x3c00)
+        b[st][3] = g == 0 ? *reinterpret_cast<const half8 *>(&raw) : half8{z, z, z, z, z, z, z, z};
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const _Float16 *wr = Wt + (16 * t + r) * kPolLdW;
+        half8 A[4];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) A[kk] = *reinterpret_cast<const half8 *>(wr + 32 * kk + 8 * g);
+        // K-step 3: columns 96..99, column 100 = b1 (against the ones column of the observation), 101..103 = 0
+        A[3] = g == 0 ? *reinterpret_cast<const half8 *>(wr + 96) : half8{z, z, z, z, z, z, z, z};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                acc[st][t] = mfma16h(A[kk], b[st][kk], kk == 0 ? floatx4{0.0f, 0.0f, 0.0f, 0.0f} : acc[st][t]);
+    }
+    POL_STAMP(3);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float q[4];
+        q_strip<4>(acc[st], F, n2, n_actions, dueling, q);
+        if (lane < 16) qs[16 * st + lane] = floatx4{q[0], q[1], q[2], q[3]};
+    }
+    POL_STAMP(4);
+    __syncthreads();                             // Q values handed over
+}
+
+// epsilon-greedy over the Q values (Trainer/DuelingDQN_Trainer.py:86-97; the Philox stream of k_dqn_act*: rn of agent i)
+__device__ __forceinline__ uint4 policy_philox(int i, uint64_t seed, uint64_t counter)
+{
+    return philox4x32_10(make_uint4((uint32_t)i, (uint32_t)counter, (uint32_t)(counter >> 32), 0xac7u),
+                         make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+
+__device__ __forceinline__ int policy_select(floatx4 q, uint4 rn, float eps, int n_actions)
+{
+    const float sample = (float)(rn.x >> 8) * (1.0f / 16777216.0f);
+    if (sample > eps) {
+        int act = 0;
+        float bq = q[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (k < n_actions && q[k] > bq) { bq = q[k]; act = k; }
+        return act;
+    }
+    return (int)(((uint64_t)rn.y * (uint64_t)n_actions) >> 32);
+}
+
 }  // namespace uavq

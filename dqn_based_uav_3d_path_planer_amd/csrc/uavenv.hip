@@ -128,7 +128,7 @@ struct StepArgs {
     uint64_t seed, tick;
     // the policy in the prologue of k_step_coop (uavenv_step_policy): Q(s) + epsilon-greedy of Trainer/DuelingDQN_Trainer.py:86-97
     const float *pol_local;            // nullable: q_local's flat parameter block
-    const uint32_t *pol_obs;           // [N][20] packed rows of the CURRENT frame
+    const uint32_t *pol_obs;           // rows of the CURRENT frame: [N][20] packed (k_step_coop) or [N][100] halfs (k_step)
     int32_t *pol_act;                  // [N] chosen action indices out (the replay ring's action plane)
     int32_t pol_dueling, pol_off;      // pol_off: LDS byte offset of the policy's tiles
     float pol_eps;
@@ -917,13 +917,25 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
 #ifndef UAVENV_KSTEP_WAVES
 #define UAVENV_KSTEP_WAVES 1      // min waves per SIMD the register allocator must leave room for (A/B knob)
 #endif
-template <typename MaskT, bool APF, int OBS>
-__global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
+// POLH (f16 rings, uavenv_step_policy on launches too large for k_step_coop; k_step_polh below): 64 agents per workgroup
+// and THREE wavefronts -- the agents and two policy wavefronts, which compute Q(s) of the 64 agents (qnet_device.hpp:
+// polh_wave: the f16-MFMA forward of k_dqn_act_h, bit-identical) while the agent wavefront waits for its state and stages
+// the world; the Q values cross through LDS and the agent lanes pick their own epsilon-greedy action.  The act launch this
+// replaces cost 7.7 us + a launch boundary at 65 536 agents.
+template <typename MaskT, bool APF, int OBS, bool POLH>
+__device__ __forceinline__ void k_step_body(const StepArgs &a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevState &S = a.st;
     const int N = a.N;
     const int n_round = (N + 63) & ~63;
+    if (POLH && (int)threadIdx.x >= 64) {                  // ---- a policy wavefront (a.block == 64)
+        // (the team's tiles share the bytes of the agent wavefront's work queue / tile slot, first touched after the barriers)
+        uavq::polh_wave(((int)threadIdx.x >> 6) - 1, a.pol_local, a.n_actions, a.pol_dueling, a.pol_obs, (int)blockIdx.x * 64, N,
+                        smem + a.obsq_off,
+                        a.dbg ? a.dbg + (((size_t)gridDim.x + blockIdx.x) * 2 + ((threadIdx.x >> 6) - 1)) * 8 : nullptr);
+        return;
+    }
     const int i = blockIdx.x * a.block + threadIdx.x;
     UAV_STAMP(0);
 
@@ -933,9 +945,19 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
     if (i < n_round) {
         const int ii = i < N ? i : N - 1;
         load_agent(S, ii, g);
-        ra = load_action_raw(a.actions, a.action_kind, ii);
+        if (!POLH) ra = load_action_raw(a.actions, a.action_kind, ii);
     }
+    uint4 pol_rn = make_uint4(0u, 0u, 0u, 0u);
+    if (POLH) pol_rn = uavq::policy_philox(i, a.pol_seed, a.pol_counter);       // under the state loads
     const WorldLds<MaskT> w = stage_world<MaskT>(smem, a);
+    if (POLH) {
+        __syncthreads();                                                       // the policy wavefronts' second barrier
+        const uavq::floatx4 q = reinterpret_cast<const uavq::floatx4 *>(smem + a.obsq_off + uavq::kPolWBytes + uavq::kPolXBytes)[threadIdx.x];
+        const int act = uavq::policy_select(q, pol_rn, a.pol_eps, a.n_actions);
+        if (i < N) a.pol_act[i] = act;
+        ra.lo = (uint32_t)act;
+        wave_lds_sync();                                                       // (the slot is the work queue from here on)
+    }
     UAV_STAMP(1);
 
     // Every launch covers N with exactly one agent per thread: a straight-line body.  (A grid-stride loop made the
@@ -945,7 +967,7 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
         const bool active = i < N;
         const int ii = active ? i : N - 1;
         unpack_flags(g);
-        const double a0 = decode_action(ra, a.action_kind, a.n_actions);
+        const double a0 = decode_action(ra, POLH ? UAVENV_ACT_INDEX_I32 : a.action_kind, a.n_actions);
         UAV_DRAIN();
         UAV_STAMP(2);
         double r = 0.0;
@@ -1027,6 +1049,19 @@ __global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
             store_obs_ctile<OBS>(a.obs, first, N - first, tile, sc, bits);
         }
     }
+}
+
+template <typename MaskT, bool APF, int OBS>
+__global__ void __launch_bounds__(256, UAVENV_KSTEP_WAVES) k_step(StepArgs a)
+{
+    k_step_body<MaskT, APF, OBS, false>(a);
+}
+
+// 64 agents per workgroup: the agent wavefront + two policy wavefronts; three wavefronts per SIMD at 65 536 agents
+template <typename MaskT>
+__global__ void __launch_bounds__(192, 3) k_step_polh(StepArgs a)
+{
+    k_step_body<MaskT, false, OBS_KIND_F16, true>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1608,6 +1643,12 @@ static void launch_step(const UavEnv *e, const StepArgs &a_in, hipStream_t s)
         UAV_LAUNCH(k_step_coop, cgrid, 256, clds);
         return;
     }
+    if (a.pol_local) {                   // uavenv_step_policy on an f16 ring (validated there: APF off, f16 MFMA net, block 64)
+        if (slot < uavq::kPolBytes) slot = uavq::kPolBytes;               // the policy team's tiles, then the agent wavefront's slot
+        a.wave_slot = slot;
+        launch_lds(k_step_polh<MaskT>, grid, 192, (size_t)a.obsq_off + (size_t)slot, s, a);
+        return;
+    }
     if (apf_split_ok) {                                                   // the lists first, in their own kernel (16-bit offsets)
         a.apf_split = 1;
         const int agents_per_block = kApfAgentsPerBlock;
@@ -2047,10 +2088,20 @@ int uavenv_step_policy(UavEnv *e, const UavDqnNet *net, const void *obs_cur, flo
         return fail(UAVENV_EINVAL, "AUTO_RESET needs a scenario bank (uavenv_load_scenarios)");
     static const int coop_env = env_int("UAVENV_COOP", -1);
     const int n2 = net->n_actions + (net->dueling ? 1 : 0);
-    if (e->cfg.obs_dtype != UAVENV_OBS_PACKED || e->cfg.apf_enabled == 1 || e->N > 49152 || coop_env == 0 ||
-        (flags & UAVENV_STEP_ONE_WAVE) || net->w != uavq::kW || net->hid != uavq::kHid || n2 > 4 || net->n_actions < 2 ||
-        net->n_actions != e->cfg.n_actions || net->mfma_dtype != UAVENV_MFMA_F32 ||
-        ((((uintptr_t)net->local) | ((uintptr_t)obs_cur)) & 15u) != 0)
+    const bool one_wave = (flags & UAVENV_STEP_ONE_WAVE) || (coop_env >= 0 ? coop_env == 0 : e->N > 49152);   // launch_step's choice
+    const bool shape_ok = e->cfg.apf_enabled != 1 && net->w == uavq::kW && net->hid == uavq::kHid && n2 <= 4 && net->n_actions >= 2 &&
+                          net->n_actions == e->cfg.n_actions && (((uintptr_t)net->local) & 15u) == 0;
+    // packed rows + f32 MFMA in k_step_coop's prologue; f16 rows + f16 MFMA in the one-wave k_step's
+    const bool coop_packed = !one_wave && e->cfg.obs_dtype == UAVENV_OBS_PACKED && net->mfma_dtype == UAVENV_MFMA_F32 &&
+                             (((uintptr_t)obs_cur) & 15u) == 0;
+    int blk = 0, grd = 0;
+    launch_geometry(e->N, blk, grd);
+    // (its workgroup -- world + the policy team's 27 KB -- must leave room for four per CU, and three wavefronts per 64 agents
+    // at 152 registers fit the chip up to 65 536 agents: beyond, the separate act launch is the faster form)
+    const bool wave_f16 = one_wave && blk == 64 && e->N <= 65536 && e->cfg.obs_dtype == UAVENV_OBS_F16 && net->mfma_dtype == UAVENV_MFMA_F16 &&
+                          (((uintptr_t)obs_cur) & 15u) == 0 && env_int("UAVENV_POLH", 1) != 0 &&
+                          (size_t)e->world_bytes + 16 + uavq::kPolBytes <= 40960;
+    if (!shape_ok || !(coop_packed || wave_f16))
         return fail(UAVENV_EINVAL, "uavenv_step_policy: this env / net takes uavenv_dqn_act + uavenv_step");
     StepArgs a = base_args(e);
     a.actions = action_out;

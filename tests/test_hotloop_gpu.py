@@ -50,6 +50,50 @@ def test_c_loop_equals_python_loop(kind, net, dtype):
     env_b.close()
 
 
+@pytest.mark.parametrize("n,kind,net,force", [(1000, "dueling", "VAnet2", True), (960, "dqn", "Qnet2", True),
+                                               (65536, "dueling", "VAnet2", False)])
+def test_f16_policy_in_the_one_wave_step_kernel(n, kind, net, force):
+    """uavenv_step_policy on an f16 ring with the f16-MFMA net (BASELINE configs[2]'s shape): the one-wave k_step computes the
+    actions in its prologue (qnet_device.hpp: PolicyH).  Same actions, transitions and updates as uavenv_dqn_act
+    (k_dqn_act_h) + uavenv_step issued separately -- bit for bit, ragged agent counts included."""
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    steps = 12
+    batch = 512 if n < 4096 else 16384
+
+    def build():
+        env = make_city26_env(n, obs_dtype=torch.float16)
+        ring = DeviceReplayRing(env, 5 * n, discrete=True)
+        if force:
+            ring.extra_flags = _lib.STEP_ONE_WAVE         # small launches normally take k_step_coop
+        ring.reset(seed=12)
+        torch.manual_seed(1)
+        return env, ring, FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0", mfma="f16")
+
+    env_a, ring_a, La = build()
+    for c in range(steps):
+        La.act(ring_a.current_obs(), 0.2, 9, c, index_out=ring_a.current_action())
+        ring_a.step_env(auto_reset=True)
+        La.learn_from_ring(ring_a, batch, 9, c)
+    env_b, ring_b, Lb = build()
+    assert ring_b.step_policy(Lb, 0.2, 9, 0)              # the fused launch is taken (not the EINVAL fallback) ...
+    env_b.close()
+    env_b, ring_b, Lb = build()                           # ... and a fresh copy runs the whole loop from C
+    loop = HotLoop(ring_b, Lb, batch, seed=9, eps=0.2)
+    loop.run(steps)
+    torch.cuda.synchronize()
+    for name in ("obs", "action", "reward", "done", "valid"):
+        assert torch.equal(getattr(ring_a, name), getattr(ring_b, name)), name
+    assert torch.equal(La.flat, Lb.flat) and float(La.loss) == float(Lb.loss)
+    assert len(torch.unique(ring_b.action)) == 3
+    loop.close()
+    env_a.close()
+    env_b.close()
+
+
 def test_rollout_only_and_learn_start():
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
     from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
