@@ -237,8 +237,10 @@ def committed_profile(args) -> dict:
         return {}
 
 
-def run_config4(args, dev):
-    """BASELINE configs[3]: 4 UAVs per env x 32 768 envs, APF avoidance on (every building moving), SAC_Trainer with
+def run_config4(args, dev, world_size=1, rank=0):
+    """(N > 1: every rank steps its own env shard -- scenario bank and ring seeded by rank -- and the SAC loop sums each
+    phase's column sums over the ranks on the stream, SACHotLoop(exchange="auto"); the ranks' weights are compared after the run.)
+    BASELINE configs[3]: 4 UAVs per env x 32 768 envs, APF avoidance on (every building moving), SAC_Trainer with
     continuous actions, one trainer per UAV slot (Envs/PathPlan_City.py:63-68).  One pass = SAC act for the four slots
     (PyTorch-ROCm) -> fused env step with APF into the packed replay ring -> for every slot: sample, one SAC update
     (Trainer/SAC_Trainer.py:325-379, PyTorch-ROCm ops; rows of agents that were waiting for their team-mates carry
@@ -249,13 +251,14 @@ def run_config4(args, dev):
     from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
     from dqn_based_uav_3d_path_planer_amd.sac import SACLearner
     U, envs = 4, args.envs
-    env = make_city26_env(envs, bank="gpu", bank_size=max(envs, 4096), bank_seed=42, device=dev, obs_dtype="packed",
+    multi = world_size > 1
+    env = make_city26_env(envs, bank="gpu", bank_size=max(envs, 4096), bank_seed=42 + rank, device=dev, obs_dtype="packed",
                           uav_per_env=U, apf_enabled=1)
     v = np.random.default_rng(42).uniform(-1.0, 1.0, (len(env.buildings), 3))
     v[:, 2] = 0.0
     env.set_buildings(env.buildings, velocities=v)
     ring = DeviceReplayRing(env, args.replay, discrete=False)
-    ring.reset(seed=1000)
+    ring.reset(seed=1000 + rank)
     a1_plane = torch.zeros((ring.frames, env.N), dtype=torch.float32, device=dev)      # second action component (:444-448)
     sac_param = {"actor": {"NetWork": "PolicyNetContinuous_SAC", "w": "100", "action_bound": "1", "hiden_dim": "64",
                            "output": "2", "lr": "0.0001"},
@@ -371,7 +374,20 @@ def run_config4(args, dev):
         # slots in one launch, the env step, one replay draw, and each phase of the fused update for the four slots in one
         # launch (8 launches per pass; --host-loop python issues the same work slot by slot from here, ~25 launches)
         from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
-        hot = SACHotLoop(ring, learners, B, seed=7, act1_plane=a1_plane, auto_reset=True, skip_done=True)
+        hot = SACHotLoop(ring, learners, B, seed=7 + rank, act1_plane=a1_plane, auto_reset=True, skip_done=True,
+                         exchange=("auto" if args.exchange in ("p2p", "coll") else None) if multi else None)
+        if multi and hot.exchange is None and args.exchange != "none":
+            hot.close()               # neither on-stream exchange came up: the Python loop, whose learners use torch.distributed
+            hot = None
+    exchange_used = None
+    if multi:
+        exchange_used = hot.exchange if hot is not None else ("none" if args.exchange == "none" else "torch.distributed per phase")
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
     def run_passes(n_passes):
         if hot is not None:
@@ -381,12 +397,19 @@ def run_config4(args, dev):
                 one_pass()
 
     run_passes(max(args.warmup, 1) * pps)
-    torch.cuda.synchronize(dev)
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_passes(pps)
-    torch.cuda.synchronize(dev)
+    fence()
     dt = time.perf_counter() - t0
+    ident = None
+    if multi:
+        got = [None] * world_size
+        sums = [float(torch.cat([L._blocks.reshape(-1), L._cblocks.reshape(-1)]).double().sum()) for L in learners] if fused else []
+        dist.all_gather_object(got, (dt, sums))
+        dt = max(g[0] for g in got)
+        ident = all(g[1] == got[0][1] for g in got)
     n_pass = args.steps * pps
     it = args.env_only_iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -400,8 +423,8 @@ def run_config4(args, dev):
     k_prof = prof.get("k_step_ms")
     k_use = max(k_ms, k_prof or 0.0)
     algo = ALGO_BYTES_PER_AGENT_STEP + 2 * 20 * 24      # APF on adds 2 * n_sub * 24 B (~20 sub-goals)
-    out = {"metric": "env-steps/sec + learner updates/sec, PathPlan_City SAC", "value": n_pass * env.N / dt,
-           "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+    out = {"metric": "env-steps/sec + learner updates/sec, PathPlan_City SAC", "value": n_pass * env.N * world_size / dt,
+           "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "passes_per_step": pps, "ms_per_pass": dt / n_pass * 1e3, "timed_region_ms": dt * 1e3,
            "learner_updates_per_s": n_pass * U / dt, "learner_samples_per_s": n_pass * U * B / dt,
@@ -424,6 +447,10 @@ def run_config4(args, dev):
                         "traffic_stale": prof.get("stale"),
                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": env.N, "kernel_ms": k_use,
                         "kernel_ms_back_to_back": k_ms, "kernel_ms_rocprofv3_committed": k_prof}}
+    if multi:
+        out["exchange"] = exchange_used
+        out["ranks_bit_identical"] = ident
+        out["config"]["parallelism"] = "env-shard x%d + per-phase gradient sum of all slots: %s" % (world_size, exchange_used)
     if fused:
         L0 = learners[0]
         out["config"]["slot0_after_run"] = {"updates": L0.epoch, "actor_loss": float(L0.loss), "critic_losses": [float(x) for x in L0.critic_losses],
@@ -967,12 +994,6 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.config == 4:
-        if world_size != 1:
-            raise SystemExit("--config 4 is a single-GPU workload")
-        torch.cuda.set_device(0)
-        print(json.dumps(run_config4(args, torch.device("cuda", 0))))
-        return
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -983,6 +1004,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
+    if args.config == 4:
+        out4 = run_config4(args, dev, world_size, rank)
+        if rank == 0:
+            print(json.dumps(out4))
+        if world_size > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     out = run_dqn(args, world_size, rank, dev)
     if rank == 0 and out is not None:
         headline = (args.config == 2 and world_size == 1 and not args.env_only and not args.explicit and args.sample_lag == 0

@@ -37,7 +37,7 @@ SYMBOLS = (
     "uavenv_randn", "uavenv_sac_loop_noise_floats", "uavenv_sac_loop_create", "uavenv_sac_loop_destroy", "uavenv_sac_loop_run",
     "uavenv_sac_loop_get", "uavenv_sac_act_multi", "uavenv_sac_critic_grad_multi", "uavenv_sac_actor_grad_multi",
     "uavenv_sac_critic_adam_multi", "uavenv_sac_actor_adam_multi",
-    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame",
+    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame", "uavenv_p2p_allreduce",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
     "uavenv_sac_actor_adam",
 )
@@ -129,7 +129,8 @@ class UavSacLoopConfig(C.Structure):
                 ("gamma", C.c_float), ("tau", C.c_float), ("action_bound", C.c_float), ("actor_lr", C.c_float),
                 ("critic_lr", C.c_float), ("alpha_lr", C.c_float), ("target_entropy", C.c_float), ("reserved1", C.c_float),
                 ("step_flags", C.c_uint32), ("reserved2", C.c_uint32),
-                ("draws_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("slot", UavSacLoopSlot * SAC_LOOP_MAX_SLOTS)]
+                ("draws_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("slot", UavSacLoopSlot * SAC_LOOP_MAX_SLOTS),
+                ("p2p", C.c_void_p), ("coll", C.c_void_p), ("xbuf_dev", C.c_void_p)]
 
 
 class UavSacLoopCursor(C.Structure):
@@ -314,6 +315,8 @@ def load() -> C.CDLL:
     lib.uavenv_per_set.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
     lib.uavenv_per_set_f32.restype = C.c_int
     lib.uavenv_per_set_f32.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
+    lib.uavenv_p2p_allreduce.restype = C.c_int
+    lib.uavenv_p2p_allreduce.argtypes = [vp, vp, i64, vp]
     lib.uavenv_per_fill_frame.restype = C.c_int
     lib.uavenv_per_fill_frame.argtypes = [per, i64, i64, f64, vp, i64, vp]
     lib.uavenv_per_weights.restype = C.c_int

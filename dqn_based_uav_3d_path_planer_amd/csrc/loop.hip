@@ -369,6 +369,7 @@ int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out)
             sl.adam_steps < 0)
             return UAVENV_EINVAL;
     }
+    if ((cfg->p2p || cfg->coll) && (!cfg->xbuf_dev || (((uintptr_t)cfg->xbuf_dev) & 15u) != 0)) return UAVENV_EINVAL;
     UavSacLoop *l = new (std::nothrow) UavSacLoop();
     if (!l) return UAVENV_ENOMEM;
     l->c = *cfg;
@@ -484,15 +485,34 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         }
         // critics (:340-357), then the actor and log_alpha on the updated critics (:359-377); the soft update (:378-379) rides
         // in critic_adam -- every phase for all U slots in one launch
-        const int rows = uavenv_sac_partial_rows(B);
+        int rows = uavenv_sac_partial_rows(B);
+        const bool multi = c.p2p || c.coll;
+        // N > 1: the U slots' column sums side by side in xbuf, summed over the ranks on the stream, one row per slot from there
+        auto exchange = [&](float **part, int stride) -> int {
+            for (int j = 0; j < U; ++j) {
+                const int r2 = uavenv_sac_reduce(part[j], rows, stride, c.xbuf_dev + (size_t)j * stride, s);
+                if (r2 != UAVENV_OK) return r2;
+                part[j] = c.xbuf_dev + (size_t)j * stride;
+            }
+            return c.p2p ? uavenv_p2p_allreduce(c.p2p, c.xbuf_dev, (int64_t)U * stride, s)
+                         : uavenv_coll_allreduce_sum(c.coll, c.xbuf_dev, (int64_t)U * stride, s);
+        };
         rc = uavenv_sac_critic_grad_multi(nets, bt, U, c.gamma, c.action_bound, pc, s);
         if (rc != UAVENV_OK) return rc;
-        rc = uavenv_sac_critic_adam_multi(nets, pc, rows, m1, v1, m2, v2, hc, sc_c, U, s);
+        if (multi) {
+            rc = exchange(pc, UAVENV_SAC_CRITIC_STRIDE);
+            if (rc != UAVENV_OK) return rc;
+        }
+        rc = uavenv_sac_critic_adam_multi(nets, pc, multi ? 1 : rows, m1, v1, m2, v2, hc, sc_c, U, s);
         if (rc != UAVENV_OK) return rc;
         for (int j = 0; j < U; ++j) bt[j].eps = zl + ((size_t)nb + (size_t)j * B) * 2;
         rc = uavenv_sac_actor_grad_multi(nets, bt, U, c.action_bound, pa, s);
         if (rc != UAVENV_OK) return rc;
-        rc = uavenv_sac_actor_adam_multi(nets, pa, rows, B, ma, va, amv, ha, c.alpha_lr, c.target_entropy, sc_a, U, s);
+        if (multi) {
+            rc = exchange(pa, UAVENV_SAC_ACTOR_STRIDE);
+            if (rc != UAVENV_OK) return rc;
+        }
+        rc = uavenv_sac_actor_adam_multi(nets, pa, multi ? 1 : rows, B, ma, va, amv, ha, c.alpha_lr, c.target_entropy, sc_a, U, s);
         if (rc != UAVENV_OK) return rc;
     }
     return UAVENV_OK;

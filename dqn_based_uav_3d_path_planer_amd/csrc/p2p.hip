@@ -244,6 +244,58 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
     }
 }
 
+// ---- the same exchange for ANY float buffer (the SAC learners' per-phase gradient rows, csrc/sac.hip): push = copy this
+// rank's buffer into slot [rank] of every rank's receive area (16-byte stores), pull = raise the flags, wait, add the slots IN
+// RANK ORDER back into the buffer.  On a sticky error the buffer is left as it was (this rank's own sums) and the host call
+// returns UAVENV_EP2P: the caller must stop stepping and re-synchronise parameters and moments from one rank.
+__global__ void __launch_bounds__(256) k_p2p_push(const float *__restrict__ buf, int count4, P2PDev d)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < count4) {
+        const float4 v = reinterpret_cast<const float4 *>(buf)[i];
+        for (int r = 0; r < d.world; ++r)
+            reinterpret_cast<float4 *>(recv_slot(d.peer[r], d.rank, d.seq, d.bucket_pad))[i] = v;
+    }
+    __threadfence_system();
+}
+
+__global__ void __launch_bounds__(256) k_p2p_pull_sum(P2PDev d, float *__restrict__ buf, int count)
+{
+    unsigned char *mine = d.peer[d.rank];
+    if (blockIdx.x == 0 && (int)threadIdx.x < d.world) {     // behind k_p2p_push on the stream: the boundary orders the flags after its stores
+        __threadfence_system();
+        __hip_atomic_store(flag_of(d.peer[threadIdx.x], d.rank), d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __shared__ uint32_t s_bad;
+    if (threadIdx.x == 0) {
+        uint32_t bad = __hip_atomic_load(d.errors + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky
+        for (int r = 0; r < d.world && !bad; ++r) {
+            uint32_t spins = 0;
+            while ((int32_t)(__hip_atomic_load(flag_of(mine, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.seq) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > d.spin_limit) {
+                    __hip_atomic_fetch_add(d.errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    bad = UAVENV_P2P_ERR_TIMEOUT;
+                    break;
+                }
+            }
+        }
+        __threadfence_system();
+        s_bad = bad;
+    }
+    __syncthreads();
+    if (s_bad) return;
+    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p < count) {
+        float sum = 0.0f;
+        for (int r = 0; r < d.world; ++r)
+            sum += __hip_atomic_load(recv_slot(mine, r, d.seq, d.bucket_pad) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[p] = sum;
+    }
+}
+
 P2PDev dev_view(const UavP2P *c, int carry, int fold)
 {
     P2PDev d;
@@ -416,6 +468,25 @@ int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *c, float lr, float beta1, 
         c->pending_idx = fold_idx;
         c->n_checks += 1;
     }
+    return *c->host_code ? UAVENV_EP2P : UAVENV_OK;
+}
+
+int uavenv_p2p_allreduce(UavP2P *c, float *buf_dev, int64_t count, void *stream)
+{
+    if (!c || !c->connected || !buf_dev || count <= 0 || (count & 3) || count > (int64_t)c->bucket_pad ||
+        (((uintptr_t)buf_dev) & 15u) != 0)
+        return UAVENV_EINVAL;
+    if (*c->host_code) return UAVENV_EP2P;                     // sticky (see the header comment)
+    c->seq += 1;
+    const int count4 = (int)(count / 4);
+    hipLaunchKernelGGL(k_p2p_push, dim3((count4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, buf_dev, count4, dev_view(c, -1, -1));
+    if (hipGetLastError() != hipSuccess) {
+        c->seq -= 1;
+        return UAVENV_EHIP;
+    }
+    hipLaunchKernelGGL(k_p2p_pull_sum, dim3(((int)count + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_view(c, -1, -1), buf_dev,
+                       (int)count);
+    if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
     return *c->host_code ? UAVENV_EP2P : UAVENV_OK;
 }
 

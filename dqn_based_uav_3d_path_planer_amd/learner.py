@@ -377,33 +377,13 @@ class FusedDQNLearner:
         check_every: the ranks compare a checksum of their weights on the device every that many updates (0 = never);
         spin_limit: polls before a flag wait gives up (0 = the library's default, about a second)."""
         C, _lib = self._C, self._lib_mod
+        from . import exchange as ex
         self._p2p = None
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        h = ex.open_p2p(self.lib, self.device, self.P + 2, check_every=check_every, spin_limit=spin_limit)
+        if h is None:
             return False
         world, rank = dist.get_world_size(), dist.get_rank()
-        ok, h = True, C.c_void_p()
-        try:
-            _lib.check(self.lib.uavenv_p2p_create(world, rank, self.P + 2, C.byref(h)), "uavenv_p2p_create")
-            _lib.check(self.lib.uavenv_p2p_configure(h, int(check_every), int(spin_limit)), "uavenv_p2p_configure")
-            mine = (C.c_ubyte * _lib.P2P_HANDLE_BYTES)()
-            _lib.check(self.lib.uavenv_p2p_handle(h, mine), "uavenv_p2p_handle")
-        except Exception:
-            ok, mine = False, (C.c_ubyte * _lib.P2P_HANDLE_BYTES)()
-        allh = [None] * world
-        my_dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        dist.all_gather_object(allh, (ok, bytes(mine), my_dev))
-        ok = all(o for o, _, _ in allh)
-        if ok:      # nothing is mapped unless this device may address every peer's memory (xGMI / PCIe peer access)
-            ok = all(self.lib.uavenv_p2p_can_reach(my_dev, d) == 1 for _, _, d in allh)
-        flags = [None] * world
-        dist.all_gather_object(flags, ok)
-        ok = all(flags)
-        if ok:
-            blob = b"".join(b for _, b, _ in allh)
-            ok = self.lib.uavenv_p2p_connect(h, C.create_string_buffer(blob, len(blob))) == 0
-        flags = [None] * world
-        dist.all_gather_object(flags, ok)
-        ok = all(flags)
+        ok, flags = True, [None] * world
         if ok and verify:
             n = self.lib.uavenv_dqn_partial_rows(64)
             stride = self.lib.uavenv_dqn_partial_stride(C.byref(self.net))
@@ -453,39 +433,10 @@ class FusedDQNLearner:
         """The RCCL fallback of the peer exchange, enqueued from C (csrc/coll.hip): rank 0 draws the communicator id,
         it travels over the process group, every rank joins.  With it the C loop (csrc/loop.hip) keeps driving the
         pass at N > 1 when csrc/p2p.hip is unavailable.  Returns whether the communicator is up on ALL ranks."""
-        C, _lib = self._C, self._lib_mod
+        from . import exchange as ex
         self._coll = None
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return False
-        world, rank = dist.get_world_size(), dist.get_rank()
-        path = _lib.rccl_path()
-        buf = (C.c_ubyte * _lib.COLL_ID_BYTES)()
-        ok = True
-        if rank == 0:
-            ok = self.lib.uavenv_coll_unique_id(path, buf) == 0
-        box = [(ok, bytes(buf))]
-        dist.broadcast_object_list(box, src=0)
-        ok, idb = box[0]
-        h = C.c_void_p()
-        if ok:
-            torch.cuda.set_device(self.device)
-            ok = self.lib.uavenv_coll_create(path, world, rank, C.create_string_buffer(idb, len(idb)), C.byref(h)) == 0
-        flags = [None] * world
-        dist.all_gather_object(flags, ok)
-        if not all(flags):
-            if h.value:
-                self.lib.uavenv_coll_destroy(h)
-            return False
-        # one exchange of a known vector against torch.distributed's result
-        t = torch.arange(self.P + 2, device=self.device, dtype=torch.float32) * 1e-3 + (rank + 1)
-        want = t.clone()
-        dist.all_reduce(want, op=dist.ReduceOp.SUM)
-        rc = self.lib.uavenv_coll_allreduce_sum(h, t.data_ptr(), self.P + 2, self._stream())
-        torch.cuda.synchronize(self.device)
-        ok = rc == 0 and bool(torch.allclose(t, want, rtol=1e-6, atol=1e-6))
-        dist.all_gather_object(flags, ok)
-        if not all(flags):
-            self.lib.uavenv_coll_destroy(h)
+        h = ex.open_coll(self.lib, self.device, self.P + 2, self._stream())
+        if h is None:
             return False
         self._coll = h
         return True

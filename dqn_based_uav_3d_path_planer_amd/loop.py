@@ -135,10 +135,15 @@ class SACHotLoop:
     per step one launch of N(0,1) draws, U x get_action, the env step (replay write included), one draw of (frame, env) pairs
     and U x the four launches of SAC_Trainer.update -- what PathPlan_City._run_eposide_fused_sac issues from Python, bit for
     bit, without the interpreter between the launches.  The ring cursor and the learners' update counts live in the C object
-    while the loop exists; `run` writes them back."""
+    while the loop exists; `run` writes them back.
+    exchange (one process per GPU, torch.distributed initialised): "p2p" (csrc/p2p.hip: every phase's column sums of all
+    slots summed over peer-mapped HBM on the stream), "coll" (RCCL from C, csrc/coll.hip), "auto" (p2p, else coll) or None;
+    `self.exchange` says what is in use (None: one GPU, or neither could be set up -- the caller keeps the Python loop, whose
+    learners exchange through torch.distributed).  Every rank must start from the same weights."""
 
     def __init__(self, ring: DeviceReplayRing, learners, batch: int, seed: int, act1_plane: torch.Tensor, counter: int = 0,
-                 info: torch.Tensor = None, is_train: bool = True, auto_reset: bool = True, skip_done: bool = True):
+                 info: torch.Tensor = None, is_train: bool = True, auto_reset: bool = True, skip_done: bool = True,
+                 exchange: str = None, spin_limit: int = 0):
         if ring.discrete or not ring.env.packed:
             raise ValueError("SACHotLoop drives the continuous-action path on a packed ring")
         env = ring.env
@@ -185,6 +190,27 @@ class SACHotLoop:
             sl.scalars = L._scalars.data_ptr()
             sl.epoch, sl.adam_steps = L.epoch, L.adam_steps
         self._keep = (act1_plane, info)
+        self.exchange, self._p2p, self._coll = None, None, None
+        if exchange is not None:
+            from . import exchange as ex
+            n = U * _lib.SAC_CRITIC_STRIDE
+            stream = torch.cuda.current_stream(d).cuda_stream
+            if exchange in ("p2p", "auto"):
+                h = ex.open_p2p(self.lib, d, n, check_every=0, spin_limit=spin_limit)
+                if h is not None and not ex.verify_p2p_allreduce(self.lib, h, d, n, stream):
+                    self.lib.uavenv_p2p_destroy(h)
+                    h = None
+                if h is not None:
+                    self._p2p, self.exchange = h, "p2p"
+            if self.exchange is None and exchange in ("coll", "auto"):
+                h = ex.open_coll(self.lib, d, n, stream)
+                if h is not None:
+                    self._coll, self.exchange = h, "coll"
+            if self.exchange is not None:
+                self._xbuf = torch.zeros(n, dtype=torch.float32, device=d)
+                cfg.p2p = self._p2p
+                cfg.coll = self._coll
+                cfg.xbuf_dev = self._xbuf.data_ptr()
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_sac_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_sac_loop_create")
         self.counter = int(counter)
@@ -193,6 +219,12 @@ class SACHotLoop:
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.uavenv_sac_loop_destroy(self._h)
             self._h = C.c_void_p()
+        if getattr(self, "_p2p", None) is not None:
+            self.lib.uavenv_p2p_destroy(self._p2p)
+            self._p2p = None
+        if getattr(self, "_coll", None) is not None:
+            self.lib.uavenv_coll_destroy(self._coll)
+            self._coll = None
 
     def __del__(self):
         try:
@@ -203,6 +235,9 @@ class SACHotLoop:
     def run(self, n_steps: int):
         s = torch.cuda.current_stream(self.ring.env.device).cuda_stream
         rc = self.lib.uavenv_sac_loop_run(self._h, int(n_steps), s)
+        if rc == _lib.EP2P:
+            raise P2PExchangeError("the peer exchange of the SAC loop raised its sticky error: stop stepping and re-synchronise "
+                                   "parameters and moments from one rank")
         if rc != 0:
             raise _lib.UavEnvError(f"uavenv_sac_loop_run failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()} / "
                                    f"{self.lib.uavenv_last_error().decode()}")

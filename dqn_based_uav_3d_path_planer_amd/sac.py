@@ -226,6 +226,36 @@ class FusedSACLearner:
         return self._lib.UavSacAdam(lr, self.beta1, self.beta2, self.adam_eps, 1.0 - self.beta1 ** t,
                                     float(np.sqrt(1.0 - self.beta2 ** t)), tau, scale)
 
+    def enable_exchange(self, kind: str = "auto", spin_limit: int = 0):
+        """The on-stream form of the N > 1 exchange (no host round trip, no torch.distributed call per phase): "p2p" =
+        uavenv_p2p_allreduce over peer-mapped HBM (csrc/p2p.hip), "coll" = the RCCL communicator driven from C
+        (csrc/coll.hip), "auto" = p2p, else coll.  Verified against torch.distributed on set-up; returns what is in use on
+        ALL ranks ("p2p" / "coll") or None (the torch.distributed path stays)."""
+        from . import exchange as ex
+        self.disable_exchange()
+        n = self._lib.SAC_CRITIC_STRIDE
+        if kind in ("p2p", "auto"):
+            h = ex.open_p2p(self.lib, self.device, n, check_every=0, spin_limit=spin_limit)
+            if h is not None and not ex.verify_p2p_allreduce(self.lib, h, self.device, n, self._stream()):
+                self.lib.uavenv_p2p_destroy(h)
+                h = None
+            if h is not None:
+                self._p2p = h
+                return "p2p"
+        if kind in ("coll", "auto"):
+            h = ex.open_coll(self.lib, self.device, n, self._stream())
+            if h is not None:
+                self._coll = h
+                return "coll"
+        return None
+
+    def disable_exchange(self):
+        if getattr(self, "_p2p", None) is not None:
+            self.lib.uavenv_p2p_destroy(self._p2p)
+        if getattr(self, "_coll", None) is not None:
+            self.lib.uavenv_coll_destroy(self._coll)
+        self._p2p, self._coll = None, None
+
     def _exchange(self, partials: torch.Tensor, rows: int):
         """Multi-GPU (one process per GPU, torch.distributed initialised): this rank's column sums, summed over the ranks
         -- the means of SACLearner._sync_grads once the Adam kernel scales by 1 / world.  -> (row tensor, 1, scale)"""
@@ -235,7 +265,15 @@ class FusedSACLearner:
         stride = partials.shape[1]
         raw = self._raw.setdefault(stride, torch.empty(stride, dtype=torch.float32, device=self.device))
         self._check(self.lib.uavenv_sac_reduce(partials.data_ptr(), rows, stride, raw.data_ptr(), self._stream()), "uavenv_sac_reduce")
-        dist.all_reduce(raw, op=dist.ReduceOp.SUM)
+        if getattr(self, "_p2p", None) is not None:
+            rc = self.lib.uavenv_p2p_allreduce(self._p2p, raw.data_ptr(), stride, self._stream())
+            if rc == self._lib.EP2P:
+                raise RuntimeError("the peer exchange raised its sticky error (timeout): stop stepping, re-synchronise from one rank")
+            self._check(rc, "uavenv_p2p_allreduce")
+        elif getattr(self, "_coll", None) is not None:
+            self._check(self.lib.uavenv_coll_allreduce_sum(self._coll, raw.data_ptr(), stride, self._stream()), "uavenv_coll_allreduce_sum")
+        else:
+            dist.all_reduce(raw, op=dist.ReduceOp.SUM)
         return raw, 1, 0.0        # (the valid-fraction column, summed over the ranks, normalises: 1 / world when all valid)
 
     # the four launches, separately (tests drive them one by one)

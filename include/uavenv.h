@@ -353,6 +353,11 @@ int uavenv_p2p_errors(UavP2P *p2p, int32_t *timeouts_out);        /* synchronise
 int uavenv_p2p_status(UavP2P *p2p, int32_t synchronise, int32_t *out4);
 /* Tests: raise the sticky error as a timeout / a mismatch would (code 0 clears it). */
 int uavenv_p2p_inject_fault(UavP2P *p2p, int32_t code);
+/* The same exchange for any float buffer (the SAC learners' per-phase gradient rows): buf_dev[i] <- sum over the ranks, in rank
+ * order, of their buf_dev[i], i < count -- two launches on the stream.  count: a multiple of 4, <= bucket_floats; buf_dev 16-byte
+ * aligned.  After a sticky error the buffer keeps this rank's own values and the call returns UAVENV_EP2P: stop stepping and
+ * re-synchronise parameters and optimiser moments from one rank.  (Use a UavP2P of its own, not the one a DQN learner drives.) */
+int uavenv_p2p_allreduce(UavP2P *p2p, float *buf_dev, int64_t count, void *stream);
 int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, UavP2P *p2p, void *stream);
 /* step_t == 0: only the rank-ordered sum, into raw_out_dev[num_params + 2] (self-test); otherwise Adam as uavenv_dqn_adam
  * (raw_out_dev nullable). */
@@ -561,6 +566,13 @@ typedef struct UavSacLoopConfig {
     int32_t *draws_dev;                      /* n_slots x batch x 2 */
     float *noise_dev;                        /* uavenv_sac_loop_noise_floats(n_slots, n_envs, batch) floats */
     UavSacLoopSlot slot[UAVENV_SAC_LOOP_MAX_SLOTS];
+    /* multi-GPU (all NULL on one GPU): every phase's column sums of all slots (uavenv_sac_reduce) are summed over the ranks on
+     * the stream -- uavenv_p2p_allreduce on p2p (bucket >= n_slots x UAVENV_SAC_CRITIC_STRIDE) or, when p2p is NULL,
+     * uavenv_coll_allreduce_sum on coll -- and the Adam kernels take that one row (the valid-fraction column normalises).
+     * uavenv_sac_loop_run returns UAVENV_EP2P once the peer exchange has raised its sticky error. */
+    struct UavP2P *p2p;
+    struct UavColl *coll;
+    float *xbuf_dev;                         /* n_slots x UAVENV_SAC_CRITIC_STRIDE floats */
 } UavSacLoopConfig;
 typedef struct UavSacLoopCursor {
     int32_t head, filled;

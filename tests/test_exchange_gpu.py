@@ -198,6 +198,17 @@ def test_bench_recovers_when_the_peer_exchange_fails_mid_run():
     assert any("sticky" in f for f in d["exchange_fallbacks"]) and d["bad_after_recovery"] is False
 
 
+def test_bench_config4_sac_on_two_ranks():
+    """`python bench.py --config 4 --gpus 2`: the SAC loop of BASELINE configs[3] on two ranks (own env shards), every phase's
+    column sums of the four slots summed over peer-mapped HBM on the stream (UavSacLoopConfig.p2p): one line, n_gpus == 2,
+    the ranks' weights bit-identical after the run."""
+    d = _bench("--config", "4", "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--envs", "512", "--batch", "512",
+               "--replay", "16384")
+    assert d["n_gpus"] == 2 and d["exchange"] == "p2p" and d["ranks_bit_identical"] is True
+    assert d["config"]["slot0_after_run"]["finite"] and d["config"]["slot0_after_run"]["updates"] > 10
+    assert d["config"]["host_loop"].startswith("csrc/loop.hip")
+
+
 def test_bench_one_gpu_line_has_the_in_loop_roofline():
     d = _bench()
     assert d["n_gpus"] == 1 and "k_step_coop<policy>" in d["roofline"]["kernel"]

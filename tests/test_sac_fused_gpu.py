@@ -180,7 +180,7 @@ def test_rejects_what_it_cannot_do(world):
         fused.learn(b, noise=(torch.zeros((100, 2), device="cuda"), torch.zeros((100, 2), device="cuda")))
 
 
-def _sac_rank_worker(rank, world, port, out_dir):
+def _sac_rank_worker(rank, world, port, out_dir, mode="dist"):
     import os
     import torch.distributed as dist
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
@@ -202,6 +202,8 @@ def _sac_rank_worker(rank, world, port, out_dir):
         ring.step_env(auto_reset=True)
     torch.manual_seed(0)                                # same initial weights everywhere
     L = FusedSACLearner(PARAM)
+    if world > 1 and mode != "dist":                    # the on-stream exchange instead of torch.distributed per phase
+        assert L.enable_exchange(mode, spin_limit=1 << 18) == mode
     g = torch.Generator().manual_seed(7)
     B = 512
     draws = torch.stack([torch.randint(0, 7, (B,), generator=g), torch.randint(0, 256, (B,), generator=g)], 1).int()
@@ -217,9 +219,10 @@ def _sac_rank_worker(rank, world, port, out_dir):
         losses.append([float(L.loss), float(L.critic_losses[0]), float(L.critic_losses[1])])
     torch.cuda.synchronize()
     torch.save({"actor": L._blocks[0].cpu(), "critics": L._cblocks[:4].cpu(), "log_alpha": float(L.log_alpha), "losses": losses},
-               os.path.join(out_dir, f"sac_w{world}_r{rank}.pt"))
+               os.path.join(out_dir, f"sac_{mode}_w{world}_r{rank}.pt"))
     if world > 1:
         dist.barrier()
+        L.disable_exchange()
         dist.destroy_process_group()
     env.close()
 
@@ -237,8 +240,8 @@ def test_fused_sac_two_ranks_equal_one_process(tmp_path):
     s.close()
     mp.spawn(_sac_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     mp.spawn(_sac_rank_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
-    r0, r1 = torch.load(os.path.join(tmp_path, "sac_w2_r0.pt")), torch.load(os.path.join(tmp_path, "sac_w2_r1.pt"))
-    one = torch.load(os.path.join(tmp_path, "sac_w1_r0.pt"))
+    r0, r1 = torch.load(os.path.join(tmp_path, "sac_dist_w2_r0.pt")), torch.load(os.path.join(tmp_path, "sac_dist_w2_r1.pt"))
+    one = torch.load(os.path.join(tmp_path, "sac_dist_w1_r0.pt"))
     assert torch.equal(r0["actor"], r1["actor"]) and torch.equal(r0["critics"], r1["critics"])     # ranks in lock-step, bit for bit
     assert r0["log_alpha"] == r1["log_alpha"] and r0["losses"] == r1["losses"]
     # vs one process: the same gradient up to the order of the sums; Adam can move an element with a ~0 gradient by a step
@@ -248,6 +251,91 @@ def test_fused_sac_two_ranks_equal_one_process(tmp_path):
     assert float(torch.quantile(dc.reshape(-1), 0.99)) <= 1e-4 and float(dc.max()) <= 8e-3
     assert abs(r0["log_alpha"] - one["log_alpha"]) <= 1e-6
     assert np.allclose(np.array(r0["losses"]), np.array(one["losses"]), rtol=2e-4, atol=1e-5)
+
+
+def test_fused_sac_peer_exchange_equals_torch_distributed(tmp_path):
+    """FusedSACLearner.enable_exchange("p2p"): each phase's column sums summed over peer-mapped HBM on the stream
+    (uavenv_p2p_allreduce, csrc/p2p.hip) instead of a torch.distributed all-reduce per phase -- two ranks on this GPU, four
+    updates: weights, log_alpha and losses bit-identical to the torch.distributed form on both ranks."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for mode in ("p2p", "dist"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_sac_rank_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+        res[mode] = [torch.load(os.path.join(tmp_path, f"sac_{mode}_w2_r{r}.pt")) for r in (0, 1)]
+    for r in (0, 1):
+        a, b = res["p2p"][r], res["dist"][r]
+        assert torch.equal(a["actor"], b["actor"]) and torch.equal(a["critics"], b["critics"])
+        assert a["log_alpha"] == b["log_alpha"] and a["losses"] == b["losses"]
+    assert torch.equal(res["p2p"][0]["actor"], res["p2p"][1]["actor"]) and torch.equal(res["p2p"][0]["critics"], res["p2p"][1]["critics"])
+
+
+def _sac_loop_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    from dqn_based_uav_3d_path_planer_amd.sac import FusedSACLearner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    U, envs, B = 2, 256, 256
+    env = make_city26_env(envs, uav_per_env=U, obs_dtype="packed")
+    ring = DeviceReplayRing(env, 12 * env.N, discrete=False)
+    ring.reset(seed=5)                                  # every rank holds the SAME shard: the sum over the ranks is 2 x one rank's
+    a1 = torch.zeros((ring.frames, env.N), dtype=torch.float32, device="cuda")
+    torch.manual_seed(0)
+    Ls = [FusedSACLearner(PARAM) for _ in range(U)]
+    loop = SACHotLoop(ring, Ls, B, seed=11, act1_plane=a1, exchange="p2p" if world > 1 else None, spin_limit=1 << 18)
+    assert loop.exchange == ("p2p" if world > 1 else None)
+    loop.run(9)
+    loop.run(8)
+    torch.cuda.synchronize()
+    torch.save({"blocks": [torch.cat([x._blocks.reshape(-1), x._cblocks.reshape(-1), x._alpha_mv, x.log_alpha.reshape(1)]).cpu() for x in Ls],
+                "ring": {k: getattr(ring, k).cpu() for k in ("obs", "action", "reward", "done", "valid")}, "a1": a1.cpu(),
+                "counts": [(x.epoch, x.adam_steps) for x in Ls], "cursor": (ring.head, ring.filled, loop.counter)},
+               os.path.join(out_dir, f"sacloop_w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+    loop.close()
+    if world > 1:
+        dist.destroy_process_group()
+    env.close()
+
+
+def test_sac_c_loop_exchanges_on_the_stream(tmp_path):
+    """uavenv_sac_loop_run at N > 1 (UavSacLoopConfig.p2p): per phase the column sums of every slot (uavenv_sac_reduce) are
+    summed over the ranks by uavenv_p2p_allreduce on the stream and the Adam kernels take that one row.  Two ranks on this
+    GPU hold the SAME shard, so the sum is exactly twice one rank's and the valid-fraction column normalises it back:
+    ring, weights, targets, Adam moments and log_alpha of both slots must equal the ONE-process loop bit for bit, on both
+    ranks (any lost, stale or doubly-added slot would show)."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    for world in (2, 1):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_sac_loop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    one = torch.load(os.path.join(tmp_path, "sacloop_w1_r0.pt"))
+    assert one["counts"][0][1] > 5                       # updates did happen
+    for r in (0, 1):
+        two = torch.load(os.path.join(tmp_path, f"sacloop_w2_r{r}.pt"))
+        assert two["cursor"] == one["cursor"] and two["counts"] == one["counts"]
+        for k in one["ring"]:
+            assert torch.equal(two["ring"][k], one["ring"][k]), k
+        assert torch.equal(two["a1"], one["a1"])
+        for j in range(2):
+            assert torch.equal(two["blocks"][j], one["blocks"][j]), (r, j)
 
 
 def test_fused_sac_against_the_executed_reference():
