@@ -40,7 +40,7 @@ def open_p2p(lib, device: torch.device, bucket_floats: int, check_every: int = 2
     except Exception:
         ok, mine = False, (C.c_ubyte * _lib.P2P_HANDLE_BYTES)()
     allh = [None] * world
-    my_dev = device.index if device.index is not None else torch.cuda.current_device()
+    my_dev = device.index if device.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else -1)
     dist.all_gather_object(allh, (ok, bytes(mine), my_dev))
     ok = all(o for o, _, _ in allh)
     if ok:
@@ -86,6 +86,8 @@ def open_coll(lib, device: torch.device, verify_floats: int, stream):
     dist.broadcast_object_list(box, src=0)
     ok, idb = box[0]
     h = C.c_void_p()
+    if ok and not torch.cuda.is_available():
+        ok = False
     if ok:
         torch.cuda.set_device(device)
         ok = lib.uavenv_coll_create(path, world, rank, C.create_string_buffer(idb, len(idb)), C.byref(h)) == 0

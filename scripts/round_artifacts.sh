@@ -17,6 +17,7 @@ find /tmp/prof_e65 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${T
 # two ranks sharing this GPU (bench.py starts them itself): the peer exchange with its in-run no-exchange leg; the fault drill
 python bench.py --gpus 2 --same-device --dist-backend gloo --no-cpu-baseline > $O/${TAG}_2rank_samedev_p2p.json 2> $O/${TAG}_2rank.err
 python bench.py --gpus 2 --same-device --dist-backend gloo --no-cpu-baseline --inject-p2p-fault 1 --no-exchange-leg > $O/${TAG}_2rank_samedev_fault_drill.json 2>> $O/${TAG}_2rank.err
+python bench.py --config 4 --gpus 2 --same-device --dist-backend gloo --envs 8192 --batch 8192 --no-cpu-baseline --steps 4 --warmup 1 > $O/${TAG}_2rank_samedev_config4_sac.json 2>> $O/${TAG}_2rank.err
 python bench.py --no-cpu-baseline --no-other-configs --per 2>/dev/null > $O/${TAG}_per_bench.json
 python -c "
 import json

@@ -130,3 +130,26 @@ def test_federated_averaging_every_fl_loop_updates(tmp_path):
         outs.append(L.q_local.state_dict())
     for q in a[1]:
         assert torch.allclose(a[1][q], (outs[0][q] + outs[1][q]) / 2, rtol=0, atol=1e-7)
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    from dqn_based_uav_3d_path_planer_amd import _lib, exchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _lib.load()
+    h1 = exchange.open_p2p(lib, torch.device("cpu"), 1024)
+    h2 = exchange.open_coll(lib, torch.device("cpu"), 64, None)
+    with open(os.path.join(out_dir, f"ex{rank}.txt"), "w") as f:
+        f.write(f"{h1 is None} {h2 is None}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_setup_fails_closed_without_a_gpu(tmp_path):
+    """exchange.open_p2p / open_coll (the set-up of csrc/p2p.hip and csrc/coll.hip between torch.distributed ranks) on a
+    host without a HIP device: every rank gets None -- the callers then keep the torch.distributed path -- and nobody is left
+    waiting in a collective of the handshake."""
+    mp.spawn(_exchange_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        assert open(os.path.join(tmp_path, f"ex{r}.txt")).read() == "True True"
