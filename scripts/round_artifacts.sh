@@ -5,6 +5,9 @@
 TAG=${1:-round}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out
 bash scripts/profile_round.sh ${TAG} > $O/${TAG}_profile.log 2>&1
+# fold the counters into profiles/summary.json HERE, so that the default bench line below carries this build's traffic
+# (traffic_stale: false); the same command is repeated in the build container on the merged gpurun_out/ files
+python scripts/summarize_profile.py ${TAG} envs16384_batch16384_dqn_packed > $O/${TAG}_summary_entry.json 2>&1
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 rm -rf /tmp/prof_c4; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4 -o bench -- python $GRAFT_REPO_ROOT/bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs) > /tmp/c4.log 2>&1
 find /tmp/prof_c4 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_config4_kernel_stats.csv
