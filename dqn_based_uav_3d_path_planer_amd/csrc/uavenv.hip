@@ -2098,7 +2098,8 @@ int uavenv_step_policy(UavEnv *e, const UavDqnNet *net, const void *obs_cur, flo
     launch_geometry(e->N, blk, grd);
     // (its workgroup -- world + the policy team's 27 KB -- must leave room for four per CU, and three wavefronts per 64 agents
     // at 152 registers fit the chip up to 65 536 agents: beyond, the separate act launch is the faster form)
-    const bool wave_f16 = one_wave && blk == 64 && e->N <= 65536 && e->cfg.obs_dtype == UAVENV_OBS_F16 && net->mfma_dtype == UAVENV_MFMA_F16 &&
+    // (an even agent count: every frame and every wavefront's 32-row half then starts and ends on a 16-byte boundary)
+    const bool wave_f16 = one_wave && blk == 64 && e->N <= 65536 && (e->N & 1) == 0 && e->cfg.obs_dtype == UAVENV_OBS_F16 && net->mfma_dtype == UAVENV_MFMA_F16 &&
                           (((uintptr_t)obs_cur) & 15u) == 0 && env_int("UAVENV_POLH", 1) != 0 &&
                           (size_t)e->world_bytes + 16 + uavq::kPolBytes <= 40960;
     if (!shape_ok || !(coop_packed || wave_f16))
