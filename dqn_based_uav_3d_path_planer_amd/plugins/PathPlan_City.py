@@ -440,6 +440,9 @@ class PathPlan_City:
         use_c = (all(p is None for p in self._sac_per) and len({t_.Batch_Size for t_ in trs}) == 1 and
                  len({bool(t_.Is_Train) for t_ in trs}) == 1 and U <= _lib.SAC_LOOP_MAX_SLOTS and
                  int(None2Value(self.param.get("sac_c_loop"), 1)) != 0)
+        if use_c and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            use_c = False        # several ranks: the learners of the Python loop exchange per phase (sac.py: _exchange); the C loop's
+                                 # on-stream exchange is set up by its owner (loop.SACHotLoop(exchange=...), bench.py --config 4 --gpus N)
         if use_c and getattr(self, "_sac_hot", None) is None:
             from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
             self._sac_hot = SACHotLoop(ring, [t_.learner for t_ in trs], trs[0].Batch_Size, seed=self.seed, act1_plane=self._a1,
