@@ -37,7 +37,7 @@ SYMBOLS = (
     "uavenv_randn", "uavenv_sac_loop_noise_floats", "uavenv_sac_loop_create", "uavenv_sac_loop_destroy", "uavenv_sac_loop_run",
     "uavenv_sac_loop_get", "uavenv_sac_act_multi", "uavenv_sac_critic_grad_multi", "uavenv_sac_actor_grad_multi",
     "uavenv_sac_critic_adam_multi", "uavenv_sac_actor_adam_multi",
-    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame", "uavenv_p2p_allreduce",
+    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame", "uavenv_p2p_allreduce", "uavenv_sac_partial_rows_n",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
     "uavenv_sac_actor_adam",
 )
@@ -102,7 +102,7 @@ class UavSacBatch(C.Structure):
     _fields_ = [("obs_packed", C.c_void_p), ("idx_s", C.c_void_p), ("idx_n", C.c_void_p), ("draws", C.c_void_p),
                 ("n_agents", C.c_int32), ("uav_per_env", C.c_int32), ("slot", C.c_int32), ("frames", C.c_int32),
                 ("act0", C.c_void_p), ("act1", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("valid", C.c_void_p),
-                ("eps", C.c_void_p), ("batch", C.c_int32), ("reserved0", C.c_int32),
+                ("eps", C.c_void_p), ("batch", C.c_int32), ("tiles_per_wg", C.c_int32),
                 ("is_weights", C.c_void_p), ("abs_td_out", C.c_void_p)]
 
 
@@ -268,6 +268,8 @@ def load() -> C.CDLL:
     lib.uavenv_sac_reduce.argtypes = [vp, i32, i32, vp, vp]
     lib.uavenv_sac_partial_rows.restype = C.c_int
     lib.uavenv_sac_partial_rows.argtypes = [i32]
+    lib.uavenv_sac_partial_rows_n.restype = C.c_int
+    lib.uavenv_sac_partial_rows_n.argtypes = [i32, i32, i32]
     lib.uavenv_sac_last_error.restype = C.c_char_p
     lib.uavenv_sac_set_debug_buffer.restype = C.c_int
     lib.uavenv_sac_set_debug_buffer.argtypes = [vp]

@@ -485,7 +485,7 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         }
         // critics (:340-357), then the actor and log_alpha on the updated critics (:359-377); the soft update (:378-379) rides
         // in critic_adam -- every phase for all U slots in one launch
-        int rows = uavenv_sac_partial_rows(B);
+        int rows = uavenv_sac_partial_rows_n(B, U, 0);       // workgroups (= partial rows) per slot of a U-slot launch
         const bool multi = c.p2p || c.coll;
         // N > 1: the U slots' column sums side by side in xbuf, summed over the ranks on the stream, one row per slot from there
         auto exchange = [&](float **part, int stride) -> int {

@@ -55,7 +55,18 @@ static_assert(kAob2 + 4 == kPa && kCobo + 2 == kPc, "flat layouts");
 constexpr int kStrideA = UAVENV_SAC_ACTOR_STRIDE;  // kPa + [actor loss sum, sum of log pi, 0, 0]
 constexpr int kStrideC = UAVENV_SAC_CRITIC_STRIDE; // 2 kPc + [loss 1 sum, loss 2 sum, 0, 0]
 static_assert(kStrideA == kPa + 4 && kStrideC == 2 * kPc + 4, "partial-row strides");
-constexpr int kTMax = 4;                           // tiles per workgroup
+constexpr int kTMax = 8;                           // tiles per workgroup
+// Tiles per workgroup of a launch that covers n_slots trainers of n_tiles tiles each: as many as it takes to bring the launch
+// down to one workgroup per CU (the staged nets -- ~26 k cycles per workgroup -- and the partial row are paid per workgroup,
+// not per tile), at most kTMax.  BASELINE configs[3]: 4 slots x 512 tiles -> 8 tiles per workgroup, 256 workgroups; one
+// slot alone -> 2.  MEASURED (configs[3] pass): 2 -> 4 tiles per workgroup 668 -> 607 us.
+static int tiles_per_wg_of(int n_tiles, int n_slots, int asked)
+{
+    static const int div = getenv("UAVENV_SAC_WGS") ? atoi(getenv("UAVENV_SAC_WGS")) : 256;      // A/B knob
+    int tpw = asked > 0 ? asked : (int)(((long long)n_tiles * n_slots + div - 1) / div);
+    if (tpw > kTMax) tpw = kTMax;
+    return tpw < 1 ? 1 : tpw;
+}
 
 struct SacArgs {
     const uint32_t *obs;                  // packed rows
@@ -913,7 +924,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgsN slots)
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArgs &g, int &grid)
+int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArgs &g, int &grid, int n_slots)
 {
     if (!n || !b || !partials) return sac_fail(UAVENV_EINVAL, "uavenv_sac: null argument");
     if (!n->actor || !n->critic1 || !n->critic2 || !n->target1 || !n->target2 || !n->log_alpha)
@@ -936,8 +947,7 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
     g.abs_td = b->abs_td_out;
     g.batch = b->batch;
     const int n_tiles = b->batch / kTile;
-    int tpw = (n_tiles + 255) / 256;
-    if (tpw > kTMax) tpw = kTMax;
+    const int tpw = tiles_per_wg_of(n_tiles, n_slots, b->tiles_per_wg);
     g.tiles_per_wg = tpw;
     grid = (n_tiles + tpw - 1) / tpw;
     g.grid = grid;
@@ -970,7 +980,7 @@ int grad_phase(bool critic, const UavSacNets *nets, const UavSacBatch *batches, 
     int grid = 0;
     for (int j = 0; j < n; ++j) {
         int gj = 0;
-        const int rc = fill_args(&nets[j], &batches[j], partials[j], slots.s[j], gj);
+        const int rc = fill_args(&nets[j], &batches[j], partials[j], slots.s[j], gj, n);
         if (rc != UAVENV_OK) return rc;
         slots.s[j].gamma = critic ? gamma : 0.0f;
         slots.s[j].bound = action_bound;
@@ -1040,10 +1050,14 @@ int uavenv_sac_set_debug_buffer(unsigned long long *dev_buf)
 
 int uavenv_sac_partial_rows(int32_t batch)
 {
-    if (batch <= 0 || batch % kTile) return UAVENV_EINVAL;
+    return uavenv_sac_partial_rows_n(batch, 1, 0);
+}
+
+int uavenv_sac_partial_rows_n(int32_t batch, int32_t n_slots, int32_t tiles_per_wg)
+{
+    if (batch <= 0 || batch % kTile || n_slots < 1 || n_slots > kSlots || tiles_per_wg < 0) return UAVENV_EINVAL;
     const int n_tiles = batch / kTile;
-    int tpw = (n_tiles + 255) / 256;
-    if (tpw > kTMax) tpw = kTMax;
+    const int tpw = tiles_per_wg_of(n_tiles, n_slots, tiles_per_wg);
     return (n_tiles + tpw - 1) / tpw;
 }
 

@@ -186,13 +186,15 @@ class FusedSACLearner:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _scratch(self, batch: int):
+        """(rows held, critic rows buffer, actor rows buffer): one row per 64-sample tile -- the most any partition writes.  A
+        launch writes one row per WORKGROUP: uavenv_sac_partial_rows_n(batch, slots in the launch, UavSacBatch.tiles_per_wg)."""
         s = self._partials.get(batch)
         if s is None:
-            rows = self.lib.uavenv_sac_partial_rows(int(batch))
-            if rows <= 0:
+            if self.lib.uavenv_sac_partial_rows(int(batch)) <= 0:
                 raise ValueError("batch must be a positive multiple of 64")
-            s = (rows, torch.empty((rows, self._lib.SAC_CRITIC_STRIDE), dtype=torch.float32, device=self.device),
-                 torch.empty((rows, self._lib.SAC_ACTOR_STRIDE), dtype=torch.float32, device=self.device))
+            cap = int(batch) // 64
+            s = (cap, torch.empty((cap, self._lib.SAC_CRITIC_STRIDE), dtype=torch.float32, device=self.device),
+                 torch.empty((cap, self._lib.SAC_ACTOR_STRIDE), dtype=torch.float32, device=self.device))
             self._partials[batch] = s
         return s
 
@@ -201,10 +203,11 @@ class FusedSACLearner:
             raise self._lib.UavEnvError(f"{what} failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()}")
 
     def make_batch(self, obs_packed: torch.Tensor, act0, act1, reward, done, *, valid=None, idx_s=None, idx_n=None,
-                   draws=None, n_agents=0, uav_per_env=1, slot=0, frames=0, is_weights=None, abs_td_out=None):
+                   draws=None, n_agents=0, uav_per_env=1, slot=0, frames=0, is_weights=None, abs_td_out=None, tiles_per_wg=0):
         """Describe the sampled transitions in place (see UavSacBatch in include/uavenv.h).  Keeps the tensors alive.
         is_weights / abs_td_out (f32 [batch], prioritised replay): importance weights into the critic losses, and where
-        uavenv_sac_critic_grad leaves |min(Q1, Q2) - td_target| per sample."""
+        uavenv_sac_critic_grad leaves |min(Q1, Q2) - td_target| per sample.  tiles_per_wg: 0 = chosen per launch; > 0 pins the
+        partition of the partial rows (and with it the summation order) whatever shares the launch."""
         keep = (obs_packed, act0, act1, reward, done, valid, idx_s, idx_n, draws, is_weights, abs_td_out)
         for t in (is_weights, abs_td_out):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
@@ -217,7 +220,7 @@ class FusedSACLearner:
         assert idx_s is None or (idx_s.dtype == torch.int32 and idx_n.dtype == torch.int32)
         b = self._lib.UavSacBatch(obs_packed.data_ptr(), ptr(idx_s), ptr(idx_n), ptr(draws), int(n_agents), int(uav_per_env),
                                   int(slot), int(frames), act0.data_ptr(), act1.data_ptr(), reward.data_ptr(), done.data_ptr(),
-                                  ptr(valid), None, n, 0, ptr(is_weights), ptr(abs_td_out))
+                                  ptr(valid), None, n, int(tiles_per_wg), ptr(is_weights), ptr(abs_td_out))
         b._keep = keep
         return b
 
@@ -279,7 +282,8 @@ class FusedSACLearner:
     # the four launches, separately (tests drive them one by one)
     def critic_grad(self, batch, eps_next: torch.Tensor):
         C = self._C
-        rows, pc, _ = self._scratch(batch.batch)
+        _, pc, _ = self._scratch(batch.batch)
+        self._rows_launched = self.lib.uavenv_sac_partial_rows_n(int(batch.batch), 1, int(batch.tiles_per_wg))   # what this launch writes
         batch.eps = eps_next.data_ptr()
         self._check(self.lib.uavenv_sac_critic_grad(C.byref(self._nets), C.byref(batch), self.gamma, self.action_bound,
                                                     pc.data_ptr(), self._stream()), "uavenv_sac_critic_grad")
@@ -287,8 +291,8 @@ class FusedSACLearner:
 
     def critic_step(self, n: int):
         C = self._C
-        rows, pc, _ = self._scratch(n)
-        pc, rows, scale = self._exchange(pc, rows)
+        _, pc, _ = self._scratch(n)
+        pc, rows, scale = self._exchange(pc, self._rows_launched)
         h = self._adam(self.critic_lr, self.tau, scale)
         cb = self._cblocks
         self._check(self.lib.uavenv_sac_critic_adam(C.byref(self._nets), pc.data_ptr(), rows, cb[4].data_ptr(), cb[5].data_ptr(),
@@ -297,7 +301,8 @@ class FusedSACLearner:
 
     def actor_grad(self, batch, eps_cur: torch.Tensor):
         C = self._C
-        rows, _, pa = self._scratch(batch.batch)
+        _, _, pa = self._scratch(batch.batch)
+        self._rows_launched = self.lib.uavenv_sac_partial_rows_n(int(batch.batch), 1, int(batch.tiles_per_wg))
         batch.eps = eps_cur.data_ptr()
         self._check(self.lib.uavenv_sac_actor_grad(C.byref(self._nets), C.byref(batch), self.action_bound, pa.data_ptr(),
                                                    self._stream()), "uavenv_sac_actor_grad")
@@ -305,8 +310,8 @@ class FusedSACLearner:
 
     def actor_step(self, n: int):
         C = self._C
-        rows, _, pa = self._scratch(n)
-        pa, rows, scale = self._exchange(pa, rows)
+        _, _, pa = self._scratch(n)
+        pa, rows, scale = self._exchange(pa, self._rows_launched)
         h = self._adam(self.actor_lr, 0.0, scale)
         self._check(self.lib.uavenv_sac_actor_adam(C.byref(self._nets), pa.data_ptr(), rows, int(n), self._blocks[1].data_ptr(),
                                                    self._blocks[2].data_ptr(), self._alpha_mv.data_ptr(), C.byref(h),

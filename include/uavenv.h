@@ -478,7 +478,10 @@ typedef struct UavSacBatch {
                                             not replay memory in the reference) carry weight 0 in EVERY loss -- critics, actor,
                                             log_alpha -- and all means are over the valid samples */
     const float *eps;                    /* batch x 2 N(0,1) draws standing for Normal.rsample() of this phase */
-    int32_t batch, reserved0;            /* batch: a multiple of 64 */
+    int32_t batch;                       /* a multiple of 64 */
+    int32_t tiles_per_wg;                /* 0: chosen per launch (uavenv_sac_partial_rows_n); > 0: this many 64-sample tiles per
+                                            workgroup (at most 8) -- fixes the partition, and so the summation order, of the
+                                            partial rows whatever else shares the launch */
     /* prioritised replay (Trainer/SAC_Trainer.py:336-352), both nullable: is_weights[s] multiplies sample s in the two critic
      * losses (mean_s w_s err_s^2: the per-sample form of `is_weights * critic_loss`); abs_td_out[s] receives
      * |min(Q1, Q2)(s, a) - td_target| of output column 0 (:351) -- written by uavenv_sac_critic_grad. */
@@ -495,7 +498,11 @@ typedef struct UavSacAdam {
  * action components land in act0[row] / act1[row].  eps: count x 2 N(0,1) draws (Normal.rsample()). */
 int uavenv_sac_act(const float *actor, const void *obs_packed, int32_t first_row, int32_t row_stride, int32_t count,
                    const float *eps, float action_bound, float *act0, float *act1, void *stream);
-int uavenv_sac_partial_rows(int32_t batch);
+int uavenv_sac_partial_rows(int32_t batch);          /* = uavenv_sac_partial_rows_n(batch, 1, 0): never less than any launch writes */
+/* Partial rows per slot that a grad launch over n_slots trainers writes (= workgroups per slot), tiles_per_wg as in UavSacBatch:
+ * 0 = as many tiles per workgroup as bring the launch down to one workgroup per CU (at most 8).  What the Adam call behind
+ * that launch must be told as `rows`. */
+int uavenv_sac_partial_rows_n(int32_t batch, int32_t n_slots, int32_t tiles_per_wg);
 const char *uavenv_sac_last_error(void);
 /* Diagnostics (UAVENV_PHASE_PROFILE builds): 16 s_memtime stamps per workgroup of uavenv_sac_critic_grad; NULL disables. */
 int uavenv_sac_set_debug_buffer(unsigned long long *dev_buf);
@@ -547,7 +554,7 @@ typedef struct UavSacLoopSlot {
     float *m_actor, *v_actor, *alpha_mv;     /* Adam moments of the actor (UAVENV_SAC_ACTOR_PARAMS each) and of log_alpha (2) */
     float *m1, *v1, *m2, *v2;                /* Adam moments of the two critics (UAVENV_SAC_CRITIC_PARAMS each) */
     float *scalars;                          /* 8 floats: critic losses [0:4], actor loss / sum log pi [4:8] of the last update */
-    float *partials_critic, *partials_actor; /* uavenv_sac_partial_rows(batch) x UAVENV_SAC_CRITIC_STRIDE / _ACTOR_STRIDE, per slot */
+    float *partials_critic, *partials_actor; /* >= uavenv_sac_partial_rows_n(batch, n_slots, 0) rows x UAVENV_SAC_CRITIC_STRIDE / _ACTOR_STRIDE, per slot */
     int32_t epoch, adam_steps;               /* update() calls so far; Adam steps actually taken (bias correction) */
 } UavSacLoopSlot;
 typedef struct UavSacLoopConfig {

@@ -169,9 +169,14 @@ def _bench(*extra, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                          "--no-other-configs", "--envs", "2048", "--batch", "2048", "--replay", "16384", "--env-only-iters", "5",
-                          *extra], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-other-configs", "--envs", "2048", "--batch", "2048", "--replay", "16384", "--env-only-iters", "5", *extra]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    if res.returncode != 0 and "--gpus" in extra:
+        # one retry for the multi-process legs: a rank start-up can fail for reasons outside this code (the rendezvous port
+        # picked by spawn_ranks taken in between; seen once in seven full-suite runs); a defect fails twice
+        print("bench.py failed once, retrying:\n" + res.stderr[-1500:], file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]

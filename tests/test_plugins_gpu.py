@@ -317,20 +317,27 @@ def test_prioritised_replay_through_the_plugins(trainer, tmp_path, monkeypatch):
     assert prio.max().item() <= 1.0 + 1e-9                                                    # clip at 1 (:219-221)
 
 
-def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch):
+@pytest.mark.parametrize("envs,batch,replay,tpw", [(512, 512, 8192, 0), (2048, 8192, 65536, 2)])
+def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch, envs, batch, replay, tpw):
     """csrc/loop.hip: uavenv_sac_loop_run -- per step the N(0,1) draws, U x get_action, the env step (APF on), one replay
     draw and U x the four launches of the fused SAC update, enqueued from C -- against the same sequence issued launch by
     launch from Python (PathPlan_City._run_eposide_fused_sac with <sac_c_loop>0</sac_c_loop>): ring, every parameter block
     of every slot (weights, targets, Adam moments, log_alpha), update counts -- bit for bit.  (Speed: both are GPU-bound at
-    this size -- ~375 us per step = ~22 latency-bound launches -- so the C loop removes the interpreter, not time.)"""
+    this size -- ~375 us per step = ~22 latency-bound launches -- so the C loop removes the interpreter, not time.)
+    Second case: 4 x 128 tiles -- the C loop's four-slot launches take two tiles per workgroup (uavenv_sac_partial_rows_n), a
+    slot alone would take one; the Python loop's learners are told the same partition (FusedSACLearner.tiles_per_wg) and the
+    comparison stays bit for bit."""
     import time
     monkeypatch.chdir(tmp_path)
     out = []
     for c_loop in ("1", "0"):
-        sim = _config4(tmp_path, 512, Batch_Size=512, replay_size=8192)
+        sim = _config4(tmp_path, envs, Batch_Size=batch, replay_size=replay)
         env = sim.env
         env.param["sac_c_loop"] = c_loop
         assert env.fast_sac
+        if c_loop == "0":
+            for b in env._sac_batches:               # the partition of the C loop's four-slot launches
+                b.tiles_per_wg = tpw
         torch.manual_seed(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -352,5 +359,5 @@ def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch):
     for j in range(4):
         assert torch.equal(a["blocks"][j], b["blocks"][j]), j
     assert a["loss"] == b["loss"]
-    print(f"fused SAC episode, 512 envs x 4 UAVs: C loop {a['us']:.0f} us/step, Python loop {b['us']:.0f} us/step")
+    print(f"fused SAC episode, {envs} envs x 4 UAVs: C loop {a['us']:.0f} us/step, Python loop {b['us']:.0f} us/step")
     assert a["us"] < 1.25 * b["us"]
