@@ -480,6 +480,11 @@ def run_config4(args, dev, world_size=1, rank=0):
                                    "flops_per_sample": 258.0e3, "samples_per_launch": B,
                                    "kernel_ms": sum(ms), "critic_grad_ms_back_to_back": ms[0], "actor_grad_ms_back_to_back": ms[1],
                                    "algorithmic_bytes_per_sample": 2 * 80 + 30, "traffic": None}
+    if multi:
+        torch.cuda.synchronize(dev)
+        dist.barrier()                       # no rank unmaps its peers while one of them may still be running a pull
+    if hot is not None:
+        hot.close()                          # (explicitly: a destructor at interpreter exit would run after the HIP runtime's own)
     env.close()
     return out
 
