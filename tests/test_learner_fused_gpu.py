@@ -230,6 +230,7 @@ def _two_rank_worker(rank, world, port, kind, net, out_dir, p2p=False):
                os.path.join(out_dir, f"w{world}_r{rank}.pt"))
     if world > 1:
         dist.barrier()
+        L.disable_p2p()
         dist.destroy_process_group()
     env.close()
 
