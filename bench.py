@@ -940,7 +940,7 @@ def run_dqn(args, world_size, rank, dev):
                        "epsilon": args.eps, "parallelism": par,
                        "sample_lag": args.sample_lag,
                        "replay": ("prioritised (ReplayTree semantics, alpha 0.6, beta 0.4 + 0.001 per update, epsilon 0.01, clip 1) -- "
-                                  "9 launches per pass from C") if args.per else "uniform without replacement"},
+                                  "8 launches per pass from C") if args.per else "uniform without replacement"},
             "roofline": {"bound": "hbm",
                          "kernel": ("k_step_coop<policy> -- the launch the timed loop issues: get_action (Q(s) + epsilon-greedy) + "
                                     "update_PathPlan + state_PathPlan + replay write") if in_loop_policy

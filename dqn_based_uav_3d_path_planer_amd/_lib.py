@@ -37,7 +37,7 @@ SYMBOLS = (
     "uavenv_randn", "uavenv_sac_loop_noise_floats", "uavenv_sac_loop_create", "uavenv_sac_loop_destroy", "uavenv_sac_loop_run",
     "uavenv_sac_loop_get", "uavenv_sac_act_multi", "uavenv_sac_critic_grad_multi", "uavenv_sac_actor_grad_multi",
     "uavenv_sac_critic_adam_multi", "uavenv_sac_actor_adam_multi",
-    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame", "uavenv_p2p_allreduce", "uavenv_sac_partial_rows_n",
+    "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame", "uavenv_per_rebuild_frame", "uavenv_p2p_allreduce", "uavenv_sac_partial_rows_n",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
     "uavenv_sac_actor_adam",
 )
@@ -319,6 +319,8 @@ def load() -> C.CDLL:
     lib.uavenv_per_set_f32.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
     lib.uavenv_p2p_allreduce.restype = C.c_int
     lib.uavenv_p2p_allreduce.argtypes = [vp, vp, i64, vp]
+    lib.uavenv_per_rebuild_frame.restype = C.c_int
+    lib.uavenv_per_rebuild_frame.argtypes = [per, i64, i64, f64, vp, i64, vp]
     lib.uavenv_per_fill_frame.restype = C.c_int
     lib.uavenv_per_fill_frame.argtypes = [per, i64, i64, f64, vp, i64, vp]
     lib.uavenv_per_weights.restype = C.c_int

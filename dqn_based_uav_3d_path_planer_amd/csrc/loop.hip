@@ -203,9 +203,12 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
         if (l->prof) tp1 = std::chrono::steady_clock::now();
         l->head = nxt;
         if (l->filled < R.frames - 1) l->filled += 1;
-        if (l->per) {                     // ReplayTree.push(error 0) for the frame just written; the new head's rows are retired
-            rc = uavenv_per_fill_frame(&c.per, (int64_t)t * (int64_t)n, (int64_t)n, pow(0.0 + (double)c.per_eps, (double)c.per_alpha),
-                                       R.valid + (size_t)t * n, (int64_t)nxt * (int64_t)n, s);
+        const bool learn_now = !lag && c.batch > 0 &&
+                               (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch);
+        const double per_new = l->per ? pow(0.0 + (double)c.per_eps, (double)c.per_alpha) : 0.0;
+        if (l->per && !learn_now) {       // ReplayTree.push(error 0) for the frame just written; the new head's rows are retired
+            rc = uavenv_per_fill_frame(&c.per, (int64_t)t * (int64_t)n, (int64_t)n, per_new, R.valid + (size_t)t * n,
+                                       (int64_t)nxt * (int64_t)n, s);           // (an update's rebuild applies them itself)
             if (rc != UAVENV_OK) return rc;
         }
         if (lag ? lag_update
@@ -215,7 +218,8 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 rc = UAVENV_OK;
             } else if (l->per) {          // ReplayTree.sample: beta first (:155), selection, importance weights
                 l->per_beta = l->per_beta + (double)c.per_beta_inc < 1.0 ? l->per_beta + (double)c.per_beta_inc : 1.0;
-                rc = uavenv_per_rebuild(&c.per, s);
+                rc = uavenv_per_rebuild_frame(&c.per, (int64_t)t * (int64_t)n, (int64_t)n, per_new, R.valid + (size_t)t * n,
+                                              (int64_t)nxt * (int64_t)n, s);
                 if (rc != UAVENV_OK) return rc;
                 rc = uavenv_per_sample(&c.per, c.batch, nullptr, c.seed, l->counter, c.per_slots_dev, c.per_prio_dev, s);
                 if (rc != UAVENV_OK) return rc;

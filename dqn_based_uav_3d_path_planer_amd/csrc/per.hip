@@ -35,7 +35,14 @@ __device__ __forceinline__ int64_t slot_of(const UavPer &p, int64_t q)
     return s >= p.capacity ? s - p.capacity : s;
 }
 
-__global__ void __launch_bounds__(256) k_per_chunk_sum(UavPer p)
+// the two fills of a replay step (k_per_fill2) applied while the priorities are being read anyway: count == 0 -> none
+struct PerFill {
+    int64_t first, count, retire_first;
+    double value;
+    const uint8_t *valid;
+};
+
+__global__ void __launch_bounds__(256) k_per_chunk_sum(UavPer p, PerFill f)
 {
     __shared__ double red[256];
     __shared__ double leaf[kChunk];
@@ -44,7 +51,18 @@ __global__ void __launch_bounds__(256) k_per_chunk_sum(UavPer p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t q = q0 + j;
-        const double v = q < p.capacity ? p.prio[slot_of(p, q)] : 0.0;
+        double v = 0.0;
+        if (q < p.capacity) {
+            const int64_t sl = slot_of(p, q);
+            if (sl >= f.first && sl < f.first + f.count) {
+                v = (!f.valid || f.valid[sl - f.first]) ? f.value : 0.0;
+                p.prio[sl] = v;
+            } else if (sl >= f.retire_first && sl < f.retire_first + f.count) {
+                p.prio[sl] = 0.0;
+            } else {
+                v = p.prio[sl];
+            }
+        }
         leaf[threadIdx.x * 4 + j] = v;
         s += v;
     }
@@ -329,10 +347,17 @@ int uavenv_per_rotation(int64_t capacity)
 
 int uavenv_per_rebuild(const UavPer *p, void *stream)
 {
-    if (!per_ok(p)) return UAVENV_EINVAL;
+    return uavenv_per_rebuild_frame(p, 0, 0, 0.0, nullptr, 0, stream);
+}
+
+int uavenv_per_rebuild_frame(const UavPer *p, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
+                             int64_t retire_first, void *stream)
+{
+    if (!per_ok(p) || first < 0 || retire_first < 0 || count < 0 || first + count > p->capacity || retire_first + count > p->capacity)
+        return UAVENV_EINVAL;
     const int nc = uavenv_per_num_chunks(p->capacity);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_per_chunk_sum, dim3(nc), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(k_per_chunk_sum, dim3(nc), dim3(256), 0, s, *p, PerFill{first, count, retire_first, priority, valid_dev});
     hipLaunchKernelGGL(k_per_prefix, dim3(1), dim3(256), 0, s, *p, nc);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }

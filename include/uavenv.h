@@ -257,6 +257,9 @@ int uavenv_per_fill(const UavPer *per, int64_t first, int64_t count, double prio
  * valid_dev[i] != 0, 0 elsewhere) and the frame that became the ring's head ([retire_first, retire_first + count) <- 0). */
 int uavenv_per_fill_frame(const UavPer *per, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
                           int64_t retire_first, void *stream);
+/* uavenv_per_fill_frame + uavenv_per_rebuild with the fills applied while the rebuild reads the priorities (one launch less). */
+int uavenv_per_rebuild_frame(const UavPer *per, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
+                             int64_t retire_first, void *stream);
 /* uavenv_per_set with f32 errors (what uavenv_dqn_grad_w / uavenv_sac_critic_grad write). */
 int uavenv_per_set_f32(const UavPer *per, const int64_t *slots_dev, const float *abs_err_dev, int32_t n, double epsilon,
                        double alpha, double clip, void *stream);

@@ -226,7 +226,7 @@ def test_bench_legs_run_small():
     """The other legs of bench.py at a small size: prioritised replay inside the C loop, the sample_lag experiment, an
     env-only point and the config 3 / 5 presets' code paths (f16 MFMA learner; explicit sizes keep them small)."""
     d = _bench("--per")
-    assert "prioritised" in d["config"]["replay"] and d["value"] > 0 and "9 launches" in d["config"]["replay"]
+    assert "prioritised" in d["config"]["replay"] and d["value"] > 0 and "8 launches" in d["config"]["replay"]
     d = _bench("--sample-lag", "1")
     assert d["config"]["sample_lag"] == 1 and d["value"] > 0
     d = _bench("--trainer", "dueling", "--mfma", "f16", "--obs-dtype", "f16")
