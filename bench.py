@@ -536,6 +536,10 @@ def other_configs(args):
             ("row e on ONE GPU (NOT a multi-GPU measurement): two ranks sharing this device, 16384 envs each, gradient bucket "
              "summed over HIP-IPC-mapped memory on the stream (csrc/p2p.hip), ranks started by bench.py itself",
              ["--gpus", "2", "--same-device", "--dist-backend", "gloo", "--steps", "8", "--warmup", "2"]),
+            ("row e for the SAC loop on ONE GPU (NOT a multi-GPU measurement): two ranks sharing this device, 8192 envs x 4 UAVs each, "
+             "every phase's gradient rows of the four slots summed over HIP-IPC-mapped memory inside uavenv_sac_loop_run",
+             ["--config", "4", "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--envs", "8192", "--batch", "8192",
+              "--steps", "4", "--warmup", "1"]),
             ("env-only 65536 agents/launch", ["--env-only", "--envs", "65536", "--steps", "40"]),
             ("env-only 262144 agents/launch", ["--env-only", "--envs", "262144", "--steps", "20"])]
     out = []
