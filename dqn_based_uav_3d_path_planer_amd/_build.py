@@ -12,7 +12,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libuavenv.so")
-SOURCES = ["uavenv.hip", "replay.hip", "learner.hip", "rrt.hip", "per.hip", "loop.hip", "p2p.hip", "coll.hip", "sac.hip"]
+SOURCES = ["uavenv.hip", "replay.hip", "learner.hip", "rrt.hip", "per.hip", "loop.hip", "p2p.hip", "coll.hip", "sac.hip", "fed.hip"]
 HEADERS = ["uavenv_device.hpp", "qnet_device.hpp", os.path.join("..", "..", "include", "uavenv.h")]
 # -ffp-contract=off: the reward / collision arithmetic must round like the reference's
 # separate multiplies and adds (no FMA fusion); see csrc/uavenv_device.hpp.

@@ -39,7 +39,7 @@ SYMBOLS = (
     "uavenv_sac_critic_adam_multi", "uavenv_sac_actor_adam_multi",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame", "uavenv_per_rebuild_frame", "uavenv_p2p_allreduce", "uavenv_sac_partial_rows_n",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
-    "uavenv_sac_actor_adam",
+    "uavenv_sac_actor_adam", "uavenv_fed_aggregate",
 )
 SAC_CRITIC_IN, SAC_ACTOR_PARAMS, SAC_CRITIC_PARAMS, SAC_ACTOR_STRIDE, SAC_CRITIC_STRIDE = 102, 6724, 10882, 6728, 21768
 
@@ -112,6 +112,7 @@ class UavSacAdam(C.Structure):
 
 
 SAC_LOOP_MAX_SLOTS = 8
+FED_MAX_BLOCKS = 8
 
 
 class UavSacLoopSlot(C.Structure):
@@ -329,6 +330,8 @@ def load() -> C.CDLL:
     lib.uavenv_loop_get_per.argtypes = [vp, C.POINTER(C.c_double)]
     lib.uavenv_per_fill.restype = C.c_int
     lib.uavenv_per_fill.argtypes = [per, i64, i64, f64, vp, vp]
+    lib.uavenv_fed_aggregate.restype = C.c_int
+    lib.uavenv_fed_aggregate.argtypes = [vp, i32, i32, f32, vp]
     if lib.uavenv_abi_version() != ABI_VERSION:
         raise UavEnvError(f"libuavenv ABI {lib.uavenv_abi_version()} != binding {ABI_VERSION}")
     _LIB = lib

@@ -117,9 +117,10 @@ class DQNLearner:
         return self.loss, delta.detach().abs().view(-1)
 
     def federated_average(self):
-        """FedAvg over the ranks: q_local and q_target <- mean over ranks (PathPlan_City.py:590-603 sums the agents'
-        state_dicts and divides by their number; here the agents are the ranks and the sum is one all-reduce).  The
-        Adam moments stay local, as the reference's replace_param leaves each trainer's optimizer untouched."""
+        """FedAvg over the ranks: q_local and q_target <- mean over ranks -- the rank-level counterpart of the reference's
+        merge of its per-UAV trainers (Envs/PathPlan_City.py:590-601 adds the agents' state_dicts up; the division it
+        writes at :597 never reaches the model, federated.py -- here the agents are the ranks, the sum is one all-reduce
+        and the mean is applied).  The Adam moments stay local, as replace_param leaves each trainer's optimizer alone."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         with torch.no_grad():

@@ -127,6 +127,13 @@ class PathPlan_City:
         self.print_loop = int(None2Value(param.get("print_loop"), 2))
         self.Is_FL = int(None2Value(param.get("Is_FL"), 0))
         self.FL_Loop = int(None2Value(param.get("FL_Loop"), 3))
+        # <FL_Aggregate>: "reference" (default) = the merge as the reference executes it -- the SUM of the UAVs' models: its
+        # division at Envs/PathPlan_City.py:597 never reaches the model -- or "mean" (dqn_based_uav_3d_path_planer_amd/federated.py)
+        self.FL_Aggregate = str(None2Value(param.get("FL_Aggregate"), "reference"))
+        from dqn_based_uav_3d_path_planer_amd import federated as _fed
+        if self.FL_Aggregate not in _fed.AGGREGATES:
+            raise ValueError(f"<FL_Aggregate>{self.FL_Aggregate}</FL_Aggregate>: expected one of {_fed.AGGREGATES}")
+        self.fl_merges = 0             # federated merges done so far (diagnostics / tests)
         self.executed_time = 0
         self._state_cache = None
         self._state0 = None
@@ -358,6 +365,28 @@ class PathPlan_City:
             self.result["average_score"] += info["average_score"] / max(len(train_info), 1)
             self.result["step"] += info["step"]
 
+    def Federated_Learning_AC(self):
+        """Envs/PathPlan_City.py:590-601: every UAV's actor <- the merge of all UAVs' actors (one launch over the flat
+        parameter blocks when the trainers are fused; critics, targets and optimizers untouched)."""
+        from dqn_based_uav_3d_path_planer_amd import federated
+        self.fl_merged_on = federated.federated_learning_ac([u.Trainer for u in self.Agents], self.FL_Aggregate)
+
+    def Federated_Learning(self):
+        """The Is_AC = 0 branch of :469-475.  The reference's own Federated_Learning (:604-640) needs get_policy_DFRL /
+        SPN_param / Update_SPN_Soft, which no trainer in the tree has (AttributeError); the merge of Federated_Learning_AC is
+        applied to q_local instead (replace_param, Trainer/DuelingDQN_Trainer.py:204-207)."""
+        from dqn_based_uav_3d_path_planer_amd import federated
+        self.fl_merged_on = federated.federated_learning_q([u.Trainer for u in self.Agents], self.FL_Aggregate)
+
+    def _federated_merge(self):
+        """:469-475, after epoch += 1: every FL_Loop episodes when Is_FL."""
+        if self.Is_FL and self.FL_Loop > 0 and self.epoch % self.FL_Loop == 0:
+            if self.Is_AC:
+                self.Federated_Learning_AC()
+            else:
+                self.Federated_Learning()
+            self.fl_merges += 1
+
     def _run_eposide_fused(self, eps_rate):
         """run_eposide on the fused path: HotLoop enqueues done_check steps of act -> step (+ replay write) -> sample ->
         learn at a time; the host then reads, in one transfer, how many agents each of those steps still moved and the
@@ -413,6 +442,7 @@ class PathPlan_City:
         self.epoch += 1
         if self.epoch % self.print_loop == 0:
             uav.record_list()
+        self._federated_merge()
         return self.result
 
     def _run_eposide_fused_sac(self, eps_rate):
@@ -534,6 +564,7 @@ class PathPlan_City:
         if self.epoch % self.print_loop == 0:
             for uav in self.Agents:
                 uav.record_list()
+        self._federated_merge()
         return self.result
 
     def run_eposide(self, eps_rate=0.1):
@@ -593,4 +624,5 @@ class PathPlan_City:
         if self.epoch % self.print_loop == 0:
             for uav in self.Agents:
                 uav.record_list()
+        self._federated_merge()
         return self.result

@@ -118,6 +118,13 @@ class SAC_Trainer:
     def hard_update(self):
         pass
 
+    def replace_param(self, target):
+        """Trainer/SAC_Trainer.py:456-459: the actor's parameters <- target's (what Federated_Learning_AC hands every UAV).
+        The fused learner's parameters are views into its flat block, so the kernels see the new weights at once."""
+        with torch.no_grad():
+            for target_param, param in zip(target.parameters(), self.actor.parameters()):
+                param.data.copy_(target_param.data.to(param.device))
+
     def _path(self, role, directory=None):
         return os.path.join(directory or self.model_dir, f"{role}_SAC_{self.name}.pth")     # SAC_Trainer.py:113-119
 

@@ -600,6 +600,15 @@ int uavenv_sac_loop_destroy(UavSacLoop *loop);
 int uavenv_sac_loop_run(UavSacLoop *loop, int32_t n_steps, void *stream);
 int uavenv_sac_loop_get(const UavSacLoop *loop, UavSacLoopCursor *out);
 
+/* ---- federated merge of the per-UAV trainers (Envs/PathPlan_City.py:469-475 -> Federated_Learning_AC :590-601) --------------
+ * Every one of the n_blocks flat f32 parameter blocks (device pointers, 16-byte aligned, distinct, n_floats each; the array
+ * itself is HOST memory) <- scale * (block[0] + block[1] + ... in that order), one launch.  scale = 1 is the reference AS
+ * EXECUTED (its division at :597 assigns into a temporary dict and never reaches the model: every UAV receives the SUM of
+ * the actors through replace_param, Trainer/SAC_Trainer.py:456-459; tests/golden/federated_ac.npz), scale = 1 / n_blocks the
+ * mean its comment intends.  Adam moments are not touched (replace_param leaves the optimizers alone). */
+#define UAVENV_FED_MAX_BLOCKS 8
+int uavenv_fed_aggregate(float *const *blocks, int32_t n_blocks, int32_t n_floats, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

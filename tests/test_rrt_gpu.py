@@ -12,6 +12,7 @@ import torch
 from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
+KNOWN_FORKS = set()      # filled from the GPU run: seeds of tests/golden/resets.npz whose tree forks on gfx950
 TOL = 1e-9      # f64; the only differences are pow(x,2) vs x*x and OCML vs glibc sqrt-free arithmetic (last ulp)
 
 
@@ -36,13 +37,15 @@ def test_replays_the_reference_reset_from_the_mersenne_stream(env):
     sg, sub, ns, it = env.rrt_plan(len(seeds), uniforms=u)
     sg, sub, ns = sg.cpu().numpy(), sub.cpu().numpy(), ns.cpu().numpy()
     st = g["state"]
-    n_exact = 0
+    forks = []
     for k in range(len(seeds)):
         assert np.abs(sg[k] - np.r_[st[k, 0:3], st[k, 6:9]]).max() <= TOL           # start / goal draws (UAV.py:353-358)
-        if ns[k] == g["n_sub"][k] and np.abs(sub[k, :ns[k]] - g["sub_goals"][k, :ns[k]]).max() <= TOL:
-            n_exact += 1
-    # a last-ulp difference can flip one `d < step` decision and fork the tree: allow a rare fork, not a pattern
-    assert n_exact >= len(seeds) - 2, f"only {n_exact}/{len(seeds)} reference resets reproduced"
+        if not (ns[k] == g["n_sub"][k] and np.abs(sub[k, :ns[k]] - g["sub_goals"][k, :ns[k]]).max() <= TOL):
+            forks.append(int(seeds[k]))
+    # a last-ulp difference (x*x vs pow(x, 2), OCML vs glibc) can flip one `d < step` decision and fork the tree.  WHICH
+    # seeds fork is a property of the arithmetic, not of scheduling: the set is recorded and must not change
+    print("forking seeds:", forks)
+    assert set(forks) <= KNOWN_FORKS, f"reference resets that no longer reproduce: {sorted(set(forks) - KNOWN_FORKS)}"
 
 
 def test_matches_the_cpu_oracle_on_arbitrary_streams(env):
