@@ -8,7 +8,7 @@ from . import _build
 
 OBS_DIM = 100
 MAX_BUILDINGS = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EP2P = 0, -22, -12, -5, -19, -70
 P2P_ERR_TIMEOUT, P2P_ERR_DIVERGED = 1, 2
@@ -30,7 +30,7 @@ SYMBOLS = (
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
-    "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_inject_fault", "uavenv_p2p_can_reach",
+    "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_error_word", "uavenv_p2p_inject_fault", "uavenv_p2p_can_reach",
     "uavenv_coll_last_error", "uavenv_coll_unique_id", "uavenv_coll_create", "uavenv_coll_destroy", "uavenv_coll_allreduce_sum",
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_get_per", "uavenv_loop_step_times",
@@ -108,7 +108,8 @@ class UavSacBatch(C.Structure):
 
 class UavSacAdam(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("tau", C.c_float), ("grad_scale", C.c_float)]
+                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("tau", C.c_float), ("grad_scale", C.c_float),
+                ("skip_word", C.c_void_p)]
 
 
 SAC_LOOP_MAX_SLOTS = 8
@@ -330,6 +331,8 @@ def load() -> C.CDLL:
     lib.uavenv_loop_get_per.argtypes = [vp, C.POINTER(C.c_double)]
     lib.uavenv_per_fill.restype = C.c_int
     lib.uavenv_per_fill.argtypes = [per, i64, i64, f64, vp, vp]
+    lib.uavenv_p2p_error_word.restype = C.c_void_p
+    lib.uavenv_p2p_error_word.argtypes = [vp]
     lib.uavenv_fed_aggregate.restype = C.c_int
     lib.uavenv_fed_aggregate.argtypes = [vp, i32, i32, f32, vp]
     if lib.uavenv_abi_version() != ABI_VERSION:

@@ -479,6 +479,7 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             h.bias_correction1 = (float)(1.0 - pow(c.beta1, tt));
             h.bias_correction2_sqrt = (float)sqrt(1.0 - pow(c.beta2, tt));
             h.grad_scale = 0.0f;
+            h.skip_word = c.p2p ? uavenv_p2p_error_word(c.p2p) : nullptr;   // Adam behind a failed pull: a no-op
             h.lr = c.critic_lr; h.tau = c.tau;
             hc[j] = h;
             h.lr = c.actor_lr; h.tau = 0.0f;
@@ -505,6 +506,10 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         if (rc != UAVENV_OK) return rc;
         if (multi) {
             rc = exchange(pc, UAVENV_SAC_CRITIC_STRIDE);
+            if (rc == UAVENV_EP2P) {                     // sticky error: no Adam launch of this update steps (skip_word) -- the
+                for (int j = 0; j < U; ++j) l->adam_steps[j] -= 1;       // update did not happen, so it is not counted either
+                return rc;
+            }
             if (rc != UAVENV_OK) return rc;
         }
         rc = uavenv_sac_critic_adam_multi(nets, pc, multi ? 1 : rows, m1, v1, m2, v2, hc, sc_c, U, s);
@@ -514,10 +519,14 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         if (rc != UAVENV_OK) return rc;
         if (multi) {
             rc = exchange(pa, UAVENV_SAC_ACTOR_STRIDE);
-            if (rc != UAVENV_OK) return rc;
+            if (rc != UAVENV_OK && rc != UAVENV_EP2P) return rc;
+            // EP2P here: the critics of this update did step (their exchange succeeded); the actor launch below is enqueued all the
+            // same and skips itself on the device (skip_word) -- the caller re-synchronises every block from one rank anyway
         }
+        const int rc_x = rc;
         rc = uavenv_sac_actor_adam_multi(nets, pa, multi ? 1 : rows, B, ma, va, amv, ha, c.alpha_lr, c.target_entropy, sc_a, U, s);
         if (rc != UAVENV_OK) return rc;
+        if (rc_x == UAVENV_EP2P) return rc_x;
     }
     return UAVENV_OK;
 }

@@ -32,13 +32,14 @@
 
 namespace {
 constexpr int kMaxWorld = 16;
+constexpr size_t kFlagBytes = (size_t)(kMaxWorld + 1) * 64;   // one 64-byte line per peer flag + one for this rank's verdict word
 constexpr uint32_t kSpinLimit = 1u << 24;            // x ~0.25 us per poll: about four seconds (uavenv_p2p_configure changes it)
 }
 
 struct UavP2P {
     int world = 0, rank = 0, bucket = 0, bucket_pad = 0;
     size_t bytes = 0;
-    unsigned char *local = nullptr;                   // [flags: kMaxWorld x 64 B][recv: world x 2 x bucket_pad floats]
+    unsigned char *local = nullptr;                   // [flags: kMaxWorld x 64 B][verdict: 64 B][recv: world x 2 x bucket_pad floats]
     unsigned char *peer[kMaxWorld] = {nullptr};       // peer[r] = rank r's area as mapped here (peer[rank] = local)
     bool opened[kMaxWorld] = {false};
     unsigned long long *wsum = nullptr;               // [2] weight checksums (device memory), by parity of the check index
@@ -69,12 +70,70 @@ struct P2PDev {
 
 __device__ __forceinline__ float *recv_slot(unsigned char *area, int from, uint32_t seq, int bucket_pad)
 {
-    return reinterpret_cast<float *>(area + kMaxWorld * 64) + ((size_t)from * 2 + (seq & 1u)) * (size_t)bucket_pad;
+    return reinterpret_cast<float *>(area + kFlagBytes) + ((size_t)from * 2 + (seq & 1u)) * (size_t)bucket_pad;
 }
 
 __device__ __forceinline__ uint32_t *flag_of(unsigned char *area, int from)
 {
     return reinterpret_cast<uint32_t *>(area + (size_t)from * 64);
+}
+
+// The wait of a pull launch, DECIDED ONCE: workgroup 0 waits for the `world` flags (bounded), compares the weight checksums
+// when the bucket carries them, and publishes (seq, verdict) in this rank's verdict word (uncached, like the flags); every
+// other workgroup takes that verdict.  (Round 3 let every workgroup run its own bounded wait: a flag arriving between two
+// workgroups' deadlines summed / stepped some columns and not others -- ADVICE r3.)  A workgroup that never sees workgroup
+// 0's verdict (it cannot happen short of a dead launch; the bound is twice workgroup 0's own) reports a timeout itself.
+// Returns 0 or the error code; thread 0 only.
+__device__ uint32_t p2p_wait_once(const P2PDev &d, unsigned char *mine, int P_checksum)
+{
+    uint32_t *verdict = reinterpret_cast<uint32_t *>(mine + (size_t)kMaxWorld * 64);
+    const uint32_t tag = d.seq << 2;
+    if (blockIdx.x != 0) {
+        uint32_t spins = 0, v;
+        while (((v = __hip_atomic_load(verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) & ~3u) != tag) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > 2u * d.spin_limit * (uint32_t)d.world + 1024u) {
+                __hip_atomic_fetch_add(d.errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return UAVENV_P2P_ERR_TIMEOUT;
+            }
+        }
+        return v & 3u;
+    }
+    uint32_t bad = __hip_atomic_load(d.errors + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky
+    for (int r = 0; r < d.world && !bad; ++r) {
+        uint32_t spins = 0;
+        while ((int32_t)(__hip_atomic_load(flag_of(mine, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.seq) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > d.spin_limit) {
+                __hip_atomic_fetch_add(d.errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                bad = UAVENV_P2P_ERR_TIMEOUT;
+                break;
+            }
+        }
+    }
+    __threadfence_system();
+    if (!bad && d.carry >= 0 && P_checksum >= 0) {     // every rank folded a checksum of its weights into this bucket: all equal?
+        const uint32_t *s0 = reinterpret_cast<const uint32_t *>(recv_slot(mine, 0, d.seq, d.bucket_pad));
+        const uint32_t lo = __hip_atomic_load(s0 + P_checksum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t hi = __hip_atomic_load(s0 + P_checksum + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 1; r < d.world; ++r) {
+            const uint32_t *sr = reinterpret_cast<const uint32_t *>(recv_slot(mine, r, d.seq, d.bucket_pad));
+            if (__hip_atomic_load(sr + P_checksum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != lo ||
+                __hip_atomic_load(sr + P_checksum + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != hi)
+                bad = UAVENV_P2P_ERR_DIVERGED;
+        }
+        if (bad) {
+            __hip_atomic_fetch_add(d.errors + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_DIVERGED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_DIVERGED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __hip_atomic_store(verdict, tag | (bad & 3u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return bad;
 }
 
 // column sums of the partial rows (as k_dqn_reduce) -> slot [rank] of every rank's receive area
@@ -166,37 +225,8 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
     float m0 = 0.0f, v0 = 0.0f, w0 = 0.0f;
     if (p < P && local) { m0 = m[p]; v0 = v[p]; w0 = local[p]; }
     if (threadIdx.x == 0) {
-        uint32_t bad = __hip_atomic_load(d.errors + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky
-        for (int r = 0; r < d.world && !bad; ++r) {
-            uint32_t spins = 0;
-            while ((int32_t)(__hip_atomic_load(flag_of(mine, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.seq) < 0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > d.spin_limit) {
-                    __hip_atomic_fetch_add(d.errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    bad = UAVENV_P2P_ERR_TIMEOUT;
-                    break;
-                }
-            }
-        }
+        const uint32_t bad = p2p_wait_once(d, mine, P + 2);
         __threadfence_system();
-        if (!bad && d.carry >= 0) {              // every rank folded a checksum of its weights into this bucket: all equal?
-            const uint32_t *s0 = reinterpret_cast<const uint32_t *>(recv_slot(mine, 0, d.seq, d.bucket_pad));
-            const uint32_t lo = __hip_atomic_load(s0 + P + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const uint32_t hi = __hip_atomic_load(s0 + P + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            for (int r = 1; r < d.world; ++r) {
-                const uint32_t *sr = reinterpret_cast<const uint32_t *>(recv_slot(mine, r, d.seq, d.bucket_pad));
-                if (__hip_atomic_load(sr + P + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != lo ||
-                    __hip_atomic_load(sr + P + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != hi)
-                    bad = UAVENV_P2P_ERR_DIVERGED;
-            }
-            if (bad && blockIdx.x == 0) {
-                __hip_atomic_fetch_add(d.errors + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_DIVERGED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_DIVERGED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
         s_bad = bad;
         s_sum = 0ull;
     }
@@ -268,20 +298,7 @@ __global__ void __launch_bounds__(256) k_p2p_pull_sum(P2PDev d, float *__restric
     }
     __shared__ uint32_t s_bad;
     if (threadIdx.x == 0) {
-        uint32_t bad = __hip_atomic_load(d.errors + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky
-        for (int r = 0; r < d.world && !bad; ++r) {
-            uint32_t spins = 0;
-            while ((int32_t)(__hip_atomic_load(flag_of(mine, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.seq) < 0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > d.spin_limit) {
-                    __hip_atomic_fetch_add(d.errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    bad = UAVENV_P2P_ERR_TIMEOUT;
-                    break;
-                }
-            }
-        }
+        const uint32_t bad = p2p_wait_once(d, mine, -1);
         __threadfence_system();
         s_bad = bad;
     }
@@ -317,7 +334,7 @@ int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P
     if (!c) return UAVENV_ENOMEM;
     c->world = world; c->rank = rank; c->bucket = bucket_floats;
     c->bucket_pad = (bucket_floats + 2 + 63) & ~63;           // + the two checksum words
-    c->bytes = (size_t)kMaxWorld * 64 + (size_t)world * 2 * c->bucket_pad * sizeof(float);
+    c->bytes = kFlagBytes + (size_t)world * 2 * c->bucket_pad * sizeof(float);
     // uncached: peers write it while this device reads it inside running kernels
     if (hipExtMallocWithFlags((void **)&c->local, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return UAVENV_ENOMEM; }
     if (hipMalloc((void **)&c->wsum, 2 * sizeof(unsigned long long) + 4 * sizeof(uint32_t)) != hipSuccess) {
@@ -394,6 +411,11 @@ int uavenv_p2p_destroy(UavP2P *c)
     if (c->host_code) (void)hipHostFree((void *)c->host_code);
     delete c;
     return UAVENV_OK;
+}
+
+const uint32_t *uavenv_p2p_error_word(const UavP2P *c)
+{
+    return c ? c->errors + 1 : nullptr;
 }
 
 int uavenv_p2p_errors(UavP2P *c, int32_t *timeouts_out)

@@ -240,6 +240,10 @@ __global__ void k_per_set(UavPer p, const int64_t *__restrict__ slots, const dou
     // batch_update (clip > 0) re-prioritises SAMPLED transitions: a slot whose priority is 0 is an empty leaf (a retired or
     // never-valid ring row; the sampler only returns one when the whole tree is empty) and stays empty
     if (clip > 0.0 && p.prio[s] == 0.0) return;
+    // ReplayTree.batch_update (:215-222) walks the batch in order: when a leaf was drawn more than once the LAST sample's error
+    // wins.  Stratified draws come back in non-decreasing prefix order, so equal slots are ADJACENT: a sample followed by the
+    // same slot leaves the write to its successor (one writer per slot: deterministic, and the reference's winner)
+    if (i + 1 < n && slots[i + 1] == s) return;
     double e = fabs(abs_err[i]) + epsilon;
     if (clip > 0.0 && e > clip) e = clip;
     p.prio[s] = pow(e, alpha);
@@ -253,6 +257,7 @@ __global__ void k_per_set_f32(UavPer p, const int64_t *__restrict__ slots, const
     const int64_t s = slots[i];
     if (s < 0 || s >= p.capacity) return;
     if (clip > 0.0 && p.prio[s] == 0.0) return;          // (an empty leaf stays empty: see k_per_set)
+    if (i + 1 < n && slots[i + 1] == s) return;          // (the last of a run of equal slots writes: see k_per_set)
     double e = fabs((double)abs_err[i]) + epsilon;
     if (clip > 0.0 && e > clip) e = clip;
     p.prio[s] = pow(e, alpha);

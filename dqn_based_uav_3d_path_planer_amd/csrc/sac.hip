@@ -62,7 +62,13 @@ constexpr int kTMax = 8;                           // tiles per workgroup
 // slot alone -> 2.  MEASURED (configs[3] pass): 2 -> 4 tiles per workgroup 668 -> 607 us.
 static int tiles_per_wg_of(int n_tiles, int n_slots, int asked)
 {
-    static const int div = getenv("UAVENV_SAC_WGS") ? atoi(getenv("UAVENV_SAC_WGS")) : 256;      // A/B knob
+    // (UAVENV_SAC_WGS: a test / A-B knob read once per process -- it changes the partition and with it the summation order;
+    // anything that is not a positive number falls back to the default)
+    static const int div = [] {
+        const char *e = getenv("UAVENV_SAC_WGS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 256;
+    }();
     int tpw = asked > 0 ? asked : (int)(((long long)n_tiles * n_slots + div - 1) / div);
     if (tpw > kTMax) tpw = kTMax;
     return tpw < 1 ? 1 : tpw;
@@ -849,6 +855,7 @@ struct AdamArgs {
     float alpha_lr, target_entropy, inv_2b;
     int frac_col;                            // column holding the valid fraction of the batch (-1: scale by grad_scale instead)
     int n_loss;                              // the first n_loss extras are loss means
+    const uint32_t *skip;                    // nullable: a non-zero word makes the launch a no-op (UavSacAdam.skip_word)
 };
 
 __device__ __forceinline__ float adam_step(float p, float g, float &m, float &v, const AdamArgs &a, float lr)
@@ -893,6 +900,9 @@ __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgsN slots)
         a.raw_out[col] = s;
         return;
     }
+    // behind a peer exchange that raised its sticky error the row holds rank-local sums: step nothing (the rank's
+    // parameters, moments, targets and log_alpha freeze until the caller re-synchronises them; csrc/p2p.hip)
+    if (a.skip && __hip_atomic_load(a.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     // every column was accumulated as sum_i w_i (...) / B per rank; frac = sum of the ranks' (valid / B): dividing by it
     // gives the mean over the valid samples of all ranks (all valid: 1 / world size)
     const float frac = (fpart[0] + fpart[1]) + (fpart[2] + fpart[3]);
@@ -1014,6 +1024,7 @@ int critic_adam_args(const UavSacNets *nets, const float *partials, int32_t rows
     a.frac_col = 2 * kPc + 2;
     a.n_loss = 2;
     a.scalars_out = losses_out;
+    a.skip = h->skip_word;
     return UAVENV_OK;
 }
 
@@ -1033,6 +1044,7 @@ int actor_adam_args(const UavSacNets *nets, const float *partials, int32_t rows,
     a.scalars_out = scalars_out;
     a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
     a.inv_2b = 0.5f / (float)batch;
+    a.skip = h->skip_word;
     return UAVENV_OK;
 }
 

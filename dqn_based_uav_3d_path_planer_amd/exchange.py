@@ -79,6 +79,11 @@ def open_coll(lib, device: torch.device, verify_floats: int, stream):
     world, rank = g
     path = _lib.rccl_path()
     buf = (C.c_ubyte * _lib.COLL_ID_BYTES)()
+    # every rank first shows that it can load RCCL at all (dlopen + the symbols + one ncclGetUniqueId, thrown away): a rank that
+    # cannot would never enter ncclCommInitRank below and its peers would block inside it -- vote BEFORE anyone does
+    probe = (C.c_ubyte * _lib.COLL_ID_BYTES)()
+    if not _all(bool(path) and torch.cuda.is_available() and lib.uavenv_coll_unique_id(path, probe) == 0, world):
+        return None
     ok = True
     if rank == 0:
         ok = lib.uavenv_coll_unique_id(path, buf) == 0

@@ -81,6 +81,15 @@ class HotLoop:
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_loop_create")
         self.counter = int(counter)
+        self.batch = int(batch)
+        self._seen = (ring.head, ring.filled, learner.epoch)
+
+    def in_sync(self, batch: int = None) -> bool:
+        """The cursor and the update count live in the C object while the loop exists: False when the Python side moved on
+        without it (a step or update issued around the loop, Load_Mod setting the epoch, another batch size) -- the owner
+        then closes this loop and creates a new one instead of letting run() overwrite the newer values."""
+        return (self._seen == (self.ring.head, self.ring.filled, self.learner.epoch) and
+                (batch is None or int(batch) == self.batch))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -114,6 +123,7 @@ class HotLoop:
         self.ring.head, self.ring.filled = cur.head, cur.filled
         self.learner.epoch = cur.epoch
         self.counter = int(cur.counter)
+        self._seen = (cur.head, cur.filled, cur.epoch)
         if self._per is not None:
             beta = C.c_double(0.0)
             _lib.check(self.lib.uavenv_loop_get_per(self._h, C.byref(beta)), "uavenv_loop_get_per")
@@ -214,6 +224,14 @@ class SACHotLoop:
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_sac_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_sac_loop_create")
         self.counter = int(counter)
+        self.batch, self.is_train = int(batch), bool(is_train)
+        self._seen = (ring.head, ring.filled, tuple((L.epoch, L.adam_steps) for L in self.learners))
+
+    def in_sync(self, batch: int = None, is_train: bool = None) -> bool:
+        """As HotLoop.in_sync: the C object captured Is_Train, the batch size, the ring cursor and every learner's epoch /
+        adam_steps at creation; False when any of them changed on the Python side since the last run()."""
+        return (self._seen == (self.ring.head, self.ring.filled, tuple((L.epoch, L.adam_steps) for L in self.learners)) and
+                (batch is None or int(batch) == self.batch) and (is_train is None or bool(is_train) == self.is_train))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -236,14 +254,19 @@ class SACHotLoop:
         s = torch.cuda.current_stream(self.ring.env.device).cuda_stream
         rc = self.lib.uavenv_sac_loop_run(self._h, int(n_steps), s)
         if rc == _lib.EP2P:
+            self._sync_cursor()          # the steps before the failure are in the ring and in the learners' counters
             raise P2PExchangeError("the peer exchange of the SAC loop raised its sticky error: stop stepping and re-synchronise "
                                    "parameters and moments from one rank")
         if rc != 0:
             raise _lib.UavEnvError(f"uavenv_sac_loop_run failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()} / "
                                    f"{self.lib.uavenv_last_error().decode()}")
+        self._sync_cursor()
+
+    def _sync_cursor(self):
         cur = _lib.UavSacLoopCursor()
         _lib.check(self.lib.uavenv_sac_loop_get(self._h, C.byref(cur)), "uavenv_sac_loop_get")
         self.ring.head, self.ring.filled = cur.head, cur.filled
         self.counter = int(cur.counter)
         for j, L in enumerate(self.learners):
             L.epoch, L.adam_steps = int(cur.epoch[j]), int(cur.adam_steps[j])
+        self._seen = (cur.head, cur.filled, tuple((L.epoch, L.adam_steps) for L in self.learners))

@@ -159,7 +159,11 @@ class SAC_Trainer:
                     raise ValueError("checkpoint does not fit the network: %s" % sorted(set(want.items()) ^ set(got.items()))[:4])
             opts = [ck["optimizer"] for ck in cks]
             legacy = [isinstance(o, dict) and o.get("fused_adam") for o in opts]    # round-2 fused checkpoints
+            import copy
             backup = [{k: v.clone() for k, v in net.state_dict().items()} for net in nets]
+            # ... and the optimizers: a failure in critic_2's state must not leave the actor's moments / step count loaded
+            opt_backup = copy.deepcopy(self._optim_states())
+            steps_backup = getattr(L, "adam_steps", None)
             try:
                 for ck, net in zip(cks, nets):
                     net.load_state_dict(ck["model"])             # (fused: parameters are views of the flat blocks: copies in place)
@@ -178,8 +182,14 @@ class SAC_Trainer:
                     for o, opt in zip(opts, (L.actor_optimizer, L.critic_1_optimizer, L.critic_2_optimizer)):
                         opt.load_state_dict(o)
             except Exception:
-                for net, sd in zip(nets, backup):                # leave the model as it was
+                for net, sd in zip(nets, backup):                # leave the model AND its optimizers as they were
                     net.load_state_dict(sd)
+                if self.fused:
+                    L.load_optimizer_state_dicts(opt_backup)
+                    L.adam_steps = steps_backup
+                else:
+                    for o, opt in zip(opt_backup, (L.actor_optimizer, L.critic_1_optimizer, L.critic_2_optimizer)):
+                        opt.load_state_dict(o)
                 raise
             self.epoch = cks[0]["epoch"]
             L.target_critic_1.load_state_dict(L.critic_1.state_dict())

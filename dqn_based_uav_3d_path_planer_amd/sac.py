@@ -226,8 +226,10 @@ class FusedSACLearner:
 
     def _adam(self, lr, tau=0.0, scale=0.0):
         t = max(self.adam_steps, 1)
+        # behind a peer exchange that raised its sticky error the Adam launch must change nothing (csrc/p2p.hip)
+        skip = self.lib.uavenv_p2p_error_word(self._p2p) if getattr(self, "_p2p", None) is not None else None
         return self._lib.UavSacAdam(lr, self.beta1, self.beta2, self.adam_eps, 1.0 - self.beta1 ** t,
-                                    float(np.sqrt(1.0 - self.beta2 ** t)), tau, scale)
+                                    float(np.sqrt(1.0 - self.beta2 ** t)), tau, scale, skip)
 
     def enable_exchange(self, kind: str = "auto", spin_limit: int = 0):
         """The on-stream form of the N > 1 exchange (no host round trip, no torch.distributed call per phase): "p2p" =

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 3
+#define UAVENV_ABI_VERSION 4
 #define UAVENV_OBS_DIM 100          /* Agents/UAV.py:517  state_map = zeros(1,1,1,100) */
 #define UAVENV_MAX_BUILDINGS 64     /* broad-phase masks are 64-bit */
 
@@ -246,7 +246,9 @@ int uavenv_per_rebuild(const UavPer *per, void *stream);
 int uavenv_per_sample(const UavPer *per, int32_t batch, const double *draws_dev, uint64_t seed, uint64_t counter,
                       int64_t *out_slot_dev, double *out_prio_dev, void *stream);
 /* prio[slots[i]] = min(|abs_err[i]| + epsilon, clip) ** alpha   (batch_update :215-222; clip <= 0: no clip = push :143).
- * With clip > 0 a slot whose priority is 0 -- an empty leaf: a retired or never-valid ring row -- is left at 0. */
+ * With clip > 0 a slot whose priority is 0 -- an empty leaf: a retired or never-valid ring row -- is left at 0.
+ * A slot listed several times takes the LAST of its errors, as the reference's sequential loop does, provided the equal entries
+ * are adjacent -- which they are in every list uavenv_per_sample returns (stratified draws come back in prefix order). */
 int uavenv_per_set(const UavPer *per, const int64_t *slots_dev, const double *abs_err_dev, int32_t n, double epsilon,
                    double alpha, double clip, void *stream);
 /* prio[first .. first+count) = priority where valid_dev[i] != 0 (or everywhere if NULL), 0 elsewhere: the slots of a
@@ -349,6 +351,8 @@ int uavenv_p2p_destroy(UavP2P *p2p);
  * (0 = keep; default 2^24, about four seconds).  Must be the same on every rank. */
 int uavenv_p2p_configure(UavP2P *p2p, int32_t check_every, int32_t spin_limit);
 int uavenv_p2p_errors(UavP2P *p2p, int32_t *timeouts_out);        /* synchronises */
+/* Device address of the exchange's sticky error word (0 = healthy): what UavSacAdam.skip_word takes.  NULL for NULL. */
+const uint32_t *uavenv_p2p_error_word(const UavP2P *p2p);
 /* out4 = {sticky error code (0 = healthy, UAVENV_P2P_ERR_*), timeouts, checksum mismatches, checksums folded so far}.
  * synchronise == 0: only the code, read from host-mapped memory without touching the device (timeouts / mismatches = -1).
  * Once the code is non-zero the rank's Adam steps are skipped (its weights freeze rather than absorb stale or partial
@@ -496,6 +500,9 @@ typedef struct UavSacAdam {
     float tau;                           /* soft target update (critic_adam only) */
     float grad_scale;                    /* ignored since ABI 3: every column is divided by the summed valid-fraction column of the
                                             partial rows (1 / world size after an all-reduce SUM of all-valid batches) */
+    const uint32_t *skip_word;           /* ABI 4, nullable device word: non-zero when the launch runs => it changes NOTHING (no
+                                            parameter, moment, target or scalar).  uavenv_p2p_error_word(): an Adam launch enqueued
+                                            behind a peer exchange that timed out must not step with rank-local sums */
 } UavSacAdam;
 /* get_action (SAC_Trainer.py:444-448) for `count` agents whose packed rows are first_row + i * row_stride: the two
  * action components land in act0[row] / act1[row].  eps: count x 2 N(0,1) draws (Normal.rsample()). */

@@ -379,10 +379,11 @@ def test_f16_mfma_learner_against_the_executed_reference(ref_name, kind, net):
     the f32 HIP learner.  What differs from the reference's f32 arithmetic: observations, fc1 weights and the H / dH
     operands of the gradient products carry an 11-bit significand (2^-11 = 4.9e-4 relative per operand, averaging over
     K = 100 / 64 terms).  Stated f16 bars:
-      losses   <= 5e-3 relative, every one of the 7 updates;
+      losses   <= 2e-4 relative, every one of the 7 updates (measured 1.4e-5);
       weights  after 7 Adam steps of lr 1e-3: Adam normalises the gradient, so operand rounding shows only where a
                gradient component is near zero -- there a weight can move by up to lr per step in either direction (hard
-               bound 2 * 7 * lr = 1.4e-2); 97 % of the weights within 3e-4 (a third of one Adam step), all within the bound."""
+               bound 2 * 7 * lr = 1.4e-2); 97 % of the weights within 5e-5 (a twentieth of one Adam step; measured 4.5e-6),
+               all within 5e-3 (measured 2.6e-3)."""
     from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
     g = load_golden(f"learner_{ref_name}.npz")
     for ring_cls in (HandRingF16,):                   # f16 rows as stored: configs[2]'s ring (the f16 kernels refuse f32 rows)
@@ -392,10 +393,10 @@ def test_f16_mfma_learner_against_the_executed_reference(ref_name, kind, net):
         ring = ring_cls(g["states"], g["next_states"], g["actions"], g["rewards"], g["dones"])
         losses = [float(L.learn_from_ring(ring, 64, 0, 0, explicit_idx=ring.idx)) for _ in range(len(g["losses"]))]
         assert L.epoch == int(g["epoch"])
-        assert np.allclose(losses, g["losses"], rtol=5e-3, atol=0), (ring_cls.__name__, losses, g["losses"])
+        assert np.allclose(losses, g["losses"], rtol=2e-4, atol=0), (ring_cls.__name__, losses, g["losses"])
         err = np.concatenate([np.abs(v.cpu().numpy() - g[pref + k]).ravel()
                               for pref, netobj in (("l1_", L.q_local), ("t1_", L.q_target))
                               for k, v in netobj.state_dict().items()])
         print(ring_cls.__name__, "max", err.max(), "q97", np.quantile(err, 0.97), "loss rel",
               np.abs(np.array(losses) / g["losses"] - 1).max())
-        assert err.max() <= 1.4e-2 and np.quantile(err, 0.97) <= 3e-4, (ring_cls.__name__, err.max(), np.quantile(err, 0.97))
+        assert err.max() <= 5e-3 and np.quantile(err, 0.97) <= 5e-5, (ring_cls.__name__, err.max(), np.quantile(err, 0.97))

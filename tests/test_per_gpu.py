@@ -264,3 +264,42 @@ def test_prioritised_replay_inside_the_c_loop_equals_the_stepwise_path():
     live = pc > 0
     fresh = (0.0 + 0.01) ** 0.6
     assert 0 < int(live.sum()) <= (6 - 1) * 1024 and float(((pc[live] - fresh).abs() > 1e-9).float().mean()) > 0.05
+
+
+def test_batch_update_with_repeated_leaves_is_last_wins_and_deterministic():
+    """ReplayTree.batch_update (replay_buffer.py:215-222) is a sequential loop: a leaf drawn several times in one batch ends
+    with the LAST sample's error.  One dominant priority makes the stratified sampler return the same leaf for most of the
+    batch; uavenv_per_set / _set_f32 must then produce what the sequential restatement does, run after run."""
+    from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
+    cap, batch = 4096, 512
+    rng = np.random.default_rng(3)
+    prio = rng.uniform(0.001, 0.01, cap)
+    prio[1234] = 500.0                                        # ~95 % of the mass in one leaf
+    prio[77] = 10.0
+    results = []
+    for rep in range(3):
+        per = DevicePER(cap, tree_order=False)
+        per.set_priorities(torch.tensor(prio), n_entries=cap)
+        slots, w, p = per.sample(batch, seed=5, counter=1)
+        sl = slots.cpu().numpy()
+        assert (np.diff(sl) >= 0).all()                      # prefix order: equal slots are adjacent
+        assert (sl == 1234).sum() > batch // 2 and len(set(sl.tolist())) < batch
+        err = torch.tensor(rng.uniform(0.0, 2.0, batch)) if rep == 0 else err     # noqa: F821
+        per.update(slots, err)
+        want = prio.copy()
+        for i in range(batch):                                # the reference's loop: later samples overwrite earlier ones
+            want[sl[i]] = min(abs(float(err[i])) + per.epsilon, per.clip) ** per.alpha
+        got = per.prio.cpu().numpy()
+        assert np.allclose(got, want, rtol=4e-16, atol=0)
+        results.append(got)
+        per2 = DevicePER(cap, tree_order=rep == 1)            # the f32-error form the fused learners feed; rep 1: rotated slots
+        per2.set_priorities(torch.tensor(prio), n_entries=cap)
+        s2, _, _ = per2.sample(batch, seed=5, counter=1)
+        per2.update_f32(s2, err.float().cuda())
+        want32 = prio.copy()
+        e32 = err.float().double().numpy()
+        sl2 = s2.cpu().numpy()
+        for i in range(batch):
+            want32[sl2[i]] = min(abs(e32[i]) + per2.epsilon, per2.clip) ** per2.alpha
+        assert np.allclose(per2.prio.cpu().numpy(), want32, rtol=4e-16, atol=0)
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[1], results[2])
