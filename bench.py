@@ -9,9 +9,10 @@ Workload at --gpus 1: BASELINE.json configs[1] -- 16 384 vectorised envs, DQN, d
 Multi-GPU is weak scaling: every rank owns its own 16 384-env shard + ring; the only exchange is the ~26 KB
 gradient bucket per update.
 
-A bench "step" (--steps K) is PASSES_PER_STEP = 128 such passes, enqueued back to back by csrc/loop.hip (one C call per
-bench step, three kernel launches per pass): one pass lasts ~35 us, so that the timed region stays >= 50 ms whatever K
-the driver picks (20 steps = 2 560 passes).  `ms_per_step` is per bench step, `ms_per_pass` per pass.
+A bench "step" (--steps K) is PASSES_PER_STEP = 1024 such passes, enqueued back to back by csrc/loop.hip (one C call per
+bench step, three kernel launches per pass): one pass lasts ~35 us, so that the timed region stays >= 0.5 s whatever K
+the driver picks (20 steps = 20 480 passes = 0.7 s; round 3 timed 88 ms, too short for a 5 s utilisation sampler to see).
+`ms_per_step` is per bench step, `ms_per_pass` per pass.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (re-executes this file under
 torch.distributed.run, one rank per GPU); launched by torch.distributed.run it just joins.  At N > 1 the line also carries
@@ -20,10 +21,12 @@ counters, and `ms_per_pass_no_exchange` from a short in-run leg without the exch
 
 Prints ONE JSON line (rank 0).  `value` = whole-job env-steps/s of the full loop (inputs resident in HBM);
 `roofline` is for the env kernel the loop launches (k_step_coop<policy>: get_action + update_PathPlan + state_PathPlan +
-replay write; HBM-bound by design), `roofline_learner` for k_dqn_grad (the largest share of the pass, MFMA);
+replay write; HBM-bound by design): `frac` prices SURVEY 8(d)'s ALGORITHMIC 604 B per agent-step, `frac_physical_stored` the
+bytes the packed layout really moves and `frac_physical_counters` the PMC traffic of the committed profile -- side by side, so
+that a lossless packing win is never read as bandwidth; `roofline_learner` for k_dqn_grad (the largest share of the pass, MFMA);
 `cpu_baseline` times the CPU oracle port on the host cores (1 core and all cores); `other_configs` (N = 1, default
 command only) carries BASELINE.json configs[2..4] and the env-only 65 536 / 262 144-agent points, each run as a child
-process of this one for >= 50 ms of timed region.
+process of this one for >= 0.5 s of timed region.
 """
 from __future__ import annotations
 
@@ -45,7 +48,7 @@ ALGO_BYTES_PER_AGENT_STEP = 604        # 137 B read + 46
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
 MFMA_F16_PEAK_TF = 2500.0              # MI355X_MICROARCH.md: bf16/f16 MFMA, dense
-PASSES_PER_STEP = 128                  # hot-path passes per bench step (see module docstring)
+PASSES_PER_STEP = 1024                 # hot-path passes per bench step (see module docstring)
 
 
 def learner_flops_per_sample(trainer: str, n_actions: int = 3) -> float:
@@ -57,6 +60,54 @@ def learner_flops_per_sample(trainer: str, n_actions: int = 3) -> float:
     n_fwd = 2 if trainer == "dqn" else 3
     bwd = 2 * (64 * 100) + 2 * (64 * n2) * 2
     return float(n_fwd * fwd + bwd)
+
+
+def physical_view(algo_bytes: int, moved_bytes: int, n_agents: int, kernel_ms: float, traffic, copy_gbs) -> dict:
+    """The HBM view of a step launch beside the algorithmic one.  `frac` (the contract's figure) prices SURVEY 8(d)'s 604 B per
+    agent-step -- what the reference's f32 layout would have to move; packed rows are a lossless 80-byte image of the 400-byte
+    observation row, so the kernel MOVES far less.  frac_physical_stored = the bytes of the layout as stored (state planes + the
+    row format in use + the policy's row read) / time / 8 TB/s; frac_physical_counters = FETCH_SIZE x 2 + WRITE_SIZE of the
+    committed PMC pass / time / 8 TB/s (None without counters).  An algorithmic GB/s above the copy bandwidth measured in this
+    same run is flagged: it is a statement about the packing, not about the memory system."""
+    sec = kernel_ms * 1e-3
+    algo_gbs = algo_bytes * n_agents / sec / 1e9
+    moved_gbs = moved_bytes * n_agents / sec / 1e9
+    out = {"frac_algorithmic": algo_gbs / HBM_PEAK_GBS,
+           "moved_bytes_per_agent_step": moved_bytes, "achieved_physical_stored_GBs": moved_gbs,
+           "frac_physical_stored": moved_gbs / HBM_PEAK_GBS,
+           "achieved_physical_counters_GBs": None if not traffic else traffic / sec / 1e9,
+           "frac_physical_counters": None if not traffic else traffic / sec / 1e9 / HBM_PEAK_GBS,
+           "packing_gain": algo_bytes / float(moved_bytes)}
+    if copy_gbs:
+        out["frac_physical_stored_of_measured_copy"] = moved_gbs / copy_gbs
+        out["algorithmic_exceeds_measured_copy"] = bool(algo_gbs > copy_gbs)
+    return out
+
+
+def measure_copy_gbs(dev) -> float:
+    """Achievable HBM bandwidth on THIS device in THIS run: device-to-device copy of 1 GiB, read + write bytes."""
+    src = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    c0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    c1.record()
+    torch.cuda.synchronize(dev)
+    return 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+
+
+def device_identity(dev) -> str:
+    """Something that tells two physical GPUs apart (ranks report it; `links_crossed` = more than one distinct value)."""
+    p = torch.cuda.get_device_properties(dev)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(p, attr, None)
+        if v is not None:
+            return "%s:%s" % (attr, v)
+    import socket
+    return "%s:cuda%d" % (socket.gethostname(), dev.index or 0)
 
 
 def parse():
@@ -184,6 +235,10 @@ def cpu_baseline(envs: int, seconds: float):
                      f"state_PathPlan, random steering, auto-reset from the packaged bank, no learner) in {dt:.1f} s on "
                      f"{cores} threads (host CPU quota of the container: {quota} cores); 1 thread: {done1} agent-steps in {dt1:.1f} s; C port of the reference's Python env "
                      f"path (oracle/uav_oracle.c, -O3, OpenMP static blocks)"}
+    out["reference_python"] = ("not run on this box: /root/reference does not travel to the GPU host.  The reference's own Python "
+                               "env path (update_PathPlan + state_PathPlan, one thread, GIL-bound) measured ~843 env-steps/s and its "
+                               "full run_eposide loop with the shipped trainer ~100 steps/s in the build container at survey time "
+                               "(BASELINE.md section 2-3); `kind: port` above is the bit-exact C restatement of that path")
     out["learner"] = cpu_learner_baseline()
     return out
 
@@ -221,12 +276,14 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def committed_profile(args) -> dict:
+def committed_profile(args, env_only: bool = False) -> dict:
     """The rocprofv3 figures of THIS command line as last committed under profiles/ (kernel-trace averages, PMC
     traffic, MFMA busy): scripts/summarize_profile.py writes profiles/summary.json keyed by workload.  `stale` says
     whether the kernel sources changed since that profile was taken."""
     path = os.path.join(ROOT, "profiles", "summary.json")
     key = "envs%d_batch%d_%s_%s" % (args.envs, args.batch, args.trainer, args.obs_dtype) + ("_mfma16" if args.mfma == "f16" else "")
+    if env_only:
+        key = "envonly%d_%s" % (args.envs * args.uav_per_env, args.obs_dtype) + ("_apf" if args.apf else "")
     try:
         d = json.load(open(path)).get(key, {})
         if d:
@@ -407,9 +464,10 @@ def run_config4(args, dev, world_size=1, rank=0):
     if multi:
         got = [None] * world_size
         sums = [float(torch.cat([L._blocks.reshape(-1), L._cblocks.reshape(-1)]).double().sum()) for L in learners] if fused else []
-        dist.all_gather_object(got, (dt, sums))
+        dist.all_gather_object(got, (dt, sums, device_identity(dev)))
         dt = max(g[0] for g in got)
         ident = all(g[1] == got[0][1] for g in got)
+        rank_devs = [g[2] for g in got]
     n_pass = args.steps * pps
     it = args.env_only_iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -423,6 +481,8 @@ def run_config4(args, dev, world_size=1, rank=0):
     k_prof = prof.get("k_step_ms")
     k_use = max(k_ms, k_prof or 0.0)
     algo = ALGO_BYTES_PER_AGENT_STEP + 2 * 20 * 24      # APF on adds 2 * n_sub * 24 B (~20 sub-goals)
+    moved = algo - 400 + ring.obs.shape[-1] * ring.obs.element_size()          # packed rows: 80 B instead of the 400-B f32 row
+    copy_gbs = measure_copy_gbs(dev) if rank == 0 else None
     out = {"metric": "env-steps/sec + learner updates/sec, PathPlan_City SAC", "value": n_pass * env.N * world_size / dt,
            "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -444,12 +504,14 @@ def run_config4(args, dev, world_size=1, rank=0):
            "roofline": {"bound": "hbm", "kernel": "k_step<APF> (update_PathPlan + Adjust_subgoal + cal_force + state_PathPlan + replay write)",
                         "achieved": algo * env.N / (k_use * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo * env.N / (k_use * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": prof.get("k_step_traffic_bytes_per_launch"),
-                        "traffic_stale": prof.get("stale"),
+                        "traffic_stale": prof.get("stale"), "measured_copy_GBs": copy_gbs,
+                        **physical_view(algo, moved, env.N, k_use, prof.get("k_step_traffic_bytes_per_launch"), copy_gbs),
                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": env.N, "kernel_ms": k_use,
                         "kernel_ms_back_to_back": k_ms, "kernel_ms_rocprofv3_committed": k_prof}}
     if multi:
         out["exchange"] = exchange_used
         out["ranks_bit_identical"] = ident
+        out["links_crossed"], out["rank_devices"] = len(set(rank_devs)) > 1, rank_devs     # False: every rank on one GPU, NOT row-e evidence
         out["config"]["parallelism"] = "env-shard x%d + per-phase gradient sum of all slots: %s" % (world_size, exchange_used)
     if fused:
         L0 = learners[0]
@@ -526,20 +588,20 @@ def run_child(extra, timeout=600):
 
 def other_configs(args):
     """BASELINE.json configs[2], [3], [4] (at one GPU's share) and the env-only 65 536 / 262 144-agent points, each
-    >= 50 ms of timed region, summarised for the headline line."""
+    >= 0.5 s of timed region (the two-rank SAC row: >= 0.3 s), summarised for the headline line."""
     runs = [("configs[2]", ["--config", "3", "--steps", "10", "--warmup", "3"]),
-            ("configs[3]", ["--config", "4", "--steps", "6", "--warmup", "2"]),
+            ("configs[3]", ["--config", "4", "--steps", "8", "--warmup", "2"]),
             ("configs[4] (one GPU's 32768-env share of the 8-GPU run)", ["--config", "5", "--steps", "12", "--warmup", "3"]),
-            ("configs[1] with prioritised replay (IsPriority_Replay = 1) on the fused path", ["--per", "--steps", "12", "--warmup", "3"]),
+            ("configs[1] with prioritised replay (IsPriority_Replay = 1) on the fused path", ["--per", "--steps", "8", "--warmup", "2"]),
             ("EXPERIMENT on configs[1] (not the benchmark's semantics): sample_lag = 1 -- update t samples transitions <= t - 1, "
-             "its gradient kernel on a second stream beside step t", ["--sample-lag", "1", "--steps", "20", "--warmup", "4"]),
+             "its gradient kernel on a second stream beside step t", ["--sample-lag", "1", "--steps", "12", "--warmup", "2"]),
             ("row e on ONE GPU (NOT a multi-GPU measurement): two ranks sharing this device, 16384 envs each, gradient bucket "
              "summed over HIP-IPC-mapped memory on the stream (csrc/p2p.hip), ranks started by bench.py itself",
              ["--gpus", "2", "--same-device", "--dist-backend", "gloo", "--steps", "8", "--warmup", "2"]),
             ("row e for the SAC loop on ONE GPU (NOT a multi-GPU measurement): two ranks sharing this device, 8192 envs x 4 UAVs each, "
              "every phase's gradient rows of the four slots summed over HIP-IPC-mapped memory inside uavenv_sac_loop_run",
              ["--config", "4", "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--envs", "8192", "--batch", "8192",
-              "--steps", "4", "--warmup", "1"]),
+              "--steps", "12", "--warmup", "2"]),
             ("env-only 65536 agents/launch", ["--env-only", "--envs", "65536", "--steps", "40"]),
             ("env-only 262144 agents/launch", ["--env-only", "--envs", "262144", "--steps", "20"])]
     out = []
@@ -553,7 +615,11 @@ def other_configs(args):
             row.update({"workload": "k_step alone, %d agents per launch, %s rows, random actions, auto-reset" % (d["envs"], d["obs_dtype"]),
                         "value": d["env_steps_per_s"], "unit": "env-steps/s", "timed_region_ms": d.get("timed_region_ms"),
                         "roofline": {"kernel": "k_step", "kernel_ms": d["k_step_ms_back_to_back"], "achieved": d["achieved_GBs"],
-                                     "unit": "GB/s", "frac": d["frac_of_8TBs"]}})
+                                     "unit": "GB/s", "frac": d["frac_of_8TBs"],
+                                     **{k: d.get(k) for k in ("frac_physical_stored", "frac_physical_counters", "moved_bytes_per_agent_step",
+                                                              "achieved_physical_stored_GBs", "achieved_physical_counters_GBs",
+                                                              "measured_copy_GBs", "algorithmic_exceeds_measured_copy", "traffic",
+                                                              "traffic_stale", "k_step_ms_rocprofv3_committed")}}})
         else:
             r, rl = d.get("roofline", {}), d.get("roofline_learner", {})
             row.update({"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
@@ -561,7 +627,10 @@ def other_configs(args):
                         "learner_updates_per_s": d.get("learner_updates_per_s"),
                         **{k: d[k] for k in ("n_gpus", "ranks_bit_identical", "exchange", "exchange_fallbacks", "p2p_timeouts",
                                              "p2p_checksum_mismatches", "p2p_checksums_compared", "ms_per_pass_no_exchange") if k in d},
-                        "roofline": {k: r.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "agents_per_launch")},
+                        **{k: d[k] for k in ("links_crossed", "rank_devices") if k in d},
+                        "roofline": {k: r.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "agents_per_launch",
+                                                           "frac_physical_stored", "frac_physical_counters", "moved_bytes_per_agent_step",
+                                                           "traffic", "traffic_stale", "algorithmic_exceeds_measured_copy")},
                         "roofline_learner": {k: rl.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "peak")}})
         out.append(row)
     return out
@@ -610,9 +679,17 @@ def run_dqn(args, world_size, rank, dev):
         ms = e0.elapsed_time(e1) / iters
         algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
         gbs = algo * env.N / (ms * 1e-3) / 1e9
+        stored = algo - (200 if args.obs_dtype == "f16" else 400) + ring.obs.shape[-1] * ring.obs.element_size()
+        prof = committed_profile(args, env_only=True)
+        copy_gbs = measure_copy_gbs(dev)
+        k_prof = prof.get("k_step_ms")
         out = {"mode": "env-only", "envs": env.N, "k_step_ms_back_to_back": ms, "timed_region_ms": ms * iters,
                "env_steps_per_s": env.N / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS,
-               "obs_dtype": args.obs_dtype, "replay_frames": ring.frames}
+               "obs_dtype": args.obs_dtype, "replay_frames": ring.frames, "measured_copy_GBs": copy_gbs,
+               "k_step_ms_rocprofv3_committed": k_prof, "traffic": prof.get("k_step_traffic_bytes_per_launch"),
+               "traffic_stale": prof.get("stale") if prof.get("k_step_traffic_bytes_per_launch") else None,
+               "traffic_source": prof.get("source") if prof.get("k_step_traffic_bytes_per_launch") else None,
+               **physical_view(algo, stored, env.N, max(ms, k_prof or 0.0), prof.get("k_step_traffic_bytes_per_launch"), copy_gbs)}
         env.close()
         return out
     net = "VAnet2" if args.trainer == "dueling" else "Qnet2"
@@ -653,7 +730,7 @@ def run_dqn(args, world_size, rank, dev):
     exchange["used"] = choose_exchange()
     counter = [0]
     py_events = []
-    ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "8"))
+    ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "64"))
     state = {"hot": None, "use_c": False}
 
     def build_loop():
@@ -783,10 +860,15 @@ def run_dqn(args, world_size, rank, dev):
     if multi and fused:
         st = learner.p2p_status() if exchange["used"] == "p2p" else {"code": 0, "timeouts": 0, "mismatches": 0, "checks": 0}
         gathered = [None] * world_size
-        dist.all_gather_object(gathered, (learner.weights_checksum(), st["code"], st["timeouts"], st["mismatches"], st["checks"]))
+        dist.all_gather_object(gathered, (learner.weights_checksum(), st["code"], st["timeouts"], st["mismatches"], st["checks"],
+                                          device_identity(dev)))
         allcs = [g[0] for g in gathered]
-        allst = [g[1:] for g in gathered]
-        multi_report = {"ranks_bit_identical": all(c == allcs[0] for c in allcs),
+        allst = [g[1:5] for g in gathered]
+        devs = [g[5] for g in gathered]
+        # links_crossed: False whenever every rank sits on the SAME physical GPU (--same-device) -- such a line exercises the
+        # entry point and the exchange code, it is NOT evidence for the multi-GPU row (no byte crossed xGMI)
+        multi_report = {"links_crossed": len(set(devs)) > 1, "rank_devices": devs,
+                        "ranks_bit_identical": all(c == allcs[0] for c in allcs),
                         "exchange": exchange["used"], "exchange_asked": exchange["asked"], "exchange_fallbacks": exchange["fallbacks"],
                         "p2p_error_code_max": max(int(x[0]) for x in allst), "p2p_timeouts": sum(int(x[1]) for x in allst),
                         "p2p_checksum_mismatches": sum(int(x[2]) for x in allst), "p2p_checksums_compared": int(allst[0][3]),
@@ -878,20 +960,7 @@ def run_dqn(args, world_size, rank, dev):
         g_b2b_ms = e0.elapsed_time(e1) / it
 
     # achievable HBM bandwidth on THIS device, same run: device-to-device copy of 1 GiB, read + write bytes
-    copy_gbs = None
-    if rank == 0:
-        src = torch.empty(1 << 28, device=dev, dtype=torch.float32)
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        c0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        c1.record()
-        torch.cuda.synchronize(dev)
-        copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-        del src, dst
+    copy_gbs = measure_copy_gbs(dev) if rank == 0 else None
 
     out = None
     if rank == 0:
@@ -900,8 +969,10 @@ def run_dqn(args, world_size, rank, dev):
         # algorithmic bytes are the SURVEY 8(d) figure for the observation the row stands for (f32: 604 B, f16: 404 B);
         # packed rows are a lossless image of the f32 row, so they are priced as f32 and simply move fewer bytes
         algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
-        stored = algo - (200 if args.obs_dtype == "f16" else 400) + ring.obs.shape[-1] * ring.obs.element_size()
+        row_bytes = ring.obs.shape[-1] * ring.obs.element_size()
+        stored = algo - (200 if args.obs_dtype == "f16" else 400) + row_bytes
         in_loop_policy = kp_ms is not None               # the loop's launch is k_step_coop<policy>; else act + k_step
+        moved = stored + (row_bytes + 4 if in_loop_policy else 0)      # the policy reads the current row and writes the action
         r_ms = kp_ms if in_loop_policy else k_ms
         achieved = algo * n_agents / (r_ms * 1e-3) / 1e9
         traffic = prof.get("k_step_policy_traffic_bytes_per_launch" if in_loop_policy else "k_step_traffic_bytes_per_launch")
@@ -955,6 +1026,7 @@ def run_dqn(args, world_size, rank, dev):
                          "algorithmic_bytes_per_agent_step": algo, "stored_bytes_per_agent_step": stored,
                          "agents_per_launch": n_agents,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
+                         **physical_view(algo, moved, n_agents, r_ms, traffic, copy_gbs),
                          "kernel_ms": r_ms,
                          "kernel_ms_definition": "max(back-to-back launches between one HIP event pair in this run, "
                                                  "rocprofv3 --kernel-trace average of the committed profile of this command)",
