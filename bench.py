@@ -160,6 +160,10 @@ def parse():
                    help="0 = the reference's strictly serial act -> step -> learn (the benchmark line).  1 = EXPERIMENT (a stated "
                         "deviation): update t samples the transitions stored before step t, so its gradient kernel runs on a "
                         "second stream beside step t (csrc/loop.hip)")
+    p.add_argument("--replan-every", type=int, default=0,
+                   help="rolling refresh of the reset bank (the reference plans a fresh path at every reset): every that many passes "
+                        "the C loop commits the slice planned in the background and starts the next one (0 = the bank stays as planned)")
+    p.add_argument("--replan-count", type=int, default=256, help="bank rows per refresh slice")
     p.add_argument("--inject-p2p-fault", type=int, default=-1,
                    help="test: rank R raises the peer exchange's sticky error before the timed region (exercises the fallback)")
     p.add_argument("--p2p-check-every", type=int, default=256, help="N > 1: on-device weight checksum compare every that many updates")
@@ -746,7 +750,8 @@ def run_dqn(args, world_size, rank, dev):
                 from dqn_based_uav_3d_path_planer_amd.replay import DevicePER
                 state["per"] = DevicePER(ring.frames * env.N, device=dev, tree_order=False)
             state["hot"] = HotLoop(ring, learner, args.batch, seed, eps=args.eps, counter=counter[0], time_every=ev_every,
-                                   sample_lag=args.sample_lag, per=state.get("per"))
+                                   sample_lag=args.sample_lag, per=state.get("per"),
+                                   replan_every=args.replan_every, replan_count=args.replan_count)
 
     build_loop()
 
@@ -962,6 +967,29 @@ def run_dqn(args, world_size, rank, dev):
     # achievable HBM bandwidth on THIS device, same run: device-to-device copy of 1 GiB, read + write bytes
     copy_gbs = measure_copy_gbs(dev) if rank == 0 else None
 
+    # ---- resets: how many the loop consumes (the fraction of agent-steps that end an episode, counted on 64 extra steps with
+    # the agent_done plane read back) against what the planner delivers (the start-up bank: measured above as t_plan; the
+    # rolling refresh: rows committed during this run)
+    p_reset = None
+    if rank == 0:
+        o_ = env.alloc_out()
+        o_.obs = None
+        tot = 0
+        for _ in range(64):
+            env.step(ring.action[0], o_, auto_reset=True)
+            tot += int(o_.agent_done.sum())
+        p_reset = tot / (64.0 * env.N)
+    refresh = env.replan_stats() if (rank == 0 and args.replan_every > 0) else None
+    planner_rows_per_s = None
+    if rank == 0:                      # the planner by itself (csrc/rrt.hip, the two LDS tiers): 16 384 fresh scenarios
+        env.rrt_plan(1024, seed=991)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        env.rrt_plan(16384, seed=992)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        planner_rows_per_s = 16384 / (e0.elapsed_time(e1) * 1e-3)
+
     out = None
     if rank == 0:
         n_agents = env.N
@@ -1012,6 +1040,18 @@ def run_dqn(args, world_size, rank, dev):
                        "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
                                       % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
+                       "resets": {"consumed_per_s": None if p_reset is None else value / world_size * p_reset,
+                                  "episode_end_fraction_of_agent_steps": p_reset,
+                                  "planner_rows_per_s": planner_rows_per_s,
+                                  "refresh": None if refresh is None else dict(
+                                      refresh, every_passes=args.replan_every, rows_per_slice=args.replan_count,
+                                      rows_committed_per_s=refresh["rows_committed"] / (dt * (args.steps + max(args.warmup, 1)) / args.steps)),
+                                  "note": "the reference plans a fresh RRT path at every reset (Agents/UAV.py:327-366); here resets draw "
+                                          "from a bank of %d scenarios planned on the GPU at start-up%s" % (
+                                              max(args.envs, 4096),
+                                              ", turned over in the background by the loop (uavenv_replan_*): the shortfall is "
+                                              "consumed_per_s - rows_committed_per_s" if refresh is not None else
+                                              " and reused for the whole run (--replan-every N turns it over in the background)")},
                        "epsilon": args.eps, "parallelism": par,
                        "sample_lag": args.sample_lag,
                        "replay": ("prioritised (ReplayTree semantics, alpha 0.6, beta 0.4 + 0.001 per update, epsilon 0.01, clip 1) -- "

@@ -20,22 +20,23 @@ OBS_F32, OBS_F16, OBS_PACKED = 0, 1, 2
 PACKED_DWORDS = 20
 MFMA_F32, MFMA_F16 = 0, 1
 P2P_HANDLE_BYTES = 64
+P2P_CHECK_MAX_BLOCKS = 40
 STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE, STEP_APF_LANE = 1, 2, 4, 8, 16
 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
-    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
+    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_replan_begin", "uavenv_replan_ready", "uavenv_replan_commit", "uavenv_replan_stats", "uavenv_bank_read", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs", "uavenv_geometry",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
-    "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_error_word", "uavenv_p2p_inject_fault", "uavenv_p2p_can_reach",
+    "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_error_word", "uavenv_p2p_check_blocks", "uavenv_p2p_inject_fault", "uavenv_p2p_can_reach",
     "uavenv_coll_last_error", "uavenv_coll_unique_id", "uavenv_coll_create", "uavenv_coll_destroy", "uavenv_coll_allreduce_sum",
     "uavenv_dqn_reduce_p2p", "uavenv_dqn_adam_p2p",
     "uavenv_loop_create", "uavenv_loop_destroy", "uavenv_loop_set_eps", "uavenv_loop_run", "uavenv_loop_get", "uavenv_loop_get_per", "uavenv_loop_step_times",
     "uavenv_randn", "uavenv_sac_loop_noise_floats", "uavenv_sac_loop_create", "uavenv_sac_loop_destroy", "uavenv_sac_loop_run",
-    "uavenv_sac_loop_get", "uavenv_sac_act_multi", "uavenv_sac_critic_grad_multi", "uavenv_sac_actor_grad_multi",
+    "uavenv_sac_loop_get", "uavenv_sac_loop_get_per", "uavenv_per_fill_frame_strided", "uavenv_sac_act_multi", "uavenv_sac_critic_grad_multi", "uavenv_sac_actor_grad_multi",
     "uavenv_sac_critic_adam_multi", "uavenv_sac_actor_adam_multi",
     "uavenv_per_num_chunks", "uavenv_per_rotation", "uavenv_per_rebuild", "uavenv_per_sample", "uavenv_per_set", "uavenv_per_fill", "uavenv_per_set_f32", "uavenv_per_weights", "uavenv_per_fill_frame", "uavenv_per_rebuild_frame", "uavenv_p2p_allreduce", "uavenv_sac_partial_rows_n",
     "uavenv_sac_act", "uavenv_sac_reduce", "uavenv_sac_partial_rows", "uavenv_sac_last_error", "uavenv_sac_set_debug_buffer", "uavenv_sac_critic_grad", "uavenv_sac_critic_adam", "uavenv_sac_actor_grad",
@@ -85,7 +86,8 @@ class UavLoopConfig(C.Structure):
                 ("per", UavPer), ("per_alpha", C.c_double), ("per_beta", C.c_double), ("per_beta_inc", C.c_double),
                 ("per_eps", C.c_double), ("per_clip", C.c_double),
                 ("per_slots_dev", C.c_void_p), ("per_prio_dev", C.c_void_p), ("per_w_dev", C.c_void_p),
-                ("per_abs_dev", C.c_void_p), ("per_idx_dev", C.c_void_p)]
+                ("per_abs_dev", C.c_void_p), ("per_idx_dev", C.c_void_p),
+                ("replan_every", C.c_int32), ("replan_count", C.c_int32), ("replan_max_iter", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class UavLoopCursor(C.Structure):
@@ -120,7 +122,9 @@ class UavSacLoopSlot(C.Structure):
     _fields_ = [("nets", UavSacNets), ("m_actor", C.c_void_p), ("v_actor", C.c_void_p), ("alpha_mv", C.c_void_p),
                 ("m1", C.c_void_p), ("v1", C.c_void_p), ("m2", C.c_void_p), ("v2", C.c_void_p), ("scalars", C.c_void_p),
                 ("partials_critic", C.c_void_p), ("partials_actor", C.c_void_p),
-                ("epoch", C.c_int32), ("adam_steps", C.c_int32)]
+                ("epoch", C.c_int32), ("adam_steps", C.c_int32),
+                ("per", UavPer), ("per_slots_dev", C.c_void_p), ("per_prio_dev", C.c_void_p), ("per_w_dev", C.c_void_p),
+                ("per_abs_dev", C.c_void_p), ("per_beta", C.c_double)]
 
 
 class UavSacLoopConfig(C.Structure):
@@ -132,7 +136,9 @@ class UavSacLoopConfig(C.Structure):
                 ("critic_lr", C.c_float), ("alpha_lr", C.c_float), ("target_entropy", C.c_float), ("reserved1", C.c_float),
                 ("step_flags", C.c_uint32), ("reserved2", C.c_uint32),
                 ("draws_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("slot", UavSacLoopSlot * SAC_LOOP_MAX_SLOTS),
-                ("p2p", C.c_void_p), ("coll", C.c_void_p), ("xbuf_dev", C.c_void_p)]
+                ("p2p", C.c_void_p), ("coll", C.c_void_p), ("xbuf_dev", C.c_void_p),
+                ("per_alpha", C.c_double), ("per_beta_inc", C.c_double), ("per_eps", C.c_double), ("per_clip", C.c_double),
+                ("check_every", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class UavSacLoopCursor(C.Structure):
@@ -178,6 +184,16 @@ def load() -> C.CDLL:
     lib.uavenv_plan_scenarios.argtypes = [vp, i32, u64, i32, vp]
     lib.uavenv_bank_stats.restype = C.c_int
     lib.uavenv_bank_stats.argtypes = [vp, vp, vp]
+    lib.uavenv_replan_begin.restype = C.c_int
+    lib.uavenv_replan_begin.argtypes = [vp, i32, i32, u64, i32, vp]
+    lib.uavenv_replan_ready.restype = C.c_int
+    lib.uavenv_replan_ready.argtypes = [vp]
+    lib.uavenv_replan_commit.restype = C.c_int
+    lib.uavenv_replan_commit.argtypes = [vp, vp]
+    lib.uavenv_replan_stats.restype = C.c_int
+    lib.uavenv_replan_stats.argtypes = [vp, vp]
+    lib.uavenv_bank_read.restype = C.c_int
+    lib.uavenv_bank_read.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.uavenv_rrt_plan.restype = C.c_int
     lib.uavenv_rrt_plan.argtypes = [vp, i32, vp, vp, i32, u64, i32, C.c_double, C.c_double, vp, vp, vp, vp, vp]
     lib.uavenv_reset_all.restype = C.c_int
@@ -331,8 +347,14 @@ def load() -> C.CDLL:
     lib.uavenv_loop_get_per.argtypes = [vp, C.POINTER(C.c_double)]
     lib.uavenv_per_fill.restype = C.c_int
     lib.uavenv_per_fill.argtypes = [per, i64, i64, f64, vp, vp]
+    lib.uavenv_p2p_check_blocks.restype = C.c_int
+    lib.uavenv_p2p_check_blocks.argtypes = [vp, vp, vp, i32, vp]
     lib.uavenv_p2p_error_word.restype = C.c_void_p
     lib.uavenv_p2p_error_word.argtypes = [vp]
+    lib.uavenv_sac_loop_get_per.restype = C.c_int
+    lib.uavenv_sac_loop_get_per.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.uavenv_per_fill_frame_strided.restype = C.c_int
+    lib.uavenv_per_fill_frame_strided.argtypes = [per, i64, i64, f64, vp, i64, i64, vp]
     lib.uavenv_fed_aggregate.restype = C.c_int
     lib.uavenv_fed_aggregate.argtypes = [vp, i32, i32, f32, vp]
     if lib.uavenv_abi_version() != ABI_VERSION:

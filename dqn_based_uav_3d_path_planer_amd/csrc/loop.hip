@@ -33,7 +33,33 @@ struct UavLoop {
     hipEvent_t ev_grad = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev;      // pairs (start, stop), recorded so far
     std::vector<hipEvent_t> pool;    // idle events
+    // rolling refresh of the reset bank: the planner runs on a low-priority stream beside the passes
+    hipStream_t plan = nullptr;
+    int32_t replan_next = 0, bank_m = 0;
+    uint64_t replan_gen = 0;
 };
+
+// Every replan_every passes: hand over the slice whose planning has finished (on the passes' stream: no reset runs meanwhile),
+// then start planning the next slice.  A slice still being planned is left alone until the next visit.
+static int replan_tick(UavLoop *l, hipStream_t s)
+{
+    const UavLoopConfig &c = l->c;
+    const int ready = uavenv_replan_ready(c.env);
+    if (ready == 0) return UAVENV_OK;
+    if (ready < -1) return ready;
+    if (ready == 1) {
+        const int rc = uavenv_replan_commit(c.env, s);
+        if (rc != UAVENV_OK) return rc;
+    }
+    int32_t count = c.replan_count < l->bank_m ? c.replan_count : l->bank_m;
+    if (l->replan_next + count > l->bank_m) l->replan_next = 0;
+    l->replan_gen += 1;
+    const int rc = uavenv_replan_begin(c.env, l->replan_next, count, c.seed * 0x9E3779B97F4A7C15ull + l->replan_gen,
+                                       c.replan_max_iter > 0 ? c.replan_max_iter : 10000, l->plan);
+    if (rc != UAVENV_OK) return rc;
+    l->replan_next += count;
+    return UAVENV_OK;
+}
 
 extern "C" {
 
@@ -74,6 +100,14 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
             return UAVENV_EHIP;
         }
     }
+    if (cfg->replan_every > 0) {
+        int32_t m = 0;
+        int lo = 0, hi = 0;
+        if (cfg->replan_count <= 0 || uavenv_bank_stats(cfg->env, &m, nullptr) != UAVENV_OK || m <= 0) { uavenv_loop_destroy(l); return UAVENV_EINVAL; }
+        l->bank_m = m;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = the numerically largest value = the LOWEST priority
+        if (hipStreamCreateWithPriority(&l->plan, hipStreamNonBlocking, lo) != hipSuccess) { uavenv_loop_destroy(l); return UAVENV_EHIP; }
+    }
     l->fuse_act = getenv("UAVENV_NO_FUSED_ACT") == nullptr;
     l->prof = getenv("UAVENV_LOOP_PROFILE") != nullptr;
     l->obs_row_bytes = (size_t)cfg->ring.n_agents * (cfg->ring.obs_dtype == UAVENV_OBS_PACKED ? UAVENV_OBS_PACKED_DWORDS * 4
@@ -91,6 +125,10 @@ int uavenv_loop_destroy(UavLoop *l)
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : l->pool) (void)hipEventDestroy(e);
     if (l->aux) { (void)hipStreamSynchronize(l->aux); (void)hipStreamDestroy(l->aux); }
+    if (l->plan) {                   // a slice still in flight is finished and dropped with the env's next begin / destroy
+        (void)hipStreamSynchronize(l->plan);
+        (void)hipStreamDestroy(l->plan);
+    }
     for (hipEvent_t e : {l->ev_grad, l->ev_join}) if (e) (void)hipEventDestroy(e);
     delete l;
     return UAVENV_OK;
@@ -147,6 +185,10 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
     const bool lag = l->aux != nullptr;
     for (int k = 0; k < n_steps; ++k) {
         const int t = l->head, nxt = t + 1 == R.frames ? 0 : t + 1;
+        if (l->plan && l->counter % (uint64_t)c.replan_every == 0) {
+            const int rr = replan_tick(l, s);
+            if (rr != UAVENV_OK) return rr;
+        }
         bool lag_update = false;
         if (lag && c.batch > 0 && l->filled > 0 &&
             (int64_t)l->filled * (int64_t)n >= (int64_t)(c.learn_start > c.batch ? c.learn_start : c.batch)) {
@@ -337,6 +379,8 @@ struct UavSacLoop {
     int32_t epoch[UAVENV_SAC_LOOP_MAX_SLOTS], adam_steps[UAVENV_SAC_LOOP_MAX_SLOTS];
     uint64_t counter;
     size_t obs_row_bytes;
+    bool per = false;                          // prioritised replay: every slot carries a UavPer
+    double per_beta[UAVENV_SAC_LOOP_MAX_SLOTS];
 };
 
 extern "C" {
@@ -374,9 +418,23 @@ int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out)
             return UAVENV_EINVAL;
     }
     if ((cfg->p2p || cfg->coll) && (!cfg->xbuf_dev || (((uintptr_t)cfg->xbuf_dev) & 15u) != 0)) return UAVENV_EINVAL;
+    int n_per = 0;
+    for (int j = 0; j < cfg->n_slots; ++j) {
+        const UavSacLoopSlot &sl = cfg->slot[j];
+        if (!sl.per.prio) continue;
+        n_per += 1;
+        const int64_t envs = cfg->ring.n_agents / cfg->n_slots;
+        if (sl.per.capacity != (int64_t)cfg->ring.frames * envs || sl.per.rot != 0 || !sl.per_slots_dev || !sl.per_prio_dev || !sl.per_w_dev ||
+            !sl.per_abs_dev)
+            return UAVENV_EINVAL;
+    }
+    if (n_per != 0 && n_per != cfg->n_slots) return UAVENV_EINVAL;          // one Trainer.xml: all slots or none
+    if (n_per && (cfg->p2p || cfg->coll)) return UAVENV_EINVAL;             // (prioritised replay is a one-GPU path here)
     UavSacLoop *l = new (std::nothrow) UavSacLoop();
     if (!l) return UAVENV_ENOMEM;
     l->c = *cfg;
+    l->per = n_per != 0;
+    for (int j = 0; j < UAVENV_SAC_LOOP_MAX_SLOTS; ++j) l->per_beta[j] = j < cfg->n_slots ? cfg->slot[j].per_beta : 0.0;
     l->head = cfg->head;
     l->filled = cfg->filled;
     l->counter = cfg->counter;
@@ -389,6 +447,13 @@ int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out)
 int uavenv_sac_loop_destroy(UavSacLoop *l)
 {
     delete l;
+    return UAVENV_OK;
+}
+
+int uavenv_sac_loop_get_per(const UavSacLoop *l, double *beta_out)
+{
+    if (!l || !beta_out) return UAVENV_EINVAL;
+    for (int j = 0; j < l->c.n_slots; ++j) beta_out[j] = l->per_beta[j];
     return UAVENV_OK;
 }
 
@@ -441,9 +506,17 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         if (rc != UAVENV_OK) return rc;
         l->head = nxt;
         if (l->filled < R.frames - 1) l->filled += 1;
+        if (l->per) {                     // ReplayTree.push(error 0) for every slot's rows of the frame just written (its column of
+            const double per_new = pow(0.0 + c.per_eps, c.per_alpha);          // the valid plane); the new head's rows are retired
+            for (int j = 0; j < U; ++j) {
+                rc = uavenv_per_fill_frame_strided(&c.slot[j].per, (int64_t)t * envs, envs, per_new, R.valid + (size_t)t * n + j, U,
+                                                   (int64_t)nxt * envs, s);
+                if (rc != UAVENV_OK) return rc;
+            }
+        }
         const bool learn = c.is_train && (int64_t)l->filled * envs > (int64_t)B;            // :383-385
         bool one_draw = false;
-        if (learn && (int64_t)l->filled * envs >= nb) {
+        if (!l->per && learn && (int64_t)l->filled * envs >= nb) {
             rc = uavenv_replay_draw(R.frames, envs, l->head, l->filled, (int32_t)nb, c.seed + 7, l->counter, c.draws_dev, s);
             if (rc != UAVENV_OK) return rc;
             one_draw = true;
@@ -459,7 +532,16 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         for (int j = 0; j < U; ++j) {
             const UavSacLoopSlot &sl = c.slot[j];
             int32_t *draws = c.draws_dev + (size_t)j * B * 2;
-            if (!one_draw) {          // the ring does not hold U x B transitions yet: one draw per slot
+            if (l->per) {             // ReplayTree.sample (:146-180): beta first (:155), selection, importance weights + (frame, env)
+                l->per_beta[j] = l->per_beta[j] + c.per_beta_inc < 1.0 ? l->per_beta[j] + c.per_beta_inc : 1.0;
+                rc = uavenv_per_rebuild(&sl.per, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_per_sample(&sl.per, B, nullptr, c.seed + 7 + (uint64_t)j, l->counter, sl.per_slots_dev, sl.per_prio_dev, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_per_weights(&sl.per, sl.per_slots_dev, sl.per_prio_dev, B, (int64_t)l->filled * envs, l->per_beta[j], envs,
+                                        sl.per_w_dev, draws, s);
+                if (rc != UAVENV_OK) return rc;
+            } else if (!one_draw) {   // the ring does not hold U x B transitions yet: one draw per slot
                 rc = uavenv_replay_draw(R.frames, envs, l->head, l->filled, B, c.seed + 7 + (uint64_t)j, l->counter, draws, s);
                 if (rc != UAVENV_OK) return rc;
             }
@@ -471,6 +553,7 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             b.n_agents = R.n_agents; b.uav_per_env = U; b.slot = j; b.frames = R.frames;
             b.act0 = act0; b.act1 = c.act1_plane; b.reward = R.reward; b.done = R.done; b.valid = R.valid;
             b.batch = B;
+            if (l->per) { b.is_weights = sl.per_w_dev; b.abs_td_out = sl.per_abs_dev; }
             b.eps = zl + ((size_t)j * B) * 2;                             // rsample() of calc_target; the actor phase's below
             bt[j] = b;
             nets[j] = sl.nets;
@@ -527,6 +610,26 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         rc = uavenv_sac_actor_adam_multi(nets, pa, multi ? 1 : rows, B, ma, va, amv, ha, c.alpha_lr, c.target_entropy, sc_a, U, s);
         if (rc != UAVENV_OK) return rc;
         if (rc_x == UAVENV_EP2P) return rc_x;
+        if (c.p2p && c.check_every > 0 && l->adam_steps[0] % c.check_every == 0) {
+            // the ranks apply bit-identical updates by construction: every check_every updates the parameter blocks of all slots
+            // (actor, both critics, both targets) are hashed and compared across the ranks on the device (csrc/p2p.hip)
+            const float *blk[UAVENV_P2P_CHECK_MAX_BLOCKS];
+            int32_t nf[UAVENV_P2P_CHECK_MAX_BLOCKS];
+            int nb_ = 0;
+            for (int j = 0; j < U; ++j) {
+                const UavSacNets &nn = c.slot[j].nets;
+                const float *ps[5] = {nn.actor, nn.critic1, nn.critic2, nn.target1, nn.target2};
+                for (int q = 0; q < 5; ++q) { blk[nb_] = ps[q]; nf[nb_] = q == 0 ? UAVENV_SAC_ACTOR_PARAMS : UAVENV_SAC_CRITIC_PARAMS; ++nb_; }
+            }
+            rc = uavenv_p2p_check_blocks(c.p2p, blk, nf, nb_, s);
+            if (rc != UAVENV_OK) return rc;
+        }
+        if (l->per) {                     // ReplayTree.batch_update (:215-222, :352) with the |TD| the critic phase left
+            for (int j = 0; j < U; ++j) {
+                rc = uavenv_per_set_f32(&c.slot[j].per, c.slot[j].per_slots_dev, c.slot[j].per_abs_dev, B, c.per_eps, c.per_alpha, c.per_clip, s);
+                if (rc != UAVENV_OK) return rc;
+            }
+        }
     }
     return UAVENV_OK;
 }

@@ -44,6 +44,7 @@ struct UavP2P {
     bool opened[kMaxWorld] = {false};
     unsigned long long *wsum = nullptr;               // [2] weight checksums (device memory), by parity of the check index
     uint32_t *errors = nullptr;                       // device: [0] timeouts, [1] sticky error code, [2] checksum mismatches
+    float *check_buf = nullptr;                       // device: four floats (16-byte aligned): the words uavenv_p2p_check_blocks pushes
     volatile uint32_t *host_code = nullptr;           // host-mapped copy of the sticky code (polled without synchronising)
     uint32_t *host_code_dev = nullptr;                // its device address
     uint32_t seq = 0;
@@ -313,6 +314,54 @@ __global__ void __launch_bounds__(256) k_p2p_pull_sum(P2PDev d, float *__restric
     }
 }
 
+// ---- weight checksums for the generic exchange (the SAC learners: their buckets are plain gradient rows with no room for the
+// DQN bucket's checksum words).  Every rank hashes the bit patterns of its parameter blocks (k_p2p_hash_blocks: 64-bit, order
+// independent, position mixed in), pushes the two words to every rank and compares the `world` pairs on the device -- the
+// compare is p2p_wait_once's, so a difference raises the same sticky error (UAVENV_P2P_ERR_DIVERGED) through the same words.
+struct HashBlocks {
+    const float *block[UAVENV_P2P_CHECK_MAX_BLOCKS];
+    int32_t n_floats[UAVENV_P2P_CHECK_MAX_BLOCKS];
+    int32_t n_blocks;
+};
+
+__global__ void __launch_bounds__(256) k_p2p_hash_blocks(HashBlocks h, unsigned long long *acc)
+{
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0ull;
+    __syncthreads();
+    const int b = (int)blockIdx.y;
+    unsigned long long mine = 0ull;
+    for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < h.n_floats[b]; p += (int)(gridDim.x * blockDim.x)) {
+        unsigned long long x = ((unsigned long long)__float_as_uint(h.block[b][p]) << 20) ^
+                               ((unsigned long long)(p + 1) + ((unsigned long long)(b + 1) << 40)) * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        mine += x;
+    }
+    atomicAdd(&s_sum, mine);                     // LDS
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) __hip_atomic_fetch_add(acc, s_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// acc -> four floats holding its two words as bit patterns (what k_p2p_push sends), acc <- 0 for the next check
+__global__ void k_p2p_hash_words(unsigned long long *acc, float *buf4)
+{
+    const unsigned long long w = *acc;
+    buf4[0] = __uint_as_float((uint32_t)w);
+    buf4[1] = __uint_as_float((uint32_t)(w >> 32));
+    buf4[2] = 0.0f; buf4[3] = 0.0f;
+    *acc = 0ull;
+}
+
+__global__ void __launch_bounds__(64) k_p2p_pull_check(P2PDev d)
+{
+    unsigned char *mine = d.peer[d.rank];
+    if (blockIdx.x == 0 && (int)threadIdx.x < d.world) {     // behind k_p2p_push on the stream
+        __threadfence_system();
+        __hip_atomic_store(flag_of(d.peer[threadIdx.x], d.rank), d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) (void)p2p_wait_once(d, mine, 0);    // words 0 / 1 of every rank's slot must agree
+}
+
 P2PDev dev_view(const UavP2P *c, int carry, int fold)
 {
     P2PDev d;
@@ -337,10 +386,11 @@ int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P
     c->bytes = kFlagBytes + (size_t)world * 2 * c->bucket_pad * sizeof(float);
     // uncached: peers write it while this device reads it inside running kernels
     if (hipExtMallocWithFlags((void **)&c->local, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return UAVENV_ENOMEM; }
-    if (hipMalloc((void **)&c->wsum, 2 * sizeof(unsigned long long) + 4 * sizeof(uint32_t)) != hipSuccess) {
+    if (hipMalloc((void **)&c->wsum, 2 * sizeof(unsigned long long) + 4 * sizeof(uint32_t) + 4 * sizeof(float)) != hipSuccess) {
         (void)hipFree(c->local); delete c; return UAVENV_ENOMEM;
     }
     c->errors = reinterpret_cast<uint32_t *>(c->wsum + 2);
+    c->check_buf = reinterpret_cast<float *>(c->errors + 4);          // (byte offset 32 of a hipMalloc block: 16-byte aligned)
     // the sticky error code also lands in host-mapped memory: the host polls it without synchronising
     if (hipHostMalloc((void **)&c->host_code, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->host_code_dev, (void *)c->host_code, 0) != hipSuccess) {
@@ -349,7 +399,7 @@ int uavenv_p2p_create(int32_t world, int32_t rank, int32_t bucket_floats, UavP2P
     }
     *c->host_code = 0;
     (void)hipMemset(c->local, 0, c->bytes);
-    (void)hipMemset(c->wsum, 0, 2 * sizeof(unsigned long long) + 4 * sizeof(uint32_t));
+    (void)hipMemset(c->wsum, 0, 2 * sizeof(unsigned long long) + 4 * sizeof(uint32_t) + 4 * sizeof(float));
     (void)hipDeviceSynchronize();
     c->peer[rank] = c->local;
     c->connected = world == 1;
@@ -490,6 +540,37 @@ int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *c, float lr, float beta1, 
         c->pending_idx = fold_idx;
         c->n_checks += 1;
     }
+    return *c->host_code ? UAVENV_EP2P : UAVENV_OK;
+}
+
+int uavenv_p2p_check_blocks(UavP2P *c, const float *const *blocks_dev, const int32_t *n_floats, int32_t n_blocks, void *stream)
+{
+    if (!c || !c->connected || !blocks_dev || !n_floats || n_blocks <= 0 || n_blocks > UAVENV_P2P_CHECK_MAX_BLOCKS) return UAVENV_EINVAL;
+    if (*c->host_code) return UAVENV_EP2P;
+    HashBlocks h;
+    int most = 0;
+    for (int b = 0; b < UAVENV_P2P_CHECK_MAX_BLOCKS; ++b) { h.block[b] = nullptr; h.n_floats[b] = 0; }
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!blocks_dev[b] || n_floats[b] <= 0) return UAVENV_EINVAL;
+        h.block[b] = blocks_dev[b]; h.n_floats[b] = n_floats[b];
+        most = n_floats[b] > most ? n_floats[b] : most;
+    }
+    h.n_blocks = n_blocks;
+    hipStream_t s = (hipStream_t)stream;
+    // wsum[0] is the accumulator (the DQN path's fold / carry pair is not used on a generic exchange: check_every = 0 there);
+    // the four floats to push live behind the error words
+    float *buf4 = reinterpret_cast<float *>(c->check_buf);
+    int gx = (most + 256 * 8 - 1) / (256 * 8);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(k_p2p_hash_blocks, dim3(gx, n_blocks), dim3(256), 0, s, h, c->wsum);
+    hipLaunchKernelGGL(k_p2p_hash_words, dim3(1), dim3(1), 0, s, c->wsum, buf4);
+    if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
+    c->seq += 1;
+    hipLaunchKernelGGL(k_p2p_push, dim3(1), dim3(256), 0, s, buf4, 1, dev_view(c, -1, -1));
+    if (hipGetLastError() != hipSuccess) { c->seq -= 1; return UAVENV_EHIP; }
+    hipLaunchKernelGGL(k_p2p_pull_check, dim3(1), dim3(64), 0, s, dev_view(c, 0, -1));      // carry >= 0: compare the pairs
+    if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
+    c->n_checks += 1;
     return *c->host_code ? UAVENV_EP2P : UAVENV_OK;
 }
 

@@ -324,10 +324,11 @@ __global__ void k_per_fill(UavPer p, int64_t first, int64_t count, double value,
 }
 
 // the two fills of a replay step in one launch: [first, first + count) as k_per_fill, [zero_first, zero_first + count) <- 0
-__global__ void k_per_fill2(UavPer p, int64_t first, int64_t count, double value, const uint8_t *__restrict__ valid, int64_t zero_first)
+__global__ void k_per_fill2(UavPer p, int64_t first, int64_t count, double value, const uint8_t *__restrict__ valid, int64_t zero_first,
+                            int64_t valid_stride)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) p.prio[first + i] = (!valid || valid[i]) ? value : 0.0;
+    if (i < count) p.prio[first + i] = (!valid || valid[i * valid_stride]) ? value : 0.0;
     else if (i < 2 * count) p.prio[zero_first + (i - count)] = 0.0;
 }
 
@@ -394,7 +395,19 @@ int uavenv_per_fill_frame(const UavPer *p, int64_t first, int64_t count, double 
         return UAVENV_EINVAL;
     if (count == 0) return UAVENV_OK;
     hipLaunchKernelGGL(k_per_fill2, dim3((unsigned)((2 * count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, first, count,
-                       priority, valid_dev, retire_first);
+                       priority, valid_dev, retire_first, (int64_t)1);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_per_fill_frame_strided(const UavPer *p, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
+                                  int64_t valid_stride, int64_t retire_first, void *stream)
+{
+    if (!per_ok(p) || first < 0 || retire_first < 0 || count < 0 || first + count > p->capacity || retire_first + count > p->capacity ||
+        valid_stride < 1)
+        return UAVENV_EINVAL;
+    if (count == 0) return UAVENV_OK;
+    hipLaunchKernelGGL(k_per_fill2, dim3((unsigned)((2 * count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, first, count,
+                       priority, valid_dev, retire_first, valid_stride);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

@@ -10,10 +10,20 @@
 //   rewire           lanes test "d < step" for 64 nodes at a time, the surviving candidates are then visited in list
 //                    order (the reference's sequential cost update).
 // Thousands of scenarios plan concurrently (one per wavefront), which is what feeds the auto-reset of the env kernels
-// without a host-side bank.  Random numbers: a counter-based Philox stream per scenario, or -- for parity tests against
+// without a host-side bank.
+//
+// Residency (round 4).  The node list lives in LDS.  Round 3 reserved 2 048 nodes (74 KB) per wavefront: ONE wavefront per CU,
+// 256 plans in flight on the whole chip, every LDS / f64 latency of the sequential iteration exposed -- 29 ms for 16 384
+// plans.  But the reference's trees are small (measured on 1 500 resets: iterations mean 118, median 84, p99 509, max 2 917;
+// nodes <= iterations), so the launch is now TWO TIERS: tier A plans every scenario with room for kTierANodes nodes (21 KB of
+// LDS with the world: seven wavefronts per CU); a scenario whose tree outgrows that is appended to a list and re-planned
+// from scratch -- same stream of draws, so the same result -- by tier B with the full 2 048-node list.  Scenarios are
+// handed out through an atomic counter (the iteration counts spread over two orders of magnitude: a static split left most
+// wavefronts idle behind the longest plan).  Random numbers: a counter-based Philox stream per scenario, or -- for parity tests against
 // the CPU oracle -- an explicit U[0,1) stream per scenario.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/uavenv.h"
 #include "uavenv_device.hpp"
@@ -37,7 +47,16 @@ struct RrtArgs {
     double *out_sub;                 // [m][K][3]
     int32_t *out_nsub;               // [m]  (<0: -needed when the path does not fit K; 1: planner gave up -> [goal])
     int32_t *out_iters;              // nullable [m]
+    int32_t first;                   // scenario index offset of the Philox stream (row r plans scenario first + r)
+    int32_t tier_b;                  // 0: tier A (every scenario); 1: tier B (plans the `flagged` list)
+    int32_t defer;                   // tier A: a scenario whose tree outgrows max_nodes is appended to `flagged` instead of giving up
+    int32_t *queue;                  // [0] next scenario of tier A, [1] number of flagged scenarios, [2] next entry of tier B
+    int32_t *flagged;                // [m] scenarios whose tree outgrew tier A's node list
+    unsigned char *node_scratch;     // LDS-free variant: scratch_wgs x kTierBNodes x (Node + parent) bytes of global memory
+    int32_t scratch_wgs;
 };
+constexpr int kTierANodes = 320;
+constexpr int kTierBNodes = 2048;
 
 struct Node {
     double x, y, z, cost;
@@ -88,31 +107,51 @@ __device__ __forceinline__ bool obstacle_free(const WorldLds<MaskT> &w, double a
     return !hit_any;
 }
 
-template <typename MaskT>
+// IN_LDS = false: the BACKGROUND form (uavenv_replan_begin, beside a running loop): no LDS at all -- the world is read from its
+// global blob (10 KB: it lives in the L2 / vector caches) and the node list sits in global scratch -- so that its wavefronts
+// fit beside ANY resident kernel.  (The learner's gradient kernel takes 140 KB of a CU's 160 KB: a planner workgroup holding
+// 21 KB of LDS on every CU would keep those workgroups waiting for milliseconds.)  Slower per plan, invisible to the passes.
+template <typename MaskT, bool IN_LDS>
 __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = (int)threadIdx.x;
-    {   // stage the world (same blob as the env kernels)
+    WorldLds<MaskT> w;
+    Node *nodes;
+    int *parent;
+    if (IN_LDS) {   // stage the world (same blob as the env kernels)
         const uint4 *src = reinterpret_cast<const uint4 *>(a.world_blob);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (int k = lane; k < a.world_bytes / 16; k += 64) dst[k] = src[k];
+        __syncthreads();
+        w.b = reinterpret_cast<const BldLds *>(smem);
+        w.aux = reinterpret_cast<const BldAux *>(smem + a.aux_off);
+        for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(smem + a.grid_off + h * a.grid_stride);
+        const int node_off = (a.world_bytes + 15) & ~15;
+        nodes = reinterpret_cast<Node *>(smem + node_off);
+        parent = reinterpret_cast<int *>(smem + node_off + (size_t)a.max_nodes * sizeof(Node));
+    } else {
+        w.b = reinterpret_cast<const BldLds *>(a.world_blob);
+        w.aux = reinterpret_cast<const BldAux *>(a.world_blob + a.aux_off);
+        for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(a.world_blob + a.grid_off + h * a.grid_stride);
+        unsigned char *mine = a.node_scratch + (size_t)blockIdx.x * (size_t)a.max_nodes * (sizeof(Node) + sizeof(int));
+        nodes = reinterpret_cast<Node *>(mine);
+        parent = reinterpret_cast<int *>(mine + (size_t)a.max_nodes * sizeof(Node));
     }
-    __syncthreads();
-    WorldLds<MaskT> w;
-    w.b = reinterpret_cast<const BldLds *>(smem);
-    w.aux = reinterpret_cast<const BldAux *>(smem + a.aux_off);
-    for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(smem + a.grid_off + h * a.grid_stride);
     w.gn = a.gn; w.inv_cell = a.inv_cell; w.W = a.W; w.Hbox = a.Hbox;
-    const int node_off = (a.world_bytes + 15) & ~15;
-    Node *nodes = reinterpret_cast<Node *>(smem + node_off);
-    int *parent = reinterpret_cast<int *>(smem + node_off + (size_t)a.max_nodes * sizeof(Node));
 
-    for (int scn = (int)blockIdx.x; scn < a.m; scn += (int)gridDim.x) {
+    const int n_work = a.tier_b ? __hip_atomic_load(a.queue + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.m;
+    for (;;) {
+        int scn = 0;
+        if (lane == 0) scn = atomicAdd(a.queue + (a.tier_b ? 2 : 0), 1);
+        scn = __shfl(scn, 0, 64);
+        if (scn >= n_work) break;
+        if (a.tier_b) scn = a.flagged[scn];
         Stream rs;
         rs.ext = a.uniforms ? a.uniforms + (size_t)scn * a.stream_len : nullptr;
-        rs.ext_n = a.stream_len; rs.t = 0; rs.seed = a.seed; rs.scn = (uint32_t)scn; rs.attempt = 0;
+        rs.ext_n = a.stream_len; rs.t = 0; rs.seed = a.seed; rs.scn = (uint32_t)(a.first + scn); rs.attempt = 0;
         int n_path = 0, iters = 0;
+        bool overflow = false;
         double sx, sy, sz, gx, gy, gz;
         const int max_attempts = a.uniforms ? 1 : 4;
         for (int attempt = 0; attempt < max_attempts; ++attempt) {
@@ -199,6 +238,10 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
                 }
             }
             iters = it;
+            if (a.defer && goal_parent < 0 && nn >= a.max_nodes && it < a.max_iter) {    // the tree outgrew tier A's list: tier B
+                overflow = true;
+                break;
+            }
             // ---- path = [start .. new_node, goal] (RRT.py:96-103)
             int count = 1;
             for (int p = goal_parent; p >= 0; p = parent[p]) count++;
@@ -220,6 +263,11 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
             }
             __syncthreads();
         }
+        if (overflow) {
+            if (lane == 0) a.flagged[atomicAdd(a.queue + 1, 1)] = scn;
+            __syncthreads();
+            continue;
+        }
         if (lane == 0) {
             a.out_nsub[scn] = n_path <= a.K ? n_path : -n_path;
             if (a.out_iters) a.out_iters[scn] = iters;
@@ -237,12 +285,100 @@ extern "C" int uavenv__world_view(const UavEnv *env, const unsigned char **blob,
                                   int32_t *grid_off, int32_t *grid_stride, int32_t *gn, double *inv_cell, double *W, double *Hbox,
                                   double *len, int32_t *mask_bytes, int32_t *K);
 
-extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
-                               int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
-                               double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev,
-                               int32_t *out_iters_dev, void *stream)
+namespace {
+
+// queue counters + the list of tier-A overflows: device scratch of this translation unit, one per device, grown on demand
+// (no internal threads, one stream at a time per env: the contract of include/uavenv.h).  A launch pair owns it from its
+// memset to the end of tier B, both on the caller's stream; two envs planning on DIFFERENT streams at once would share it,
+// so every call takes its own region of the ring of kScratchSlots.
+constexpr int kScratchSlots = 4;
+struct RrtScratch {
+    int32_t *buf = nullptr;
+    int cap = 0;            // scenarios per slot
+    int next = 0;
+};
+RrtScratch g_scratch[16];
+
+int32_t *scratch_for(int m)
 {
-    if (!env || m <= 0 || !out_start_goal_dev || !out_sub_dev || !out_nsub_dev || max_iter <= 0 || step_size <= 0 ||
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    RrtScratch &sc = g_scratch[dev];
+    if (sc.cap < m) {
+        if (sc.buf) { (void)hipDeviceSynchronize(); (void)hipFree(sc.buf); sc.buf = nullptr; }
+        const int cap = m < 4096 ? 4096 : m;
+        if (hipMalloc((void **)&sc.buf, (size_t)kScratchSlots * (size_t)(cap + 4) * sizeof(int32_t)) != hipSuccess) { sc.cap = 0; return nullptr; }
+        sc.cap = cap;
+    }
+    int32_t *p = sc.buf + (size_t)sc.next * (size_t)(sc.cap + 4);
+    sc.next = (sc.next + 1) % kScratchSlots;
+    return p;
+}
+
+template <typename MaskT>
+int launch_tiers(RrtArgs a, hipStream_t s)
+{
+    static bool attr = false;
+    const size_t world = (size_t)((a.world_bytes + 15) & ~15);
+    const size_t lds_b = world + (size_t)kTierBNodes * (sizeof(Node) + sizeof(int));
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rrt_plan<MaskT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_b) != hipSuccess)
+            return UAVENV_EHIP;
+        attr = true;
+    }
+    static const int tier_a_nodes = [] {          // A/B knob (UAVENV_RRT_TIER_A=2048: the round-3 single tier)
+        const char *e = getenv("UAVENV_RRT_TIER_A");
+        const int v = e ? atoi(e) : 0;
+        return v >= 16 && v <= kTierBNodes ? v : kTierANodes;
+    }();
+    int32_t *scr = scratch_for(a.m);
+    if (!scr) return UAVENV_ENOMEM;
+    a.queue = scr;
+    a.flagged = scr + 4;
+    if (hipMemsetAsync(scr, 0, 4 * sizeof(int32_t), s) != hipSuccess) return UAVENV_EHIP;
+    if (a.node_scratch) {                                     // the background form: one launch, no LDS, the full node list
+        a.max_nodes = kTierBNodes;
+        a.tier_b = 0;
+        a.defer = 0;
+        const int grid = a.m < a.scratch_wgs ? a.m : a.scratch_wgs;
+        hipLaunchKernelGGL((k_rrt_plan<MaskT, false>), dim3(grid), dim3(64), 0, s, a);
+        return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+    }
+    // tier A: seven wavefronts per CU (21 KB of LDS each); more workgroups than that only queue up behind them
+    a.max_nodes = tier_a_nodes;
+    a.tier_b = 0;
+    a.defer = tier_a_nodes < kTierBNodes ? 1 : 0;            // (a full-size tier A is the round-3 single launch: nothing to defer)
+    const size_t lds_a = world + (size_t)a.max_nodes * (sizeof(Node) + sizeof(int));
+    const int per_cu = (int)(160 * 1024 / (lds_a + 512));
+    int grid_a = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+    if (grid_a > a.m) grid_a = a.m;
+    hipLaunchKernelGGL((k_rrt_plan<MaskT, true>), dim3(grid_a), dim3(64), lds_a, s, a);
+    if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
+    if (a.max_nodes < kTierBNodes) {
+        a.max_nodes = kTierBNodes;
+        a.tier_b = 1;
+        a.defer = 0;
+        const int grid_b = a.m < 256 ? a.m : 256;
+        hipLaunchKernelGGL((k_rrt_plan<MaskT, true>), dim3(grid_b), dim3(64), lds_b, s, a);
+        if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
+    }
+    return UAVENV_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t uavenv_rrt_scratch_bytes(int32_t wgs) { return (int64_t)wgs * kTierBNodes * (int64_t)(sizeof(Node) + sizeof(int)); }
+
+// node_scratch != NULL (uavenv_rrt_scratch_bytes(scratch_wgs) bytes of device memory): the LDS-free background form on
+// scratch_wgs wavefronts; NULL: the two LDS tiers.
+extern "C" int uavenv_rrt_plan_at(UavEnv *env, int32_t first, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
+                                  int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
+                                  double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev,
+                                  int32_t *out_iters_dev, void *node_scratch, int32_t scratch_wgs, void *stream)
+{
+    if (node_scratch && scratch_wgs <= 0) return UAVENV_EINVAL;
+    if (!env || m <= 0 || first < 0 || !out_start_goal_dev || !out_sub_dev || !out_nsub_dev || max_iter <= 0 || step_size <= 0 ||
         obstacle_step <= 0 || (uniforms_dev && stream_len <= 0))
         return UAVENV_EINVAL;
     RrtArgs a;
@@ -253,29 +389,26 @@ extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_
         return UAVENV_EINVAL;
     a.len = len; a.width = a.W; a.h = a.Hbox;
     a.m = m; a.max_iter = max_iter;
-    a.max_nodes = 2048;
+    a.max_nodes = kTierBNodes;
     a.step_size = step_size; a.obstacle_step = obstacle_step;
     a.start_goal_in = start_goal_dev; a.uniforms = uniforms_dev; a.stream_len = stream_len; a.seed = seed;
     a.out_start_goal = out_start_goal_dev; a.out_sub = out_sub_dev; a.out_nsub = out_nsub_dev; a.out_iters = out_iters_dev;
-    const size_t lds = (size_t)((a.world_bytes + 15) & ~15) + (size_t)a.max_nodes * (sizeof(Node) + sizeof(int));
-    const int grid = m < 4096 ? m : 4096;
+    a.first = first; a.tier_b = 0; a.defer = 0; a.queue = nullptr; a.flagged = nullptr;
+    a.node_scratch = (unsigned char *)node_scratch; a.scratch_wgs = scratch_wgs;
     hipStream_t s = (hipStream_t)stream;
-    if (mask_bytes == 4) {
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rrt_plan<uint32_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UAVENV_EHIP;
-            attr = true;
-        }
-        hipLaunchKernelGGL((k_rrt_plan<uint32_t>), dim3(grid), dim3(64), lds, s, a);
-    } else {
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rrt_plan<uint64_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return UAVENV_EHIP;
-            attr = true;
-        }
-        hipLaunchKernelGGL((k_rrt_plan<uint64_t>), dim3(grid), dim3(64), lds, s, a);
-    }
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+    return mask_bytes == 4 ? launch_tiers<uint32_t>(a, s) : launch_tiers<uint64_t>(a, s);
+}
+
+extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
+                               int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
+                               double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev,
+                               int32_t *out_iters_dev, void *stream)
+{
+    // UAVENV_RRT_BACKGROUND=<wavefronts> (tests): run the LDS-free background form here too, so that the parity tests of the
+    // planner (Mersenne replay, oracle streams) cover it
+    static const int bg_wgs = [] { const char *e = getenv("UAVENV_RRT_BACKGROUND"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 4096 ? v : 0; }();
+    static void *bg_scratch = nullptr;
+    if (bg_wgs && !bg_scratch && hipMalloc(&bg_scratch, (size_t)uavenv_rrt_scratch_bytes(bg_wgs)) != hipSuccess) return UAVENV_ENOMEM;
+    return uavenv_rrt_plan_at(env, 0, m, start_goal_dev, uniforms_dev, stream_len, seed, max_iter, step_size, obstacle_step,
+                              out_start_goal_dev, out_sub_dev, out_nsub_dev, out_iters_dev, bg_wgs ? bg_scratch : nullptr, bg_wgs, stream);
 }

@@ -34,6 +34,11 @@
 
 using namespace uav;
 
+extern "C" int uavenv_rrt_plan_at(UavEnv *env, int32_t first, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
+                                  int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
+                                  double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev,
+                                  int32_t *out_iters_dev, void *node_scratch, int32_t scratch_wgs, void *stream);
+extern "C" int64_t uavenv_rrt_scratch_bytes(int32_t wgs);
 extern "C" int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
                                int32_t stream_len, uint64_t seed, int32_t max_iter, double step_size, double obstacle_step,
                                double *out_start_goal_dev, double *out_sub_dev, int32_t *out_nsub_dev,
@@ -159,6 +164,17 @@ struct UavEnv {
     int bank_m = 0;
     uint64_t seed = 0, tick = 0;
     unsigned long long *dbg = nullptr;
+    // rolling refresh of the bank (uavenv_replan_*): staged plans of one slice + bookkeeping
+    double *rp_sg = nullptr, *rp_sub = nullptr;
+    int32_t *rp_nsub = nullptr;        // [cap] staged n_sub, then [cap] in-use flags
+    int32_t *rp_counters = nullptr;    // [4] rows committed / skipped: in use / skipped: no plan (cumulative)
+    int rp_cap = 0, rp_first = 0, rp_count = 0;
+    void *rp_nodes = nullptr;          // node lists of the background planner's wavefronts (global memory: it uses no LDS)
+    int rp_wgs = 0;
+    bool rp_pending = false;
+    hipEvent_t rp_done = nullptr;
+    int world_gen = 0, rp_world_gen = 0;
+    long long rp_calls = 0, rp_rows_planned = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1729,6 +1745,12 @@ int uavenv_destroy(UavEnv *e)
     (void)hipFree(e->bank_sg);
     (void)hipFree(e->bank_sub);
     (void)hipFree(e->bank_nsub);
+    (void)hipFree(e->rp_sg);
+    (void)hipFree(e->rp_sub);
+    (void)hipFree(e->rp_nsub);
+    (void)hipFree(e->rp_nodes);
+    (void)hipFree(e->rp_counters);
+    if (e->rp_done) (void)hipEventDestroy(e->rp_done);
     delete e;
     return UAVENV_OK;
 }
@@ -1861,6 +1883,7 @@ int uavenv_set_buildings(UavEnv *e, const double *b5, const double *v3, int32_t 
     e->gn = gn;
     e->mask_bytes = mask_bytes;
     e->have_world = true;
+    e->world_gen += 1;                 // a refresh planned for the old world is dropped at commit
     return UAVENV_OK;
 }
 
@@ -1968,6 +1991,130 @@ int uavenv_plan_scenarios(UavEnv *e, int32_t m, uint64_t seed, int32_t max_iter,
     (void)hipFree(e->bank_sg); (void)hipFree(e->bank_sub); (void)hipFree(e->bank_nsub);   // hipFree waits for the device
     e->bank_replaced = replaced;
     e->bank_sg = sg; e->bank_sub = sub; e->bank_nsub = ns; e->bank_m = m;
+    return UAVENV_OK;
+}
+
+// ---- rolling refresh of the bank ------------------------------------------------------------------------------------------
+// The reference plans a fresh path at EVERY reset (Agents/UAV.py:327-366 -> PathPlan/RRT.py:63-105); the env kernels reset
+// from a bank planned in advance.  These three calls keep the bank turning over while the loop runs: PLAN a slice of new
+// scenarios into a staging area (any stream: it touches neither the bank nor an agent, so it can run beside the step
+// kernels), then COMMIT on the step kernels' stream: a bank row of the slice takes its new plan unless an agent is flying it
+// (agents keep a scenario id and read their sub-goal list from the bank) or the new plan is unusable.
+__global__ void k_bank_mark(StepArgs a, int first, int count, int32_t *inuse)
+{
+    const DevState &S = a.st;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x) {
+        const int scn = S.I(I_SCN)[i];
+        if (scn >= first && scn < first + count) inuse[scn - first] = 1;
+    }
+}
+
+// one wavefront-sized group of threads per row: K x 3 doubles + 6 + 1
+__global__ void __launch_bounds__(256) k_bank_commit(double *bank_sg, double *bank_sub, int32_t *bank_nsub, int first, int count, int K,
+                                                     const double *sg, const double *sub, const int32_t *nsub, const int32_t *inuse,
+                                                     int32_t *counters)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int r = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (r >= count) return;
+    const int n = nsub[r];
+    const bool ok = n >= 2 && n <= K && inuse[r] == 0;
+    if (lane == 0) atomicAdd(&counters[ok ? 0 : (inuse[r] ? 1 : 2)], 1);
+    if (!ok) return;
+    const size_t row = (size_t)(first + r);
+    for (int q = lane; q < K * 3; q += 64) bank_sub[row * K * 3 + q] = sub[(size_t)r * K * 3 + q];
+    if (lane < 6) bank_sg[row * 6 + lane] = sg[(size_t)r * 6 + lane];
+    if (lane == 6) bank_nsub[row] = n;
+}
+
+int uavenv_replan_begin(UavEnv *e, int32_t first, int32_t count, uint64_t seed, int32_t max_iter, void *plan_stream)
+{
+    if (!e || first < 0 || count <= 0 || max_iter <= 0) return fail(UAVENV_EINVAL, "uavenv_replan_begin: bad argument");
+    if (!e->have_world || e->bank_m <= 0) return fail(UAVENV_EINVAL, "uavenv_replan_begin: no world / no bank to refresh");
+    if (first + count > e->bank_m) return fail(UAVENV_EINVAL, "uavenv_replan_begin: rows [%d, %d) outside the bank of %d", first, first + count, e->bank_m);
+    if (e->rp_pending) return fail(UAVENV_EINVAL, "uavenv_replan_begin: the previous slice has not been committed");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int K = e->cfg.max_subgoals;
+    if (e->rp_cap < count) {           // (first call, or a larger slice: the one place this API allocates)
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(e->rp_sg); (void)hipFree(e->rp_sub); (void)hipFree(e->rp_nsub);
+        e->rp_sg = e->rp_sub = nullptr; e->rp_nsub = nullptr; e->rp_cap = 0;
+        HIP_TRY(hipMalloc((void **)&e->rp_sg, (size_t)count * 6 * 8));
+        HIP_TRY(hipMalloc((void **)&e->rp_sub, (size_t)count * K * 3 * 8));
+        HIP_TRY(hipMalloc((void **)&e->rp_nsub, (size_t)2 * count * 4));
+        e->rp_cap = count;
+    }
+    if (!e->rp_counters) {
+        HIP_TRY(hipMalloc((void **)&e->rp_counters, 16));
+        HIP_TRY(hipMemset(e->rp_counters, 0, 16));
+    }
+    if (!e->rp_done) HIP_TRY(hipEventCreateWithFlags(&e->rp_done, hipEventDisableTiming));
+    if (!e->rp_nodes) {                // UAVENV_REPLAN_WGS: how many wavefronts plan in the background (default 128: half a wavefront per CU)
+        const char *ev = getenv("UAVENV_REPLAN_WGS");
+        const int v = ev ? atoi(ev) : 0;
+        e->rp_wgs = v > 0 && v <= 4096 ? v : 128;
+        HIP_TRY(hipMalloc(&e->rp_nodes, (size_t)uavenv_rrt_scratch_bytes(e->rp_wgs)));
+    }
+    // the Philox stream of row r is keyed by (seed, first + r): every refresh passes its own seed (generation)
+    int rc = uavenv_rrt_plan_at(e, first, count, nullptr, nullptr, 0, seed, max_iter, 30.0, 5.0, e->rp_sg, e->rp_sub, e->rp_nsub,
+                                nullptr, e->rp_nodes, e->rp_wgs, plan_stream);
+    if (rc != UAVENV_OK) return fail(rc, "uavenv_replan_begin: planner launch failed");
+    HIP_TRY(hipEventRecord(e->rp_done, (hipStream_t)plan_stream));
+    e->rp_first = first; e->rp_count = count; e->rp_pending = true; e->rp_world_gen = e->world_gen;
+    e->rp_calls += 1; e->rp_rows_planned += count;
+    return UAVENV_OK;
+}
+
+int uavenv_replan_ready(UavEnv *e)
+{
+    if (!e) return UAVENV_EINVAL;
+    if (!e->rp_pending) return -1;
+    const hipError_t q = hipEventQuery(e->rp_done);
+    if (q == hipSuccess) return 1;
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(UAVENV_EHIP, "uavenv_replan_ready: %s", hipGetErrorString(q));
+}
+
+int uavenv_replan_commit(UavEnv *e, void *stream)
+{
+    if (!e) return fail(UAVENV_EINVAL, "null env");
+    if (!e->rp_pending) return fail(UAVENV_EINVAL, "uavenv_replan_commit: nothing planned");
+    e->rp_pending = false;
+    if (e->rp_world_gen != e->world_gen || e->rp_first + e->rp_count > e->bank_m) return UAVENV_OK;   // planned for another world / bank: dropped
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipStreamWaitEvent(s, e->rp_done, 0));
+    const int cap = e->rp_cap, count = e->rp_count;
+    int32_t *inuse = e->rp_nsub + cap, *counters = e->rp_counters;
+    HIP_TRY(hipMemsetAsync(inuse, 0, (size_t)count * 4, s));
+    StepArgs a = base_args(e);
+    hipLaunchKernelGGL(k_bank_mark, dim3((e->N + 255) / 256 < 1024 ? (e->N + 255) / 256 : 1024), dim3(256), 0, s, a, e->rp_first, count, inuse);
+    hipLaunchKernelGGL(k_bank_commit, dim3((count + 3) / 4), dim3(256), 0, s, e->bank_sg, e->bank_sub, e->bank_nsub, e->rp_first, count,
+                       e->cfg.max_subgoals, e->rp_sg, e->rp_sub, e->rp_nsub, inuse, counters);
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
+int uavenv_bank_read(UavEnv *e, int32_t first, int32_t count, double *host_sg, double *host_sub, int32_t *host_nsub)
+{
+    if (!e || first < 0 || count <= 0 || first + count > e->bank_m) return fail(UAVENV_EINVAL, "uavenv_bank_read: rows outside the bank");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t K3 = (size_t)e->cfg.max_subgoals * 3;
+    if (host_sg) HIP_TRY(hipMemcpy(host_sg, e->bank_sg + (size_t)first * 6, (size_t)count * 6 * 8, hipMemcpyDeviceToHost));
+    if (host_sub) HIP_TRY(hipMemcpy(host_sub, e->bank_sub + (size_t)first * K3, (size_t)count * K3 * 8, hipMemcpyDeviceToHost));
+    if (host_nsub) HIP_TRY(hipMemcpy(host_nsub, e->bank_nsub + first, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return UAVENV_OK;
+}
+
+int uavenv_replan_stats(UavEnv *e, int64_t *out5)
+{
+    if (!e || !out5) return fail(UAVENV_EINVAL, "null argument");
+    out5[0] = e->rp_calls; out5[1] = e->rp_rows_planned; out5[2] = out5[3] = out5[4] = 0;
+    if (e->rp_counters) {
+        int32_t c[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(c, e->rp_counters, 16, hipMemcpyDeviceToHost));     // synchronises
+        out5[2] = c[0]; out5[3] = c[1]; out5[4] = c[2];
+    }
     return UAVENV_OK;
 }
 

@@ -130,6 +130,35 @@ class VecPathPlanEnv:
         _lib.check(self.lib.uavenv_bank_stats(self._h, C.byref(m), C.byref(r)), "uavenv_bank_stats")
         return m.value, r.value
 
+    # -- rolling refresh of the bank (the reference plans at every reset; include/uavenv.h: uavenv_replan_*) --------------
+    def replan_begin(self, first: int, count: int, seed: int, max_iter: int = 10000, stream: Optional[torch.cuda.Stream] = None):
+        """Plan `count` fresh scenarios for bank rows [first, first + count) in the background (no LDS: fits beside any
+        kernel); stream: where the planner runs (default: the current stream)."""
+        s = self._stream() if stream is None else stream.cuda_stream
+        _lib.check(self.lib.uavenv_replan_begin(self._h, int(first), int(count), int(seed), int(max_iter), s), "uavenv_replan_begin")
+
+    def replan_ready(self) -> int:
+        """1 = planned, 0 = still planning, -1 = nothing pending."""
+        return int(self.lib.uavenv_replan_ready(self._h))
+
+    def replan_commit(self):
+        """Hand the planned slice over on the current stream: rows no agent is flying take their new plan."""
+        _lib.check(self.lib.uavenv_replan_commit(self._h, self._stream()), "uavenv_replan_commit")
+
+    def replan_stats(self) -> dict:
+        out = (C.c_int64 * 5)()
+        _lib.check(self.lib.uavenv_replan_stats(self._h, out), "uavenv_replan_stats")
+        return dict(zip(("refreshes", "rows_planned", "rows_committed", "rows_in_use", "rows_without_plan"), (int(x) for x in out)))
+
+    def bank_read(self, first: int = 0, count: Optional[int] = None):
+        """-> (start_goal [count, 6], sub_goals [count, K, 3], n_sub [count]) of the bank rows, as numpy arrays."""
+        count = self.n_scenarios - first if count is None else int(count)
+        sg = np.zeros((count, 6))
+        sub = np.zeros((count, self.K, 3))
+        ns = np.zeros(count, dtype=np.int32)
+        _lib.check(self.lib.uavenv_bank_read(self._h, int(first), count, sg.ctypes.data, sub.ctypes.data, ns.ctypes.data), "uavenv_bank_read")
+        return sg, sub, ns
+
     def rrt_plan(self, m: int, *, start_goal=None, uniforms=None, seed: int = 0, max_iter: int = 10000,
                  step_size: float = 30.0, obstacle_step: float = 5.0):
         """The GPU planner alone -> (start_goal [m,6], sub_goals [m,K,3], n_sub [m], iters [m]) device tensors."""

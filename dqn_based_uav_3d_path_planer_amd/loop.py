@@ -22,7 +22,8 @@ class P2PExchangeError(_lib.UavEnvError):
 class HotLoop:
     def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
                  counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
-                 time_every: int = 0, info: torch.Tensor = None, per=None, sample_lag: int = 0):
+                 time_every: int = 0, info: torch.Tensor = None, per=None, sample_lag: int = 0,
+                 replan_every: int = 0, replan_count: int = 0, replan_max_iter: int = 10000):
         """per: a replay.DevicePER over the ring's frames * N slots -- prioritised replay (IsPriority_Replay = 1) inside the C
         loop: new-frame priorities, rebuild, ReplayTree.sample, importance weights, the weighted update and batch_update are
         enqueued per pass (csrc/loop.hip); per.beta / per.n_entries are kept in step."""
@@ -56,6 +57,9 @@ class HotLoop:
         cfg.loss_dev = learner.loss.data_ptr()
         cfg.time_every = int(time_every)
         cfg.sample_lag = int(sample_lag)     # 1: experiment -- update t samples transitions <= t - 1, gradient beside the step
+        # rolling refresh of the reset bank: every replan_every passes the loop commits the planned slice and starts planning the
+        # next replan_count bank rows on a low-priority stream beside the passes (the reference plans at EVERY reset)
+        cfg.replan_every, cfg.replan_count, cfg.replan_max_iter = int(replan_every), int(replan_count), int(replan_max_iter)
         if info is not None:        # [frames, N] uint8: the info code of every transition (episode statistics)
             assert info.dtype == torch.uint8 and tuple(info.shape) == (ring.frames, env.N) and info.is_contiguous()
             cfg.info_dev = info.data_ptr()
@@ -153,7 +157,10 @@ class SACHotLoop:
 
     def __init__(self, ring: DeviceReplayRing, learners, batch: int, seed: int, act1_plane: torch.Tensor, counter: int = 0,
                  info: torch.Tensor = None, is_train: bool = True, auto_reset: bool = True, skip_done: bool = True,
-                 exchange: str = None, spin_limit: int = 0):
+                 exchange: str = None, spin_limit: int = 0, pers=None):
+        """pers: one replay.DevicePER per UAV slot (capacity ring.frames * n_envs, tree_order=False) -- prioritised replay, the
+        reference's own use of ReplayTree (Trainer/SAC_Trainer.py:336-352), inside the C loop: per step and slot the new frame's
+        priorities, rebuild, ReplayTree.sample, importance weights, the four update phases (weights in, |TD| out), batch_update."""
         if ring.discrete or not ring.env.packed:
             raise ValueError("SACHotLoop drives the continuous-action path on a packed ring")
         env = ring.env
@@ -199,6 +206,26 @@ class SACHotLoop:
             sl.m1, sl.v1, sl.m2, sl.v2 = (L._cblocks[k].data_ptr() for k in (4, 5, 6, 7))
             sl.scalars = L._scalars.data_ptr()
             sl.epoch, sl.adam_steps = L.epoch, L.adam_steps
+        self._pers = list(pers) if pers is not None and any(p is not None for p in pers) else None
+        if self._pers is not None:
+            if len(self._pers) != U or any(p is None for p in self._pers):
+                raise ValueError("prioritised replay in the SAC loop: one DevicePER per UAV slot, all slots or none")
+            p0 = self._pers[0]
+            cfg.per_alpha, cfg.per_beta_inc, cfg.per_eps, cfg.per_clip = p0.alpha, p0.beta_inc, p0.epsilon, p0.clip
+            self._per_bufs = []
+            for j, p in enumerate(self._pers):
+                if p.capacity != ring.frames * n_envs or p._c.rot != 0:
+                    raise ValueError("each slot's DevicePER must cover ring.frames * n_envs slots in slot order (tree_order=False)")
+                if (p.alpha, p.beta_inc, p.epsilon, p.clip) != (p0.alpha, p0.beta_inc, p0.epsilon, p0.clip):
+                    raise ValueError("the slots' prioritised replays must share their hyper-parameters")
+                b = int(batch)
+                bufs = (torch.zeros(b, dtype=torch.int64, device=d), torch.zeros(b + (b + 255) // 256, dtype=torch.float64, device=d),
+                        torch.zeros(b, dtype=torch.float32, device=d), torch.zeros(b, dtype=torch.float32, device=d))
+                self._per_bufs.append(bufs)
+                sl = cfg.slot[j]
+                sl.per = p._c
+                sl.per_slots_dev, sl.per_prio_dev, sl.per_w_dev, sl.per_abs_dev = (t.data_ptr() for t in bufs)
+                sl.per_beta = p.beta
         self._keep = (act1_plane, info)
         self.exchange, self._p2p, self._coll = None, None, None
         if exchange is not None:
@@ -270,3 +297,11 @@ class SACHotLoop:
         for j, L in enumerate(self.learners):
             L.epoch, L.adam_steps = int(cur.epoch[j]), int(cur.adam_steps[j])
         self._seen = (cur.head, cur.filled, tuple((L.epoch, L.adam_steps) for L in self.learners))
+        if self._pers is not None:
+            beta = (C.c_double * len(self._pers))()
+            _lib.check(self.lib.uavenv_sac_loop_get_per(self._h, beta), "uavenv_sac_loop_get_per")
+            n_envs = self.ring.env.N // len(self._pers)
+            for j, p in enumerate(self._pers):
+                p.beta = float(beta[j])
+                p.n_entries = self.ring.filled * n_envs
+                p._dirty = True

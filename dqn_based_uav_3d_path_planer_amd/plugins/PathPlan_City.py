@@ -470,9 +470,11 @@ class PathPlan_City:
         act0, act1 = ring.action.view(-1), self._a1.view(-1)
         n_steps, ended = 0, False
         # the whole step sequence enqueued from C (csrc/loop.hip: uavenv_sac_loop_run) when the slots share one batch size and
-        # replay is uniform; the Python loop below issues the same launches one by one (prioritised replay, mixed settings)
+        # their replay kind (uniform, or prioritised = the reference's ReplayTree use, SAC_Trainer.py:336-352); the Python loop
+        # below issues the same launches one by one (mixed settings, several ranks, <sac_c_loop>0</sac_c_loop>)
         trs = [u.Trainer for u in self.Agents]
-        use_c = (all(p is None for p in self._sac_per) and len({t_.Batch_Size for t_ in trs}) == 1 and
+        all_per = all(p is not None for p in self._sac_per)
+        use_c = ((all(p is None for p in self._sac_per) or all_per) and len({t_.Batch_Size for t_ in trs}) == 1 and
                  len({bool(t_.Is_Train) for t_ in trs}) == 1 and U <= _lib.SAC_LOOP_MAX_SLOTS and
                  int(None2Value(self.param.get("sac_c_loop"), 1)) != 0)
         if use_c and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
@@ -486,7 +488,7 @@ class PathPlan_City:
             from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
             self._sac_hot = SACHotLoop(ring, [t_.learner for t_ in trs], trs[0].Batch_Size, seed=self.seed, act1_plane=self._a1,
                                        counter=self._sac_counter, info=self._info, is_train=bool(trs[0].Is_Train),
-                                       auto_reset=False, skip_done=True)
+                                       auto_reset=False, skip_done=True, pers=self._sac_per if all_per else None)
         z = getattr(self, "_sac_noise", None)
         while not ended:
             t0 = ring.head
@@ -569,6 +571,7 @@ class PathPlan_City:
                 tr.save()
         self.Train_statistics(items)
         self.steps_last_episode = n_steps
+        self.sac_c_loop_used = bool(use_c)          # (tests: which of the two issue paths ran)
         self.epoch += 1
         if self.epoch % self.print_loop == 0:
             for uav in self.Agents:

@@ -122,6 +122,27 @@ int uavenv_load_scenarios(UavEnv *env, const double *host_start_goal, const doub
 int uavenv_plan_scenarios(UavEnv *env, int32_t m, uint64_t seed, int32_t max_iter, void *stream);
 /* Size of the scenario bank in use and how many of its scenarios are copies of a neighbour (0 for a loaded bank). */
 int uavenv_bank_stats(const UavEnv *env, int32_t *m, int32_t *replaced);
+/* Rolling refresh of the bank while a loop runs -- the reference plans a fresh path at EVERY reset (Agents/UAV.py:327-366 ->
+ * PathPlan/RRT.py:63-105); the env kernels reset from a bank, and these calls keep that bank turning over:
+ *   uavenv_replan_begin   plans `count` new scenarios for bank rows [first, first + count) into the env's staging area on
+ *                         plan_stream.  It touches neither the bank nor an agent, so plan_stream may be a (low-priority) stream
+ *                         BESIDE the one the step kernels run on.  Philox stream (seed, row): pass a new seed per refresh.
+ *                         One slice in flight at a time (UAVENV_EINVAL otherwise); allocates on its first call.
+ *   uavenv_replan_ready   1 = that planning has finished, 0 = still running, -1 = nothing pending (never blocks).
+ *   uavenv_replan_commit  enqueues, on `stream` -- the stream of the step kernels, so that no reset runs meanwhile -- the
+ *                         hand-over: a row takes its new start / goal / sub-goal list unless an agent currently flies it
+ *                         (agents read their list from the bank) or the new plan is unusable (planner gave up / > K nodes);
+ *                         such rows keep their old plan and are retried by the next refresh that covers them.  Waits (on the
+ *                         stream, not the host) for the planning if it is still running.
+ *   uavenv_replan_stats   out5 = {refreshes begun, rows planned, rows committed, rows skipped: in use, rows skipped: no plan}
+ *                         (synchronises). */
+int uavenv_replan_begin(UavEnv *env, int32_t first, int32_t count, uint64_t seed, int32_t max_iter, void *plan_stream);
+int uavenv_replan_ready(UavEnv *env);
+int uavenv_replan_commit(UavEnv *env, void *stream);
+int uavenv_replan_stats(UavEnv *env, int64_t *out5);
+/* Rows [first, first + count) of the bank in use, into host memory (any pointer may be NULL): start/goal count x 6, sub-goal
+ * lists count x K x 3, n_sub count.  Diagnostics / tests; synchronises the device. */
+int uavenv_bank_read(UavEnv *env, int32_t first, int32_t count, double *host_start_goal, double *host_subgoals, int32_t *host_nsub);
 /* The planner itself, for callers that bring their own start/goal (m x 6, nullable) and/or their own U[0,1) stream
  * (m x stream_len, nullable; parity tests replay CPython's Mersenne stream).  out_nsub < 0: path needs -n > K slots. */
 int uavenv_rrt_plan(UavEnv *env, int32_t m, const double *start_goal_dev, const double *uniforms_dev,
@@ -259,6 +280,10 @@ int uavenv_per_fill(const UavPer *per, int64_t first, int64_t count, double prio
  * valid_dev[i] != 0, 0 elsewhere) and the frame that became the ring's head ([retire_first, retire_first + count) <- 0). */
 int uavenv_per_fill_frame(const UavPer *per, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
                           int64_t retire_first, void *stream);
+/* uavenv_per_fill_frame with the valid flag of slot first + i at valid_dev[i * valid_stride]: one UAV slot's column of a frame's
+ * valid plane (rows e * uav_per_env + slot; each SAC trainer keeps its own tree over its slot's transitions). */
+int uavenv_per_fill_frame_strided(const UavPer *per, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
+                                  int64_t valid_stride, int64_t retire_first, void *stream);
 /* uavenv_per_fill_frame + uavenv_per_rebuild with the fills applied while the rebuild reads the priorities (one launch less). */
 int uavenv_per_rebuild_frame(const UavPer *per, int64_t first, int64_t count, double priority, const uint8_t *valid_dev,
                              int64_t retire_first, void *stream);
@@ -365,6 +390,14 @@ int uavenv_p2p_inject_fault(UavP2P *p2p, int32_t code);
  * aligned.  After a sticky error the buffer keeps this rank's own values and the call returns UAVENV_EP2P: stop stepping and
  * re-synchronise parameters and optimiser moments from one rank.  (Use a UavP2P of its own, not the one a DQN learner drives.) */
 int uavenv_p2p_allreduce(UavP2P *p2p, float *buf_dev, int64_t count, void *stream);
+/* Are the ranks' parameters still bit-identical?  Hashes the bit patterns of n_blocks flat f32 blocks (device pointers in a HOST
+ * array, n_floats[b] each) on the device, sends the 64-bit result to every rank and compares the `world` results on the device
+ * -- four small launches on the stream, no host round trip.  A difference raises the exchange's sticky error
+ * (UAVENV_P2P_ERR_DIVERGED: uavenv_p2p_status, UAVENV_EP2P from then on), exactly like the DQN bucket's built-in checksum; the
+ * generic exchange has no room for one in its buffers, so its owners call this every so many updates (uavenv_sac_loop_run:
+ * UavSacLoopConfig.check_every).  Every rank must call it at the same point of the sequence. */
+#define UAVENV_P2P_CHECK_MAX_BLOCKS 40
+int uavenv_p2p_check_blocks(UavP2P *p2p, const float *const *blocks_dev, const int32_t *n_floats, int32_t n_blocks, void *stream);
 int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, UavP2P *p2p, void *stream);
 /* step_t == 0: only the rank-ordered sum, into raw_out_dev[num_params + 2] (self-test); otherwise Adam as uavenv_dqn_adam
  * (raw_out_dev nullable). */
@@ -434,6 +467,10 @@ typedef struct UavLoopConfig {
     float *per_w_dev;            /* batch */
     float *per_abs_dev;          /* batch */
     int32_t *per_idx_dev;        /* batch x 2 */
+    /* rolling refresh of the reset bank (uavenv_replan_*; 0 = off, the bank stays as planned): every replan_every passes the
+     * loop commits the slice whose planning has finished and starts planning the next replan_count rows of the bank (rotating)
+     * on a low-priority stream of its own, beside the passes. */
+    int32_t replan_every, replan_count, replan_max_iter, reserved1;
 } UavLoopConfig;
 typedef struct UavLoopCursor {
     int32_t head, filled, epoch, reserved0;
@@ -566,6 +603,13 @@ typedef struct UavSacLoopSlot {
     float *scalars;                          /* 8 floats: critic losses [0:4], actor loss / sum log pi [4:8] of the last update */
     float *partials_critic, *partials_actor; /* >= uavenv_sac_partial_rows_n(batch, n_slots, 0) rows x UAVENV_SAC_CRITIC_STRIDE / _ACTOR_STRIDE, per slot */
     int32_t epoch, adam_steps;               /* update() calls so far; Adam steps actually taken (bias correction) */
+    /* prioritised replay (the reference's own use of ReplayTree, Trainer/SAC_Trainer.py:336-352); per.prio NULL = uniform.  One
+     * tree per slot over ITS transitions: capacity = frames x n_envs, data slot = frame * n_envs + env.  All slots or none. */
+    UavPer per;
+    int64_t *per_slots_dev;                  /* batch */
+    double *per_prio_dev;                    /* batch + (batch + 255) / 256 */
+    float *per_w_dev, *per_abs_dev;          /* batch each: importance weights in, |TD| out */
+    double per_beta;                         /* ReplayTree.beta when the loop is created */
 } UavSacLoopSlot;
 typedef struct UavSacLoopConfig {
     UavEnv *env;
@@ -590,6 +634,13 @@ typedef struct UavSacLoopConfig {
     struct UavP2P *p2p;
     struct UavColl *coll;
     float *xbuf_dev;                         /* n_slots x UAVENV_SAC_CRITIC_STRIDE floats */
+    /* ReplayTree's hyper-parameters (replay_buffer.py:123-131) when the slots carry a UavPer: per step the loop enqueues, per
+     * slot, new-frame priorities ((0 + eps) ** alpha where valid) + retiring the new head -> rebuild -> ReplayTree.sample (Philox
+     * (seed + 7 + slot, counter)) -> importance weights -> the four update phases (weights into the critic losses, |TD| out) ->
+     * batch_update.  The draws of a slot then come from its tree (draws_dev receives the (frame, env) pairs). */
+    double per_alpha, per_beta_inc, per_eps, per_clip;
+    int32_t check_every, reserved3;          /* p2p only: compare the ranks' weight checksums (uavenv_p2p_check_blocks over every slot's
+                                                actor, critics and targets) every that many updates; 0 = never */
 } UavSacLoopConfig;
 typedef struct UavSacLoopCursor {
     int32_t head, filled;
@@ -606,6 +657,8 @@ int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out);
 int uavenv_sac_loop_destroy(UavSacLoop *loop);
 int uavenv_sac_loop_run(UavSacLoop *loop, int32_t n_steps, void *stream);
 int uavenv_sac_loop_get(const UavSacLoop *loop, UavSacLoopCursor *out);
+/* ReplayTree.beta of every slot as the loop left it (n_slots doubles). */
+int uavenv_sac_loop_get_per(const UavSacLoop *loop, double *beta_out);
 
 /* ---- federated merge of the per-UAV trainers (Envs/PathPlan_City.py:469-475 -> Federated_Learning_AC :590-601) --------------
  * Every one of the n_blocks flat f32 parameter blocks (device pointers, 16-byte aligned, distinct, n_floats each; the array

@@ -276,6 +276,7 @@ def test_prioritised_replay_stays_on_the_fused_sac_path(tmp_path, monkeypatch):
     torch.manual_seed(0)
     res = env.run_eposide(0.1)
     assert env.Check_uav_Done() and np.isfinite(float(res["loss"]))
+    assert env.sac_c_loop_used            # prioritised replay runs INSIDE uavenv_sac_loop_run (round 4), not from the Python loop
     ring = env._ring
     reprioritised = 0
     for j, per in enumerate(env._sac_per):
@@ -317,8 +318,8 @@ def test_prioritised_replay_through_the_plugins(trainer, tmp_path, monkeypatch):
     assert prio.max().item() <= 1.0 + 1e-9                                                    # clip at 1 (:219-221)
 
 
-@pytest.mark.parametrize("envs,batch,replay,tpw", [(512, 512, 8192, 0), (2048, 8192, 65536, 2)])
-def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch, envs, batch, replay, tpw):
+@pytest.mark.parametrize("envs,batch,replay,tpw,per", [(512, 512, 8192, 0, 0), (2048, 8192, 65536, 2, 0), (512, 512, 8192, 0, 1)])
+def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch, envs, batch, replay, tpw, per):
     """csrc/loop.hip: uavenv_sac_loop_run -- per step the N(0,1) draws, U x get_action, the env step (APF on), one replay
     draw and U x the four launches of the fused SAC update, enqueued from C -- against the same sequence issued launch by
     launch from Python (PathPlan_City._run_eposide_fused_sac with <sac_c_loop>0</sac_c_loop>): ring, every parameter block
@@ -326,15 +327,18 @@ def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch, envs, batch, r
     this size -- ~375 us per step = ~22 latency-bound launches -- so the C loop removes the interpreter, not time.)
     Second case: 4 x 128 tiles -- the C loop's four-slot launches take two tiles per workgroup (uavenv_sac_partial_rows_n), a
     slot alone would take one; the Python loop's learners are told the same partition (FusedSACLearner.tiles_per_wg) and the
-    comparison stays bit for bit."""
+    comparison stays bit for bit.
+    Third case: IsPriority_Replay = 1 -- the reference's own use of ReplayTree (Trainer/SAC_Trainer.py:336-352) INSIDE the C
+    loop (per step and slot: new-frame priorities, rebuild, ReplayTree.sample, importance weights, the update with weights in
+    and |TD| out, batch_update) against the same launches issued from Python: priorities and beta of every slot's tree too."""
     import time
     monkeypatch.chdir(tmp_path)
     out = []
     for c_loop in ("1", "0"):
-        sim = _config4(tmp_path, envs, Batch_Size=batch, replay_size=replay)
+        sim = _config4(tmp_path, envs, Batch_Size=batch, replay_size=replay, IsPriority_Replay=per)
         env = sim.env
         env.param["sac_c_loop"] = c_loop
-        assert env.fast_sac
+        assert env.fast_sac and all((p is not None) == bool(per) for p in env._sac_per)
         if c_loop == "0":
             for b in env._sac_batches:               # the partition of the C loop's four-slot launches
                 b.tiles_per_wg = tpw
@@ -344,14 +348,18 @@ def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch, envs, batch, r
         res = env.run_eposide(0.1)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / env.steps_last_episode
-        assert (getattr(env, "_sac_hot", None) is not None) == (c_loop == "1")
+        assert (getattr(env, "_sac_hot", None) is not None) == (c_loop == "1") and env.sac_c_loop_used == (c_loop == "1")
         L = [u.Trainer.learner for u in env.Agents]
         out.append(dict(ring={k: getattr(env._ring, k).clone() for k in ("obs", "action", "reward", "done", "valid")},
                         a1=env._a1.clone(), blocks=[torch.cat([x._blocks.reshape(-1), x._cblocks.reshape(-1), x._alpha_mv,
                                                                x.log_alpha.reshape(1)]) for x in L],
                         counts=[(x.epoch, x.adam_steps) for x in L], cursor=(env._ring.head, env._ring.filled, env._sac_counter),
-                        steps=env.steps_last_episode, us=dt * 1e6, loss=float(res["loss"])))
+                        steps=env.steps_last_episode, us=dt * 1e6, loss=float(res["loss"]),
+                        per=[(p.prio.clone(), p.beta, p.n_entries) for p in env._sac_per if p is not None]))
     a, b = out
+    assert len(a["per"]) == (4 if per else 0)
+    for (pa, ba, na), (pb, bb, nb_) in zip(a["per"], b["per"]):
+        assert torch.equal(pa, pb) and ba == bb and na == nb_ and ba > 0.4
     assert a["cursor"] == b["cursor"] and a["counts"] == b["counts"] and a["steps"] == b["steps"] and a["steps"] >= 150
     for k in a["ring"]:
         assert torch.equal(a["ring"][k], b["ring"][k]), k
