@@ -189,7 +189,7 @@ def load() -> C.CDLL:
     lib.uavenv_replan_ready.restype = C.c_int
     lib.uavenv_replan_ready.argtypes = [vp]
     lib.uavenv_replan_commit.restype = C.c_int
-    lib.uavenv_replan_commit.argtypes = [vp, vp]
+    lib.uavenv_replan_commit.argtypes = [vp, i32, vp]
     lib.uavenv_replan_stats.restype = C.c_int
     lib.uavenv_replan_stats.argtypes = [vp, vp]
     lib.uavenv_bank_read.restype = C.c_int

@@ -48,7 +48,7 @@ static int replan_tick(UavLoop *l, hipStream_t s)
     if (ready == 0) return UAVENV_OK;
     if (ready < -1) return ready;
     if (ready == 1) {
-        const int rc = uavenv_replan_commit(c.env, s);
+        const int rc = uavenv_replan_commit(c.env, 0, s);
         if (rc != UAVENV_OK) return rc;
     }
     int32_t count = c.replan_count < l->bank_m ? c.replan_count : l->bank_m;

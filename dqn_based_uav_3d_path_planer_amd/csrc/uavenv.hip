@@ -2018,8 +2018,9 @@ __global__ void __launch_bounds__(256) k_bank_commit(double *bank_sg, double *ba
     const int r = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= count) return;
     const int n = nsub[r];
-    const bool ok = n >= 2 && n <= K && inuse[r] == 0;
-    if (lane == 0) atomicAdd(&counters[ok ? 0 : (inuse[r] ? 1 : 2)], 1);
+    const bool used = inuse && inuse[r] != 0;
+    const bool ok = n >= 2 && n <= K && !used;
+    if (lane == 0) atomicAdd(&counters[ok ? 0 : (used ? 1 : 2)], 1);
     if (!ok) return;
     const size_t row = (size_t)(first + r);
     for (int q = lane; q < K * 3; q += 64) bank_sub[row * K * 3 + q] = sub[(size_t)r * K * 3 + q];
@@ -2075,7 +2076,7 @@ int uavenv_replan_ready(UavEnv *e)
     return fail(UAVENV_EHIP, "uavenv_replan_ready: %s", hipGetErrorString(q));
 }
 
-int uavenv_replan_commit(UavEnv *e, void *stream)
+int uavenv_replan_commit(UavEnv *e, int32_t force, void *stream)
 {
     if (!e) return fail(UAVENV_EINVAL, "null env");
     if (!e->rp_pending) return fail(UAVENV_EINVAL, "uavenv_replan_commit: nothing planned");
@@ -2085,9 +2086,13 @@ int uavenv_replan_commit(UavEnv *e, void *stream)
     HIP_TRY(hipStreamWaitEvent(s, e->rp_done, 0));
     const int cap = e->rp_cap, count = e->rp_count;
     int32_t *inuse = e->rp_nsub + cap, *counters = e->rp_counters;
-    HIP_TRY(hipMemsetAsync(inuse, 0, (size_t)count * 4, s));
-    StepArgs a = base_args(e);
-    hipLaunchKernelGGL(k_bank_mark, dim3((e->N + 255) / 256 < 1024 ? (e->N + 255) / 256 : 1024), dim3(256), 0, s, a, e->rp_first, count, inuse);
+    if (force) {                       // the caller resets EVERY agent next (an episode boundary): no list is being flown
+        inuse = nullptr;
+    } else {
+        HIP_TRY(hipMemsetAsync(inuse, 0, (size_t)count * 4, s));
+        StepArgs a = base_args(e);
+        hipLaunchKernelGGL(k_bank_mark, dim3((e->N + 255) / 256 < 1024 ? (e->N + 255) / 256 : 1024), dim3(256), 0, s, a, e->rp_first, count, inuse);
+    }
     hipLaunchKernelGGL(k_bank_commit, dim3((count + 3) / 4), dim3(256), 0, s, e->bank_sg, e->bank_sub, e->bank_nsub, e->rp_first, count,
                        e->cfg.max_subgoals, e->rp_sg, e->rp_sub, e->rp_nsub, inuse, counters);
     HIP_TRY(hipGetLastError());

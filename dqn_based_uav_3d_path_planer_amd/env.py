@@ -141,9 +141,10 @@ class VecPathPlanEnv:
         """1 = planned, 0 = still planning, -1 = nothing pending."""
         return int(self.lib.uavenv_replan_ready(self._h))
 
-    def replan_commit(self):
-        """Hand the planned slice over on the current stream: rows no agent is flying take their new plan."""
-        _lib.check(self.lib.uavenv_replan_commit(self._h, self._stream()), "uavenv_replan_commit")
+    def replan_commit(self, force: bool = False):
+        """Hand the planned slice over on the current stream: rows no agent is flying take their new plan (force: every row
+        -- the caller resets all agents next)."""
+        _lib.check(self.lib.uavenv_replan_commit(self._h, 1 if force else 0, self._stream()), "uavenv_replan_commit")
 
     def replan_stats(self) -> dict:
         out = (C.c_int64 * 5)()

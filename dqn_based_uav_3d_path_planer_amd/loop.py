@@ -148,7 +148,8 @@ class SACHotLoop:
     """The off-policy loop with one fused SAC trainer per UAV slot (BASELINE configs[3]'s shape), enqueued by csrc/loop.hip:
     per step one launch of N(0,1) draws, U x get_action, the env step (replay write included), one draw of (frame, env) pairs
     and U x the four launches of SAC_Trainer.update -- what PathPlan_City._run_eposide_fused_sac issues from Python, bit for
-    bit, without the interpreter between the launches.  The ring cursor and the learners' update counts live in the C object
+    bit, without the interpreter between the launches.  With the peer exchange (N > 1) the ranks' parameter blocks are hashed and
+    compared on the device every check_every updates (uavenv_p2p_check_blocks): a difference raises the exchange's sticky error.  The ring cursor and the learners' update counts live in the C object
     while the loop exists; `run` writes them back.
     exchange (one process per GPU, torch.distributed initialised): "p2p" (csrc/p2p.hip: every phase's column sums of all
     slots summed over peer-mapped HBM on the stream), "coll" (RCCL from C, csrc/coll.hip), "auto" (p2p, else coll) or None;
@@ -157,7 +158,7 @@ class SACHotLoop:
 
     def __init__(self, ring: DeviceReplayRing, learners, batch: int, seed: int, act1_plane: torch.Tensor, counter: int = 0,
                  info: torch.Tensor = None, is_train: bool = True, auto_reset: bool = True, skip_done: bool = True,
-                 exchange: str = None, spin_limit: int = 0, pers=None):
+                 exchange: str = None, spin_limit: int = 0, pers=None, check_every: int = 64):
         """pers: one replay.DevicePER per UAV slot (capacity ring.frames * n_envs, tree_order=False) -- prioritised replay, the
         reference's own use of ReplayTree (Trainer/SAC_Trainer.py:336-352), inside the C loop: per step and slot the new frame's
         priorities, rebuild, ReplayTree.sample, importance weights, the four update phases (weights in, |TD| out), batch_update."""
@@ -247,6 +248,7 @@ class SACHotLoop:
                 self._xbuf = torch.zeros(n, dtype=torch.float32, device=d)
                 cfg.p2p = self._p2p
                 cfg.coll = self._coll
+                cfg.check_every = int(check_every) if self._p2p is not None else 0
                 cfg.xbuf_dev = self._xbuf.data_ptr()
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_sac_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_sac_loop_create")
@@ -276,6 +278,14 @@ class SACHotLoop:
             self.close()
         except Exception:
             pass
+
+    def p2p_status(self, synchronise: bool = True) -> dict:
+        """{code, timeouts, mismatches, checks} of the peer exchange (code 1 = timeout, 2 = the ranks' weights diverged)."""
+        if self._p2p is None:
+            return {"code": 0, "timeouts": 0, "mismatches": 0, "checks": 0}
+        out = (C.c_int32 * 4)()
+        _lib.check(self.lib.uavenv_p2p_status(self._p2p, 1 if synchronise else 0, out), "uavenv_p2p_status")
+        return {"code": int(out[0]), "timeouts": int(out[1]), "mismatches": int(out[2]), "checks": int(out[3])}
 
     def run(self, n_steps: int):
         s = torch.cuda.current_stream(self.ring.env.device).cuda_stream

@@ -141,6 +141,12 @@ class PathPlan_City:
         self._episode = 0
         self._ring = self._hot = self._info = None
         self.done_check = max(1, int(None2Value(param.get("done_check"), 8)))
+        # <fresh_plans> (default 1 on a GPU backend): UAV.reset plans a new RRT path at EVERY reset (Agents/UAV.py:327-366); here a
+        # slice of <fresh_plans_rows> bank rows is planned in the background of each episode and handed over at the next
+        # episode boundary, where every agent is reset anyway (_refresh_bank)
+        self.fresh_plans = int(None2Value(param.get("fresh_plans"), 1)) != 0 and hasattr(self.backend, "replan_begin")
+        self.fresh_plans_rows = int(None2Value(param.get("fresh_plans_rows"), 4096))
+        self._replan_next, self._plan_stream = 0, None
         tr0 = self.Agents[0].Trainer
         self.fast = bool(self._want_fast and getattr(self.backend, "packed", False) and getattr(tr0, "fused", False))
         # fusion is decided HERE: a trainer that came up fused but whose env cannot offer the packed ring is moved to the
@@ -307,8 +313,33 @@ class PathPlan_City:
         pts = torch.tensor([[float(p.x), float(p.y), float(p.z)]], dtype=torch.float64)
         return int(self.backend.threaten_rate(pts)[0])
 
+    def _refresh_bank(self):
+        """Call right before the reset of every agent that opens an episode: the slice planned while the last episode ran is
+        handed over in full (no agent flies a list at an episode boundary), and the next slice of the bank starts planning on
+        a low-priority stream beside this episode (csrc/rrt.hip, the LDS-free background form)."""
+        if not self.fresh_plans:
+            return
+        b = self.backend
+        m = getattr(b, "n_scenarios", 0)
+        if m <= 0:
+            return
+        if self._plan_stream is None:
+            lo = torch.cuda.Stream.priority_range()[0] if hasattr(torch.cuda.Stream, "priority_range") else 0
+            self._plan_stream = torch.cuda.Stream(device=b.device, priority=lo)
+        ready = b.replan_ready()
+        if ready == 0:
+            return                      # still planning: this boundary keeps the bank as it is (never stall an episode on the planner)
+        if ready == 1:
+            b.replan_commit(force=True)
+        count = min(m, max(1, self.fresh_plans_rows), max(256, 4 * b.N))      # about what this episode's resets draw, x4
+        if self._replan_next + count > m:
+            self._replan_next = 0
+        b.replan_begin(self._replan_next, count, seed=(self.seed + 1) * 1000003 + self._episode, stream=self._plan_stream)
+        self._replan_next += count
+
     def Scene_Random_Reset(self):
         self._episode += 1
+        self._refresh_bank()
         self._obs = self.backend.reset(self.seed + self._episode)
         self._invalidate()
         self._paths = [[] for _ in range(self.num_UAV)]                                       # UAV.py:338
@@ -399,6 +430,7 @@ class PathPlan_City:
         uav = self.Agents[0]
         tr, ring = uav.Trainer, self._ring
         self._episode += 1
+        self._refresh_bank()
         self.backend.reset(self.seed + self._episode, obs=ring.obs[ring.head])      # UAV.reset everywhere; the replay stays
         self._obs_raw = ring.obs[ring.head]
         self._invalidate()
@@ -460,6 +492,7 @@ class PathPlan_City:
         self.Reset_Result(eps_rate)
         ring, U, N = self._ring, self.num_UAV, self.backend.N
         self._episode += 1
+        self._refresh_bank()
         self.backend.reset(self.seed + self._episode, obs=ring.obs[ring.head])
         self._obs_raw = ring.obs[ring.head]
         self._invalidate()

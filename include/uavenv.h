@@ -133,12 +133,14 @@ int uavenv_bank_stats(const UavEnv *env, int32_t *m, int32_t *replaced);
  *                         hand-over: a row takes its new start / goal / sub-goal list unless an agent currently flies it
  *                         (agents read their list from the bank) or the new plan is unusable (planner gave up / > K nodes);
  *                         such rows keep their old plan and are retried by the next refresh that covers them.  Waits (on the
- *                         stream, not the host) for the planning if it is still running.
+ *                         stream, not the host) for the planning if it is still running.  force != 0: the caller is about to
+ *                         reset EVERY agent (uavenv_reset_all: an episode boundary of the plugin path), so no list is in use
+ *                         and every usable plan is taken.
  *   uavenv_replan_stats   out5 = {refreshes begun, rows planned, rows committed, rows skipped: in use, rows skipped: no plan}
  *                         (synchronises). */
 int uavenv_replan_begin(UavEnv *env, int32_t first, int32_t count, uint64_t seed, int32_t max_iter, void *plan_stream);
 int uavenv_replan_ready(UavEnv *env);
-int uavenv_replan_commit(UavEnv *env, void *stream);
+int uavenv_replan_commit(UavEnv *env, int32_t force, void *stream);
 int uavenv_replan_stats(UavEnv *env, int64_t *out5);
 /* Rows [first, first + count) of the bank in use, into host memory (any pointer may be NULL): start/goal count x 6, sub-goal
  * lists count x K x 3, n_sub count.  Diagnostics / tests; synchronises the device. */

@@ -369,3 +369,35 @@ def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch, envs, batch, r
     assert a["loss"] == b["loss"]
     print(f"fused SAC episode, {envs} envs x 4 UAVs: C loop {a['us']:.0f} us/step, Python loop {b['us']:.0f} us/step")
     assert a["us"] < 1.25 * b["us"]
+
+
+def test_fresh_plans_between_episodes(tmp_path, monkeypatch):
+    """UAV.reset plans a new RRT path at every reset (Agents/UAV.py:327-366).  The plugin plans a slice of the reset bank in the
+    background of each episode (csrc/rrt.hip, LDS-free form, low-priority stream) and hands it over at the next episode
+    boundary, where every agent is reset anyway: after a few episodes the bank is not the one the env was built with, every row
+    is still a valid path, and <fresh_plans>0</fresh_plans> keeps the bank fixed."""
+    from dqn_based_uav_3d_path_planer_amd import driver
+    monkeypatch.chdir(tmp_path)
+    xml = driver.make_config_dir(str(tmp_path), "DQN", num_envs=64, num_uav=1)
+    env = driver.simulator(xml).env
+    assert env.fresh_plans and env.fast
+    sg0, _, _ = env.backend.bank_read()
+    for _ in range(4):
+        env.run_eposide(0.5)
+    torch.cuda.synchronize()
+    st = env.backend.replan_stats()
+    sg1, sub1, ns1 = env.backend.bank_read()
+    assert st["refreshes"] >= 2 and st["rows_committed"] >= 200 and st["rows_in_use"] == 0, st
+    changed = np.any(sg1 != sg0, axis=1)
+    assert changed.sum() >= 200 and ((ns1 >= 2) & (ns1 <= env.backend.K)).all()
+    for k in np.nonzero(changed)[0][:100]:
+        p = sub1[k, :ns1[k]]
+        assert np.array_equal(p[0], sg1[k, :3]) and np.array_equal(p[-1], sg1[k, 3:])
+    s = open(xml).read().replace("<num_UAV>", "<fresh_plans>0</fresh_plans>\n        <num_UAV>", 1)
+    open(xml, "w").write(s)
+    env2 = driver.simulator(xml).env
+    assert not env2.fresh_plans
+    b0 = env2.backend.bank_read()[0]
+    env2.run_eposide(0.5)
+    env2.run_eposide(0.5)
+    assert np.array_equal(env2.backend.bank_read()[0], b0) and env2.backend.replan_stats()["refreshes"] == 0

@@ -275,7 +275,7 @@ def test_fused_sac_peer_exchange_equals_torch_distributed(tmp_path):
     assert torch.equal(res["p2p"][0]["actor"], res["p2p"][1]["actor"]) and torch.equal(res["p2p"][0]["critics"], res["p2p"][1]["critics"])
 
 
-def _sac_loop_worker(rank, world, port, out_dir):
+def _sac_loop_worker(rank, world, port, out_dir, nudge=False):
     import os
     import torch.distributed as dist
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
@@ -294,11 +294,37 @@ def _sac_loop_worker(rank, world, port, out_dir):
     a1 = torch.zeros((ring.frames, env.N), dtype=torch.float32, device="cuda")
     torch.manual_seed(0)
     Ls = [FusedSACLearner(PARAM) for _ in range(U)]
-    loop = SACHotLoop(ring, Ls, B, seed=11, act1_plane=a1, exchange="p2p" if world > 1 else None, spin_limit=1 << 18)
+    loop = SACHotLoop(ring, Ls, B, seed=11, act1_plane=a1, exchange="p2p" if world > 1 else None, spin_limit=1 << 18, check_every=4)
     assert loop.exchange == ("p2p" if world > 1 else None)
     loop.run(9)
+    if nudge:                                           # one rank's critic drifts by one ulp: the next checksum compare must notice
+        from dqn_based_uav_3d_path_planer_amd.loop import P2PExchangeError
+        torch.cuda.synchronize()
+        st0 = loop.p2p_status()
+        assert st0["code"] == 0 and st0["checks"] >= 1 and st0["mismatches"] == 0
+        if rank == 1:
+            w = Ls[1]._cblocks[0]
+            w[77] = torch.nextafter(w[77], w[77] + 1)
+        raised = False
+        try:
+            for _ in range(6):
+                loop.run(4)
+                torch.cuda.synchronize()
+        except P2PExchangeError:
+            raised = True
+        st = loop.p2p_status()
+        torch.save({"raised": raised, "status": st, "counts": [(x.epoch, x.adam_steps) for x in Ls], "cursor": (ring.head, ring.filled)},
+                   os.path.join(out_dir, f"sacnudge_r{rank}.pt"))
+        dist.barrier()
+        loop.close()
+        dist.destroy_process_group()
+        env.close()
+        return
     loop.run(8)
     torch.cuda.synchronize()
+    if world > 1:
+        st = loop.p2p_status()
+        assert st["code"] == 0 and st["checks"] >= 2 and st["mismatches"] == 0, st
     torch.save({"blocks": [torch.cat([x._blocks.reshape(-1), x._cblocks.reshape(-1), x._alpha_mv, x.log_alpha.reshape(1)]).cpu() for x in Ls],
                 "ring": {k: getattr(ring, k).cpu() for k in ("obs", "action", "reward", "done", "valid")}, "a1": a1.cpu(),
                 "counts": [(x.epoch, x.adam_steps) for x in Ls], "cursor": (ring.head, ring.filled, loop.counter)},
@@ -336,6 +362,27 @@ def test_sac_c_loop_exchanges_on_the_stream(tmp_path):
         assert torch.equal(two["a1"], one["a1"])
         for j in range(2):
             assert torch.equal(two["blocks"][j], one["blocks"][j]), (r, j)
+
+
+def test_sac_c_loop_notices_diverged_ranks(tmp_path):
+    """The generic peer exchange carries no checksum words: uavenv_sac_loop_run hashes every slot's actor / critics /
+    targets every check_every updates and the ranks compare the hashes on the device (uavenv_p2p_check_blocks).  Two ranks on
+    this GPU, one critic weight of rank 1 moved by one ulp: within check_every updates BOTH ranks carry the sticky error
+    UAVENV_P2P_ERR_DIVERGED, run() raises, and the cursor / update counts were written back before it did."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sac_loop_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    for r in (0, 1):
+        d = torch.load(os.path.join(tmp_path, f"sacnudge_r{r}.pt"))
+        assert d["raised"] and d["status"]["code"] == 2 and d["status"]["mismatches"] >= 1, d
+        assert d["cursor"][1] > 9 and d["counts"][0][0] > 9                          # SACHotLoop.run synced before raising
+    a, b = (torch.load(os.path.join(tmp_path, f"sacnudge_r{r}.pt")) for r in (0, 1))
+    assert a["counts"] == b["counts"]
 
 
 def test_fused_sac_against_the_executed_reference():
