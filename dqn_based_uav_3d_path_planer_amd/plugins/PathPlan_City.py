@@ -145,7 +145,7 @@ class PathPlan_City:
         # slice of <fresh_plans_rows> bank rows is planned in the background of each episode and handed over at the next
         # episode boundary, where every agent is reset anyway (_refresh_bank)
         self.fresh_plans = int(None2Value(param.get("fresh_plans"), 1)) != 0 and hasattr(self.backend, "replan_begin")
-        self.fresh_plans_rows = int(None2Value(param.get("fresh_plans_rows"), 4096))
+        self.fresh_plans_rows = int(None2Value(param.get("fresh_plans_rows"), 256))   # ~what the planner finishes beside one episode
         self._replan_next, self._plan_stream = 0, None
         tr0 = self.Agents[0].Trainer
         self.fast = bool(self._want_fast and getattr(self.backend, "packed", False) and getattr(tr0, "fused", False))
@@ -326,12 +326,9 @@ class PathPlan_City:
         if self._plan_stream is None:
             lo = torch.cuda.Stream.priority_range()[0] if hasattr(torch.cuda.Stream, "priority_range") else 0
             self._plan_stream = torch.cuda.Stream(device=b.device, priority=lo)
-        ready = b.replan_ready()
-        if ready == 0:
-            return                      # still planning: this boundary keeps the bank as it is (never stall an episode on the planner)
-        if ready == 1:
-            b.replan_commit(force=True)
-        count = min(m, max(1, self.fresh_plans_rows), max(256, 4 * b.N))      # about what this episode's resets draw, x4
+        if b.replan_ready() >= 0:       # (a slice still being planned is waited for ON THE STREAM: what the bank holds after N
+            b.replan_commit(force=True)  #  episodes depends on the seeds only, never on timing -- runs stay reproducible)
+        count = min(m, max(1, self.fresh_plans_rows))
         if self._replan_next + count > m:
             self._replan_next = 0
         b.replan_begin(self._replan_next, count, seed=(self.seed + 1) * 1000003 + self._episode, stream=self._plan_stream)
