@@ -483,6 +483,11 @@ def run_config4(args, dev, world_size=1, rank=0):
     k_ms = e0.elapsed_time(e1) / it
     prof = committed_profile(args)
     k_prof = prof.get("k_step_ms")
+    if k_prof is not None and prof.get("k_apf_adjust_ms") is not None:     # the env step with APF is the launch pair
+        k_prof += prof["k_apf_adjust_ms"]
+    tr4 = prof.get("k_step_traffic_bytes_per_launch")
+    if tr4 is not None and prof.get("k_apf_adjust_traffic_bytes_per_launch") is not None:
+        tr4 += prof["k_apf_adjust_traffic_bytes_per_launch"]
     k_use = max(k_ms, k_prof or 0.0)
     algo = ALGO_BYTES_PER_AGENT_STEP + 2 * 20 * 24      # APF on adds 2 * n_sub * 24 B (~20 sub-goals)
     moved = algo - 400 + ring.obs.shape[-1] * ring.obs.element_size()          # packed rows: 80 B instead of the 400-B f32 row
@@ -505,11 +510,11 @@ def run_config4(args, dev, world_size=1, rank=0):
                                   if fused else "SAC on PyTorch-ROCm ops (f32)" +
                                   (", each slot's sample + update replayed as one HIP graph" if graphs is not None else ", eager")),
                       "env": "fused HIP k_step with APF"},
-           "roofline": {"bound": "hbm", "kernel": "k_step<APF> (update_PathPlan + Adjust_subgoal + cal_force + state_PathPlan + replay write)",
+           "roofline": {"bound": "hbm", "kernel": "k_apf_adjust + k_step<APF> (Adjust_subgoal for the launch, then update_PathPlan + cal_force + state_PathPlan + replay write)",
                         "achieved": algo * env.N / (k_use * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo * env.N / (k_use * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": prof.get("k_step_traffic_bytes_per_launch"),
+                        "frac": algo * env.N / (k_use * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr4,
                         "traffic_stale": prof.get("stale"), "measured_copy_GBs": copy_gbs,
-                        **physical_view(algo, moved, env.N, k_use, prof.get("k_step_traffic_bytes_per_launch"), copy_gbs),
+                        **physical_view(algo, moved, env.N, k_use, tr4, copy_gbs),
                         "algorithmic_bytes_per_agent_step": algo, "agents_per_launch": env.N, "kernel_ms": k_use,
                         "kernel_ms_back_to_back": k_ms, "kernel_ms_rocprofv3_committed": k_prof}}
     if multi:

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --env-only-iters 50 $*"
+ARGS="--steps ${PROF_STEPS:-2} --warmup 1 --no-cpu-baseline --no-other-configs --env-only-iters 50 $*"
 rm -rf /tmp/prof_$TAG
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS) > $OUT/${TAG}_stats.log 2>&1
 find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
@@ -14,9 +14,15 @@ tail -1 $OUT/${TAG}_stats.log > $OUT/${TAG}_bench_under_rocprof.json
 head -12 $OUT/${TAG}_kernel_stats.csv
 PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --env-only-iters 20 $*"
 : > $OUT/${TAG}_pmc.txt
-for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
-           "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
-           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+# PMC_SETS=traffic: only the two HBM-traffic passes (FETCH_SIZE, WRITE_SIZE: separate passes, MI355X_MICROARCH.md)
+if [ "$PMC_SETS" = "traffic" ]; then
+  SETS=("FETCH_SIZE" "WRITE_SIZE")
+else
+  SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+        "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
+        "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT")
+fi
+for PMC in "${SETS[@]}"; do
   N=$(echo $PMC | cut -d' ' -f1)
   rm -rf /tmp/pmc_$N
   (cd /tmp && rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d /tmp/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py $PARGS) > /tmp/pmc_$N.log 2>&1
@@ -28,9 +34,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 try:
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        for short in ("k_step", "k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam", "k_sac"):
+        for short in ("k_step", "k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam", "k_apf_adjust", "k_sac_critic_grad", "k_sac_actor_grad", "k_sac_reduce_adam", "k_sac"):
             if short in k:
-                if short == "k_step" and k.rstrip().endswith("true>(StepArgs)"):
+                if short == "k_step" and (k.rstrip().endswith("true>(StepArgs)") or "k_step_polh" in k):
                     short = "k_step_policy"          # the step kernel with the policy in its prologue
                 agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 break

@@ -21,8 +21,8 @@ def short_name(full):
     """kernel family of a rocprofv3 kernel name; the step kernel that carries the policy in its prologue
     (k_step_coop<..., true>) is its own family"""
     if "k_step" in full:
-        return "k_step_policy" if full.rstrip().endswith("true>(StepArgs)") else "k_step"
-    for short in ("k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam"):
+        return "k_step_policy" if (full.rstrip().endswith("true>(StepArgs)") or "k_step_polh" in full) else "k_step"
+    for short in ("k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam", "k_apf_adjust", "k_sac_critic_grad", "k_sac_actor_grad", "k_sac_reduce_adam"):
         if short in full:
             return short
     return None
@@ -40,7 +40,7 @@ for line in open(pmc):
     m = re.match(r"\S+ (\S+) (\S+) n=(\d+) mean=([0-9.eE+-]+)", line)
     if m:
         c[(m.group(1), m.group(2))] = float(m.group(4))
-for k in ("k_step", "k_step_policy", "k_dqn_grad", "k_dqn_reduce_adam"):
+for k in ("k_step", "k_step_policy", "k_dqn_grad", "k_dqn_reduce_adam", "k_apf_adjust", "k_sac_critic_grad", "k_sac_actor_grad"):
     f, w = c.get((k, "FETCH_SIZE")), c.get((k, "WRITE_SIZE"))
     if f is not None and w is not None:
         # gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; KB units
