@@ -163,7 +163,12 @@ def parse():
     p.add_argument("--replan-every", type=int, default=0,
                    help="rolling refresh of the reset bank (the reference plans a fresh path at every reset): every that many passes "
                         "the C loop commits the slice planned in the background and starts the next one (0 = the bank stays as planned)")
-    p.add_argument("--replan-count", type=int, default=256, help="bank rows per refresh slice")
+    p.add_argument("--replan-count", type=int, default=4096,
+                   help="bank rows per refresh slice.  A slice lasts as long as its longest tree (~20-25 ms: a few reset scenarios "
+                        "need thousands of RRT iterations), so the refresh rate is rows per slice / that time: large slices")
+    p.add_argument("--bank-size", type=int, default=0,
+                   help="reset scenarios planned at start-up (0 = max(envs, 4096); 4 x envs with --replan-every: a refresh skips rows an "
+                        "agent is flying, and with as many rows as agents that is 63 %% of them)")
     p.add_argument("--inject-p2p-fault", type=int, default=-1,
                    help="test: rank R raises the peer exchange's sticky error before the timed region (exercises the fallback)")
     p.add_argument("--p2p-check-every", type=int, default=256, help="N > 1: on-device weight checksum compare every that many updates")
@@ -657,7 +662,8 @@ def run_dqn(args, world_size, rank, dev):
         if not args.env_only:
             raise SystemExit("--apf / --uav-per-env are env-only diagnostics")
         extra = dict(apf_enabled=1 if args.apf else 0, uav_per_env=args.uav_per_env)
-    env = make_city26_env(args.envs, bank=args.bank, bank_size=max(args.envs, 4096), bank_seed=42 + rank, device=dev,
+    bank_size = args.bank_size or (4 * args.envs if args.replan_every > 0 else max(args.envs, 4096))
+    env = make_city26_env(args.envs, bank=args.bank, bank_size=bank_size, bank_seed=42 + rank, device=dev,
                           obs_dtype=obs_dtype, cell_size=args.cell, **extra)
     if args.apf:
         v = np.random.default_rng(42).uniform(-1.0, 1.0, (len(env.buildings), 3))
@@ -1043,7 +1049,7 @@ def run_dqn(args, world_size, rank, dev):
                        "learner": "fused HIP kernels (%s MFMA)" % ldt if fused else "PyTorch-ROCm ops",
                        "learner_dtype": ldt if fused else ("f32" if args.obs_dtype == "f32" else "f16 autocast"),
                        "reset_bank": ("%d scenarios planned on the GPU (RRT, %.0f ms incl. env construction)"
-                                      % (max(args.envs, 4096), t_plan * 1e3)) if args.bank == "gpu"
+                                      % (bank_size, t_plan * 1e3)) if args.bank == "gpu"
                        else "1024 packaged reference resets",
                        "resets": {"consumed_per_s": None if p_reset is None else value / world_size * p_reset,
                                   "episode_end_fraction_of_agent_steps": p_reset,
@@ -1053,7 +1059,7 @@ def run_dqn(args, world_size, rank, dev):
                                       rows_committed_per_s=refresh["rows_committed"] / (dt * (args.steps + max(args.warmup, 1)) / args.steps)),
                                   "note": "the reference plans a fresh RRT path at every reset (Agents/UAV.py:327-366); here resets draw "
                                           "from a bank of %d scenarios planned on the GPU at start-up%s" % (
-                                              max(args.envs, 4096),
+                                              bank_size,
                                               ", turned over in the background by the loop (uavenv_replan_*): the shortfall is "
                                               "consumed_per_s - rows_committed_per_s" if refresh is not None else
                                               " and reused for the whole run (--replan-every N turns it over in the background)")},

@@ -26,7 +26,7 @@ STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE, STEP_APF_LANE = 1, 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
-    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_replan_begin", "uavenv_replan_ready", "uavenv_replan_commit", "uavenv_replan_stats", "uavenv_bank_read", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
+    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_replan_begin", "uavenv_replan_ready", "uavenv_replan_commit", "uavenv_replan_stats", "uavenv_bank_read", "uavenv_set_moved_word", "uavenv_tick", "uavenv_dqn_reduce_adam_gated", "uavenv_per_set_f32_gated", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs", "uavenv_geometry",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
@@ -87,7 +87,8 @@ class UavLoopConfig(C.Structure):
                 ("per_eps", C.c_double), ("per_clip", C.c_double),
                 ("per_slots_dev", C.c_void_p), ("per_prio_dev", C.c_void_p), ("per_w_dev", C.c_void_p),
                 ("per_abs_dev", C.c_void_p), ("per_idx_dev", C.c_void_p),
-                ("replan_every", C.c_int32), ("replan_count", C.c_int32), ("replan_max_iter", C.c_int32), ("reserved1", C.c_int32)]
+                ("replan_every", C.c_int32), ("replan_count", C.c_int32), ("replan_max_iter", C.c_int32), ("reserved1", C.c_int32),
+                ("moved_dev", C.c_void_p)]
 
 
 class UavLoopCursor(C.Structure):
@@ -111,7 +112,7 @@ class UavSacBatch(C.Structure):
 class UavSacAdam(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("tau", C.c_float), ("grad_scale", C.c_float),
-                ("skip_word", C.c_void_p)]
+                ("skip_word", C.c_void_p), ("go_word", C.c_void_p), ("go_value", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 SAC_LOOP_MAX_SLOTS = 8
@@ -138,7 +139,7 @@ class UavSacLoopConfig(C.Structure):
                 ("draws_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("slot", UavSacLoopSlot * SAC_LOOP_MAX_SLOTS),
                 ("p2p", C.c_void_p), ("coll", C.c_void_p), ("xbuf_dev", C.c_void_p),
                 ("per_alpha", C.c_double), ("per_beta_inc", C.c_double), ("per_eps", C.c_double), ("per_clip", C.c_double),
-                ("check_every", C.c_int32), ("reserved3", C.c_int32)]
+                ("moved_dev", C.c_void_p), ("check_every", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class UavSacLoopCursor(C.Structure):
@@ -192,6 +193,10 @@ def load() -> C.CDLL:
     lib.uavenv_replan_commit.argtypes = [vp, i32, vp]
     lib.uavenv_replan_stats.restype = C.c_int
     lib.uavenv_replan_stats.argtypes = [vp, vp]
+    lib.uavenv_set_moved_word.restype = C.c_int
+    lib.uavenv_set_moved_word.argtypes = [vp, vp]
+    lib.uavenv_tick.restype = C.c_uint64
+    lib.uavenv_tick.argtypes = [vp]
     lib.uavenv_bank_read.restype = C.c_int
     lib.uavenv_bank_read.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.uavenv_rrt_plan.restype = C.c_int
@@ -320,6 +325,8 @@ def load() -> C.CDLL:
     lib.uavenv_dqn_adam.argtypes = [net, vp, f32, f32, f32, f32, i32, i32, vp, vp]
     lib.uavenv_dqn_reduce_adam.restype = C.c_int
     lib.uavenv_dqn_reduce_adam.argtypes = [net, vp, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp]
+    lib.uavenv_dqn_reduce_adam_gated.restype = C.c_int
+    lib.uavenv_dqn_reduce_adam_gated.argtypes = [net, vp, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp, C.c_uint32, vp]
     lib.uavenv_dqn_act.restype = C.c_int
     lib.uavenv_dqn_act.argtypes = [net, vp, i32, i32, f32, u64, u64, vp, vp, vp, vp]
     per, f64 = C.POINTER(UavPer), C.c_double
@@ -335,6 +342,8 @@ def load() -> C.CDLL:
     lib.uavenv_per_set.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
     lib.uavenv_per_set_f32.restype = C.c_int
     lib.uavenv_per_set_f32.argtypes = [per, vp, vp, i32, f64, f64, f64, vp]
+    lib.uavenv_per_set_f32_gated.restype = C.c_int
+    lib.uavenv_per_set_f32_gated.argtypes = [per, vp, vp, i32, f64, f64, f64, vp, C.c_uint32, vp]
     lib.uavenv_p2p_allreduce.restype = C.c_int
     lib.uavenv_p2p_allreduce.argtypes = [vp, vp, i64, vp]
     lib.uavenv_per_rebuild_frame.restype = C.c_int

@@ -1630,8 +1630,13 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
                                                          float *__restrict__ local, float *__restrict__ target,
                                                          float *__restrict__ m, float *__restrict__ v, float lr,
                                                          float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                         int hard_update, float *__restrict__ loss, float *__restrict__ raw)
+                                                         int hard_update, float *__restrict__ loss, float *__restrict__ raw,
+                                                         const uint32_t *__restrict__ go_word, uint32_t go_value)
 {
+    // gated update (uavenv_dqn_reduce_adam_gated): the step kernel of this pass stamps go_word with go_value when it moved at
+    // least one agent; a pass in which every agent had already finished leaves the learner exactly as it is (the reference's loop
+    // has left run_eposide by then, Envs/PathPlan_City.py:456-459)
+    if (go_word && *go_word != go_value) return;
     __shared__ float cnt_part[4];
     const int tid = (int)threadIdx.x;
     const int p = (int)blockIdx.x * 32 + tid;
@@ -2127,6 +2132,14 @@ int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials, int32_t 
                            float beta2, float eps, int32_t step_t, int32_t hard_update, float *loss_out, float *raw_out,
                            void *stream)
 {
+    return uavenv_dqn_reduce_adam_gated(net, partials, n_partials, lr, beta1, beta2, eps, step_t, hard_update, loss_out, raw_out,
+                                        nullptr, 0u, stream);
+}
+
+int uavenv_dqn_reduce_adam_gated(const UavDqnNet *net, const float *partials, int32_t n_partials, float lr, float beta1,
+                                 float beta2, float eps, int32_t step_t, int32_t hard_update, float *loss_out, float *raw_out,
+                                 const uint32_t *go_word_dev, uint32_t go_value, void *stream)
+{
     if (!net_ok(net) || !net->target || !net->m || !net->v || !partials || n_partials <= 0 || step_t <= 0)
         return UAVENV_EINVAL;
     const int P = uavenv_dqn_num_params(net);
@@ -2134,7 +2147,7 @@ int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials, int32_t 
     const float bc2 = 1.0f - powf(beta2, (float)step_t);
     hipLaunchKernelGGL(k_dqn_reduce_adam, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
                        P, uavenv_dqn_partial_stride(net), net->local, net->target, net->m, net->v, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update,
-                       loss_out, raw_out);
+                       loss_out, raw_out, go_word_dev, go_value);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

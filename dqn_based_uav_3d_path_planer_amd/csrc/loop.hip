@@ -100,6 +100,10 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
             return UAVENV_EHIP;
         }
     }
+    if (cfg->moved_dev) {
+        if (cfg->p2p || cfg->coll || cfg->sample_lag != 0) { uavenv_loop_destroy(l); return UAVENV_EINVAL; }
+        if (uavenv_set_moved_word(cfg->env, cfg->moved_dev) != UAVENV_OK) { uavenv_loop_destroy(l); return UAVENV_EINVAL; }
+    }
     if (cfg->replan_every > 0) {
         int32_t m = 0;
         int lo = 0, hi = 0;
@@ -122,6 +126,7 @@ int uavenv_loop_destroy(UavLoop *l)
     if (l->prof && l->t_host[3] > 0)
         fprintf(stderr, "uavenv_loop host us per pass: act+step %.2f grad %.2f adam %.2f (%.0f passes)\n", 1e6 * l->t_host[0] / l->t_host[3],
                 1e6 * l->t_host[1] / l->t_host[3], 1e6 * l->t_host[2] / l->t_host[3], l->t_host[3]);
+    if (l->c.moved_dev) (void)uavenv_set_moved_word(l->c.env, nullptr);
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : l->pool) (void)hipEventDestroy(e);
     if (l->aux) { (void)hipStreamSynchronize(l->aux); (void)hipStreamDestroy(l->aux); }
@@ -294,13 +299,15 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 if (rc != UAVENV_OK) return rc;
                 rc = uavenv_dqn_adam(&c.net, c.raw_dev, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, s);
             } else {
-                rc = uavenv_dqn_reduce_adam(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2,
-                                            c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);
+                // (moved_dev: no update behind a step that moved nobody -- the word was stamped with this pass's tick by the step)
+                rc = uavenv_dqn_reduce_adam_gated(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2,
+                                                  c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, c.moved_dev,
+                                                  (uint32_t)uavenv_tick(c.env), s);
             }
             if (rc != UAVENV_OK) return rc;
             if (l->per) {                 // ReplayTree.batch_update (:215-222)
-                rc = uavenv_per_set_f32(&c.per, c.per_slots_dev, c.per_abs_dev, c.batch, (double)c.per_eps, (double)c.per_alpha,
-                                        (double)c.per_clip, s);
+                rc = uavenv_per_set_f32_gated(&c.per, c.per_slots_dev, c.per_abs_dev, c.batch, (double)c.per_eps, (double)c.per_alpha,
+                                              (double)c.per_clip, c.moved_dev, (uint32_t)uavenv_tick(c.env), s);
                 if (rc != UAVENV_OK) return rc;
             }
             if (l->prof) {
@@ -430,6 +437,8 @@ int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out)
     }
     if (n_per != 0 && n_per != cfg->n_slots) return UAVENV_EINVAL;          // one Trainer.xml: all slots or none
     if (n_per && (cfg->p2p || cfg->coll)) return UAVENV_EINVAL;             // (prioritised replay is a one-GPU path here)
+    if (cfg->moved_dev && (cfg->p2p || cfg->coll)) return UAVENV_EINVAL;    // (so is the gated update)
+    if (cfg->moved_dev && uavenv_set_moved_word(cfg->env, cfg->moved_dev) != UAVENV_OK) return UAVENV_EINVAL;
     UavSacLoop *l = new (std::nothrow) UavSacLoop();
     if (!l) return UAVENV_ENOMEM;
     l->c = *cfg;
@@ -446,6 +455,7 @@ int uavenv_sac_loop_create(const UavSacLoopConfig *cfg, UavSacLoop **out)
 
 int uavenv_sac_loop_destroy(UavSacLoop *l)
 {
+    if (l && l->c.moved_dev) (void)uavenv_set_moved_word(l->c.env, nullptr);
     delete l;
     return UAVENV_OK;
 }
@@ -563,6 +573,9 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             h.bias_correction2_sqrt = (float)sqrt(1.0 - pow(c.beta2, tt));
             h.grad_scale = 0.0f;
             h.skip_word = c.p2p ? uavenv_p2p_error_word(c.p2p) : nullptr;   // Adam behind a failed pull: a no-op
+            h.go_word = c.moved_dev;                                          // ... and behind a step that moved nobody
+            h.go_value = (uint32_t)uavenv_tick(c.env);
+            h.reserved0 = 0;
             h.lr = c.critic_lr; h.tau = c.tau;
             hc[j] = h;
             h.lr = c.actor_lr; h.tau = 0.0f;
@@ -626,7 +639,8 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         }
         if (l->per) {                     // ReplayTree.batch_update (:215-222, :352) with the |TD| the critic phase left
             for (int j = 0; j < U; ++j) {
-                rc = uavenv_per_set_f32(&c.slot[j].per, c.slot[j].per_slots_dev, c.slot[j].per_abs_dev, B, c.per_eps, c.per_alpha, c.per_clip, s);
+                rc = uavenv_per_set_f32_gated(&c.slot[j].per, c.slot[j].per_slots_dev, c.slot[j].per_abs_dev, B, c.per_eps, c.per_alpha,
+                                              c.per_clip, c.moved_dev, (uint32_t)uavenv_tick(c.env), s);
                 if (rc != UAVENV_OK) return rc;
             }
         }

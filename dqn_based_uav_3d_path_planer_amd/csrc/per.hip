@@ -250,10 +250,11 @@ __global__ void k_per_set(UavPer p, const int64_t *__restrict__ slots, const dou
 }
 
 __global__ void k_per_set_f32(UavPer p, const int64_t *__restrict__ slots, const float *__restrict__ abs_err, int n,
-                              double epsilon, double alpha, double clip)
+                              double epsilon, double alpha, double clip, const uint32_t *__restrict__ go_word, uint32_t go_value)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
+    if (go_word && *go_word != go_value) return;         // (gated: see uavenv_per_set_f32_gated)
     const int64_t s = slots[i];
     if (s < 0 || s >= p.capacity) return;
     if (clip > 0.0 && p.prio[s] == 0.0) return;          // (an empty leaf stays empty: see k_per_set)
@@ -414,10 +415,16 @@ int uavenv_per_fill_frame_strided(const UavPer *p, int64_t first, int64_t count,
 int uavenv_per_set_f32(const UavPer *p, const int64_t *slots_dev, const float *abs_err_dev, int32_t n, double epsilon,
                        double alpha, double clip, void *stream)
 {
+    return uavenv_per_set_f32_gated(p, slots_dev, abs_err_dev, n, epsilon, alpha, clip, nullptr, 0u, stream);
+}
+
+int uavenv_per_set_f32_gated(const UavPer *p, const int64_t *slots_dev, const float *abs_err_dev, int32_t n, double epsilon,
+                             double alpha, double clip, const uint32_t *go_word_dev, uint32_t go_value, void *stream)
+{
     if (!per_ok(p) || !slots_dev || !abs_err_dev || n < 0) return UAVENV_EINVAL;
     if (n == 0) return UAVENV_OK;
     hipLaunchKernelGGL(k_per_set_f32, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, slots_dev, abs_err_dev, n,
-                       epsilon, alpha, clip);
+                       epsilon, alpha, clip, go_word_dev, go_value);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

@@ -85,6 +85,38 @@ __device__ __forceinline__ double ldist(double ax, double ay, double az, double 
     return sqrt(dx * dx + dy * dy + dz * dz);
 }
 
+// Squared distance: the argument ldist() hands to sqrt, bit for bit (same expression, -ffp-contract=off).
+__device__ __forceinline__ double ldist2(double ax, double ay, double az, double bx, double by, double bz)
+{
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    return dx * dx + dy * dy + dz * dz;
+}
+// Comparisons of sqrt values decided on their arguments wherever the arguments are clearly apart (round 4: the sqrt -- ~30 f64
+// instructions on gfx950 -- was most of a node's cost in the nearest-node and rewire scans).  The device sqrt is within one ulp
+// (2^-52 relative) of the true root, so arguments that differ by more than kBand = 2^-48 relative have roots ordered the same
+// way; closer arguments -- practically only exact ties -- fall back to comparing the roots themselves.  The decisions are
+// therefore EXACTLY those of the round-3 code that took the root of every distance.
+constexpr double kBand = 1.0 / 281474976710656.0;     // 2^-48
+// is sqrt(a2) < sqrt(b2) ?
+__device__ __forceinline__ bool root_less(double a2, double b2)
+{
+    if (a2 < b2 * (1.0 - kBand)) return true;
+    if (a2 > b2 * (1.0 + kBand)) return false;
+    return sqrt(a2) < sqrt(b2);
+}
+// is sqrt(a2) < s ?   (s2 = s * s: its rounding, 2^-53 relative, is far inside the band)
+__device__ __forceinline__ bool root_less_than(double a2, double s, double s2)
+{
+    if (a2 < s2 * (1.0 - kBand)) return true;
+    if (a2 > s2 * (1.0 + kBand)) return false;
+    return sqrt(a2) < s;
+}
+__device__ __forceinline__ bool root_equal(double a2, double b2)
+{
+    if (a2 < b2 * (1.0 - kBand) || a2 > b2 * (1.0 + kBand)) return false;
+    return sqrt(a2) == sqrt(b2);
+}
+
 // RRT.obstacle_free (RRT.py:48-56): sample points a + (b-a)*i/(steps+1), i = 0..steps, one lane each.
 template <typename MaskT>
 __device__ __forceinline__ bool obstacle_free(const WorldLds<MaskT> &w, double ax, double ay, double az, double bx,
@@ -117,7 +149,10 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = (int)threadIdx.x;
     WorldLds<MaskT> w;
-    Node *nodes;
+    // the node list, structure of arrays: [x | y | z | cost] of max_nodes doubles each, then the parents.  (An array of 32-byte
+    // structs made every scan read with a 32-byte lane stride: half the LDS banks idle; and one node per lane per round left each
+    // round waiting out a full LDS round trip -- the scans below take four rounds' operands at once.)
+    double *NX, *NY, *NZ, *NC;
     int *parent;
     if (IN_LDS) {   // stage the world (same blob as the env kernels)
         const uint4 *src = reinterpret_cast<const uint4 *>(a.world_blob);
@@ -128,16 +163,17 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
         w.aux = reinterpret_cast<const BldAux *>(smem + a.aux_off);
         for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(smem + a.grid_off + h * a.grid_stride);
         const int node_off = (a.world_bytes + 15) & ~15;
-        nodes = reinterpret_cast<Node *>(smem + node_off);
+        NX = reinterpret_cast<double *>(smem + node_off);
         parent = reinterpret_cast<int *>(smem + node_off + (size_t)a.max_nodes * sizeof(Node));
     } else {
         w.b = reinterpret_cast<const BldLds *>(a.world_blob);
         w.aux = reinterpret_cast<const BldAux *>(a.world_blob + a.aux_off);
         for (int h = 0; h < 3; ++h) w.g[h] = reinterpret_cast<const MaskT *>(a.world_blob + a.grid_off + h * a.grid_stride);
         unsigned char *mine = a.node_scratch + (size_t)blockIdx.x * (size_t)a.max_nodes * (sizeof(Node) + sizeof(int));
-        nodes = reinterpret_cast<Node *>(mine);
+        NX = reinterpret_cast<double *>(mine);
         parent = reinterpret_cast<int *>(mine + (size_t)a.max_nodes * sizeof(Node));
     }
+    NY = NX + a.max_nodes; NZ = NY + a.max_nodes; NC = NZ + a.max_nodes;
     w.gn = a.gn; w.inv_cell = a.inv_cell; w.W = a.W; w.Hbox = a.Hbox;
 
     const int n_work = a.tier_b ? __hip_atomic_load(a.queue + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.m;
@@ -165,7 +201,7 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
                 sx = rs.uniform(10, 210); sy = rs.uniform(1, 10); sz = 0.0;
                 gx = rs.uniform(330, 490); gy = rs.uniform(420, 490); gz = 0.0;
             }
-            if (lane == 0) { nodes[0] = Node{sx, sy, sz, 0.0}; parent[0] = -1; }
+            if (lane == 0) { NX[0] = sx; NY[0] = sy; NZ[0] = sz; NC[0] = 0.0; parent[0] = -1; }
             __syncthreads();
             int nn = 1, goal_parent = -1;
             int it = 0;
@@ -178,20 +214,28 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
                     rx = gx; ry = gy; rz = gz;
                 }
                 // ---- nearest_node (RRT.py:36-37): first minimum
-                double bd = 1e300;
+                double bd = 1e300;                    // SQUARED distance of the best node so far (see root_less)
                 int bi = 0x7fffffff;
-                for (int k = lane; k < nn; k += 64) {
-                    const Node q = nodes[k];
-                    const double d = ldist(q.x, q.y, q.z, rx, ry, rz);
-                    if (d < bd) { bd = d; bi = k; }
+                for (int k0 = lane; k0 < nn; k0 += 256) {          // four rounds' operands in flight together
+                    double qx[4], qy[4], qz[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + 64 * u < nn ? k0 + 64 * u : k0;     // (a repeat of k0 can never win: same root, not a lower index)
+                        qx[u] = NX[k]; qy[u] = NY[k]; qz[u] = NZ[k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double d = ldist2(qx[u], qy[u], qz[u], rx, ry, rz);
+                        if (k0 + 64 * u < nn && root_less(d, bd)) { bd = d; bi = k0 + 64 * u; }
+                    }
                 }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
                     const double od = __shfl_xor(bd, off, 64);
                     const int oi = __shfl_xor(bi, off, 64);
-                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                    if (root_less(od, bd) || (oi < bi && root_equal(od, bd))) { bd = od; bi = oi; }
                 }
-                const Node nr = nodes[bi];
+                const Node nr = Node{NX[bi], NY[bi], NZ[bi], NC[bi]};
                 // ---- steer (RRT.py:39-46); np.linalg.norm == sqrt(ddot) == an FMA chain on the reference platform
                 double dx = rx - nr.x, dy = ry - nr.y, dz = rz - nr.z;
                 const double length = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
@@ -204,21 +248,32 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
                 }
                 if (!obstacle_free(w, nr.x, nr.y, nr.z, nx, ny, nz, a.obstacle_step)) continue;     // :77-78
                 const int me = nn;
+                const double step2 = a.step_size * a.step_size;
                 double my_cost = nr.cost + ldist(nr.x, nr.y, nr.z, nx, ny, nz);
                 int my_parent = bi;
                 // ---- rewire (RRT.py:84-90), sequential over the list, 64 distance tests at a time
-                for (int base = 0; base < nn; base += 64) {
-                    const int k = base + lane;
-                    bool near = false;
-                    if (k < nn) {
-                        const Node q = nodes[k];
-                        near = ldist(q.x, q.y, q.z, nx, ny, nz) < a.step_size;
-                    }
-                    unsigned long long mask = __ballot(near);
+                for (int base4 = 0; base4 < nn; base4 += 256) {
+                  double qx[4], qy[4], qz[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                      const int k = base4 + 64 * u + lane < nn ? base4 + 64 * u + lane : 0;
+                      qx[u] = NX[k]; qy[u] = NY[k]; qz[u] = NZ[k];
+                  }
+                  unsigned long long masks[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                      const bool near = base4 + 64 * u + lane < nn &&
+                                        root_less_than(ldist2(qx[u], qy[u], qz[u], nx, ny, nz), a.step_size, step2);   // Loc.distance < step (RRT.py:86)
+                      masks[u] = __ballot(near);
+                  }
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    const int base = base4 + 64 * u;
+                    unsigned long long mask = masks[u];
                     while (mask) {
                         const int b = __builtin_ctzll(mask);
                         mask &= mask - 1;
-                        const Node q = nodes[base + b];
+                        const Node q = Node{NX[base + b], NY[base + b], NZ[base + b], NC[base + b]};
                         const double d = ldist(q.x, q.y, q.z, nx, ny, nz);
                         if (my_cost > q.cost + d) {
                             if (obstacle_free(w, q.x, q.y, q.z, nx, ny, nz, a.obstacle_step)) {
@@ -227,8 +282,9 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
                             }
                         }
                     }
+                  }
                 }
-                if (lane == 0) { nodes[me] = Node{nx, ny, nz, my_cost}; parent[me] = my_parent; }
+                if (lane == 0) { NX[me] = nx; NY[me] = ny; NZ[me] = nz; NC[me] = my_cost; parent[me] = my_parent; }
                 nn += 1;
                 __syncthreads();
                 if (ldist(nx, ny, nz, gx, gy, gz) <= a.step_size) {                       // :92-94
@@ -254,7 +310,7 @@ __global__ void __launch_bounds__(64) k_rrt_plan(RrtArgs a)
                         out[3 * k] = gx; out[3 * k + 1] = gy; out[3 * k + 2] = gz;
                         for (int p = goal_parent; p >= 0; p = parent[p]) {
                             --k;
-                            out[3 * k] = nodes[p].x; out[3 * k + 1] = nodes[p].y; out[3 * k + 2] = nodes[p].z;
+                            out[3 * k] = NX[p]; out[3 * k + 1] = NY[p]; out[3 * k + 2] = NZ[p];
                         }
                     }
                     for (int q = count * 3 + lane; q < a.K * 3; q += 64) out[q] = 0.0;

@@ -856,6 +856,8 @@ struct AdamArgs {
     int frac_col;                            // column holding the valid fraction of the batch (-1: scale by grad_scale instead)
     int n_loss;                              // the first n_loss extras are loss means
     const uint32_t *skip;                    // nullable: a non-zero word makes the launch a no-op (UavSacAdam.skip_word)
+    const uint32_t *go;                      // nullable: the launch is a no-op unless *go == go_value (UavSacAdam.go_word)
+    uint32_t go_value;
 };
 
 __device__ __forceinline__ float adam_step(float p, float g, float &m, float &v, const AdamArgs &a, float lr)
@@ -903,6 +905,8 @@ __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgsN slots)
     // behind a peer exchange that raised its sticky error the row holds rank-local sums: step nothing (the rank's
     // parameters, moments, targets and log_alpha freeze until the caller re-synchronises them; csrc/p2p.hip)
     if (a.skip && __hip_atomic_load(a.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    // ... and behind a step that moved no agent there is no update at all (the reference has left its episode loop)
+    if (a.go && *a.go != a.go_value) return;
     // every column was accumulated as sum_i w_i (...) / B per rank; frac = sum of the ranks' (valid / B): dividing by it
     // gives the mean over the valid samples of all ranks (all valid: 1 / world size)
     const float frac = (fpart[0] + fpart[1]) + (fpart[2] + fpart[3]);
@@ -1025,6 +1029,7 @@ int critic_adam_args(const UavSacNets *nets, const float *partials, int32_t rows
     a.n_loss = 2;
     a.scalars_out = losses_out;
     a.skip = h->skip_word;
+    a.go = h->go_word; a.go_value = h->go_value;
     return UAVENV_OK;
 }
 
@@ -1045,6 +1050,7 @@ int actor_adam_args(const UavSacNets *nets, const float *partials, int32_t rows,
     a.log_alpha = nets->log_alpha; a.alpha_mv = alpha_mv; a.alpha_lr = alpha_lr; a.target_entropy = target_entropy;
     a.inv_2b = 0.5f / (float)batch;
     a.skip = h->skip_word;
+    a.go = h->go_word; a.go_value = h->go_value;
     return UAVENV_OK;
 }
 

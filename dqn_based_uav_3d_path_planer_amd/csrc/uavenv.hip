@@ -138,6 +138,9 @@ struct StepArgs {
     int32_t pol_dueling, pol_off;      // pol_off: LDS byte offset of the policy's tiles
     float pol_eps;
     uint64_t pol_seed, pol_counter;
+    // uavenv_set_moved_word: stamped with moved_value by a step launch that moved at least one agent (valid = 1)
+    uint32_t *moved_word;
+    uint32_t moved_value;
 };
 
 struct UavEnv {
@@ -164,6 +167,7 @@ struct UavEnv {
     int bank_m = 0;
     uint64_t seed = 0, tick = 0;
     unsigned long long *dbg = nullptr;
+    uint32_t *moved_word = nullptr;    // uavenv_set_moved_word
     // rolling refresh of the bank (uavenv_replan_*): staged plans of one slice + bookkeeping
     double *rp_sg = nullptr, *rp_sub = nullptr;
     int32_t *rp_nsub = nullptr;        // [cap] staged n_sub, then [cap] in-use flags
@@ -1051,6 +1055,7 @@ __device__ __forceinline__ void k_step_body(const StepArgs &a)
             if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
             if (a.info) a.info[i] = (uint8_t)info;
             if (a.valid) a.valid[i] = (uint8_t)valid;
+            if (a.moved_word && valid) *a.moved_word = a.moved_value;       // (every writer stores the same value)
             if (a.energy64) a.energy64[i] = energy;
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);
@@ -1324,6 +1329,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
             if (a.info) a.info[i] = (uint8_t)info;
             if (a.valid) a.valid[i] = (uint8_t)valid;
+            if (a.moved_word && valid) *a.moved_word = a.moved_value;       // (every writer stores the same value)
             if (a.energy64) a.energy64[i] = energy;
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);
@@ -1551,6 +1557,8 @@ static StepArgs base_args(const UavEnv *e)
     a.bank.m = e->bank_m;
     a.seed = e->seed;
     a.tick = e->tick;
+    a.moved_word = e->moved_word;
+    a.moved_value = (uint32_t)(e->tick + 1);
     a.dbg = e->dbg;
     return a;
 }
@@ -2098,6 +2106,15 @@ int uavenv_replan_commit(UavEnv *e, int32_t force, void *stream)
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }
+
+int uavenv_set_moved_word(UavEnv *e, uint32_t *dev_word)
+{
+    if (!e) return fail(UAVENV_EINVAL, "null env");
+    e->moved_word = dev_word;
+    return UAVENV_OK;
+}
+
+uint64_t uavenv_tick(const UavEnv *e) { return e ? e->tick : 0; }
 
 int uavenv_bank_read(UavEnv *e, int32_t first, int32_t count, double *host_sg, double *host_sub, int32_t *host_nsub)
 {

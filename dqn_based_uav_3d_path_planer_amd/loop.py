@@ -23,7 +23,7 @@ class HotLoop:
     def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
                  counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
                  time_every: int = 0, info: torch.Tensor = None, per=None, sample_lag: int = 0,
-                 replan_every: int = 0, replan_count: int = 0, replan_max_iter: int = 10000):
+                 replan_every: int = 0, replan_count: int = 0, replan_max_iter: int = 10000, gate_updates: bool = False):
         """per: a replay.DevicePER over the ring's frames * N slots -- prioritised replay (IsPriority_Replay = 1) inside the C
         loop: new-frame priorities, rebuild, ReplayTree.sample, importance weights, the weighted update and batch_update are
         enqueued per pass (csrc/loop.hip); per.beta / per.n_entries are kept in step."""
@@ -60,6 +60,11 @@ class HotLoop:
         # rolling refresh of the reset bank: every replan_every passes the loop commits the planned slice and starts planning the
         # next replan_count bank rows on a low-priority stream beside the passes (the reference plans at EVERY reset)
         cfg.replan_every, cfg.replan_count, cfg.replan_max_iter = int(replan_every), int(replan_count), int(replan_max_iter)
+        # gate_updates: no learner update behind a step that moved nobody (every agent had already finished: the reference has left
+        # its episode loop by then, Envs/PathPlan_City.py:456-459; the fused plugin path only looks every <done_check> steps)
+        self._moved = torch.zeros(1, dtype=torch.int32, device=env.device) if gate_updates else None
+        if self._moved is not None:
+            cfg.moved_dev = self._moved.data_ptr()
         if info is not None:        # [frames, N] uint8: the info code of every transition (episode statistics)
             assert info.dtype == torch.uint8 and tuple(info.shape) == (ring.frames, env.N) and info.is_contiguous()
             cfg.info_dev = info.data_ptr()
@@ -158,7 +163,7 @@ class SACHotLoop:
 
     def __init__(self, ring: DeviceReplayRing, learners, batch: int, seed: int, act1_plane: torch.Tensor, counter: int = 0,
                  info: torch.Tensor = None, is_train: bool = True, auto_reset: bool = True, skip_done: bool = True,
-                 exchange: str = None, spin_limit: int = 0, pers=None, check_every: int = 64):
+                 exchange: str = None, spin_limit: int = 0, pers=None, check_every: int = 64, gate_updates: bool = False):
         """pers: one replay.DevicePER per UAV slot (capacity ring.frames * n_envs, tree_order=False) -- prioritised replay, the
         reference's own use of ReplayTree (Trainer/SAC_Trainer.py:336-352), inside the C loop: per step and slot the new frame's
         priorities, rebuild, ReplayTree.sample, importance weights, the four update phases (weights in, |TD| out), batch_update."""
@@ -227,6 +232,9 @@ class SACHotLoop:
                 sl.per = p._c
                 sl.per_slots_dev, sl.per_prio_dev, sl.per_w_dev, sl.per_abs_dev = (t.data_ptr() for t in bufs)
                 sl.per_beta = p.beta
+        self._moved = torch.zeros(1, dtype=torch.int32, device=d) if gate_updates else None      # as HotLoop(gate_updates)
+        if self._moved is not None:
+            cfg.moved_dev = self._moved.data_ptr()
         self._keep = (act1_plane, info)
         self.exchange, self._p2p, self._coll = None, None, None
         if exchange is not None:

@@ -440,14 +440,18 @@ class PathPlan_City:
         if self._hot is None:
             self._hot = HotLoop(ring, tr.learner, tr.Batch_Size if tr.Is_Train else 0, seed=self.seed, eps=eps_rate,
                                 learn_start=tr.Batch_Size + 1, auto_reset=False, skip_done=True, info=self._info,
-                                per=getattr(self, "_per", None), counter=getattr(self, "_hot_counter", 0))
+                                per=getattr(self, "_per", None), counter=getattr(self, "_hot_counter", 0), gate_updates=True)
         self._hot.set_eps(eps_rate if tr.Is_Train else 0.0)
         k = 1 if self.record_path else min(self.done_check, ring.frames - 2)
         n_steps, ended = 0, False
         dev = self.backend.device
+        epoch0, passes = tr.learner.epoch, 0
+        per = getattr(self, "_per", None)
+        beta0 = per.beta if per is not None else None
         while not ended:
             t0 = ring.head
             self._hot.run(k)
+            passes += k
             fr = (t0 + torch.arange(k, device=dev)) % ring.frames
             v = ring.valid[fr].bool()                                                # [k, N] agents moved by each step
             inf = self._info[fr]
@@ -464,6 +468,15 @@ class PathPlan_City:
             self._invalidate()
             if self.record_path:
                 self._record_paths(range(self.num_UAV))
+        # The passes enqueued behind the last moving step changed nothing on the device (HotLoop(gate_updates): the Adam launch and
+        # batch_update check the word the step kernel stamps) -- the counters follow: the learner has taken exactly one update per
+        # moving step, as the reference's loop, which leaves right after the last one (Envs/PathPlan_City.py:456-459)
+        undo = min(passes - n_steps, tr.learner.epoch - epoch0)
+        if undo > 0:
+            tr.learner.epoch -= undo
+            if per is not None:
+                per.beta = min(1.0, beta0 + (tr.learner.epoch - epoch0) * per.beta_inc)
+        self.surplus_passes_last_episode = passes - n_steps
         tr.loss = tr.learner.loss
         item = {"loss": tr.learner.loss, "sum_epoch": tr.epoch, "score": uav.score, "average_score": uav.score,
                 "step": uav.Step, "energy_cost": uav.energy_cost_total, "task_collect": uav.task_collect,
@@ -518,11 +531,23 @@ class PathPlan_City:
             from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
             self._sac_hot = SACHotLoop(ring, [t_.learner for t_ in trs], trs[0].Batch_Size, seed=self.seed, act1_plane=self._a1,
                                        counter=self._sac_counter, info=self._info, is_train=bool(trs[0].Is_Train),
-                                       auto_reset=False, skip_done=True, pers=self._sac_per if all_per else None)
+                                       auto_reset=False, skip_done=True, pers=self._sac_per if all_per else None,
+                                       gate_updates=True)
         z = getattr(self, "_sac_noise", None)
+        # no update behind a step that moved nobody (see _run_eposide_fused): the C loop gates on the device; the Python loop below
+        # hands every learner the same (word, tick) pair
+        Ls = [t_.learner for t_ in trs]
+        count0 = [(L.epoch, L.adam_steps) for L in Ls]
+        beta0 = [None if p is None else p.beta for p in self._sac_per]
+        passes = 0
+        if not use_c:
+            if getattr(self, "_sac_moved", None) is None:
+                self._sac_moved = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.uavenv_set_moved_word(self.backend._h, self._sac_moved.data_ptr()), "uavenv_set_moved_word")
         while not ended:
             t0 = ring.head
             nb = self._draws_all.shape[0]
+            passes += k
             for _ in range(0 if use_c else k):
                 t = ring.head
                 self._sac_counter += 1
@@ -537,6 +562,9 @@ class PathPlan_City:
                 for j, uav in enumerate(self.Agents):
                     uav.Trainer.learner.act_rows(self._flat, t * N + j, U, self.num_envs, act0, act1, eps=za[j])
                 ring.step_env(auto_reset=False, skip_done=True, info=self._info)
+                go = (self._sac_moved.data_ptr(), int(lib.uavenv_tick(self.backend._h)))
+                for L in Ls:
+                    L.go = go
                 for j, per in enumerate(self._sac_per):      # ReplayTree.push(error 0) for the slot's rows of the frame just written
                     if per is not None:
                         per.fill(t * self.num_envs, self.num_envs, 0.0, valid=ring.valid[t].view(self.num_envs, U)[:, j].contiguous())
@@ -560,7 +588,7 @@ class PathPlan_City:
                         per, pb = self._sac_per[j], self._sac_per_bufs[j]
                         per.sample_into(tr.Batch_Size, self.seed + 7 + j, self._sac_counter, pb, self.num_envs)
                         tr.learner.learn(self._sac_batches[j], noise=(zl[0, o:o + tr.Batch_Size], zl[1, o:o + tr.Batch_Size]))
-                        per.update_f32(pb["slots"], pb["abs"])
+                        per.update_f32(pb["slots"], pb["abs"], go=go)
                     elif learn[j]:
                         if not nd:  # the ring does not hold sum(Batch_Size) transitions yet: one draw per slot
                             _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, tr.Batch_Size,
@@ -589,6 +617,19 @@ class PathPlan_City:
             self._invalidate()
             if self.record_path:
                 self._record_paths(range(U))
+        if not use_c:
+            _lib.check(lib.uavenv_set_moved_word(self.backend._h, None), "uavenv_set_moved_word")
+            for L in Ls:
+                L.go = None
+        surplus = passes - n_steps
+        for j, L in enumerate(Ls):           # the counters follow the device: update() ran once per moving step
+            if surplus > 0:
+                L.epoch -= min(surplus, L.epoch - count0[j][0])
+                L.adam_steps -= min(surplus, L.adam_steps - count0[j][1])
+                if self._sac_per[j] is not None:
+                    p = self._sac_per[j]
+                    p.beta = min(1.0, beta0[j] + (L.adam_steps - count0[j][1]) * p.beta_inc)
+        self.surplus_passes_last_episode = surplus
         items = []
         for uav in self.Agents:
             tr = uav.Trainer

@@ -230,10 +230,13 @@ class DevicePER:
                     w=torch.zeros(batch, dtype=torch.float32, device=d), abs=torch.zeros(batch, dtype=torch.float32, device=d),
                     pairs=pairs if pairs is not None else torch.zeros((batch, 2), dtype=torch.int32, device=d))
 
-    def update_f32(self, slots: torch.Tensor, abs_errors: torch.Tensor):
-        """ReplayTree.batch_update (:215-222) from f32 |TD errors| already on the device."""
-        _lib.check(self.lib.uavenv_per_set_f32(C.byref(self._c), slots.data_ptr(), abs_errors.data_ptr(), slots.numel(),
-                                               self.epsilon, self.alpha, self.clip, self._stream()), "uavenv_per_set_f32")
+    def update_f32(self, slots: torch.Tensor, abs_errors: torch.Tensor, go=None):
+        """ReplayTree.batch_update (:215-222) from f32 |TD errors| already on the device.  go = (device word, value): nothing
+        changes unless the word holds the value (uavenv_set_moved_word)."""
+        gw, gv = go if go is not None else (None, 0)
+        _lib.check(self.lib.uavenv_per_set_f32_gated(C.byref(self._c), slots.data_ptr(), abs_errors.data_ptr(), slots.numel(),
+                                                     self.epsilon, self.alpha, self.clip, gw, int(gv) & 0xffffffff, self._stream()),
+                   "uavenv_per_set_f32")
         self._dirty = True
 
     def sample(self, batch: int, seed: int = 0, counter: int = 0, draws: torch.Tensor = None):

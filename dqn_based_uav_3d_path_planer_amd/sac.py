@@ -228,8 +228,11 @@ class FusedSACLearner:
         t = max(self.adam_steps, 1)
         # behind a peer exchange that raised its sticky error the Adam launch must change nothing (csrc/p2p.hip)
         skip = self.lib.uavenv_p2p_error_word(self._p2p) if getattr(self, "_p2p", None) is not None else None
+        # go = (device word, value): the update changes nothing unless the word holds the value (uavenv_set_moved_word: the step
+        # of this pass moved at least one agent); None = always
+        go = getattr(self, "go", None) or (None, 0)
         return self._lib.UavSacAdam(lr, self.beta1, self.beta2, self.adam_eps, 1.0 - self.beta1 ** t,
-                                    float(np.sqrt(1.0 - self.beta2 ** t)), tau, scale, skip)
+                                    float(np.sqrt(1.0 - self.beta2 ** t)), tau, scale, skip, go[0], int(go[1]) & 0xffffffff, 0)
 
     def enable_exchange(self, kind: str = "auto", spin_limit: int = 0):
         """The on-stream form of the N > 1 exchange (no host round trip, no torch.distributed call per phase): "p2p" =

@@ -142,6 +142,14 @@ int uavenv_replan_begin(UavEnv *env, int32_t first, int32_t count, uint64_t seed
 int uavenv_replan_ready(UavEnv *env);
 int uavenv_replan_commit(UavEnv *env, int32_t force, void *stream);
 int uavenv_replan_stats(UavEnv *env, int64_t *out5);
+/* "Did this step move anyone?" on the device.  After uavenv_set_moved_word(env, w) every step launch (uavenv_step /
+ * uavenv_step_policy) that moves at least one agent -- valid = 1: not skipped as done, not masked out -- stores
+ * (uint32_t)uavenv_tick(env) AS RETURNED AFTER THAT CALL into *w (device memory); a launch that moves nobody leaves *w alone.
+ * uavenv_dqn_reduce_adam_gated / UavSacAdam.go_word take (w, that value): the learner update behind a step that moved nobody
+ * changes nothing -- the reference has left its episode loop by then (Envs/PathPlan_City.py:456-459), the fused plugin path
+ * only looks every <done_check> steps.  NULL turns it off. */
+int uavenv_set_moved_word(UavEnv *env, uint32_t *dev_word);
+uint64_t uavenv_tick(const UavEnv *env);             /* step launches enqueued so far (+ resets: see uavenv_reset_all) */
 /* Rows [first, first + count) of the bank in use, into host memory (any pointer may be NULL): start/goal count x 6, sub-goal
  * lists count x K x 3, n_sub count.  Diagnostics / tests; synchronises the device. */
 int uavenv_bank_read(UavEnv *env, int32_t first, int32_t count, double *host_start_goal, double *host_subgoals, int32_t *host_nsub);
@@ -292,6 +300,10 @@ int uavenv_per_rebuild_frame(const UavPer *per, int64_t first, int64_t count, do
 /* uavenv_per_set with f32 errors (what uavenv_dqn_grad_w / uavenv_sac_critic_grad write). */
 int uavenv_per_set_f32(const UavPer *per, const int64_t *slots_dev, const float *abs_err_dev, int32_t n, double epsilon,
                        double alpha, double clip, void *stream);
+/* ... that leaves every priority alone unless *go_word_dev == go_value when it runs (uavenv_set_moved_word): batch_update belongs
+ * to an update, and there is none behind a step that moved nobody. */
+int uavenv_per_set_f32_gated(const UavPer *per, const int64_t *slots_dev, const float *abs_err_dev, int32_t n, double epsilon,
+                             double alpha, double clip, const uint32_t *go_word_dev, uint32_t go_value, void *stream);
 /* ReplayTree.sample (:163-178), the part after the selection: is_weights[i] = (n_entries * p_i / int(total)) ** -beta,
  * divided by their maximum (f32 out); a zero priority gets weight 0; int(total) < 1 counts as 1.  Also splits each slot
  * into the (frame, agent) pair uavenv_dqn_grad takes (frame_agent_out_dev nullable, batch x 2 int32; slot = frame *
@@ -347,6 +359,11 @@ int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials_dev, int32_t n
 int uavenv_dqn_adam(const UavDqnNet *net, const float *raw_dev, float lr, float beta1, float beta2, float eps,
                     int32_t step_t, int32_t hard_update, float *loss_out_dev, void *stream);
 /* Single-GPU fast path: uavenv_dqn_reduce + uavenv_dqn_adam in ONE launch (raw_out_dev nullable). */
+/* uavenv_dqn_reduce_adam that changes NOTHING (weights, moments, target, loss) unless *go_word_dev == go_value when it runs
+ * (uavenv_set_moved_word); go_word_dev NULL = always. */
+int uavenv_dqn_reduce_adam_gated(const UavDqnNet *net, const float *partials, int32_t n_partials, float lr, float beta1,
+                                 float beta2, float eps, int32_t step_t, int32_t hard_update, float *loss_out, float *raw_out,
+                                 const uint32_t *go_word_dev, uint32_t go_value, void *stream);
 int uavenv_dqn_reduce_adam(const UavDqnNet *net, const float *partials_dev, int32_t n_partials, float lr, float beta1,
                            float beta2, float eps, int32_t step_t, int32_t hard_update, float *loss_out_dev,
                            float *raw_out_dev, void *stream);
@@ -473,6 +490,9 @@ typedef struct UavLoopConfig {
      * loop commits the slice whose planning has finished and starts planning the next replan_count rows of the bank (rotating)
      * on a low-priority stream of its own, beside the passes. */
     int32_t replan_every, replan_count, replan_max_iter, reserved1;
+    /* nullable device word: the loop registers it with the env (uavenv_set_moved_word) and gates every update on "this pass's
+     * step moved at least one agent" (uavenv_dqn_reduce_adam_gated).  Single-GPU form only (no p2p / coll). */
+    uint32_t *moved_dev;
 } UavLoopConfig;
 typedef struct UavLoopCursor {
     int32_t head, filled, epoch, reserved0;
@@ -542,6 +562,9 @@ typedef struct UavSacAdam {
     const uint32_t *skip_word;           /* ABI 4, nullable device word: non-zero when the launch runs => it changes NOTHING (no
                                             parameter, moment, target or scalar).  uavenv_p2p_error_word(): an Adam launch enqueued
                                             behind a peer exchange that timed out must not step with rank-local sums */
+    const uint32_t *go_word;             /* ABI 4, nullable: the launch changes nothing unless *go_word == go_value when it runs
+                                            (uavenv_set_moved_word: no update behind a step that moved nobody) */
+    uint32_t go_value, reserved0;
 } UavSacAdam;
 /* get_action (SAC_Trainer.py:444-448) for `count` agents whose packed rows are first_row + i * row_stride: the two
  * action components land in act0[row] / act1[row].  eps: count x 2 N(0,1) draws (Normal.rsample()). */
@@ -641,6 +664,7 @@ typedef struct UavSacLoopConfig {
      * (seed + 7 + slot, counter)) -> importance weights -> the four update phases (weights into the critic losses, |TD| out) ->
      * batch_update.  The draws of a slot then come from its tree (draws_dev receives the (frame, env) pairs). */
     double per_alpha, per_beta_inc, per_eps, per_clip;
+    uint32_t *moved_dev;                     /* as UavLoopConfig.moved_dev: no update of any slot behind a step that moved nobody */
     int32_t check_every, reserved3;          /* p2p only: compare the ranks' weight checksums (uavenv_p2p_check_blocks over every slot's
                                                 actor, critics and targets) every that many updates; 0 = never */
 } UavSacLoopConfig;

@@ -195,6 +195,36 @@ def test_bench_starts_its_own_ranks_and_checks_them():
     assert d["config"]["host_loop"].startswith("csrc/loop.hip")
 
 
+def test_same_device_runs_are_labelled_as_such():
+    """links_crossed: a line whose ranks all sat on ONE physical GPU (--same-device) must say so -- it exercises the entry point
+    and the exchange code, it is not evidence for the multi-GPU row (no byte crossed xGMI)."""
+    d = _bench("--gpus", "2", "--same-device", "--dist-backend", "gloo", "--no-exchange-leg")
+    assert d["links_crossed"] is False and len(d["rank_devices"]) == 2 and d["rank_devices"][0] == d["rank_devices"][1]
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs (one rank per device)")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("exchange", ["p2p", "coll"])
+def test_two_ranks_on_two_devices(exchange):
+    """The N > 1 path with one rank per DEVICE (skipped on a one-GPU box, e.g. the round-end test box): `bench.py --gpus 2`
+    over the nccl (= RCCL) backend -- the peer exchange maps the other device's HBM through HIP IPC after
+    hipDeviceCanAccessPeer said yes; `--exchange coll` drives an RCCL communicator from C with more than one rank (RCCL
+    refuses two ranks per device, so this is the only place it can run).  links_crossed must be True here."""
+    d = _bench("--gpus", "2", "--exchange", exchange, "--p2p-check-every", "16")
+    assert d["n_gpus"] == 2 and d["links_crossed"] is True and d["ranks_bit_identical"] is True
+    assert d["exchange"] in ((exchange,) if exchange == "coll" else ("p2p", "coll"))       # p2p may fall back where peers cannot map
+    assert d["p2p_timeouts"] == 0 and d["p2p_checksum_mismatches"] == 0
+
+
+@needs_two_gpus
+def test_sac_loop_on_two_devices():
+    d = _bench("--config", "4", "--gpus", "2", "--envs", "512", "--batch", "512", "--replay", "16384")
+    assert d["n_gpus"] == 2 and d["links_crossed"] is True and d["ranks_bit_identical"] is True
+    assert d["exchange"] in ("p2p", "coll")
+
+
 def test_bench_recovers_when_the_peer_exchange_fails_mid_run():
     """Rank 1's exchange raises its sticky error before the timed region: every rank must notice, drop to the collective
     (torch.distributed here: RCCL refuses two ranks on one device), take rank 0's weights, and finish bit-identical."""

@@ -401,3 +401,41 @@ def test_fresh_plans_between_episodes(tmp_path, monkeypatch):
     env2.run_eposide(0.5)
     env2.run_eposide(0.5)
     assert np.array_equal(env2.backend.bank_read()[0], b0) and env2.backend.replan_stats()["refreshes"] == 0
+
+
+@pytest.mark.parametrize("trainer", ["DQN", "SAC"])
+def test_done_check_does_not_change_what_is_learnt(trainer, tmp_path, monkeypatch):
+    """The fused episode paths look at the device only every <done_check> steps, so up to done_check - 1 passes are enqueued
+    behind the last moving step.  Round 4: those passes change nothing -- the step kernel stamps a device word when it moves
+    an agent and the Adam launches / batch_update check it (uavenv_set_moved_word, uavenv_dqn_reduce_adam_gated,
+    UavSacAdam.go_word) -- so the learner takes exactly one update per moving step, as the reference's loop, which leaves
+    right after the last one (Envs/PathPlan_City.py:456-459).  done_check = 1 (no surplus pass can exist) and done_check = 8
+    must therefore end with the same weights, moments, update counts -- bit for bit."""
+    from dqn_based_uav_3d_path_planer_amd import driver
+    monkeypatch.chdir(tmp_path)
+    out = []
+    for dc in (1, 8):
+        if trainer == "SAC":
+            sim = _config4(tmp_path, 128, Batch_Size=128, replay_size=8192)
+        else:
+            sim = driver.simulator(driver.make_config_dir(str(tmp_path), "DQN", num_envs=256, num_uav=1))
+        env = sim.env
+        env.done_check = dc
+        assert env.fast or env.fast_sac
+        torch.manual_seed(0)
+        for _ in range(2):
+            env.run_eposide(0.2)
+        torch.cuda.synchronize()
+        if trainer == "SAC":
+            L = [u.Trainer.learner for u in env.Agents]
+            blocks = [torch.cat([x._blocks.reshape(-1), x._cblocks.reshape(-1), x._alpha_mv, x.log_alpha.reshape(1)]).clone() for x in L]
+            counts = [(x.epoch, x.adam_steps) for x in L]
+        else:
+            L = env.Agents[0].Trainer.learner
+            blocks, counts = [L.flat.clone()], [(L.epoch,)]
+        out.append((blocks, counts, env.steps_last_episode, env.surplus_passes_last_episode))
+    a, b = out
+    assert a[3] == 0 and a[2] == b[2] and a[1] == b[1], (a[1:], b[1:])
+    assert b[3] == (-b[2]) % 8                       # done_check = 8 did enqueue passes behind the end of the episode ...
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)                     # ... and they changed nothing
