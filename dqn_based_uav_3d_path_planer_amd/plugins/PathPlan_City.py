@@ -415,6 +415,18 @@ class PathPlan_City:
                 self.Federated_Learning()
             self.fl_merges += 1
 
+    def _rewind_ring(self, surplus: int):
+        """Take the passes enqueued behind the end of the episode out of the replay cursor: they stored rows with valid = 0
+        (nobody moved) -- the reference stores nothing after its loop has ended.  head goes back by `surplus` frames; the frames
+        those passes wrote into are no longer counted as filled (on a ring that had wrapped they overwrote its oldest frames)."""
+        if surplus <= 0:
+            return
+        ring = self._ring
+        ring.head = (ring.head - surplus) % ring.frames
+        ring.filled = max(0, ring.filled - surplus)
+        self._obs_raw = ring.obs[ring.head]
+        self._invalidate()
+
     def _run_eposide_fused(self, eps_rate):
         """run_eposide on the fused path: HotLoop enqueues done_check steps of act -> step (+ replay write) -> sample ->
         learn at a time; the host then reads, in one transfer, how many agents each of those steps still moved and the
@@ -477,6 +489,13 @@ class PathPlan_City:
             if per is not None:
                 per.beta = min(1.0, beta0 + (tr.learner.epoch - epoch0) * per.beta_inc)
         self.surplus_passes_last_episode = passes - n_steps
+        if passes > n_steps:             # ... and neither the replay cursor nor the Philox counter remembers them
+            self._hot_counter = self._hot.counter - (passes - n_steps)
+            self._hot.close()
+            self._hot = None
+            self._rewind_ring(passes - n_steps)
+            if per is not None:
+                per.n_entries = ring.filled * self.backend.N
         tr.loss = tr.learner.loss
         item = {"loss": tr.learner.loss, "sum_epoch": tr.epoch, "score": uav.score, "average_score": uav.score,
                 "step": uav.Step, "energy_cost": uav.energy_cost_total, "task_collect": uav.task_collect,
@@ -630,6 +649,15 @@ class PathPlan_City:
                     p = self._sac_per[j]
                     p.beta = min(1.0, beta0[j] + (L.adam_steps - count0[j][1]) * p.beta_inc)
         self.surplus_passes_last_episode = surplus
+        if surplus > 0:
+            self._sac_counter -= surplus
+            if getattr(self, "_sac_hot", None) is not None:
+                self._sac_hot.close()
+                self._sac_hot = None
+            self._rewind_ring(surplus)
+            for p in self._sac_per:
+                if p is not None:
+                    p.n_entries = ring.filled * self.num_envs
         items = []
         for uav in self.Agents:
             tr = uav.Trainer

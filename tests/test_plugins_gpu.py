@@ -410,15 +410,19 @@ def test_done_check_does_not_change_what_is_learnt(trainer, tmp_path, monkeypatc
     an agent and the Adam launches / batch_update check it (uavenv_set_moved_word, uavenv_dqn_reduce_adam_gated,
     UavSacAdam.go_word) -- so the learner takes exactly one update per moving step, as the reference's loop, which leaves
     right after the last one (Envs/PathPlan_City.py:456-459).  done_check = 1 (no surplus pass can exist) and done_check = 8
-    must therefore end with the same weights, moments, update counts -- bit for bit."""
+    must therefore end with the same weights, moments, update counts -- bit for bit.  (The replay cursor and the Philox counter
+    are rewound past those passes too; the ring is sized so that it does not wrap here: on a wrapped ring the surplus passes
+    overwrite its oldest frames, a different number of them for a different done_check.)"""
     from dqn_based_uav_3d_path_planer_amd import driver
     monkeypatch.chdir(tmp_path)
     out = []
     for dc in (1, 8):
         if trainer == "SAC":
-            sim = _config4(tmp_path, 128, Batch_Size=128, replay_size=8192)
+            sim = _config4(tmp_path, 128, Batch_Size=128, replay_size=400000)
         else:
-            sim = driver.simulator(driver.make_config_dir(str(tmp_path), "DQN", num_envs=256, num_uav=1))
+            xml = driver.make_config_dir(str(tmp_path), "DQN", num_envs=256, num_uav=1)
+            _set_xml(tmp_path / "config" / "Trainer.xml", replay_size=800000)
+            sim = driver.simulator(xml)
         env = sim.env
         env.done_check = dc
         assert env.fast or env.fast_sac
@@ -435,7 +439,7 @@ def test_done_check_does_not_change_what_is_learnt(trainer, tmp_path, monkeypatc
             blocks, counts = [L.flat.clone()], [(L.epoch,)]
         out.append((blocks, counts, env.steps_last_episode, env.surplus_passes_last_episode))
     a, b = out
-    assert a[3] == 0 and a[2] == b[2] and a[1] == b[1], (a[1:], b[1:])
-    assert b[3] == (-b[2]) % 8                       # done_check = 8 did enqueue passes behind the end of the episode ...
+    assert a[3] == 1 and a[2] == b[2] and a[1] == b[1], (a[1:], b[1:])      # (the pass that notices the end is always there)
+    assert 1 <= b[3] <= 8 and (b[2] + b[3]) % 8 == 0  # done_check = 8 enqueued whole chunks behind the end of the episode ...
     for x, y in zip(a[0], b[0]):
         assert torch.equal(x, y)                     # ... and they changed nothing
