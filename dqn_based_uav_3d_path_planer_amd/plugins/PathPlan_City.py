@@ -459,6 +459,7 @@ class PathPlan_City:
         dev = self.backend.device
         epoch0, passes = tr.learner.epoch, 0
         per = getattr(self, "_per", None)
+        self.hot_loop_with_per = self._hot._per is not None
         beta0 = per.beta if per is not None else None
         while not ended:
             t0 = ring.head

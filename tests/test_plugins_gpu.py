@@ -254,7 +254,7 @@ def test_prioritised_replay_stays_on_the_fused_path(tmp_path, monkeypatch):
     tr = env.Agents[0].Trainer
     assert env.fast and tr.fused and env._per is not None
     res = env.run_eposide(0.3)
-    assert env._hot is not None and env._hot._per is env._per
+    assert env.hot_loop_with_per            # the C loop ran with the DevicePER inside (the loop object is rebuilt per episode)
     assert env.Check_uav_Done() and np.isfinite(float(res["loss"])) and tr.epoch > 100
     per, ring = env._per, env._ring
     prio = per.prio.view(ring.frames, -1)
