@@ -1636,7 +1636,7 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
     // gated update (uavenv_dqn_reduce_adam_gated): the step kernel of this pass stamps go_word with go_value when it moved at
     // least one agent; a pass in which every agent had already finished leaves the learner exactly as it is (the reference's loop
     // has left run_eposide by then, Envs/PathPlan_City.py:456-459)
-    if (go_word && *go_word != go_value) return;
+    if (go_word && __hip_atomic_load(go_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != go_value) return;
     __shared__ float cnt_part[4];
     const int tid = (int)threadIdx.x;
     const int p = (int)blockIdx.x * 32 + tid;

@@ -254,7 +254,7 @@ __global__ void k_per_set_f32(UavPer p, const int64_t *__restrict__ slots, const
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
-    if (go_word && *go_word != go_value) return;         // (gated: see uavenv_per_set_f32_gated)
+    if (go_word && __hip_atomic_load(go_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != go_value) return;   // (gated: see uavenv_per_set_f32_gated)
     const int64_t s = slots[i];
     if (s < 0 || s >= p.capacity) return;
     if (clip > 0.0 && p.prio[s] == 0.0) return;          // (an empty leaf stays empty: see k_per_set)

@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_adam(AdamArgsN slots)
     // parameters, moments, targets and log_alpha freeze until the caller re-synchronises them; csrc/p2p.hip)
     if (a.skip && __hip_atomic_load(a.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     // ... and behind a step that moved no agent there is no update at all (the reference has left its episode loop)
-    if (a.go && *a.go != a.go_value) return;
+    if (a.go && __hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.go_value) return;
     // every column was accumulated as sum_i w_i (...) / B per rank; frac = sum of the ranks' (valid / B): dividing by it
     // gives the mean over the valid samples of all ranks (all valid: 1 / world size)
     const float frac = (fpart[0] + fpart[1]) + (fpart[2] + fpart[3]);

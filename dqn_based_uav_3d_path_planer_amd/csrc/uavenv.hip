@@ -1055,7 +1055,8 @@ __device__ __forceinline__ void k_step_body(const StepArgs &a)
             if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
             if (a.info) a.info[i] = (uint8_t)info;
             if (a.valid) a.valid[i] = (uint8_t)valid;
-            if (a.moved_word && valid) *a.moved_word = a.moved_value;       // (every writer stores the same value)
+            if (a.moved_word && valid)                                       // (every writer stores the same value)
+                __hip_atomic_store(a.moved_word, a.moved_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.energy64) a.energy64[i] = energy;
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);
@@ -1329,7 +1330,8 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
             if (a.info) a.info[i] = (uint8_t)info;
             if (a.valid) a.valid[i] = (uint8_t)valid;
-            if (a.moved_word && valid) *a.moved_word = a.moved_value;       // (every writer stores the same value)
+            if (a.moved_word && valid)                                       // (every writer stores the same value)
+                __hip_atomic_store(a.moved_word, a.moved_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.energy64) a.energy64[i] = energy;
             // ---- state write-back
             if (valid || did_reset) store_agent(S, i, g);

@@ -335,6 +335,8 @@ def test_sac_c_loop_equals_the_python_loop(tmp_path, monkeypatch, envs, batch, r
     monkeypatch.chdir(tmp_path)
     out = []
     for c_loop in ("1", "0"):
+        torch.manual_seed(0)        # BEFORE the trainers are built: this torch build seeds its default generator from the OS, so an
+                                    # env built first in a process would otherwise start from other weights than the second one
         sim = _config4(tmp_path, envs, Batch_Size=batch, replay_size=replay, IsPriority_Replay=per)
         env = sim.env
         env.param["sac_c_loop"] = c_loop
