@@ -106,7 +106,7 @@ class UavSacBatch(C.Structure):
                 ("n_agents", C.c_int32), ("uav_per_env", C.c_int32), ("slot", C.c_int32), ("frames", C.c_int32),
                 ("act0", C.c_void_p), ("act1", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("valid", C.c_void_p),
                 ("eps", C.c_void_p), ("batch", C.c_int32), ("tiles_per_wg", C.c_int32),
-                ("is_weights", C.c_void_p), ("abs_td_out", C.c_void_p)]
+                ("is_weights", C.c_void_p), ("abs_td_out", C.c_void_p), ("td_scratch", C.c_void_p)]
 
 
 class UavSacAdam(C.Structure):
@@ -125,7 +125,7 @@ class UavSacLoopSlot(C.Structure):
                 ("partials_critic", C.c_void_p), ("partials_actor", C.c_void_p),
                 ("epoch", C.c_int32), ("adam_steps", C.c_int32),
                 ("per", UavPer), ("per_slots_dev", C.c_void_p), ("per_prio_dev", C.c_void_p), ("per_w_dev", C.c_void_p),
-                ("per_abs_dev", C.c_void_p), ("per_beta", C.c_double)]
+                ("per_abs_dev", C.c_void_p), ("per_beta", C.c_double), ("td_dev", C.c_void_p)]
 
 
 class UavSacLoopConfig(C.Structure):

@@ -564,6 +564,7 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             b.act0 = act0; b.act1 = c.act1_plane; b.reward = R.reward; b.done = R.done; b.valid = R.valid;
             b.batch = B;
             if (l->per) { b.is_weights = sl.per_w_dev; b.abs_td_out = sl.per_abs_dev; }
+            b.td_scratch = sl.td_dev;
             b.eps = zl + ((size_t)j * B) * 2;                             // rsample() of calc_target; the actor phase's below
             bt[j] = b;
             nets[j] = sl.nets;

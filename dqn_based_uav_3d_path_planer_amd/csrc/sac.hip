@@ -92,6 +92,7 @@ struct SacArgs {
     const float *is_w;
     float *abs_td;
     int grid;                             // workgroups of this slot (a batched launch's grid.x is the maximum over its slots)
+    float *td;                            // nullable [batch][2]: the td targets in global memory (k_sac_td writes, stage II reads)
 };
 // A launch covers up to kSlots independent SAC trainers (one per UAV slot, Envs/PathPlan_City.py:59-69): blockIdx.y = slot.
 // One trainer at BASELINE configs[3]'s batch fills the chip by itself; small runs (a few tiles per slot) are a chain of
@@ -124,6 +125,7 @@ constexpr int kPsLd = 28;                          // dwords per sample of the p
 constexpr int kCritStage2F = kWSetF + kTileF + 4 * kTile * kLh + kTile * 4 + 64;     // (the critic phase keeps an f32 X tile)
 constexpr int kCritTdOff = kCritStage2F > kTileF + 2 * kWSetF ? kCritStage2F : kTileF + 2 * kWSetF;
 constexpr size_t kSacCriticLds = (size_t)(kCritTdOff + kTMax * kTile * 3) * 4;      // td targets [.][2] + critic 1's Q[0] per sample
+constexpr size_t kSacTdLds = (size_t)(kTileF + 2 * kWSetF) * 4;                    // actor fc1 + both target critics
 constexpr size_t kSacActorLds = (size_t)(kTileF + 2 * kWSetF + kTile * kPsLd + 2 * kTile * kLh + kTile * 4 + 64) * 4;
 static_assert(kSacActorLds <= 160 * 1024 && kSacCriticLds <= 160 * 1024, "LDS budget");
 
@@ -501,6 +503,83 @@ __device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
     if (NEXT || !CRITIC) { T.e0 = g.eps[2 * smp]; T.e1 = g.eps[2 * smp + 1]; } else { T.e0 = T.e1 = 0.0f; }
 }
 
+// stage I's inputs for this lane's sample of tile `tile` (wavefront wv of the four that share the tile)
+struct TileInS {
+    PRow R;
+    float rew, nd, e0, e1;
+};
+__device__ __forceinline__ void tile_in_s(const SacArgs &g, int tile, int wv, TileInS &T)
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15;
+    const int smp = tile * kTile + 16 * wv + r;
+    uint32_t rs, rn;
+    sample_rows(g, smp, rs, rn);
+    prow_load(T.R, g.obs + (size_t)rn * kPackedDwords);
+    T.rew = g.reward[rs];
+    T.nd = 1.0f - (float)g.done[rs];
+    T.e0 = g.eps[2 * smp];
+    T.e1 = g.eps[2 * smp + 1];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase A, stage I as a launch of its own (round 4): the td targets of the whole batch into SacArgs.td (global, [batch][2]).
+// Stage I keeps three nets resident (118 KB) but needs no per-tile scratch, so TWO tiles can be in flight per workgroup: eight
+// wavefronts -- waves 0-3 take the even tiles of the workgroup's range, waves 4-7 the odd ones -- share the staged nets, two
+// wavefronts per SIMD, and an f32 MFMA of one overlaps the VALU work (actor head, layer 2, the row decode) of the other.  Same
+// device functions on the same operands as the fused stage I of k_sac_critic_grad: bit-identical td targets.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_sac_td(SacArgsN slots)
+{
+    const SacArgs &g = slots.s[blockIdx.y];
+    if ((int)blockIdx.x >= g.grid) return;
+    extern __shared__ __align__(16) float lds[];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, half = tid >> 8, r = lane & 15, gq = lane >> 4;
+    const int n_tiles = g.batch / kTile;
+    const int t0 = (int)blockIdx.x * g.tiles_per_wg;
+    const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
+    const float alpha = expf(*g.log_alpha);
+    float *Wa = lds;
+    const WSet S1 = wset_at(lds + kTileF), S2 = wset_at(lds + kTileF + kWSetF);
+    TileInS T;
+    if (half < nt) tile_in_s(g, t0 + half, wv, T);
+    if (half == 0) {                                   // waves 0-3 stage (the helpers are written for 256 threads)
+        CritRegs C1, C2;
+        critic_issue(C1, g.t1);
+        critic_issue(C2, g.t2);
+        stage_actor(Wa, g.actor);
+        critic_commit(S1, C1);
+        critic_commit(S2, C2);
+    }
+    W2Frag<4> Fa;
+    w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+    __syncthreads();
+    for (int j = half; j < nt; j += 2) {
+        TileInS Tn = T;
+        if (j + 2 < nt) tile_in_s(g, t0 + j + 2, wv, Tn);
+        floatx4 acc[4], acc2[4];
+        fwd_strip_packed(Wa, T.R, acc);
+        float o[4];
+        q_strip<4>(acc, Fa, 4, 4, 0, o);
+        ActorOut A;
+        actor_head(o, T.e0, T.e1, A);
+        const float a0 = A.act[0] * g.bound, a1 = A.act[1] * g.bound;
+        float q1[2], q2[2];
+        {   // (the two heads' fragments are re-read per use: 64 registers that two wavefronts per SIMD do not have; L1 hits)
+            W2Frag<2> Fo;
+            w2_load<2>(Fo, g.t1 + kCoWo, g.t1 + kCobo, 2);
+            critic_fwd(S1, T.R, a0, a1, Fo, acc, acc2, q1);
+            w2_load<2>(Fo, g.t2 + kCoWo, g.t2 + kCobo, 2);
+            critic_fwd(S2, T.R, a0, a1, Fo, acc, acc2, q2);
+        }
+        if (gq == 0) {
+            float *td = g.td + ((size_t)(t0 + j) * kTile + 16 * wv + r) * 2;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) td[d] = T.rew + g.gamma * (fminf(q1[d], q2[d]) + alpha * (-A.lp[d])) * T.nd;
+        }
+        T = Tn;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // phase A: the critics
 // ---------------------------------------------------------------------------------------------------------------------
@@ -520,7 +599,8 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
     S_STAMP(0);
 
     // ---- stage I: td target = r + gamma (min(Q_t1, Q_t2)(s', a') - alpha log pi(a' | s')) (1 - done)      (:122-131)
-    {
+    // (g.td: k_sac_td has already left the td targets of the whole batch in global memory -- stage I is skipped)
+    if (!g.td) {
         float *Wa = lds;
         const WSet S1 = wset_at(lds + kTileF), S2 = wset_at(lds + kTileF + kWSetF);
         TileIn T;
@@ -586,7 +666,7 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
         for (int j = 0; j < nt; ++j) {
             TileIn Tn = T;
             if (j + 1 < nt) tile_in<false, true>(g, t0 + j + 1, Tn);
-            const float *td = tds + (j * kTile + 16 * wv + r) * 2;
+            const float *td = g.td ? g.td + ((size_t)(t0 + j) * kTile + 16 * wv + r) * 2 : tds + (j * kTile + 16 * wv + r) * 2;
             floatx4 acc1[4], acc2[4];
             float q[2];
             critic_fwd(S, T.R, T.a0, T.a1, Fo, acc1, acc2, q);
@@ -814,22 +894,41 @@ __global__ void __launch_bounds__(256) k_sac_act(SacActArgsN slots)
     W2Frag<4> Fa;
     w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
     const int n_tiles = (g.count + kTile - 1) / kTile;
-    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
-        const int i = tile * kTile + 16 * wv + r;
+    // A workgroup walks several tiles (the launch is sized to two workgroups per CU: round 3 gave every 64-agent tile a workgroup
+    // of its own, and staging fc1 -- 25.6 KB per workgroup -- was most of its 27 us at 4 x 32 768 agents); the next tile's row and
+    // draws are requested before this tile is computed.
+    auto fetch = [&](int tile, PRow &R, float &e0, float &e1, size_t &row, int &i) {
+        i = tile * kTile + 16 * wv + r;
         const int ii = i < g.count ? i : g.count - 1;
-        const size_t row = (size_t)g.first + (size_t)ii * g.stride;
-        PRow R;
+        row = (size_t)g.first + (size_t)ii * g.stride;
         prow_load(R, g.obs + row * kPackedDwords);
+        e0 = g.eps[2 * ii];
+        e1 = g.eps[2 * ii + 1];
+    };
+    int tile = (int)blockIdx.x;
+    if (tile >= n_tiles) return;
+    PRow R;
+    float e0, e1;
+    size_t row;
+    int i;
+    fetch(tile, R, e0, e1, row, i);
+    for (; tile < n_tiles; tile += (int)gridDim.x) {
+        PRow Rn = R;
+        float e0n = e0, e1n = e1;
+        size_t rown = row;
+        int in = i;
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + (int)gridDim.x, Rn, e0n, e1n, rown, in);
         floatx4 acc[4];
         fwd_strip_packed(W1s, R, acc);
         float o[4];
         q_strip<4>(acc, Fa, 4, 4, 0, o);
         ActorOut A;
-        actor_head(o, g.eps[2 * ii], g.eps[2 * ii + 1], A);
+        actor_head(o, e0, e1, A);
         if (gq == 0 && i < g.count) {
             g.act0[row] = A.act[0] * g.bound;
             g.act1[row] = A.act[1] * g.bound;
         }
+        R = Rn; e0 = e0n; e1 = e1n; row = rown; i = in;
     }
 }
 
@@ -959,6 +1058,7 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
     g.eps = b->eps;
     g.is_w = b->is_weights;
     g.abs_td = b->abs_td_out;
+    g.td = b->td_scratch;
     g.batch = b->batch;
     const int n_tiles = b->batch / kTile;
     const int tpw = tiles_per_wg_of(n_tiles, n_slots, b->tiles_per_wg);
@@ -1000,7 +1100,25 @@ int grad_phase(bool critic, const UavSacNets *nets, const UavSacBatch *batches, 
         slots.s[j].bound = action_bound;
         grid = gj > grid ? gj : grid;
     }
-    static bool attr_c = false, attr_a = false;
+    static bool attr_c = false, attr_a = false, attr_t = false;
+    if (critic) {
+        // stage I as a launch of its own (two tiles in flight per workgroup) when EVERY slot brought a td scratch; otherwise the
+        // fused kernel computes the td targets itself (bit-identical either way: the same device functions on the same operands)
+        bool split = getenv("UAVENV_SAC_FUSED_TD") == nullptr;
+        for (int j = 0; j < n; ++j) split = split && slots.s[j].td != nullptr;
+        if (split) {
+            if (!attr_t) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_sac_td), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kSacTdLds) != hipSuccess)
+                    return sac_fail(UAVENV_EHIP, "uavenv_sac: cannot raise the dynamic LDS limit");
+                attr_t = true;
+            }
+            hipLaunchKernelGGL(k_sac_td, dim3(grid, n), dim3(512), kSacTdLds, s, slots);
+            if (hipGetLastError() != hipSuccess) return sac_fail(UAVENV_EHIP, "uavenv_sac: launch failed");
+        } else {
+            for (int j = 0; j < n; ++j) slots.s[j].td = nullptr;
+        }
+    }
     return critic ? launch_phase(k_sac_critic_grad, attr_c, kSacCriticLds, slots, n, grid, s)
                   : launch_phase(k_sac_actor_grad, attr_a, kSacActorLds, slots, n, grid, s);
 }
@@ -1093,7 +1211,11 @@ int uavenv_sac_act_multi(const float *const *actors, const void *obs_packed, con
                                 action_bound, act0, act1};
     }
     const int n_tiles = (count + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_sac_act, dim3(n_tiles < 512 ? n_tiles : 512, n), dim3(256), kSacActLds, (hipStream_t)stream, slots);
+    // two workgroups per CU over all slots of the launch (UAVENV_SAC_ACT_WGS: A/B knob, workgroups per launch)
+    static const int act_wgs = [] { const char *e = getenv("UAVENV_SAC_ACT_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    int gx = act_wgs / n;
+    gx = gx < 1 ? 1 : gx;
+    hipLaunchKernelGGL(k_sac_act, dim3(n_tiles < gx ? n_tiles : gx, n), dim3(256), kSacActLds, (hipStream_t)stream, slots);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : sac_fail(UAVENV_EHIP, "uavenv_sac_act: launch failed");
 }
 

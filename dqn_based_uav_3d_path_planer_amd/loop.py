@@ -203,6 +203,7 @@ class SACHotLoop:
         cfg.actor_lr, cfg.critic_lr, cfg.alpha_lr, cfg.target_entropy = L0.actor_lr, L0.critic_lr, L0.alpha_lr, L0.target_entropy
         cfg.step_flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | ring.extra_flags
         cfg.draws_dev, cfg.noise_dev = self._draws.data_ptr(), self._noise.data_ptr()
+        self._td = []
         for j, L in enumerate(self.learners):
             sl = cfg.slot[j]
             _, pc, pa = L._scratch(int(batch))           # every slot's own partial rows: the phases run for all slots at once
@@ -212,6 +213,8 @@ class SACHotLoop:
             sl.m1, sl.v1, sl.m2, sl.v2 = (L._cblocks[k].data_ptr() for k in (4, 5, 6, 7))
             sl.scalars = L._scalars.data_ptr()
             sl.epoch, sl.adam_steps = L.epoch, L.adam_steps
+            self._td.append(torch.empty(2 * int(batch), dtype=torch.float32, device=d))     # td targets of the slot's update
+            sl.td_dev = self._td[-1].data_ptr()
         self._pers = list(pers) if pers is not None and any(p is not None for p in pers) else None
         if self._pers is not None:
             if len(self._pers) != U or any(p is None for p in self._pers):

@@ -218,10 +218,11 @@ class FusedSACLearner:
         assert valid is None or valid.dtype == torch.uint8
         assert draws is None or (draws.dtype == torch.int32 and draws.is_contiguous())
         assert idx_s is None or (idx_s.dtype == torch.int32 and idx_n.dtype == torch.int32)
+        td = torch.empty(2 * n, dtype=torch.float32, device=self.device)      # the td targets of an update (k_sac_td -> k_sac_critic_grad)
         b = self._lib.UavSacBatch(obs_packed.data_ptr(), ptr(idx_s), ptr(idx_n), ptr(draws), int(n_agents), int(uav_per_env),
                                   int(slot), int(frames), act0.data_ptr(), act1.data_ptr(), reward.data_ptr(), done.data_ptr(),
-                                  ptr(valid), None, n, int(tiles_per_wg), ptr(is_weights), ptr(abs_td_out))
-        b._keep = keep
+                                  ptr(valid), None, n, int(tiles_per_wg), ptr(is_weights), ptr(abs_td_out), td.data_ptr())
+        b._keep = keep + (td,)
         return b
 
     def _adam(self, lr, tau=0.0, scale=0.0):

@@ -553,6 +553,10 @@ typedef struct UavSacBatch {
      * |min(Q1, Q2)(s, a) - td_target| of output column 0 (:351) -- written by uavenv_sac_critic_grad. */
     const float *is_weights;
     float *abs_td_out;
+    float *td_scratch;                   /* ABI 4, nullable: batch x 2 floats of device scratch.  With it uavenv_sac_critic_grad computes the
+                                            td targets (:122-131) in a launch of its own -- two tiles in flight per workgroup, two
+                                            wavefronts per SIMD -- and the gradient kernel reads them from here; without it the
+                                            gradient kernel computes them itself.  Bit-identical either way. */
 } UavSacBatch;
 typedef struct UavSacAdam {
     float lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt;   /* 1 - beta1^t, sqrt(1 - beta2^t) */
@@ -635,6 +639,7 @@ typedef struct UavSacLoopSlot {
     double *per_prio_dev;                    /* batch + (batch + 255) / 256 */
     float *per_w_dev, *per_abs_dev;          /* batch each: importance weights in, |TD| out */
     double per_beta;                         /* ReplayTree.beta when the loop is created */
+    float *td_dev;                           /* nullable: batch x 2 floats (UavSacBatch.td_scratch of this slot's updates) */
 } UavSacLoopSlot;
 typedef struct UavSacLoopConfig {
     UavEnv *env;

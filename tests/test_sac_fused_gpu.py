@@ -468,3 +468,32 @@ def test_prioritised_replay_in_the_fused_sac_update(world):
         pf, pr = dict(getattr(fused, name).named_parameters()), dict(getattr(ref, name).named_parameters())
         d = torch.cat([(pf[n] - pr[n]).abs().reshape(-1) for n in names])
         assert float(torch.quantile(d, 0.99)) <= 0.02 * lr and float(d.max()) <= 2.0 * lr, (name, float(d.max()))
+
+
+@pytest.mark.parametrize("B,tpw", [(64, 0), (4096, 0), (20480, 0), (8192, 8), (8192, 3)])
+def test_td_targets_as_a_launch_of_their_own_change_nothing(world, B, tpw):
+    """Round 4: with UavSacBatch.td_scratch the critic phase computes the td targets (Trainer/SAC_Trainer.py:122-131) in k_sac_td --
+    eight wavefronts per workgroup, two tiles in flight, the staged actor + target critics shared -- and k_sac_critic_grad reads
+    them from global memory; without it (UAVENV_SAC_FUSED_TD=1: the round-3 form) the gradient kernel computes them itself.  Same
+    device functions on the same operands: the partial rows (gradients, losses, valid fraction) must agree BIT FOR BIT, for one,
+    several and an odd number of tiles per workgroup (the two halves of a workgroup then walk 2 and 1 tiles)."""
+    import os
+    fused, _ = _pair(seed=7)
+    b, td, w, (e_next, e_cur) = _batch(world, fused, B, seed=21)
+    b.tiles_per_wg = tpw
+    assert b.td_scratch
+    rows = []
+    for fused_td in ("", "1"):
+        if fused_td:
+            os.environ["UAVENV_SAC_FUSED_TD"] = "1"
+        else:
+            os.environ.pop("UAVENV_SAC_FUSED_TD", None)
+        try:
+            pc = fused.critic_grad(b, e_next)
+            torch.cuda.synchronize()
+            n = fused._rows_launched
+            rows.append(pc[:n].clone())
+        finally:
+            os.environ.pop("UAVENV_SAC_FUSED_TD", None)
+    assert rows[0].shape == rows[1].shape and torch.isfinite(rows[0]).all()
+    assert torch.equal(rows[0], rows[1])
