@@ -122,10 +122,10 @@ constexpr int kPsLd = 28;                          // dwords per sample of the p
                                                    // 4 apart are 48 banks apart)
 // LDS maps (floats).  Critic phase, stage I: actor fc1 | target 1 | target 2; stage II: critic | X | H1 H2 dH1 dH2 | dq | red;
 // the td targets of the workgroup's tiles live behind both.  Actor phase: actor fc1 | critic 1 | critic 2 | Ps | H dH | dq | red.
-constexpr int kCritStage2F = kWSetF + kTileF + 4 * kTile * kLh + kTile * 4 + 64;     // (the critic phase keeps an f32 X tile)
+constexpr int kTdSetF_ = 2 * kHid * 104 * 2 / 4 + kHid * 20 + kHid * kLh + kHid;      // = kTdSetF (defined with the split layer 1 below)
+constexpr int kCritStage2F = kTdSetF_ + kTileF + 4 * kTile * kLh + kTile * 4 + 64;   // (the critic phase keeps an f32 X tile)
 constexpr int kCritTdOff = kCritStage2F > kTileF + 2 * kWSetF ? kCritStage2F : kTileF + 2 * kWSetF;
 constexpr size_t kSacCriticLds = (size_t)(kCritTdOff + kTMax * kTile * 3) * 4;      // td targets [.][2] + critic 1's Q[0] per sample
-constexpr size_t kSacTdLds = (size_t)(kTileF + 2 * kWSetF) * 4;                    // actor fc1 + both target critics
 constexpr size_t kSacActorLds = (size_t)(kTileF + 2 * kWSetF + kTile * kPsLd + 2 * kTile * kLh + kTile * 4 + 64) * 4;
 static_assert(kSacActorLds <= 160 * 1024 && kSacCriticLds <= 160 * 1024, "LDS budget");
 
@@ -149,6 +149,172 @@ __device__ __forceinline__ void stage_actor(float *W1s, const float *flat)
     w_issue(v, flat);
     const float bias = threadIdx.x < kHid ? flat[kHid * kW + threadIdx.x] : 0.0f;
     w_commit(W1s, v, bias);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Layer 1 at f32 accuracy on the f16 matrix pipe (round 4; the forward-only kernels k_sac_act and k_sac_td).
+// 80 of the 100 observation columns are 0 / 1 flags (Agents/UAV.py:533-566): exact in f16.  fc1 is staged as TWO f16 terms,
+// hi = f16(w) and mid = f16((w - hi) * 2^11) (22-23 significant bits together; the power-of-two scale keeps the residual out
+// of f16's subnormals), so that the flag part of H^T = W1 X^T is three v_mfma_f32_16x16x32_f16 per term and 16 hidden units
+// (K = columns 0..95; the B operand of a lane = the eight flag bits of its sample's columns 32 kk + 8 g .., expanded to
+// 0 / 1.0 halves -- the scalar columns' bits are 0 in the packed words, so their f16 weights meet zeros) instead of twenty
+// f32 MFMAs of twice the latency; the 16 scalar columns (0..10, 86..89), the ones column (bias) and the critics' two action
+// columns go through four / five v_mfma_f32_16x16x4_f32 steps against an f32 [64][20] block.  Two accumulators per 16 hidden
+// units (the mid term is summed on its own and scaled back by 2^-11 at the end); every product is exact, the sums are f32.
+// MFMA cycles of one layer-1 strip: 24 x 16 + 16..20 x 32 = 0.9-1.0 k instead of 104 x 32 = 3.3 k.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kLdHs = 104;                          // halves per row of a term tile (52 dwords: a ds_read_b128 phase covers all banks)
+constexpr int kScK = 20;                            // scalar K: columns 0..10 | 86..89 | 100 (ones / b1) | 101 | 102 | 0 | 0
+constexpr int kSplitBytes = 2 * kHid * kLdHs * 2 + kHid * kScK * 4;          // 31 744 per staged layer 1
+constexpr int kSplitF = kSplitBytes / 4;
+struct W1Split {
+    _Float16 *hi, *mid;
+    float *sc;
+};
+__device__ __forceinline__ W1Split w1split_at(float *p)
+{
+    W1Split S;
+    S.hi = reinterpret_cast<_Float16 *>(p);
+    S.mid = S.hi + kHid * kLdHs;
+    S.sc = reinterpret_cast<float *>(S.mid + kHid * kLdHs);
+    return S;
+}
+// scalar-block index of observation column c (-1: a flag or constant-zero column)
+__device__ __forceinline__ int sc_index(int c)
+{
+    return c <= 10 ? c : (c >= 86 && c <= 89 ? c - 75 : -1);
+}
+__device__ __forceinline__ void split_store(const W1Split &S, int row, int col, float w)
+{
+    if (col < 96) {
+        const _Float16 h = (_Float16)w;
+        S.hi[row * kLdHs + col] = h;
+        S.mid[row * kLdHs + col] = (_Float16)((w - (float)h) * 2048.0f);
+    }
+    const int k = sc_index(col);
+    if (k >= 0) S.sc[row * kScK + k] = w;
+}
+// actor fc1 (64 x 100 f32, rows consecutive) + b1 -> the split form; 256 threads (the first 256 of the workgroup)
+__device__ __forceinline__ void stage_actor_split(const W1Split &S, const float *flat)
+{
+    floatx4 v[kStageIters];
+    w_issue(v, flat);
+    const int tid = (int)threadIdx.x;
+    const float bias = tid < kHid ? flat[kHid * kW + tid] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int c = it * 256 + tid;
+        if (c < kStageChunks) {
+            const int row = c / 25, q = c - row * 25;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_store(S, row, 4 * q + e, v[it][e]);
+        }
+    }
+    if (tid < kHid) {
+        float *d = S.sc + tid * kScK + 15;
+        d[0] = bias; d[1] = 0.0f; d[2] = 0.0f; d[3] = 0.0f; d[4] = 0.0f;
+    }
+}
+// eight flag bits -> eight halves (0 / 1.0) as the B operand of v_mfma_f32_16x16x32_f16
+__device__ __forceinline__ half8 bits_to_half8(uint32_t byte)
+{
+    uintx4 d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        d[k] = ((byte >> (2 * k)) & 1u ? 0x3c00u : 0u) | ((byte >> (2 * k + 1)) & 1u ? 0x3c000000u : 0u);
+    return *reinterpret_cast<const half8 *>(&d);
+}
+// the pre-activations of layer 1 for this lane's sample (the C/D layout of fwd_strip_packed: registers = hidden units
+// 16 t + 4 g + reg).  EXT: scalar-block entries 16 / 17 carry the critics' action columns.
+template <bool EXT>
+__device__ __forceinline__ void fwd_strip_split_ahead(const W1Split &S, const PRow &R, floatx4 (&acc)[4], float e0 = 0.0f, float e1 = 0.0f)
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    constexpr int NS = EXT ? 5 : 4;
+    // every operand of the strip is requested first (24 x 16 bytes + 16 / 20 floats per lane, all in flight): with one wavefront per
+    // SIMD nothing else hides an LDS round trip per K block (stage II of the critic phase: the forward cost 2.0 k cycles with
+    // load -> MFMA per block against 3.3 k on the f32 pipe; ~1.1 k like this)
+    half8 ah[3][4], al[3][4];
+    float as[NS][4];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ah[kk][t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
+            al[kk][t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
+        }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) as[i][t] = S.sc[(16 * t + r) * kScK + 4 * i + g];
+    const float x[kScK] = {R.sc[0], R.sc[1], R.sc[2], R.sc[3], R.sc[4], R.sc[5], R.sc[6], R.sc[7], R.sc[8], R.sc[9], R.sc[10],
+                           R.sg[0], R.sg[1], R.sg[2], R.sg[3], 1.0f, EXT ? e0 : 0.0f, EXT ? e1 : 0.0f, 0.0f, 0.0f};
+    half8 b[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const uint32_t word = kk == 0 ? R.m0 : (kk == 1 ? R.m1 : R.m2);
+        b[kk] = bits_to_half8((word >> (8 * g)) & 0xffu);
+    }
+    float bv[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) bv[i] = g == 0 ? x[4 * i] : (g == 1 ? x[4 * i + 1] : (g == 2 ? x[4 * i + 2] : x[4 * i + 3]));
+    floatx4 am[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; am[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    // ---- the flag columns: K = 96 in three blocks of 32, two terms
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t] = mfma16h(ah[kk][t], b[kk], acc[t]); am[t] = mfma16h(al[kk][t], b[kk], am[t]); }
+    // ---- the scalar columns, the ones column and (EXT) the action: f32, K index 4 i + g
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(as[i][t], bv[i], acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = fmaf(am[t][q], 1.0f / 2048.0f, acc[t][q]);
+}
+
+// the same with the operands of one K block in flight at a time: for the kernels that run two wavefronts per SIMD (k_sac_td,
+// k_sac_act), where the other wavefront hides the LDS round trips and 116 more registers per lane would not fit
+template <bool EXT>
+__device__ __forceinline__ void fwd_strip_split(const W1Split &S, const PRow &R, floatx4 (&acc)[4], float e0 = 0.0f, float e1 = 0.0f)
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    floatx4 am[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; am[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const uint32_t word = kk == 0 ? R.m0 : (kk == 1 ? R.m1 : R.m2);
+        const half8 b = bits_to_half8((word >> (8 * g)) & 0xffu);
+        half8 ah[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ah[t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
+            al[t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t] = mfma16h(ah[t], b, acc[t]); am[t] = mfma16h(al[t], b, am[t]); }
+    }
+    const float x[kScK] = {R.sc[0], R.sc[1], R.sc[2], R.sc[3], R.sc[4], R.sc[5], R.sc[6], R.sc[7], R.sc[8], R.sc[9], R.sc[10],
+                           R.sg[0], R.sg[1], R.sg[2], R.sg[3], 1.0f, EXT ? e0 : 0.0f, EXT ? e1 : 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < (EXT ? 5 : 4); ++i) {
+        const float bv = g == 0 ? x[4 * i] : (g == 1 ? x[4 * i + 1] : (g == 2 ? x[4 * i + 2] : x[4 * i + 3]));
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = S.sc[(16 * t + r) * kScK + 4 * i + g];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t], bv, acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = fmaf(am[t][q], 1.0f / 2048.0f, acc[t][q]);
 }
 
 // critic fc1 (64 x 102: input column c < 100 -> tile column c, the two action columns -> 101, 102, b1 -> 100) and fc2,
@@ -311,6 +477,26 @@ __device__ __forceinline__ void actor_head(const float (&o)[4], float e0, float 
         lp -= logf(1.0f - th * th + 1e-7f);
         A.act[d] = act; A.lp[d] = lp; A.mu[d] = mu; A.sd[d] = sd; A.spre[d] = s;
     }
+}
+
+// One action dimension of the head (the forward-only kernels: the four lane groups of a sample hold the same four head outputs, so
+// group g evaluates dimension g & 1 only -- half the transcendental work; the full head above made k_sac_act VALU-bound once
+// layer 1 had left the f32 matrix pipe).  Same arithmetic as actor_head for that dimension.
+struct ActorOne {
+    float act, lp;
+};
+__device__ __forceinline__ ActorOne actor_head_one(float m, float sraw, float e)
+{
+    const float mu = tanhf(m);
+    const float sp = sraw > 20.0f ? sraw : log1pf(expf(sraw));
+    const float sd = tanhf(sp);
+    const float ns = mu + sd * e;
+    const float df = ns - mu;
+    float lp = -(df * df) / (2.0f * (sd * sd)) - logf(sd) - 0.9189385332046727f;
+    const float act = tanhf(ns);
+    const float th = tanhf(act);
+    lp -= logf(1.0f - th * th + 1e-7f);
+    return ActorOne{act, lp};
 }
 
 // the lane's packed row (+ {1, a0, a1, 0}: tile columns 100..103) into the packed-row tile; one lane per sample calls it
@@ -503,6 +689,60 @@ __device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
     if (NEXT || !CRITIC) { T.e0 = g.eps[2 * smp]; T.e1 = g.eps[2 * smp + 1]; } else { T.e0 = T.e1 = 0.0f; }
 }
 
+// one staged target critic of k_sac_td: layer 1 in the split form, fc2 [64][kLh] and b2 as in WSet
+struct TdSet {
+    W1Split W1;
+    float *W2s, *b2s;
+};
+constexpr int kTdSetF = kSplitF + kHid * kLh + kHid;
+static_assert(kTdSetF == kTdSetF_, "LDS map");
+constexpr size_t kSacTdLds = (size_t)(kSplitF + 2 * kTdSetF) * 4;      // actor layer 1 + both target critics: 132 KB
+__device__ __forceinline__ TdSet tdset_at(float *p)
+{
+    return TdSet{w1split_at(p), p + kSplitF, p + kSplitF + kHid * kLh};
+}
+// critic fc1 (64 x 102: the two action columns -> scalar-block entries 16 / 17, b1 -> 15), fc2, b2 from the registers of
+// critic_issue; 256 threads
+__device__ __forceinline__ void critic_commit_split(const TdSet &S, const CritRegs &C)
+{
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < kCritIters; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < kCritPieces) {
+            const int row = idx / (kIn / 2), q = idx - row * (kIn / 2);
+            if (q < kW / 2) {
+                split_store(S.W1, row, 2 * q, C.w1[it].x);
+                split_store(S.W1, row, 2 * q + 1, C.w1[it].y);
+            } else {                                    // input columns 100, 101: the action
+                S.W1.sc[row * kScK + 16] = C.w1[it].x;
+                S.W1.sc[row * kScK + 17] = C.w1[it].y;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = it * 256 + tid, row = c >> 4, q = c & 15;
+        *reinterpret_cast<floatx4 *>(S.W2s + row * kLh + 4 * q) = C.w2[it];
+    }
+    if (tid < kHid) {
+        float *d = S.W1.sc + tid * kScK;
+        d[15] = C.b1; d[18] = 0.0f; d[19] = 0.0f;
+        S.b2s[tid] = C.b2;
+    }
+}
+template <bool AHEAD = false>
+__device__ __forceinline__ void critic_fwd_split(const TdSet &S, const PRow &R, float a0, float a1, const W2Frag<2> &Fo,
+                                                 floatx4 (&acc1)[4], floatx4 (&acc2)[4], float (&q)[2])
+{
+    if (AHEAD) fwd_strip_split_ahead<true>(S.W1, R, acc1, a0, a1);
+    else fwd_strip_split<true>(S.W1, R, acc1, a0, a1);
+    floatx4 h1[4];
+    relu4(acc1, h1);
+    layer2_fwd(WSet{nullptr, S.W2s, S.b2s}, h1, acc2);
+    q_strip<2>(acc2, Fo, 2, 2, 0, q);
+}
+
 // stage I's inputs for this lane's sample of tile `tile` (wavefront wv of the four that share the tile)
 struct TileInS {
     PRow R;
@@ -538,44 +778,45 @@ __global__ void __launch_bounds__(512) k_sac_td(SacArgsN slots)
     const int t0 = (int)blockIdx.x * g.tiles_per_wg;
     const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
     const float alpha = expf(*g.log_alpha);
-    float *Wa = lds;
-    const WSet S1 = wset_at(lds + kTileF), S2 = wset_at(lds + kTileF + kWSetF);
+    // LDS: actor layer 1 (split form) | target 1: layer 1 (split), fc2, b2 | target 2: the same
+    const W1Split Wa = w1split_at(lds);
+    const TdSet S1 = tdset_at(lds + kSplitF), S2 = tdset_at(lds + kSplitF + kTdSetF);
     TileInS T;
     if (half < nt) tile_in_s(g, t0 + half, wv, T);
     if (half == 0) {                                   // waves 0-3 stage (the helpers are written for 256 threads)
         CritRegs C1, C2;
         critic_issue(C1, g.t1);
         critic_issue(C2, g.t2);
-        stage_actor(Wa, g.actor);
-        critic_commit(S1, C1);
-        critic_commit(S2, C2);
+        stage_actor_split(Wa, g.actor);
+        critic_commit_split(S1, C1);
+        critic_commit_split(S2, C2);
     }
-    W2Frag<4> Fa;
-    w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
     __syncthreads();
     for (int j = half; j < nt; j += 2) {
         TileInS Tn = T;
         if (j + 2 < nt) tile_in_s(g, t0 + j + 2, wv, Tn);
         floatx4 acc[4], acc2[4];
-        fwd_strip_packed(Wa, T.R, acc);
+        fwd_strip_split<false>(Wa, T.R, acc);
         float o[4];
-        q_strip<4>(acc, Fa, 4, 4, 0, o);
-        ActorOut A;
-        actor_head(o, T.e0, T.e1, A);
-        const float a0 = A.act[0] * g.bound, a1 = A.act[1] * g.bound;
+        {
+            W2Frag<4> Fa;                          // (re-read per tile, like the critics' heads below: registers)
+            w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
+            q_strip<4>(acc, Fa, 4, 4, 0, o);
+        }
+        const int d = gq & 1;                      // this lane group's action dimension (the critics' layer 1 takes a0 from the
+        const ActorOne A = actor_head_one(d ? o[1] : o[0], d ? o[3] : o[2], d ? T.e1 : T.e0);      // lanes of group 0, a1 from group 1)
+        const float a0 = A.act * g.bound, a1 = a0;
         float q1[2], q2[2];
         {   // (the two heads' fragments are re-read per use: 64 registers that two wavefronts per SIMD do not have; L1 hits)
             W2Frag<2> Fo;
             w2_load<2>(Fo, g.t1 + kCoWo, g.t1 + kCobo, 2);
-            critic_fwd(S1, T.R, a0, a1, Fo, acc, acc2, q1);
+            critic_fwd_split(S1, T.R, a0, a1, Fo, acc, acc2, q1);
             w2_load<2>(Fo, g.t2 + kCoWo, g.t2 + kCobo, 2);
-            critic_fwd(S2, T.R, a0, a1, Fo, acc, acc2, q2);
+            critic_fwd_split(S2, T.R, a0, a1, Fo, acc, acc2, q2);
         }
-        if (gq == 0) {
-            float *td = g.td + ((size_t)(t0 + j) * kTile + 16 * wv + r) * 2;
-#pragma unroll
-            for (int d = 0; d < 2; ++d) td[d] = T.rew + g.gamma * (fminf(q1[d], q2[d]) + alpha * (-A.lp[d])) * T.nd;
-        }
+        if (gq < 2)                                // group d writes component d
+            g.td[((size_t)(t0 + j) * kTile + 16 * wv + r) * 2 + d] =
+                T.rew + g.gamma * (fminf(d ? q1[1] : q1[0], d ? q2[1] : q2[0]) + alpha * (-A.lp)) * T.nd;
         T = Tn;
     }
 }
@@ -644,15 +885,21 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
     __syncthreads();
     S_STAMP(2);
     // ---- stage II: Q1 / Q2 (s, a): loss, backward, weight gradients
-    const WSet S = wset_at(lds);
-    float *Xs = lds + kWSetF;
+    // (the critic's layer 1 in the split form: its forward runs at f32 accuracy on the f16 matrix pipe, "Layer 1 at f32 accuracy")
+    const TdSet SS = tdset_at(lds);
+    const WSet S = WSet{nullptr, SS.W2s, SS.b2s};
+    float *Xs = lds + kTdSetF;
     float *H1s = Xs + kTileF, *H2s = H1s + kTile * kLh, *dH1s = H2s + kTile * kLh, *dH2s = dH1s + kTile * kLh;
     float *dqs = dH2s + kTile * kLh, *red = dqs + kTile * 4;
     for (int c = 0; c < 2; ++c) {
         const float *flat = c ? g.c2 : g.c1;
         TileIn T;
         tile_in<false, true>(g, t0, T);
-        stage_critic(S, flat);
+        {
+            CritRegs C;
+            critic_issue(C, flat);
+            critic_commit_split(SS, C);
+        }
         W2Frag<2> Fo;
         w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
         __syncthreads();
@@ -669,7 +916,7 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
             const float *td = g.td ? g.td + ((size_t)(t0 + j) * kTile + 16 * wv + r) * 2 : tds + (j * kTile + 16 * wv + r) * 2;
             floatx4 acc1[4], acc2[4];
             float q[2];
-            critic_fwd(S, T.R, T.a0, T.a1, Fo, acc1, acc2, q);
+            critic_fwd_split<true>(SS, T.R, T.a0, T.a1, Fo, acc1, acc2, q);
             const float e0 = q[0] - td[0], e1 = q[1] - td[1];
             const float ww = T.w * T.isw;                                // validity x importance-sampling weight (1 without PER)
             const float dq0 = ww * e0 * inv_b, dq1 = ww * e1 * inv_b;    // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
@@ -881,15 +1128,15 @@ struct SacActArgs {
 struct SacActArgsN {
     SacActArgs s[kSlots];
 };
-constexpr size_t kSacActLds = (size_t)kTileF * 4;
+constexpr size_t kSacActLds = (size_t)kSplitBytes;
 
 __global__ void __launch_bounds__(256) k_sac_act(SacActArgsN slots)
 {
     const SacActArgs &g = slots.s[blockIdx.y];
     extern __shared__ __align__(16) float lds[];
-    float *W1s = lds;
+    const W1Split W1s = w1split_at(lds);
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
-    stage_actor(W1s, g.actor);
+    stage_actor_split(W1s, g.actor);
     __syncthreads();
     W2Frag<4> Fa;
     w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
@@ -902,8 +1149,8 @@ __global__ void __launch_bounds__(256) k_sac_act(SacActArgsN slots)
         const int ii = i < g.count ? i : g.count - 1;
         row = (size_t)g.first + (size_t)ii * g.stride;
         prow_load(R, g.obs + row * kPackedDwords);
-        e0 = g.eps[2 * ii];
-        e1 = g.eps[2 * ii + 1];
+        e0 = g.eps[2 * ii + (gq & 1)];          // lane group g evaluates action dimension g & 1
+        e1 = 0.0f;
     };
     int tile = (int)blockIdx.x;
     if (tile >= n_tiles) return;
@@ -919,15 +1166,12 @@ __global__ void __launch_bounds__(256) k_sac_act(SacActArgsN slots)
         int in = i;
         if (tile + (int)gridDim.x < n_tiles) fetch(tile + (int)gridDim.x, Rn, e0n, e1n, rown, in);
         floatx4 acc[4];
-        fwd_strip_packed(W1s, R, acc);
+        fwd_strip_split<false>(W1s, R, acc);
         float o[4];
         q_strip<4>(acc, Fa, 4, 4, 0, o);
-        ActorOut A;
-        actor_head(o, e0, e1, A);
-        if (gq == 0 && i < g.count) {
-            g.act0[row] = A.act[0] * g.bound;
-            g.act1[row] = A.act[1] * g.bound;
-        }
+        const int d = gq & 1;
+        const ActorOne A = actor_head_one(d ? o[1] : o[0], d ? o[3] : o[2], e0);
+        if (gq < 2 && i < g.count) (d ? g.act1 : g.act0)[row] = A.act * g.bound;
         R = Rn; e0 = e0n; e1 = e1n; row = rown; i = in;
     }
 }

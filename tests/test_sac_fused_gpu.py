@@ -474,9 +474,12 @@ def test_prioritised_replay_in_the_fused_sac_update(world):
 def test_td_targets_as_a_launch_of_their_own_change_nothing(world, B, tpw):
     """Round 4: with UavSacBatch.td_scratch the critic phase computes the td targets (Trainer/SAC_Trainer.py:122-131) in k_sac_td --
     eight wavefronts per workgroup, two tiles in flight, the staged actor + target critics shared -- and k_sac_critic_grad reads
-    them from global memory; without it (UAVENV_SAC_FUSED_TD=1: the round-3 form) the gradient kernel computes them itself.  Same
-    device functions on the same operands: the partial rows (gradients, losses, valid fraction) must agree BIT FOR BIT, for one,
-    several and an odd number of tiles per workgroup (the two halves of a workgroup then walk 2 and 1 tiles)."""
+    them from global memory; without it (UAVENV_SAC_FUSED_TD=1: the round-3 form) the gradient kernel computes them itself.
+    k_sac_td runs layer 1 of its three forwards at f32 accuracy on the f16 matrix pipe (fc1 as two f16 terms against the exact
+    0 / 1 flag columns, the scalar columns in f32: csrc/sac.hip "Layer 1 at f32 accuracy"): every product is exact and only the
+    order of the f32 sums differs, so the td targets agree to ~1e-7 and the partial rows (gradients, losses, valid fraction)
+    to 2e-6 relative L2 -- for one, several and an odd number of tiles per workgroup (the two halves of a workgroup then
+    walk 2 and 1 tiles)."""
     import os
     fused, _ = _pair(seed=7)
     b, td, w, (e_next, e_cur) = _batch(world, fused, B, seed=21)
@@ -496,4 +499,7 @@ def test_td_targets_as_a_launch_of_their_own_change_nothing(world, B, tpw):
         finally:
             os.environ.pop("UAVENV_SAC_FUSED_TD", None)
     assert rows[0].shape == rows[1].shape and torch.isfinite(rows[0]).all()
-    assert torch.equal(rows[0], rows[1])
+    a, b_ = rows[0].double().sum(0), rows[1].double().sum(0)
+    rel = float((a - b_).norm() / b_.norm())
+    print("split vs fused td: partial rows rel L2", rel)
+    assert rel <= 2e-6, rel
