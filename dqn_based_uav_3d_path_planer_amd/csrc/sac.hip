@@ -388,15 +388,23 @@ __device__ __forceinline__ void layer2_fwd(const WSet &S, const floatx4 (&h1)[4]
     const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t2 = 0; t2 < 4; ++t2) acc2[t2] = *reinterpret_cast<const floatx4 *>(S.b2s + 16 * t2 + 4 * g);
+    // the A operands of K block t + 1 are requested before the sixteen MFMAs of block t (one wavefront per SIMD: nothing else
+    // hides the LDS round trip)
+    floatx4 a[4], an[4];
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) a[t2] = *reinterpret_cast<const floatx4 *>(S.W2s + (16 * t2 + r) * kLh + 4 * g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        floatx4 a[4];
+        if (t + 1 < 4) {
 #pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) a[t2] = *reinterpret_cast<const floatx4 *>(S.W2s + (16 * t2 + r) * kLh + 16 * t + 4 * g);
+            for (int t2 = 0; t2 < 4; ++t2) an[t2] = *reinterpret_cast<const floatx4 *>(S.W2s + (16 * t2 + r) * kLh + 16 * (t + 1) + 4 * g);
+        }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
             for (int t2 = 0; t2 < 4; ++t2) acc2[t2] = mfma16(a[t2][reg], h1[t][reg], acc2[t2]);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) a[t2] = an[t2];
     }
 }
 
@@ -406,14 +414,29 @@ __device__ __forceinline__ void layer2_bwd(const WSet &S, const floatx4 (&dh2)[4
     const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) dh1[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    // sixteen operands (one K block: four rows of W2, four column tiles) in flight ahead of the sixteen MFMAs that use them
+    float w[4][4], wn[4][4];
 #pragma unroll
-    for (int t2 = 0; t2 < 4; ++t2)
+    for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const float *row = S.W2s + (16 * t2 + 4 * g + reg) * kLh + r;
+        for (int t = 0; t < 4; ++t) w[reg][t] = S.W2s[(4 * g + reg) * kLh + r + 16 * t];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dh1[t] = mfma16(row[16 * t], dh2[t2][reg], dh1[t]);
+    for (int t2 = 0; t2 < 4; ++t2) {
+        if (t2 + 1 < 4) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wn[reg][t] = S.W2s[(16 * (t2 + 1) + 4 * g + reg) * kLh + r + 16 * t];
         }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dh1[t] = mfma16(w[reg][t], dh2[t2][reg], dh1[t]);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[reg][t] = wn[reg][t];
+    }
 }
 
 // Q(s, a) of a staged critic for this lane's sample; acc1 / acc2 keep the pre-activations
@@ -978,6 +1001,12 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
 // ---------------------------------------------------------------------------------------------------------------------
 // phase B: the actor (critics already updated).  Actor fc1 and both critics stay in LDS; one pass over the tiles.
 // ---------------------------------------------------------------------------------------------------------------------
+// (Round 4, measured and dropped: the actor phase as TWO passes over the workgroup's tiles -- pass 1 with the actor's layer 1 and
+// both critics resident in the split form (all three forwards' layer 1 on the f16 matrix pipe), pass 2 re-using the critics' LDS
+// for the products' scratch and recomputing the actor's layer 1 -- fits the 160 KB that one pass in the split form does not
+// (170 KB), passes every test, and is no faster: 0.5317 vs 0.5330 ms per configs[3] pass at eight tiles per workgroup, 56 vs
+// 50 us at two.  The ~6.6 k matrix cycles a tile it saves are what the second pass over the rows costs; at ~49 k cycles a tile
+// the phase is bound by its VALU / transcendental / LDS chain, not by the matrix pipe.)
 __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
 {
     const SacArgs &g = slots.s[blockIdx.y];
@@ -1023,9 +1052,23 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
         fwd_strip_packed(Wa, T.R, acc);
         float o[4];
         q_strip<4>(acc, Fa, 4, 4, 0, o);
-        ActorOut A;
-        actor_head(o, T.e0, T.e1, A);
-        const float a0 = A.act[0] * g.bound, a1 = A.act[1] * g.bound;
+        // The four lane groups of a sample hold the same head outputs: group g evaluates action dimension g & 1 only (half the
+        // transcendental work of the full head) and the groups exchange what the others need -- group_sum4 over values that are
+        // zero in the groups of the other dimension is twice the value (two groups per dimension), so x 0.5 is exact.
+        const int hd = gq & 1;
+        const float hm = hd ? o[1] : o[0], hs = hd ? o[3] : o[2], he = hd ? T.e1 : T.e0;
+        const float h_mu = tanhf(hm);
+        const float h_sp = hs > 20.0f ? hs : log1pf(expf(hs));
+        const float h_sd = tanhf(h_sp);
+        const float h_ns = h_mu + h_sd * he;
+        const float h_df = h_ns - h_mu;
+        float h_lp = -(h_df * h_df) / (2.0f * (h_sd * h_sd)) - logf(h_sd) - 0.9189385332046727f;
+        const float h_act = tanhf(h_ns);
+        const float h_th = tanhf(h_act);
+        const float h_u = 1.0f - h_th * h_th + 1e-7f;
+        h_lp -= logf(h_u);
+        const float a0 = 0.5f * group_sum4(hd ? 0.0f : h_act) * g.bound, a1 = 0.5f * group_sum4(hd ? h_act : 0.0f) * g.bound;
+        const float lp_both = 0.5f * group_sum4(h_lp);                      // log pi of both dimensions, in every lane
         // Q1, Q2 (s, a~): the minimum picks, per (sample, output), the critic that dL/dq = -1 / (2B) flows into (ties: critic 1)
         floatx4 c1a[4], c1b[4], c2a[4], c2b[4];
         float q1[2], q2[2];
@@ -1033,8 +1076,8 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
         critic_fwd(S2, T.R, a0, a1, Fo2, c2a, c2b, q2);
         const bool m0 = q2[0] < q1[0], m1 = q2[1] < q1[1];
         if (gq == 0) {
-            s_lp += T.w * (A.lp[0] + A.lp[1]);
-            s_loss += T.w * (alpha * (A.lp[0] + A.lp[1]) - ((m0 ? q2[0] : q1[0]) + (m1 ? q2[1] : q1[1])));       // :364-365
+            s_lp += T.w * lp_both;
+            s_loss += T.w * (alpha * lp_both - ((m0 ? q2[0] : q1[0]) + (m1 ? q2[1] : q1[1])));       // :364-365
             s_cnt += T.w;
         }
         float da0 = 0.0f, da1 = 0.0f;
@@ -1049,18 +1092,18 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
         da1 = group_sum4(da1);
         // the actor's backward
         float dout[4];
-        const float ev[2] = {T.e0, T.e1}, dav[2] = {da0, da1};
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const float th = tanhf(A.act[d]);
-            const float u = 1.0f - th * th + 1e-7f;
-            const float dact = w_lp * (2.0f * th * (1.0f - th * th) / u) + g.bound * dav[d];
-            const float dns = dact * (1.0f - A.act[d] * A.act[d]);
-            const float dsd = dns * ev[d] - w_lp / A.sd[d];
-            const float s = A.spre[d];
-            const float sig = s > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-s));
-            dout[d] = dns * (1.0f - A.mu[d] * A.mu[d]);                       // fc_mu pre-activation
-            dout[2 + d] = dsd * (1.0f - A.sd[d] * A.sd[d]) * sig;             // fc_std pre-activation
+        {   // this lane group's dimension, then all four head gradients into every lane
+            const float dav = hd ? da1 : da0;
+            const float dact = w_lp * (2.0f * h_th * (1.0f - h_th * h_th) / h_u) + g.bound * dav;
+            const float dns = dact * (1.0f - h_act * h_act);
+            const float dsd = dns * he - w_lp / h_sd;
+            const float sig = hs > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-hs));
+            const float d_mu = dns * (1.0f - h_mu * h_mu);                    // fc_mu pre-activation
+            const float d_sd = dsd * (1.0f - h_sd * h_sd) * sig;              // fc_std pre-activation
+            dout[0] = 0.5f * group_sum4(hd ? 0.0f : d_mu);
+            dout[1] = 0.5f * group_sum4(hd ? d_mu : 0.0f);
+            dout[2] = 0.5f * group_sum4(hd ? 0.0f : d_sd);
+            dout[3] = 0.5f * group_sum4(hd ? d_sd : 0.0f);
         }
         floatx4 h[4], dh[4];
         relu4(acc, h);
