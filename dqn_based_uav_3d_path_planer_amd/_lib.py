@@ -28,7 +28,7 @@ SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
     "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_replan_begin", "uavenv_replan_ready", "uavenv_replan_commit", "uavenv_replan_stats", "uavenv_bank_read", "uavenv_set_moved_word", "uavenv_tick", "uavenv_dqn_reduce_adam_gated", "uavenv_per_set_f32_gated", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs", "uavenv_geometry",
-    "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_select_actions",
+    "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_replay_draw_valid", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
     "uavenv_p2p_create", "uavenv_p2p_handle", "uavenv_p2p_connect", "uavenv_p2p_destroy", "uavenv_p2p_errors",
     "uavenv_p2p_configure", "uavenv_p2p_status", "uavenv_p2p_error_word", "uavenv_p2p_check_blocks", "uavenv_p2p_inject_fault", "uavenv_p2p_can_reach",
@@ -117,6 +117,7 @@ class UavSacAdam(C.Structure):
 
 SAC_LOOP_MAX_SLOTS = 8
 FED_MAX_BLOCKS = 8
+DRAW_MAX_TRIES = 8
 
 
 class UavSacLoopSlot(C.Structure):
@@ -131,7 +132,7 @@ class UavSacLoopSlot(C.Structure):
 class UavSacLoopConfig(C.Structure):
     _fields_ = [("env", C.c_void_p), ("ring", UavReplayRing), ("act1_plane", C.c_void_p), ("info_dev", C.c_void_p),
                 ("n_slots", C.c_int32), ("batch", C.c_int32), ("head", C.c_int32), ("filled", C.c_int32),
-                ("is_train", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64), ("counter", C.c_uint64),
+                ("is_train", C.c_int32), ("valid_draws", C.c_int32), ("seed", C.c_uint64), ("counter", C.c_uint64),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double),
                 ("gamma", C.c_float), ("tau", C.c_float), ("action_bound", C.c_float), ("actor_lr", C.c_float),
                 ("critic_lr", C.c_float), ("alpha_lr", C.c_float), ("target_entropy", C.c_float), ("reserved1", C.c_float),
@@ -227,6 +228,8 @@ def load() -> C.CDLL:
     lib.uavenv_obs_unpack.argtypes = [vp, i64, vp, i32, vp]
     lib.uavenv_replay_draw.restype = C.c_int
     lib.uavenv_replay_draw.argtypes = [i32, i32, i32, i32, i32, u64, u64, vp, vp]
+    lib.uavenv_replay_draw_valid.restype = C.c_int
+    lib.uavenv_replay_draw_valid.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, u64, u64, vp, vp]
     lib.uavenv_p2p_create.restype = C.c_int
     lib.uavenv_p2p_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
     lib.uavenv_p2p_handle.restype = C.c_int

@@ -275,6 +275,14 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 if (rc != UAVENV_OK) return rc;
                 rc = uavenv_dqn_grad_w(&R, l->head, l->filled, c.batch, c.seed, l->counter, c.per_idx_dev, &c.net, c.kind, c.gamma,
                                        c.huber, c.per_w_dev, c.per_abs_dev, c.partials_dev, s);
+            } else if ((c.step_flags & UAVENV_STEP_SKIP_DONE) != 0 && c.per_idx_dev && R.valid) {
+                // finished agents are skipped, not restarted: their rows stay in the ring with valid = 0 (the reference stores
+                // nothing for them) -- the batch is drawn over the valid rows only and handed to the update as explicit pairs
+                rc = uavenv_replay_draw_valid(R.frames, n, l->head, l->filled, c.batch, 1, 1, 0, R.valid, UAVENV_DRAW_MAX_TRIES, c.seed,
+                                              l->counter, c.per_idx_dev, s);
+                if (rc != UAVENV_OK) return rc;
+                rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, c.per_idx_dev, &c.net, c.kind, c.gamma,
+                                     c.huber, c.partials_dev, s);
             } else {
                 rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
                                      c.huber, c.partials_dev, s);
@@ -526,8 +534,13 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
         }
         const bool learn = c.is_train && (int64_t)l->filled * envs > (int64_t)B;            // :383-385
         bool one_draw = false;
+        const bool valid_only = c.valid_draws != 0;
         if (!l->per && learn && (int64_t)l->filled * envs >= nb) {
-            rc = uavenv_replay_draw(R.frames, envs, l->head, l->filled, (int32_t)nb, c.seed + 7, l->counter, c.draws_dev, s);
+            // finished agents are skipped, not restarted: their rows stay in the ring with valid = 0, and the draws go over the
+            // valid rows only (the reference's buffers never hold such rows)
+            rc = valid_only ? uavenv_replay_draw_valid(R.frames, envs, l->head, l->filled, B, U, U, 0, R.valid, UAVENV_DRAW_MAX_TRIES,
+                                                       c.seed + 7, l->counter, c.draws_dev, s)
+                            : uavenv_replay_draw(R.frames, envs, l->head, l->filled, (int32_t)nb, c.seed + 7, l->counter, c.draws_dev, s);
             if (rc != UAVENV_OK) return rc;
             one_draw = true;
         }
@@ -552,7 +565,9 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
                                         sl.per_w_dev, draws, s);
                 if (rc != UAVENV_OK) return rc;
             } else if (!one_draw) {   // the ring does not hold U x B transitions yet: one draw per slot
-                rc = uavenv_replay_draw(R.frames, envs, l->head, l->filled, B, c.seed + 7 + (uint64_t)j, l->counter, draws, s);
+                rc = valid_only ? uavenv_replay_draw_valid(R.frames, envs, l->head, l->filled, B, 1, U, j, R.valid, UAVENV_DRAW_MAX_TRIES,
+                                                           c.seed + 7 + (uint64_t)j, l->counter, draws, s)
+                                : uavenv_replay_draw(R.frames, envs, l->head, l->filled, B, c.seed + 7 + (uint64_t)j, l->counter, draws, s);
                 if (rc != UAVENV_OK) return rc;
             }
             l->adam_steps[j] += 1;

@@ -89,6 +89,33 @@ __global__ void k_replay_draw(int frames, int n_agents, int head, int batch, Rep
     }
 }
 
+// The draws over VALID rows only.  The reference's buffers never hold a row of a finished agent (run_eposide stops pushing for it,
+// Envs/PathPlan_City.py:456-459; BaseClass/replay_buffer.py:41-51 samples what was pushed); the ring keeps such rows with valid = 0.
+// Draw s of slot j (s in [j * batch, (j + 1) * batch)) looks at permutation positions s, s + S, s + 2 S, ... (S = n_slots * batch,
+// positions < D) until the row (frame, env, first_slot + j) is valid: rejection sampling over a bijection, so accepted rows are
+// uniform over the valid ones and stay distinct within a slot.  A draw that runs out of tries keeps its first row (valid = 0: weight
+// 0 in the update, the behaviour before this kernel).
+__global__ void k_replay_draw_valid(int frames, int n_envs, int head, int batch, int n_slots, int uav, int first_slot,
+                                    const unsigned char *__restrict__ valid, int max_tries, ReplayPerm perm, int32_t *__restrict__ out)
+{
+    const int total = batch * n_slots;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
+        const int slot = first_slot + s / batch;
+        int f0 = 0, e0 = 0;
+        bool found = false;
+        for (int t = 0; t < max_tries && !found; ++t) {
+            const uint64_t q = (uint64_t)s + (uint64_t)t * (uint64_t)total;
+            if (q >= (uint64_t)perm.D) break;
+            int f, e;
+            replay_slot_to_frame(perm, replay_perm_apply(perm, (uint32_t)q), head, frames, f, e);
+            if (t == 0) { f0 = f; e0 = e; }
+            if (valid[((size_t)f * n_envs + e) * uav + slot]) { f0 = f; e0 = e; found = true; }
+        }
+        out[2 * s] = f0;
+        out[2 * s + 1] = e0;
+    }
+}
+
 // Trainer/DuelingDQN_Trainer.py:86-97: sample > eps -> argmax_a Q(s,a) (first maximum, as torch.max), else randrange(A).
 __global__ void k_select_actions(const float *__restrict__ q, int n, int A, float eps, uint64_t seed, uint64_t counter,
                                  int32_t *__restrict__ idx_out, float *__restrict__ steer_out)
@@ -175,6 +202,23 @@ int uavenv_replay_draw(int32_t frames, int32_t n_agents, int32_t head, int32_t f
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_replay_draw, dim3(grid), dim3(block), 0, (hipStream_t)stream, frames, n_agents, head, batch,
                        replay_perm(seed, counter, (uint32_t)filled * (uint32_t)n_agents, (uint32_t)n_agents), frame_agent_out);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+int uavenv_replay_draw_valid(int32_t frames, int32_t n_envs, int32_t head, int32_t filled, int32_t batch, int32_t n_slots,
+                             int32_t uav_per_env, int32_t first_slot, const uint8_t *valid, int32_t max_tries, uint64_t seed,
+                             uint64_t counter, int32_t *frame_agent_out, void *stream)
+{
+    if (!frame_agent_out || !valid || frames < 2 || n_envs <= 0 || batch <= 0 || n_slots <= 0 || uav_per_env <= 0 || first_slot < 0 ||
+        first_slot + n_slots > uav_per_env || max_tries <= 0 || filled <= 0 || filled > frames - 1 || head < 0 || head >= frames ||
+        (uint64_t)filled * (uint64_t)n_envs >= (1ull << 32) || (int64_t)batch * n_slots >= (1ll << 31))
+        return UAVENV_EINVAL;
+    const int block = 256;
+    int grid = (batch * n_slots + block - 1) / block;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_replay_draw_valid, dim3(grid), dim3(block), 0, (hipStream_t)stream, frames, n_envs, head, batch, n_slots,
+                       uav_per_env, first_slot, valid, max_tries,
+                       replay_perm(seed, counter, (uint32_t)filled * (uint32_t)n_envs, (uint32_t)n_envs), frame_agent_out);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

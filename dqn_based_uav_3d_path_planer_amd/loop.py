@@ -23,7 +23,8 @@ class HotLoop:
     def __init__(self, ring: DeviceReplayRing, learner: FusedDQNLearner, batch: int, seed: int, eps: float = 0.1,
                  counter: int = 0, learn_start: int = 0, auto_reset: bool = True, skip_done: bool = None,
                  time_every: int = 0, info: torch.Tensor = None, per=None, sample_lag: int = 0,
-                 replan_every: int = 0, replan_count: int = 0, replan_max_iter: int = 10000, gate_updates: bool = False):
+                 replan_every: int = 0, replan_count: int = 0, replan_max_iter: int = 10000, gate_updates: bool = False,
+                 valid_draws: bool = None):
         """per: a replay.DevicePER over the ring's frames * N slots -- prioritised replay (IsPriority_Replay = 1) inside the C
         loop: new-frame priorities, rebuild, ReplayTree.sample, importance weights, the weighted update and batch_update are
         enqueued per pass (csrc/loop.hip); per.beta / per.n_entries are kept in step."""
@@ -87,6 +88,16 @@ class HotLoop:
             cfg.per_eps, cfg.per_clip = per.epsilon, per.clip
             cfg.per_slots_dev, cfg.per_prio_dev, cfg.per_w_dev, cfg.per_abs_dev, cfg.per_idx_dev = \
                 (t.data_ptr() for t in self._per_bufs)
+        # valid_draws (default: on when finished agents are skipped and not restarted): the rows such agents leave in the ring
+        # (valid = 0) are not drawn -- the reference never stores them (Envs/PathPlan_City.py:456-459) -- instead of drawn with weight 0
+        if valid_draws is None:
+            valid_draws = bool(skip_done) and not auto_reset
+        self._draw_idx = None
+        if valid_draws and per is None and batch > 0:
+            if not skip_done:
+                raise ValueError("valid_draws needs skip_done (with auto-reset every stored row is valid)")
+            self._draw_idx = torch.zeros((int(batch), 2), dtype=torch.int32, device=env.device)
+            cfg.per_idx_dev = self._draw_idx.data_ptr()
         self._h = C.c_void_p()
         _lib.check(self.lib.uavenv_loop_create(C.byref(cfg), C.byref(self._h)), "uavenv_loop_create")
         self.counter = int(counter)
@@ -163,8 +174,11 @@ class SACHotLoop:
 
     def __init__(self, ring: DeviceReplayRing, learners, batch: int, seed: int, act1_plane: torch.Tensor, counter: int = 0,
                  info: torch.Tensor = None, is_train: bool = True, auto_reset: bool = True, skip_done: bool = True,
-                 exchange: str = None, spin_limit: int = 0, pers=None, check_every: int = 64, gate_updates: bool = False):
-        """pers: one replay.DevicePER per UAV slot (capacity ring.frames * n_envs, tree_order=False) -- prioritised replay, the
+                 exchange: str = None, spin_limit: int = 0, pers=None, check_every: int = 64, gate_updates: bool = False,
+                 valid_draws: bool = None):
+        """valid_draws (default: on when finished agents are skipped and not restarted): the uniform draws go over the valid rows
+        only (uavenv_replay_draw_valid) -- the reference never stores a row for a finished agent (Envs/PathPlan_City.py:456-459).
+        pers: one replay.DevicePER per UAV slot (capacity ring.frames * n_envs, tree_order=False) -- prioritised replay, the
         reference's own use of ReplayTree (Trainer/SAC_Trainer.py:336-352), inside the C loop: per step and slot the new frame's
         priorities, rebuild, ReplayTree.sample, importance weights, the four update phases (weights in, |TD| out), batch_update."""
         if ring.discrete or not ring.env.packed:
@@ -197,6 +211,7 @@ class SACHotLoop:
         cfg.n_slots, cfg.batch = U, int(batch)
         cfg.head, cfg.filled = ring.head, ring.filled
         cfg.is_train = 1 if is_train else 0
+        cfg.valid_draws = int(bool(skip_done) and not auto_reset) if valid_draws is None else int(bool(valid_draws))
         cfg.seed, cfg.counter = int(seed), int(counter)
         cfg.beta1, cfg.beta2, cfg.adam_eps = L0.beta1, L0.beta2, L0.adam_eps
         cfg.gamma, cfg.tau, cfg.action_bound = L0.gamma, L0.tau, L0.action_bound

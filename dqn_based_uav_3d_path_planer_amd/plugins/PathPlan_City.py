@@ -594,11 +594,13 @@ class PathPlan_City:
                 uniform = [l and self._sac_per[j] is None for j, l in enumerate(learn)]
                 nd = 0
                 if any(uniform):    # distinct (frame, env) pairs for all slots at once (each slot reads its own rows of them)
-                    nd = nb if ring.filled * self.num_envs >= nb else 0
+                    nd = nb if ring.filled * self.num_envs >= nb and len({t_.Batch_Size for t_ in trs}) == 1 else 0
                     if nd:
-                        _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, nd, self.seed + 7,
-                                                          self._sac_counter, self._draws_all.data_ptr(),
-                                                          torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
+                        # (over the valid rows only: finished agents are skipped here, and the reference never stores their rows)
+                        _lib.check(lib.uavenv_replay_draw_valid(ring.frames, self.num_envs, ring.head, ring.filled, nd // U, U, U, 0,
+                                                                ring.valid.data_ptr(), _lib.DRAW_MAX_TRIES, self.seed + 7,
+                                                                self._sac_counter, self._draws_all.data_ptr(),
+                                                                torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw_valid")
                 o = 0
                 for j, uav in enumerate(self.Agents):
                     tr = uav.Trainer
@@ -611,9 +613,11 @@ class PathPlan_City:
                         per.update_f32(pb["slots"], pb["abs"], go=go)
                     elif learn[j]:
                         if not nd:  # the ring does not hold sum(Batch_Size) transitions yet: one draw per slot
-                            _lib.check(lib.uavenv_replay_draw(ring.frames, self.num_envs, ring.head, ring.filled, tr.Batch_Size,
-                                                              self.seed + 7 + j, self._sac_counter, self._draws[j].data_ptr(),
-                                                              torch.cuda.current_stream(dev).cuda_stream), "uavenv_replay_draw")
+                            _lib.check(lib.uavenv_replay_draw_valid(ring.frames, self.num_envs, ring.head, ring.filled, tr.Batch_Size,
+                                                                    1, U, j, ring.valid.data_ptr(), _lib.DRAW_MAX_TRIES,
+                                                                    self.seed + 7 + j, self._sac_counter, self._draws[j].data_ptr(),
+                                                                    torch.cuda.current_stream(dev).cuda_stream),
+                                       "uavenv_replay_draw_valid")
                         tr.learner.learn(self._sac_batches[j], noise=(zl[0, o:o + tr.Batch_Size], zl[1, o:o + tr.Batch_Size]))
                     else:
                         tr.learner.epoch += 1                                                   # :322-333

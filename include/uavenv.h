@@ -245,6 +245,18 @@ int uavenv_obs_unpack(const void *packed_dev, int64_t n, void *out_dev, int32_t 
  * transitions uavenv_replay_sample / uavenv_dqn_grad use for the same (seed, counter, head, filled). */
 int uavenv_replay_draw(int32_t frames, int32_t n_agents, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
                        uint64_t counter, int32_t *frame_agent_out_dev, void *stream);
+/* The same draws over VALID rows only -- the reference's buffers never hold a row of a finished agent (run_eposide stops pushing
+ * for it, Envs/PathPlan_City.py:456-459; BaseClass/replay_buffer.py:41-51), the ring keeps such rows with valid = 0.  (frame, env)
+ * pairs for n_slots UAV slots at once: slot first_slot + j takes draws [j * batch, (j + 1) * batch) and tests ITS row
+ * valid_dev[(frame * n_envs + env) * uav_per_env + slot] (the ring's valid plane).  Draw s looks at permutation positions s,
+ * s + S, s + 2 S, ... (S = n_slots * batch; positions below filled * n_envs; at most max_tries of them) and takes the first
+ * valid row: rejection sampling over a bijection -- uniform over the valid rows, distinct within a slot.  With every row valid
+ * the result equals uavenv_replay_draw(batch * n_slots).  A draw that finds no valid row keeps its first one (weight 0 in the
+ * update through the valid plane). */
+#define UAVENV_DRAW_MAX_TRIES 8
+int uavenv_replay_draw_valid(int32_t frames, int32_t n_envs, int32_t head, int32_t filled, int32_t batch, int32_t n_slots,
+                             int32_t uav_per_env, int32_t first_slot, const uint8_t *valid_dev, int32_t max_tries, uint64_t seed,
+                             uint64_t counter, int32_t *frame_env_out_dev, void *stream);
 
 /* epsilon-greedy over Q-values (Trainer/DuelingDQN_Trainer.py:86-97): q_dev N x A f32 (row-major).
  * Writes the chosen index (int32, nullable) and its steering value (f32, nullable). */
@@ -332,8 +344,8 @@ typedef struct UavDqnNet {
 int uavenv_dqn_num_params(const UavDqnNet *net);
 /* Diagnostics (UAVENV_PHASE_PROFILE builds): 8 s_memtime stamps per workgroup of uavenv_dqn_grad; NULL disables. */
 int uavenv_dqn_set_debug_buffer(unsigned long long *dev_buf);
-/* Partial-gradient scratch: uavenv_dqn_partial_rows(batch) rows of uavenv_dqn_partial_stride(net) floats (16-byte
- * aligned base); row layout = the parameter layout, then loss sum and valid count at [num_params], [num_params + 1]. */
+/* Partial-gradient scratch: uavenv_dqn_partial_rows(batch) rows of uavenv_dqn_partial_stride(net) floats (a multiple
+ * of 32, so rows keep the base's alignment; base 16-byte aligned at least, 128 for the fewest fetches); row layout = the parameter layout, then loss sum and valid count at [num_params], [num_params + 1]. */
 int uavenv_dqn_partial_stride(const UavDqnNet *net);
 int uavenv_dqn_partial_rows(int32_t batch);
 /* One learn_off_policy() gradient (Trainer/DQN_Trainer.py:93-121, DDQN_Trainer.py:84-105): draws `batch` transitions
@@ -485,7 +497,9 @@ typedef struct UavLoopConfig {
     double *per_prio_dev;        /* batch + (batch + 255) / 256 (priorities, then uavenv_per_weights' scratch) */
     float *per_w_dev;            /* batch */
     float *per_abs_dev;          /* batch */
-    int32_t *per_idx_dev;        /* batch x 2 */
+    int32_t *per_idx_dev;        /* batch x 2 (frame, agent) pairs of the batch.  Without `per`: non-null + UAVENV_STEP_SKIP_DONE in
+                                  * step_flags = uniform draws over the VALID rows only (uavenv_replay_draw_valid), handed to the
+                                  * update as explicit pairs; null = the update draws for itself over every stored row */
     /* rolling refresh of the reset bank (uavenv_replan_*; 0 = off, the bank stays as planned): every replan_every passes the
      * loop commits the slice whose planning has finished and starts planning the next replan_count rows of the bank (rotating)
      * on a low-priority stream of its own, beside the passes. */
@@ -624,7 +638,8 @@ int uavenv_sac_actor_adam(const UavSacNets *nets, const float *partials, int32_t
  * call.  Per step: one launch of N(0,1) draws (uavenv_randn) for every rsample() of the step, get_action of all U slots
  * (uavenv_sac_act_multi), uavenv_step (replay write included), one uavenv_replay_draw, and the four phases of the fused update
  * for all U slots at once (the *_multi entry points) -- what plugins/PathPlan_City._run_eposide_fused_sac issues from Python slot
- * by slot (~22 launches per step), bit for bit, in 8.  Uniform replay; slots with prioritised replay stay on the Python loop. */
+ * by slot (~22 launches per step), bit for bit, in 8.  Uniform replay (over valid rows only when the step flags skip finished
+ * agents: uavenv_replay_draw_valid) or prioritised replay per slot (UavSacLoopSlot.per). */
 typedef struct UavSacLoopSlot {
     UavSacNets nets;
     float *m_actor, *v_actor, *alpha_mv;     /* Adam moments of the actor (UAVENV_SAC_ACTOR_PARAMS each) and of log_alpha (2) */
@@ -649,7 +664,10 @@ typedef struct UavSacLoopConfig {
     int32_t n_slots;                         /* = uav_per_env: slot j trains on rows e * n_slots + j */
     int32_t batch;                           /* per slot; multiple of 64 */
     int32_t head, filled;
-    int32_t is_train, reserved0;
+    int32_t is_train;
+    int32_t valid_draws;                     /* != 0 (needs ring.valid): the uniform draws go over the VALID rows only
+                                                (uavenv_replay_draw_valid) -- for loops that skip finished agents instead of
+                                                restarting them; 0: over every stored row (rows with valid = 0 weigh 0) */
     uint64_t seed, counter;
     double beta1, beta2, adam_eps;           /* torch.optim.Adam's (doubles: the bias corrections are formed in double) */
     float gamma, tau, action_bound, actor_lr, critic_lr, alpha_lr, target_entropy, reserved1;

@@ -90,6 +90,30 @@ def replay_draws(batch: int, seed: int, counter: int, head: int, filled: int, fr
     return f.astype(np.int64), agent.astype(np.int64)
 
 
+def replay_draws_valid(batch: int, n_slots: int, uav_per_env: int, first_slot: int, valid: np.ndarray, max_tries: int, seed: int,
+                       counter: int, head: int, filled: int, frames: int, n_envs: int):
+    """uavenv_replay_draw_valid: -> (frame [n_slots * batch], env [n_slots * batch], found [n_slots * batch]).  valid: the ring's
+    plane [frames][n_envs * uav_per_env].  Draw s of slot first_slot + s // batch walks permutation positions s, s + S, s + 2 S,
+    ... (S = n_slots * batch, positions < filled * n_envs, at most max_tries) to the first row of ITS slot with valid != 0; a draw
+    that finds none keeps its first row."""
+    S, D = batch * n_slots, filled * n_envs
+    n_pos = min(D, S * max_tries)
+    f_all, e_all = replay_draws(n_pos, seed, counter, head, filled, frames, n_envs)
+    valid = np.asarray(valid).reshape(frames, n_envs, uav_per_env)
+    f_out, e_out, found = f_all[:S].copy(), e_all[:S].copy(), np.zeros(S, dtype=bool)
+    slot = first_slot + np.arange(S) // batch
+    for t in range(max_tries):
+        q = np.arange(S) + t * S
+        ok = (q < D) & ~found
+        if not ok.any():
+            break
+        qq = q[ok]
+        hit = valid[f_all[qq], e_all[qq], slot[ok]] != 0
+        idx = np.nonzero(ok)[0][hit]
+        f_out[idx], e_out[idx], found[idx] = f_all[qq[hit]], e_all[qq[hit]], True
+    return f_out, e_out, found
+
+
 def act_draws(n: int, seed: int, counter: int, n_actions: int):
     """-> (u [n] float32 in [0,1), random_action [n]) of the epsilon-greedy stream: greedy iff u > eps."""
     lo, hi = counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF

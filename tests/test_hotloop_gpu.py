@@ -166,3 +166,65 @@ def test_sample_lag_experiment_equals_its_serial_statement():
     loop.close()
     env_a.close()
     env_b.close()
+
+
+def test_loop_that_skips_finished_agents_draws_valid_rows_only():
+    """HotLoop(auto_reset=False, skip_done=True) -- the plugin's episode loop -- leaves the rows of finished agents in the ring
+    with valid = 0; the reference's ReplayMemory never holds them (Envs/PathPlan_City.py:456-459), so the update's batch is drawn
+    over the valid rows only (uavenv_replay_draw_valid -> explicit pairs) and equals, bit for bit, an update from the Python side
+    on the pairs oracle/philox.py predicts."""
+    import numpy as np
+    from oracle import philox as px
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    n, batch = 2048, 1024
+
+    def build():
+        env = make_city26_env(n, obs_dtype="packed")
+        ring = DeviceReplayRing(env, 200 * n, discrete=True)
+        ring.reset(seed=12)
+        torch.manual_seed(1)
+        return env, ring, FusedDQNLearner(dict(PARAM, NetWork="Qnet2"), "dqn", device="cuda:0")
+
+    env, ring, L = build()
+    loop = HotLoop(ring, L, batch, seed=3, eps=0.3, auto_reset=False, skip_done=True, gate_updates=True)
+    assert loop._draw_idx is not None
+    env_b, ring_b, Lb = build()
+    checked = dead_seen = 0
+    for t in range(150):
+        loop.run(1)
+        torch.cuda.synchronize()
+        moved = bool(ring.valid[(ring.head - 1) % ring.frames].any())
+        # the same pass from Python on the second copy: policy + step, then an update on the pairs the oracle predicts
+        assert ring_b.step_policy(Lb, 0.3, 3, t, auto_reset=False, skip_done=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ring.valid, ring_b.valid) and torch.equal(ring.action, ring_b.action)
+        if ring.filled * n < batch:
+            continue
+        valid = ring_b.valid.cpu().numpy()
+        f, e, found = px.replay_draws_valid(batch, 1, 1, 0, valid, _lib.DRAW_MAX_TRIES, 3, t, ring_b.head, ring_b.filled, ring_b.frames, n)
+        got = loop._draw_idx.cpu().numpy()
+        assert (got[:, 0] == f).all() and (got[:, 1] == e).all()
+        back = (ring.head - 1 - np.arange(ring.filled)) % ring.frames
+        dead_frac = float((valid[back] == 0).mean())
+        assert int((~found).sum()) <= 3 + 3 * batch * dead_frac ** 8
+        dead_seen = max(dead_seen, dead_frac)
+        if moved:
+            idx = torch.tensor(np.stack([f, e], 1).astype(np.int32), device="cuda").contiguous()
+            Lb.learn_from_ring(ring_b, batch, seed=3, counter=t, explicit_idx=idx)
+            torch.cuda.synchronize()
+        assert torch.equal(L.flat, Lb.flat), t
+        checked += 1
+        if t == 1:      # agents at every age from here on: they run out of steps (:456-465) one by one (the first step of an
+            for ev, rg in ((env, ring), (env_b, ring_b)):    # episode pops the aliased start node and zeroes Step, so not before it)
+                st, sub, alias = ev.get_state(0, n, want_sub=True)
+                step = np.random.default_rng(6).integers(0, 150, n).astype(np.int32)
+                ev.set_state(0, np.c_[st[:, 0:5], st[:, 6:9]], step, st[:, 11].astype(np.int32), sub, alias=alias)
+                ev.observe(rg.obs[rg.head])
+    assert checked > 100 and dead_seen > 0.3, (checked, dead_seen)
+    loop.close()
+    env.close()
+    env_b.close()

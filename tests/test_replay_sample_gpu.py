@@ -70,6 +70,60 @@ def test_draw_entry_point_matches_oracle_and_is_uniform():
     assert hits.max() <= 5                  # 131 072 draws into 1 M slots: Poisson(1/8), P(>= 6 somewhere) ~ 1e-6
 
 
+@pytest.mark.parametrize("dead", [0.0, 0.35, 0.9])
+def test_draws_over_valid_rows_only(dead):
+    """uavenv_replay_draw_valid (the draws of loops that skip finished agents: the reference's buffers never hold a row of a
+    finished agent, Envs/PathPlan_City.py:456-459, BaseClass/replay_buffer.py:41-51) against oracle/philox.py's restatement:
+    rejection over the permutation -- every accepted row is valid, rows stay distinct within a slot, every valid row is equally
+    likely, and with every row valid the draws are uavenv_replay_draw's."""
+    from oracle import philox as px
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    lib = _lib.load()
+    frames, n_envs, U, head, filled, batch = 33, 2048, 4, 9, 32, 1024
+    rng = np.random.default_rng(4)
+    valid = (rng.random((frames, n_envs * U)) >= dead).astype(np.uint8)
+    vd = torch.tensor(valid, device="cuda")
+    out = torch.empty((U * batch, 2), dtype=torch.int32, device="cuda")
+    hits = np.zeros((U, filled * n_envs), dtype=np.int64)
+    for counter in range(6):
+        _lib.check(lib.uavenv_replay_draw_valid(frames, n_envs, head, filled, batch, U, U, 0, vd.data_ptr(), _lib.DRAW_MAX_TRIES, 91,
+                                                counter, out.data_ptr(), None), "draw_valid")
+        got = out.cpu().numpy()
+        f, e, found = px.replay_draws_valid(batch, U, U, 0, valid, _lib.DRAW_MAX_TRIES, 91, counter, head, filled, frames, n_envs)
+        assert (got[:, 0] == f).all() and (got[:, 1] == e).all()
+        slot = np.arange(U * batch) // batch
+        ok = valid.reshape(frames, n_envs, U)[f, e, slot] != 0
+        assert (ok == found).all()
+        if dead == 0.0:
+            f0, e0 = px.replay_draws(U * batch, 91, counter, head, filled, frames, n_envs)
+            assert found.all() and (f == f0).all() and (e == e0).all()
+        elif dead < 0.5:
+            assert found.mean() > 0.999                                   # 0.35 ** 8 = 2e-4 of the draws run out of tries
+        back = (head - 1 - f) % frames
+        assert back.min() >= 0 and back.max() < filled
+        for j in range(U):
+            m = (slot == j) & found
+            rows = back[m] * n_envs + e[m]
+            assert len(np.unique(rows)) == m.sum()                        # distinct within a slot
+            np.add.at(hits[j], rows, 1)
+        # one slot alone (the per-slot form: the ring does not hold U x batch transitions yet)
+        _lib.check(lib.uavenv_replay_draw_valid(frames, n_envs, head, filled, batch, 1, U, 2, vd.data_ptr(), _lib.DRAW_MAX_TRIES, 91,
+                                                counter, out.data_ptr(), None), "draw_valid")
+        f1, e1, _ = px.replay_draws_valid(batch, 1, U, 2, valid, _lib.DRAW_MAX_TRIES, 91, counter, head, filled, frames, n_envs)
+        got = out[:batch].cpu().numpy()
+        assert (got[:, 0] == f1).all() and (got[:, 1] == e1).all()
+    if dead == 0.35:        # uniform over the valid rows: hits per valid row ~ Poisson(6 * 1024 / #valid), never on an invalid one
+        for j in range(U):
+            back_all = np.arange(filled * n_envs) // n_envs
+            f_all = (head - 1 - back_all) % frames
+            v = valid.reshape(frames, n_envs, U)[f_all, np.arange(filled * n_envs) % n_envs, j] != 0
+            assert hits[j][~v].sum() == 0
+            lam = 6 * batch / v.sum()
+            per_frame = np.array([hits[j][(back_all == b) & v].sum() for b in range(filled)])
+            expect = np.array([lam * ((back_all == b) & v).sum() for b in range(filled)])
+            assert np.abs(per_frame - expect).max() < 5 * np.sqrt(expect.max())
+
+
 def test_fused_learner_draws_the_same_transitions_as_sample():
     """k_dqn_grad's in-kernel draw == uavenv_replay_sample's: learning from the ring with (seed, counter) equals
     learning from the explicit (frame, agent) list the oracle predicts -- bit for bit."""

@@ -337,6 +337,53 @@ def _sac_loop_worker(rank, world, port, out_dir, nudge=False):
     env.close()
 
 
+def test_sac_c_loop_draws_valid_rows_only(world):
+    """A loop that skips finished agents instead of restarting them (the plugin's episode loop) leaves their rows in the ring with
+    valid = 0; the reference's buffers never hold such rows (Envs/PathPlan_City.py:456-459), so the batches are drawn over the
+    valid rows only (UavSacLoopConfig.valid_draws -> uavenv_replay_draw_valid): every (frame, env) pair a slot's update used is a
+    valid row of THAT slot, while the ring holds plenty that are not."""
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.loop import SACHotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    from dqn_based_uav_3d_path_planer_amd.sac import FusedSACLearner
+    U, envs, B = 2, 512, 256
+    env = make_city26_env(envs, uav_per_env=U, obs_dtype="packed")
+    ring = DeviceReplayRing(env, 200 * env.N, discrete=False)
+    ring.reset(seed=5)
+    a1 = torch.zeros((ring.frames, env.N), dtype=torch.float32, device="cuda")
+    torch.manual_seed(0)
+    Ls = [FusedSACLearner(PARAM) for _ in range(U)]
+    loop = SACHotLoop(ring, Ls, B, seed=11, act1_plane=a1, auto_reset=False, skip_done=True, gate_updates=True)
+    checked = dead_rows_seen = 0
+    for t in range(150):
+        loop.run(1)
+        torch.cuda.synchronize()
+        if t == 1:      # agents at every age from here on: they run out of steps (:456-465) one by one (the first step of an episode
+            st, sub, alias = env.get_state(0, env.N, want_sub=True)      # pops the aliased start node and zeroes Step: not before it)
+            step = np.random.default_rng(6).integers(0, 150, env.N).astype(np.int32)
+            env.set_state(0, np.c_[st[:, 0:5], st[:, 6:9]], step, st[:, 11].astype(np.int32), sub, alias=alias)
+            env.observe(ring.obs[ring.head])
+        if t < 3 or t % 7:
+            continue
+        v = ring.valid.view(ring.frames, envs, U)
+        d = loop._draws.view(U, B, 2).long()
+        back = (ring.head - 1 - torch.arange(ring.filled, device="cuda")) % ring.frames
+        stored_dead = int((v[back] == 0).sum())
+        if not bool(v[(ring.head - 1) % ring.frames].any()):
+            break                                       # nobody moved any more: the updates are gated off from here on
+        for j in range(U):
+            ok = v[d[j, :, 0], d[j, :, 1], j] != 0
+            dead_frac = float((v[back][:, :, j] == 0).float().mean())
+            # (a draw gives up after UAVENV_DRAW_MAX_TRIES = 8 invalid rows in a row and keeps its first one: weight 0)
+            assert int((~ok).sum()) <= 3 + 3 * B * dead_frac ** 8, (t, j, int((~ok).sum()), dead_frac)
+            assert len(torch.unique(d[j, :, 0] * envs + d[j, :, 1])) == B
+        checked += 1
+        dead_rows_seen = max(dead_rows_seen, stored_dead)
+    assert checked >= 10 and dead_rows_seen > 20 * B, (checked, dead_rows_seen)
+    loop.close()
+    env.close()
+
+
 def test_sac_c_loop_exchanges_on_the_stream(tmp_path):
     """uavenv_sac_loop_run at N > 1 (UavSacLoopConfig.p2p): per phase the column sums of every slot (uavenv_sac_reduce) are
     summed over the ranks by uavenv_p2p_allreduce on the stream and the Adam kernels take that one row.  Two ranks on this
