@@ -122,11 +122,11 @@ constexpr int kPsLd = 28;                          // dwords per sample of the p
                                                    // 4 apart are 48 banks apart)
 // LDS maps (floats).  Critic phase, stage I: actor fc1 | target 1 | target 2; stage II: critic | X | H1 H2 dH1 dH2 | dq | red;
 // the td targets of the workgroup's tiles live behind both.  Actor phase: actor fc1 | critic 1 | critic 2 | Ps | H dH | dq | red.
-constexpr int kTdSetF_ = 2 * kHid * 104 * 2 / 4 + kHid * 20 + kHid * kLh + kHid;      // = kTdSetF (defined with the split layer 1 below)
+constexpr int kTdSetF_ = 2 * kHid * 88 * 2 / 4 + kHid * 20 + kHid * kLh + kHid;       // = kTdSetF (defined with the split layer 1 below)
 constexpr int kCritStage2F = kTdSetF_ + kTileF + 4 * kTile * kLh + kTile * 4 + 64;   // (the critic phase keeps an f32 X tile)
 constexpr int kCritTdOff = kCritStage2F > kTileF + 2 * kWSetF ? kCritStage2F : kTileF + 2 * kWSetF;
 constexpr size_t kSacCriticLds = (size_t)(kCritTdOff + kTMax * kTile * 3) * 4;      // td targets [.][2] + critic 1's Q[0] per sample
-constexpr size_t kSacActorLds = (size_t)(kTileF + 2 * kWSetF + kTile * kPsLd + 2 * kTile * kLh + kTile * 4 + 64) * 4;
+constexpr size_t kSacActorLds = (size_t)(kTileF + 2 * kWSetF + kTile * kPsLd + 2 * kTile * kLh + kTile * 4 + 64) * 4;   // (the split forms: same sizes)
 static_assert(kSacActorLds <= 160 * 1024 && kSacCriticLds <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void sample_rows(const SacArgs &g, int smp, uint32_t &rs, uint32_t &rn)
@@ -157,17 +157,22 @@ __device__ __forceinline__ void stage_actor(float *W1s, const float *flat)
 // 80 of the 100 observation columns are 0 / 1 flags (Agents/UAV.py:533-566): exact in f16.  fc1 is staged as TWO f16 terms,
 // hi = f16(w) and mid = f16((w - hi) * 2^11) (22-23 significant bits together; the power-of-two scale keeps the residual out
 // of f16's subnormals), so that the flag part of H^T = W1 X^T is three v_mfma_f32_16x16x32_f16 per term and 16 hidden units
-// (K = columns 0..95; the B operand of a lane = the eight flag bits of its sample's columns 32 kk + 8 g .., expanded to
-// 0 / 1.0 halves -- the scalar columns' bits are 0 in the packed words, so their f16 weights meet zeros) instead of twenty
-// f32 MFMAs of twice the latency; the 16 scalar columns (0..10, 86..89), the ones column (bias) and the critics' two action
+// (K = columns 8..95 + eight idle positions: bit c of the row's 96 flag bits is column c, and columns 0..7 are scalars whose bits
+// are always 0, so the term tiles drop them; the B operand of a lane = the eight flag bits of its sample's columns
+// 8 + 32 kk + 8 g .., expanded to 0 / 1.0 halves -- the other scalar columns' bits are 0 in the packed words too, so their f16
+// weights meet zeros) instead of twenty f32 MFMAs of twice the latency; the 16 scalar columns (0..10, 86..89), the ones column (bias) and the critics' two action
 // columns go through four / five v_mfma_f32_16x16x4_f32 steps against an f32 [64][20] block.  Two accumulators per 16 hidden
 // units (the mid term is summed on its own and scaled back by 2^-11 at the end); every product is exact, the sums are f32.
 // MFMA cycles of one layer-1 strip: 24 x 16 + 16..20 x 32 = 0.9-1.0 k instead of 104 x 32 = 3.3 k.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kLdHs = 104;                          // halves per row of a term tile (52 dwords: a ds_read_b128 phase covers all banks)
+constexpr int kLdHs = 88;                           // halves per row of a term tile: columns 8..95 (44 dwords: the sixteen rows of a
+                                                    // ds_read_b128 phase start 4 banks apart mod 64 -- all banks, once).  A staged
+                                                    // layer 1 is then exactly as large as the f32 tile it replaces (kTileF floats)
+constexpr int kFlagC0 = 8;                          // first column held by the term tiles
 constexpr int kScK = 20;                            // scalar K: columns 0..10 | 86..89 | 100 (ones / b1) | 101 | 102 | 0 | 0
-constexpr int kSplitBytes = 2 * kHid * kLdHs * 2 + kHid * kScK * 4;          // 31 744 per staged layer 1
+constexpr int kSplitBytes = 2 * kHid * kLdHs * 2 + kHid * kScK * 4;          // 27 648 per staged layer 1
 constexpr int kSplitF = kSplitBytes / 4;
+static_assert(kSplitF == kTileF, "a staged layer 1 in the split form fits where the f32 tile was");
 struct W1Split {
     _Float16 *hi, *mid;
     float *sc;
@@ -187,10 +192,10 @@ __device__ __forceinline__ int sc_index(int c)
 }
 __device__ __forceinline__ void split_store(const W1Split &S, int row, int col, float w)
 {
-    if (col < 96) {
+    if (col >= kFlagC0 && col < 96) {
         const _Float16 h = (_Float16)w;
-        S.hi[row * kLdHs + col] = h;
-        S.mid[row * kLdHs + col] = (_Float16)((w - (float)h) * 2048.0f);
+        S.hi[row * kLdHs + col - kFlagC0] = h;
+        S.mid[row * kLdHs + col - kFlagC0] = (_Float16)((w - (float)h) * 2048.0f);
     }
     const int k = sc_index(col);
     if (k >= 0) S.sc[row * kScK + k] = w;
@@ -225,6 +230,17 @@ __device__ __forceinline__ half8 bits_to_half8(uint32_t byte)
         d[k] = ((byte >> (2 * k)) & 1u ? 0x3c00u : 0u) | ((byte >> (2 * k + 1)) & 1u ? 0x3c000000u : 0u);
     return *reinterpret_cast<const half8 *>(&d);
 }
+// K slot q = 4 kk + g of the flag part (lane group g, K block kk): columns 8 (q + 1) .. 8 (q + 1) + 7 = byte q + 1 of the row's
+// twelve flag bytes, at halves 8 q of a term-tile row; slot 11 is idle (B = 0, A re-reads slot 0: finite values)
+__device__ __forceinline__ uint32_t flag_byte(const PRow &R, int kk, int g)
+{
+    const uint32_t lo = kk == 0 ? R.m0 : (kk == 1 ? R.m1 : R.m2), hi = kk == 0 ? R.m1 : (kk == 1 ? R.m2 : 0u);
+    return g == 3 ? (hi & 0xffu) : ((lo >> (8 * (g + 1))) & 0xffu);
+}
+__device__ __forceinline__ int flag_aoff(int kk, int g)
+{
+    return (kk == 2 && g == 3) ? 0 : 32 * kk + 8 * g;
+}
 // the pre-activations of layer 1 for this lane's sample (the C/D layout of fwd_strip_packed: registers = hidden units
 // 16 t + 4 g + reg).  EXT: scalar-block entries 16 / 17 carry the critics' action columns.
 template <bool EXT>
@@ -241,8 +257,8 @@ __device__ __forceinline__ void fwd_strip_split_ahead(const W1Split &S, const PR
     for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            ah[kk][t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
-            al[kk][t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
+            ah[kk][t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + flag_aoff(kk, g));
+            al[kk][t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + flag_aoff(kk, g));
         }
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -252,17 +268,14 @@ __device__ __forceinline__ void fwd_strip_split_ahead(const W1Split &S, const PR
                            R.sg[0], R.sg[1], R.sg[2], R.sg[3], 1.0f, EXT ? e0 : 0.0f, EXT ? e1 : 0.0f, 0.0f, 0.0f};
     half8 b[3];
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
-        const uint32_t word = kk == 0 ? R.m0 : (kk == 1 ? R.m1 : R.m2);
-        b[kk] = bits_to_half8((word >> (8 * g)) & 0xffu);
-    }
+    for (int kk = 0; kk < 3; ++kk) b[kk] = bits_to_half8(flag_byte(R, kk, g));
     float bv[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) bv[i] = g == 0 ? x[4 * i] : (g == 1 ? x[4 * i + 1] : (g == 2 ? x[4 * i + 2] : x[4 * i + 3]));
     floatx4 am[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; am[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    // ---- the flag columns: K = 96 in three blocks of 32, two terms
+    // ---- the flag columns: K = 96 slots (88 columns) in three blocks of 32, two terms
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
@@ -289,13 +302,12 @@ __device__ __forceinline__ void fwd_strip_split(const W1Split &S, const PRow &R,
     for (int t = 0; t < 4; ++t) { acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; am[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) {
-        const uint32_t word = kk == 0 ? R.m0 : (kk == 1 ? R.m1 : R.m2);
-        const half8 b = bits_to_half8((word >> (8 * g)) & 0xffu);
+        const half8 b = bits_to_half8(flag_byte(R, kk, g));
         half8 ah[4], al[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            ah[t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
-            al[t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + 32 * kk + 8 * g);
+            ah[t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + flag_aoff(kk, g));
+            al[t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + flag_aoff(kk, g));
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc[t] = mfma16h(ah[t], b, acc[t]); am[t] = mfma16h(al[t], b, am[t]); }
@@ -719,7 +731,7 @@ struct TdSet {
 };
 constexpr int kTdSetF = kSplitF + kHid * kLh + kHid;
 static_assert(kTdSetF == kTdSetF_, "LDS map");
-constexpr size_t kSacTdLds = (size_t)(kSplitF + 2 * kTdSetF) * 4;      // actor layer 1 + both target critics: 132 KB
+constexpr size_t kSacTdLds = (size_t)(kSplitF + 2 * kTdSetF) * 4;      // actor layer 1 + both target critics: 120 KB
 __device__ __forceinline__ TdSet tdset_at(float *p)
 {
     return TdSet{w1split_at(p), p + kSplitF, p + kSplitF + kHid * kLh};
@@ -764,6 +776,20 @@ __device__ __forceinline__ void critic_fwd_split(const TdSet &S, const PRow &R, 
     relu4(acc1, h1);
     layer2_fwd(WSet{nullptr, S.W2s, S.b2s}, h1, acc2);
     q_strip<2>(acc2, Fo, 2, 2, 0, q);
+}
+
+// action_grad_part on a critic staged in the split form (its action columns are scalar-block entries 16 / 17)
+__device__ __forceinline__ void action_grad_part_split(const TdSet &S, const floatx4 (&dh1)[4], float &da0, float &da1)
+{
+    const int g = ((int)threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float *wr = S.W1.sc + (16 * t + 4 * g + reg) * kScK + 16;
+            da0 = fmaf(wr[0], dh1[t][reg], da0);
+            da1 = fmaf(wr[1], dh1[t][reg], da1);
+        }
 }
 
 // stage I's inputs for this lane's sample of tile `tile` (wavefront wv of the four that share the tile)
@@ -1001,12 +1027,10 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
 // ---------------------------------------------------------------------------------------------------------------------
 // phase B: the actor (critics already updated).  Actor fc1 and both critics stay in LDS; one pass over the tiles.
 // ---------------------------------------------------------------------------------------------------------------------
-// (Round 4, measured and dropped: the actor phase as TWO passes over the workgroup's tiles -- pass 1 with the actor's layer 1 and
-// both critics resident in the split form (all three forwards' layer 1 on the f16 matrix pipe), pass 2 re-using the critics' LDS
-// for the products' scratch and recomputing the actor's layer 1 -- fits the 160 KB that one pass in the split form does not
-// (170 KB), passes every test, and is no faster: 0.5317 vs 0.5330 ms per configs[3] pass at eight tiles per workgroup, 56 vs
-// 50 us at two.  The ~6.6 k matrix cycles a tile it saves are what the second pass over the rows costs; at ~49 k cycles a tile
-// the phase is bound by its VALU / transcendental / LDS chain, not by the matrix pipe.)
+// Round 4: all three layer-1 forwards (the actor's, both critics') in the split form -- with 88-halves term rows a staged layer 1
+// is exactly as large as the f32 tile it replaces, so the phase keeps its LDS map.  (An earlier form with 104-halves rows needed
+// 170 KB; the two-pass variant built around that limit passed every test and was no faster -- the matrix cycles it saved were
+// what its second pass over the rows cost.)
 __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
 {
     const SacArgs &g = slots.s[blockIdx.y];
@@ -1019,19 +1043,20 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
     const float alpha = expf(*g.log_alpha);
     const float inv_2b = 0.5f / (float)g.batch;
     const float g_lp = alpha * inv_2b;                                 // d loss / d log pi per element
-    float *Wa = lds;
-    const WSet S1 = wset_at(lds + kTileF), S2 = wset_at(lds + kTileF + kWSetF);
-    uint32_t *Ps = reinterpret_cast<uint32_t *>(lds + kTileF + 2 * kWSetF);
-    float *H1s = lds + kTileF + 2 * kWSetF + kTile * kPsLd, *dH1s = H1s + kTile * kLh, *dqs = dH1s + kTile * kLh, *red = dqs + kTile * 4;
+    const W1Split Wa = w1split_at(lds);
+    const TdSet S1 = tdset_at(lds + kSplitF), S2 = tdset_at(lds + kSplitF + kTdSetF);
+    const WSet L1 = WSet{nullptr, S1.W2s, S1.b2s}, L2 = WSet{nullptr, S2.W2s, S2.b2s};      // (the 64 x 64 layers, for the backward)
+    uint32_t *Ps = reinterpret_cast<uint32_t *>(lds + kSplitF + 2 * kTdSetF);
+    float *H1s = lds + kSplitF + 2 * kTdSetF + kTile * kPsLd, *dH1s = H1s + kTile * kLh, *dqs = dH1s + kTile * kLh, *red = dqs + kTile * 4;
     TileIn T;
     tile_in<false, false>(g, t0, T);
     {
         CritRegs C1, C2;
         critic_issue(C1, g.c1);
         critic_issue(C2, g.c2);
-        stage_actor(Wa, g.actor);
-        critic_commit(S1, C1);
-        critic_commit(S2, C2);
+        stage_actor_split(Wa, g.actor);
+        critic_commit_split(S1, C1);
+        critic_commit_split(S2, C2);
     }
     W2Frag<4> Fa;
     w2_load<4>(Fa, g.actor + kAoW2, g.actor + kAob2, 4);
@@ -1049,7 +1074,7 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
         const float w_lp = g_lp * T.w, w_2b = inv_2b * T.w;               // this sample's weight in the two loss terms
         // a~, log pi(a~ | s)
         floatx4 acc[4];
-        fwd_strip_packed(Wa, T.R, acc);
+        fwd_strip_split<false>(Wa, T.R, acc);       // (the all-operands-first form spills here: 0.529 against 0.522 ms per configs[3] pass)
         float o[4];
         q_strip<4>(acc, Fa, 4, 4, 0, o);
         // The four lane groups of a sample hold the same head outputs: group g evaluates action dimension g & 1 only (half the
@@ -1072,8 +1097,8 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
         // Q1, Q2 (s, a~): the minimum picks, per (sample, output), the critic that dL/dq = -1 / (2B) flows into (ties: critic 1)
         floatx4 c1a[4], c1b[4], c2a[4], c2b[4];
         float q1[2], q2[2];
-        critic_fwd(S1, T.R, a0, a1, Fo1, c1a, c1b, q1);
-        critic_fwd(S2, T.R, a0, a1, Fo2, c2a, c2b, q2);
+        critic_fwd_split<false>(S1, T.R, a0, a1, Fo1, c1a, c1b, q1);
+        critic_fwd_split<false>(S2, T.R, a0, a1, Fo2, c2a, c2b, q2);
         const bool m0 = q2[0] < q1[0], m1 = q2[1] < q1[1];
         if (gq == 0) {
             s_lp += T.w * lp_both;
@@ -1083,10 +1108,10 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
         float da0 = 0.0f, da1 = 0.0f;
         {
             floatx4 dh1[4], dh2[4];
-            critic_bwd(S2, Fo2, c2a, c2b, m0 ? -w_2b : 0.0f, m1 ? -w_2b : 0.0f, dh1, dh2);
-            action_grad_part(S2, dh1, da0, da1);
-            critic_bwd(S1, Fo1, c1a, c1b, m0 ? 0.0f : -w_2b, m1 ? 0.0f : -w_2b, dh1, dh2);
-            action_grad_part(S1, dh1, da0, da1);
+            critic_bwd(L2, Fo2, c2a, c2b, m0 ? -w_2b : 0.0f, m1 ? -w_2b : 0.0f, dh1, dh2);
+            action_grad_part_split(S2, dh1, da0, da1);
+            critic_bwd(L1, Fo1, c1a, c1b, m0 ? 0.0f : -w_2b, m1 ? 0.0f : -w_2b, dh1, dh2);
+            action_grad_part_split(S1, dh1, da0, da1);
         }
         da0 = group_sum4(da0);
         da1 = group_sum4(da1);
