@@ -268,6 +268,197 @@ __device__ __forceinline__ floatx4 mfma16h(half8 a, half8 b, floatx4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Layer 1 at f32 accuracy on the f16 matrix pipe (round 4: the SAC kernels of sac.hip; the policy of k_dqn_act_packed and of k_step_coop's prologue).
+// 80 of the 100 observation columns are 0 / 1 flags (Agents/UAV.py:533-566): exact in f16.  fc1 is staged as TWO f16 terms,
+// hi = f16(w) and mid = f16((w - hi) * 2^11) (22-23 significant bits together; the power-of-two scale keeps the residual out
+// of f16's subnormals), so that the flag part of H^T = W1 X^T is three v_mfma_f32_16x16x32_f16 per term and 16 hidden units
+// (K = columns 8..95 + eight idle positions: bit c of the row's 96 flag bits is column c, and columns 0..7 are scalars whose bits
+// are always 0, so the term tiles drop them; the B operand of a lane = the eight flag bits of its sample's columns
+// 8 + 32 kk + 8 g .., expanded to 0 / 1.0 halves -- the other scalar columns' bits are 0 in the packed words too, so their f16
+// weights meet zeros) instead of twenty f32 MFMAs of twice the latency; the 16 scalar columns (0..10, 86..89), the ones column (bias) and the critics' two action
+// columns go through four / five v_mfma_f32_16x16x4_f32 steps against an f32 [64][20] block.  Two accumulators per 16 hidden
+// units (the mid term is summed on its own and scaled back by 2^-11 at the end); every product is exact, the sums are f32.
+// MFMA cycles of one layer-1 strip: 24 x 16 + 16..20 x 32 = 0.9-1.0 k instead of 104 x 32 = 3.3 k.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kLdHs = 88;                           // halves per row of a term tile: columns 8..95 (44 dwords: the sixteen rows of a
+                                                    // ds_read_b128 phase start 4 banks apart mod 64 -- all banks, once).  A staged
+                                                    // layer 1 is then exactly as large as the f32 tile it replaces (kTileF floats)
+constexpr int kFlagC0 = 8;                          // first column held by the term tiles
+constexpr int kScK = 20;                            // scalar K: columns 0..10 | 86..89 | 100 (ones / b1) | 101 | 102 | 0 | 0
+constexpr int kSplitBytes = 2 * kHid * kLdHs * 2 + kHid * kScK * 4;          // 27 648 per staged layer 1
+constexpr int kSplitF = kSplitBytes / 4;
+static_assert(kSplitF == kTileF, "a staged layer 1 in the split form fits where the f32 tile was");
+struct W1Split {
+    _Float16 *hi, *mid;
+    float *sc;
+};
+__device__ __forceinline__ W1Split w1split_at(float *p)
+{
+    W1Split S;
+    S.hi = reinterpret_cast<_Float16 *>(p);
+    S.mid = S.hi + kHid * kLdHs;
+    S.sc = reinterpret_cast<float *>(S.mid + kHid * kLdHs);
+    return S;
+}
+// scalar-block index of observation column c (-1: a flag or constant-zero column)
+__device__ __forceinline__ int sc_index(int c)
+{
+    return c <= 10 ? c : (c >= 86 && c <= 89 ? c - 75 : -1);
+}
+__device__ __forceinline__ void split_store(const W1Split &S, int row, int col, float w)
+{
+    if (col >= kFlagC0 && col < 96) {
+        const _Float16 h = (_Float16)w;
+        S.hi[row * kLdHs + col - kFlagC0] = h;
+        S.mid[row * kLdHs + col - kFlagC0] = (_Float16)((w - (float)h) * 2048.0f);
+    }
+    const int k = sc_index(col);
+    if (k >= 0) S.sc[row * kScK + k] = w;
+}
+// fc1 (64 x 100 f32, the registers of w_issue) + b1 -> the split form; 256 threads.  A thread's piece = four consecutive columns
+// 4 q .. 4 q + 3 of one row: pieces 2..23 go to the term tiles as two 8-byte stores, the scalar columns (pieces 0, 1, 2, 21, 22) to
+// the f32 block; columns 95..99 are constant zero in every row (their weights never meet a non-zero operand).
+__device__ __forceinline__ void w_commit_split(const W1Split &S, const floatx4 (&v)[kStageIters], float bias)
+{
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int c = it * 256 + tid;
+        if (c < kStageChunks) {
+            const int row = c / 25, q = c - row * 25;
+            const floatx4 w = v[it];
+            if (q >= 2 && q < 24) {
+                half4 h, m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (_Float16)w[e];
+                    m[e] = (_Float16)((w[e] - (float)h[e]) * 2048.0f);
+                }
+                *reinterpret_cast<half4 *>(S.hi + row * kLdHs + 4 * q - kFlagC0) = h;
+                *reinterpret_cast<half4 *>(S.mid + row * kLdHs + 4 * q - kFlagC0) = m;
+            }
+            float *sc = S.sc + row * kScK;
+            if (q < 2) *reinterpret_cast<floatx4 *>(sc + 4 * q) = w;                       // columns 0..7
+            else if (q == 2) { sc[8] = w[0]; sc[9] = w[1]; sc[10] = w[2]; }                 // 8, 9, 10
+            else if (q == 21) { sc[11] = w[2]; sc[12] = w[3]; }                             // 86, 87
+            else if (q == 22) { sc[13] = w[0]; sc[14] = w[1]; }                             // 88, 89
+        }
+    }
+    if (tid < kHid) {
+        float *d = S.sc + tid * kScK + 15;
+        d[0] = bias; d[1] = 0.0f; d[2] = 0.0f; d[3] = 0.0f; d[4] = 0.0f;
+    }
+}
+// eight flag bits -> eight halves (0 / 1.0) as the B operand of v_mfma_f32_16x16x32_f16
+__device__ __forceinline__ half8 bits_to_half8(uint32_t byte)
+{
+    uintx4 d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        d[k] = ((byte >> (2 * k)) & 1u ? 0x3c00u : 0u) | ((byte >> (2 * k + 1)) & 1u ? 0x3c000000u : 0u);
+    return *reinterpret_cast<const half8 *>(&d);
+}
+// K slot q = 4 kk + g of the flag part (lane group g, K block kk): columns 8 (q + 1) .. 8 (q + 1) + 7 = byte q + 1 of the row's
+// twelve flag bytes, at halves 8 q of a term-tile row; slot 11 is idle (B = 0, A re-reads slot 0: finite values)
+__device__ __forceinline__ uint32_t flag_byte(const PRow &R, int kk, int g)
+{
+    const uint32_t lo = kk == 0 ? R.m0 : (kk == 1 ? R.m1 : R.m2), hi = kk == 0 ? R.m1 : (kk == 1 ? R.m2 : 0u);
+    return g == 3 ? (hi & 0xffu) : ((lo >> (8 * (g + 1))) & 0xffu);
+}
+__device__ __forceinline__ int flag_aoff(int kk, int g)
+{
+    return (kk == 2 && g == 3) ? 0 : 32 * kk + 8 * g;
+}
+// the pre-activations of layer 1 for this lane's sample (the C/D layout of fwd_strip_packed: registers = hidden units
+// 16 t + 4 g + reg).  EXT: scalar-block entries 16 / 17 carry the critics' action columns.
+template <bool EXT>
+__device__ __forceinline__ void fwd_strip_split_ahead(const W1Split &S, const PRow &R, floatx4 (&acc)[4], float e0 = 0.0f, float e1 = 0.0f)
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    constexpr int NS = EXT ? 5 : 4;
+    // every operand of the strip is requested first (24 x 16 bytes + 16 / 20 floats per lane, all in flight): with one wavefront per
+    // SIMD nothing else hides an LDS round trip per K block (stage II of the critic phase: the forward cost 2.0 k cycles with
+    // load -> MFMA per block against 3.3 k on the f32 pipe; ~1.1 k like this)
+    half8 ah[3][4], al[3][4];
+    float as[NS][4];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ah[kk][t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + flag_aoff(kk, g));
+            al[kk][t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + flag_aoff(kk, g));
+        }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) as[i][t] = S.sc[(16 * t + r) * kScK + 4 * i + g];
+    const float x[kScK] = {R.sc[0], R.sc[1], R.sc[2], R.sc[3], R.sc[4], R.sc[5], R.sc[6], R.sc[7], R.sc[8], R.sc[9], R.sc[10],
+                           R.sg[0], R.sg[1], R.sg[2], R.sg[3], 1.0f, EXT ? e0 : 0.0f, EXT ? e1 : 0.0f, 0.0f, 0.0f};
+    half8 b[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) b[kk] = bits_to_half8(flag_byte(R, kk, g));
+    float bv[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) bv[i] = g == 0 ? x[4 * i] : (g == 1 ? x[4 * i + 1] : (g == 2 ? x[4 * i + 2] : x[4 * i + 3]));
+    floatx4 am[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; am[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    // ---- the flag columns: K = 96 slots (88 columns) in three blocks of 32, two terms
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t] = mfma16h(ah[kk][t], b[kk], acc[t]); am[t] = mfma16h(al[kk][t], b[kk], am[t]); }
+    // ---- the scalar columns, the ones column and (EXT) the action: f32, K index 4 i + g
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(as[i][t], bv[i], acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = fmaf(am[t][q], 1.0f / 2048.0f, acc[t][q]);
+}
+
+// the same with the operands of one K block in flight at a time: for the kernels that run two wavefronts per SIMD (k_sac_td,
+// k_sac_act), where the other wavefront hides the LDS round trips and 116 more registers per lane would not fit
+template <bool EXT>
+__device__ __forceinline__ void fwd_strip_split(const W1Split &S, const PRow &R, floatx4 (&acc)[4], float e0 = 0.0f, float e1 = 0.0f)
+{
+    const int lane = (int)threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    floatx4 am[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; am[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const half8 b = bits_to_half8(flag_byte(R, kk, g));
+        half8 ah[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ah[t] = *reinterpret_cast<const half8 *>(S.hi + (16 * t + r) * kLdHs + flag_aoff(kk, g));
+            al[t] = *reinterpret_cast<const half8 *>(S.mid + (16 * t + r) * kLdHs + flag_aoff(kk, g));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t] = mfma16h(ah[t], b, acc[t]); am[t] = mfma16h(al[t], b, am[t]); }
+    }
+    const float x[kScK] = {R.sc[0], R.sc[1], R.sc[2], R.sc[3], R.sc[4], R.sc[5], R.sc[6], R.sc[7], R.sc[8], R.sc[9], R.sc[10],
+                           R.sg[0], R.sg[1], R.sg[2], R.sg[3], 1.0f, EXT ? e0 : 0.0f, EXT ? e1 : 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < (EXT ? 5 : 4); ++i) {
+        const float bv = g == 0 ? x[4 * i] : (g == 1 ? x[4 * i + 1] : (g == 2 ? x[4 * i + 2] : x[4 * i + 3]));
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = S.sc[(16 * t + r) * kScK + 4 * i + g];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[t], bv, acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = fmaf(am[t][q], 1.0f / 2048.0f, acc[t][q]);
+}
+
+
 // LDS of a 64-agent policy team: the fc1 tile in f16 (row stride 104 halfs = 52 dwords: the 16 rows of a ds_read_b128 phase
 // start 4 banks apart and cover all 64), the 64 raw observation rows (200 bytes each, as in memory), 64 x 16 bytes of Q values.
 constexpr int kPolLdW = 104;
