@@ -496,12 +496,13 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     const uint32_t *obs = reinterpret_cast<const uint32_t *>(g.ring.obs);
     floatx4 vWl[kStageIters], vWt[kStageIters];
-    float pb1 = 0.0f, pb1t = 0.0f, pw[4] = {0, 0, 0, 0}, pt[4] = {0, 0, 0, 0}, pb2 = 0.0f, pb2t = 0.0f;
+    SplitScRegs vSl, vSt;
+    float pw[4] = {0, 0, 0, 0}, pt[4] = {0, 0, 0, 0}, pb2 = 0.0f, pb2t = 0.0f;
     if (FIRST) {
         w_issue(vWl, g.local);
         const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
-        const int kb = tid < kHid ? tid : kHid - 1;
-        pb1 = nl.b1[kb]; pb1t = nt.b1[kb];
+        w_issue_sc(vSl, g.local, nl.b1);
+        w_issue_sc(vSt, g.target, nt.b1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = tid + 256 * k < n2 * kHid ? tid + 256 * k : 0;
@@ -534,7 +535,7 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     if (FIRST) w_issue(vWt, g.target);
 
     if (FIRST) {
-        w_commit(L.W1l, vWl, pb1);
+        w_commit_split(w1split_at(L.W1l), vWl, vSl);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (tid + 256 * k < n2 * kHid) { L.W2l[tid + 256 * k] = pw[k]; L.W2t[tid + 256 * k] = pt[k]; }
@@ -543,7 +544,7 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     }
     L_STAMP(1);
     floatx4 hl[4];
-    fwd_strip_packed(L.W1l, Rs, hl);
+    fwd_strip_split<false>(w1split_at(L.W1l), Rs, hl);
     L_STAMP(6);
     constexpr bool kKeepW2 = NMAX <= 4;
     W2Frag<NMAX> Fl;
@@ -552,14 +553,14 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
     if (gq == 0) prow_store_lds(L.Ps + (wv * 16 + r) * kPackedDwords, Rs);     // the s rows, for the dW1 product
     if (FIRST) {
-        w_commit(L.W1t, vWt, pb1t);
+        w_commit_split(w1split_at(L.W1t), vWt, vSt);
         __syncthreads();                      // target weights staged
     }
     L_STAMP(2);
     int best = 0;
     floatx4 ht[4];
     if (g.kind == 1) {                        // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
-        fwd_strip_packed(L.W1l, Rn, ht);
+        fwd_strip_split<false>(w1split_at(L.W1l), Rn, ht);
         float qn_l[NMAX];
         if (!kKeepW2) w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
         q_strip<NMAX>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
@@ -568,7 +569,7 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
         for (int a = 1; a < NMAX; ++a)
             if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }           // torch.max: first maximum
     }
-    fwd_strip_packed(L.W1t, Rn, ht);
+    fwd_strip_split<false>(w1split_at(L.W1t), Rn, ht);
     L_STAMP(7);
     float qt[NMAX];
     {
@@ -700,19 +701,6 @@ __device__ __forceinline__ void w_issue_half(floatx4 (&v)[kStageIters], const fl
     }
 }
 
-__device__ __forceinline__ void w_commit_half(float *dst, floatx4 (&v)[kStageIters], float bias, int t256)
-{
-#pragma unroll
-    for (int it = 0; it < kStageIters; ++it) {
-        const int c = it * 256 + t256;
-        if (c < kStageChunks) {
-            const int row = c / 25, q = c - row * 25;
-            *reinterpret_cast<floatx4 *>(dst + row * kLd + 4 * q) = v[it];
-        }
-    }
-    if (t256 < kHid) *reinterpret_cast<floatx4 *>(dst + t256 * kLd + kW) = floatx4{bias, 0.0f, 0.0f, 0.0f};
-}
-
 struct GradAcc8 {
     floatx4 acc[4];                  // group 0: dW1^T k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and the dW2^T tile
     float csum[6];                   // group 0: column sums of dout (NMAX = 4), loss sum, valid count of its strips
@@ -729,11 +717,12 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     const uint32_t *obs = reinterpret_cast<const uint32_t *>(g.ring.obs);
     const float *net = grp == 0 ? g.local : g.target;
     floatx4 vW[kStageIters];
-    float pb1 = 0.0f, pw[4] = {0, 0, 0, 0}, pb2 = 0.0f;
+    SplitScRegs vS;
+    float pw[4] = {0, 0, 0, 0}, pb2 = 0.0f;
     if (FIRST) {                              // group 0 stages q_local's weights, group 1 q_target's
         w_issue_half(vW, net, t256);
         const NetDev nv = net_view(net, n2);
-        pb1 = nv.b1[t256 < kHid ? t256 : kHid - 1];
+        w_issue_sc(vS, net, nv.b1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) pw[k] = nv.W2[t256 + 256 * k < n2 * kHid ? t256 + 256 * k : 0];
         pb2 = nv.b2[t256 < n2 ? t256 : 0];
@@ -763,7 +752,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
         p_w = g.is_w ? g.is_w[smp] : 1.0f;
     }
     if (FIRST) {
-        w_commit_half(grp == 0 ? L.W1l : L.W1t, vW, pb1, t256);
+        w_commit_split(w1split_at(grp == 0 ? L.W1l : L.W1t), vW, vS);
         float *W2 = grp == 0 ? L.W2l : L.W2t, *b2 = grp == 0 ? L.b2l : L.b2t;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -777,7 +766,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     float ql[NMAX];
     if (grp == 0) {
         // ---- q_local(s): pre-activations stay in registers for the backward pass
-        fwd_strip_packed(L.W1l, R, hl);
+        fwd_strip_split<false>(w1split_at(L.W1l), R, hl);
         w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
         q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
         if (gq == 0) prow_store_lds(L.Ps + (strip * 16 + r) * kPackedDwords, R);    // the s rows, for the dW1 product
@@ -786,7 +775,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
         int best = 0;
         floatx4 ht[4];
         if (g.kind == 1) {                    // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
-            fwd_strip_packed(L.W1l, R, ht);
+            fwd_strip_split<false>(w1split_at(L.W1l), R, ht);
             W2Frag<NMAX> F;
             w2_load<NMAX>(F, L.W2l, L.b2l, n2);
             float qn_l[NMAX];
@@ -796,7 +785,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
             for (int a = 1; a < NMAX; ++a)
                 if (a < g.n_actions && qn_l[a] > bq) { bq = qn_l[a]; best = a; }       // torch.max: first maximum
         }
-        fwd_strip_packed(L.W1t, R, ht);
+        fwd_strip_split<false>(w1split_at(L.W1t), R, ht);
         W2Frag<NMAX> Ft;
         w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
         float qt[NMAX];
@@ -1755,14 +1744,14 @@ __global__ void __launch_bounds__(256) k_dqn_act(ActArgs g)
     }
 }
 
-// Packed observations: no observation tile -- every lane loads the packed row of its env and generates the MFMA operand
-// from it (fwd_strip_packed); LDS holds the weights only.
+// Packed observations: no observation tile -- every lane loads the packed row of its env and generates the MFMA operands
+// from it (fwd_strip_split, qnet_device.hpp "Layer 1 at f32 accuracy on the f16 matrix pipe"); LDS holds the weights only.
 template <int NMAX>
 __global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
 {
     extern __shared__ __align__(16) float lds[];
-    float *W1 = lds;                        // [64][108] fc1 (+ b1 in column 100)
-    float *W2 = W1 + kTileF;                // [16][64]
+    const W1Split W1 = w1split_at(lds);     // fc1 + b1 in the split form (kTileF floats)
+    float *W2 = lds + kSplitF;              // [16][64]
     float *b2 = W2 + kMaxOut * kHid;        // [16]
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
@@ -1770,7 +1759,8 @@ __global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
     const int i = (int)blockIdx.x * kTile + wv * 16 + r;
     floatx4 vW[kStageIters];
     w_issue(vW, g.local);
-    const float pb1 = nl.b1[tid < kHid ? tid : kHid - 1];
+    SplitScRegs vS;
+    w_issue_sc(vS, g.local, nl.b1);
     float pw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) pw[k] = nl.W2[tid + 256 * k < n2 * kHid ? tid + 256 * k : 0];
@@ -1780,14 +1770,14 @@ __global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
     // the epsilon-greedy draw of this lane's env: a serial chain, computed under the loads' round trip
     const uint4 rn = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
                                    make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
-    w_commit(W1, vW, pb1);
+    w_commit_split(W1, vW, vS);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (tid + 256 * k < n2 * kHid) W2[tid + 256 * k] = pw[k];
     if (tid < n2) b2[tid] = pb2;
     __syncthreads();
     floatx4 h[4];
-    fwd_strip_packed(W1, R, h);
+    fwd_strip_split<false>(W1, R, h);
     float q[NMAX];
     {
         W2Frag<NMAX> F;

@@ -317,38 +317,49 @@ __device__ __forceinline__ void split_store(const W1Split &S, int row, int col, 
     if (k >= 0) S.sc[row * kScK + k] = w;
 }
 // fc1 (64 x 100 f32, the registers of w_issue) + b1 -> the split form; 256 threads.  A thread's piece = four consecutive columns
-// 4 q .. 4 q + 3 of one row: pieces 2..23 go to the term tiles as two 8-byte stores, the scalar columns (pieces 0, 1, 2, 21, 22) to
-// the f32 block; columns 95..99 are constant zero in every row (their weights never meet a non-zero operand).
-__device__ __forceinline__ void w_commit_split(const W1Split &S, const floatx4 (&v)[kStageIters], float bias)
+// 4 q .. 4 q + 3 of one row: pieces 2..23 go to the term tiles as two 8-byte stores.  The f32 block (the 15 scalar columns, b1,
+// four zeros) is loaded a second time, straight from memory, five entries per thread (w_issue_sc, in flight with w_issue's loads):
+// picking those columns out of the pieces took eight conditional LDS stores per piece -- 1.4 us of a 6 us launch, measured on
+// k_dqn_act_packed; columns 95..99 are constant zero in every row (their weights never meet a non-zero operand).
+struct SplitScRegs {
+    float v[5];
+};
+__device__ __forceinline__ void w_issue_sc(SplitScRegs &R, const float *W, const float *b1)
 {
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, row = (tid >> 2) & 63, part = tid & 3;      // (any 256 consecutive threads of a workgroup)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int k = 5 * part + i;                             // scalar-block entry: columns 0..10 | 86..89 | b1 | 0 0 0 0
+        const int col = k < 11 ? k : 75 + k;
+        const float *src = k < 15 ? W + row * kW + col : b1 + row;
+        const float x = *src;
+        R.v[i] = k <= 15 ? x : 0.0f;
+    }
+}
+__device__ __forceinline__ void w_commit_split(const W1Split &S, const floatx4 (&v)[kStageIters], const SplitScRegs &R)
+{
+    const int tid = (int)threadIdx.x & 255;                                       // (the 256 threads that called w_issue / w_issue_sc)
+    // every piece is converted first, branch-free: seven independent chains for the scheduler to interleave
+    half4 h[kStageIters], m[kStageIters];
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[it][e] = (_Float16)v[it][e];
+            m[it][e] = (_Float16)((v[it][e] - (float)h[it][e]) * 2048.0f);
+        }
 #pragma unroll
     for (int it = 0; it < kStageIters; ++it) {
         const int c = it * 256 + tid;
-        if (c < kStageChunks) {
-            const int row = c / 25, q = c - row * 25;
-            const floatx4 w = v[it];
-            if (q >= 2 && q < 24) {
-                half4 h, m;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = (_Float16)w[e];
-                    m[e] = (_Float16)((w[e] - (float)h[e]) * 2048.0f);
-                }
-                *reinterpret_cast<half4 *>(S.hi + row * kLdHs + 4 * q - kFlagC0) = h;
-                *reinterpret_cast<half4 *>(S.mid + row * kLdHs + 4 * q - kFlagC0) = m;
-            }
-            float *sc = S.sc + row * kScK;
-            if (q < 2) *reinterpret_cast<floatx4 *>(sc + 4 * q) = w;                       // columns 0..7
-            else if (q == 2) { sc[8] = w[0]; sc[9] = w[1]; sc[10] = w[2]; }                 // 8, 9, 10
-            else if (q == 21) { sc[11] = w[2]; sc[12] = w[3]; }                             // 86, 87
-            else if (q == 22) { sc[13] = w[0]; sc[14] = w[1]; }                             // 88, 89
+        const int row = c / 25, q = c - row * 25;
+        if (c < kStageChunks && q >= 2 && q < 24) {
+            *reinterpret_cast<half4 *>(S.hi + row * kLdHs + 4 * q - kFlagC0) = h[it];
+            *reinterpret_cast<half4 *>(S.mid + row * kLdHs + 4 * q - kFlagC0) = m[it];
         }
     }
-    if (tid < kHid) {
-        float *d = S.sc + tid * kScK + 15;
-        d[0] = bias; d[1] = 0.0f; d[2] = 0.0f; d[3] = 0.0f; d[4] = 0.0f;
-    }
+    float *d = S.sc + (tid >> 2) * kScK + 5 * (tid & 3);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) d[i] = R.v[i];
 }
 // eight flag bits -> eight halves (0 / 1.0) as the B operand of v_mfma_f32_16x16x32_f16
 __device__ __forceinline__ half8 bits_to_half8(uint32_t byte)

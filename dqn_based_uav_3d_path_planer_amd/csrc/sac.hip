@@ -156,10 +156,10 @@ __device__ __forceinline__ void stage_actor(float *W1s, const float *flat)
 __device__ __forceinline__ void stage_actor_split(const W1Split &S, const float *flat)
 {
     floatx4 v[kStageIters];
+    SplitScRegs sc;
     w_issue(v, flat);
-    const int tid = (int)threadIdx.x;
-    const float bias = tid < kHid ? flat[kHid * kW + tid] : 0.0f;
-    w_commit_split(S, v, bias);
+    w_issue_sc(sc, flat, flat + kHid * kW);
+    w_commit_split(S, v, sc);
 }
 
 // critic fc1 (64 x 102: input column c < 100 -> tile column c, the two action columns -> 101, 102, b1 -> 100) and fc2,

@@ -1135,13 +1135,14 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     UAV_STAMP(0);
 
     // ---- policy prologue, part 1: fc1 + the packed row of this lane's agent (strip wv, row lane & 15) in flight
-    float *pW1 = reinterpret_cast<float *>(smem + a.pol_off);               // [64][108]
-    float *pW2 = pW1 + uavq::kTileF;                                        // [16][64]
+    const uavq::W1Split pW1 = uavq::w1split_at(reinterpret_cast<float *>(smem + a.pol_off));      // fc1 + b1, split form (kTileF floats)
+    float *pW2 = reinterpret_cast<float *>(smem + a.pol_off) + uavq::kSplitF;                     // [16][64]
     float *pb2 = pW2 + uavq::kMaxOut * uavq::kHid;                          // [16]
     int32_t *pact = reinterpret_cast<int32_t *>(pb2 + uavq::kMaxOut);       // [64] chosen actions of the workgroup's agents
     uavq::floatx4 vW[uavq::kStageIters];
     uavq::PRow prow;
-    float pol_b1 = 0.0f, pol_w2[4] = {0, 0, 0, 0}, pol_b2v = 0.0f;
+    uavq::SplitScRegs pol_sc;
+    float pol_w2[4] = {0, 0, 0, 0}, pol_b2v = 0.0f;
     uint4 pol_rn = make_uint4(0u, 0u, 0u, 0u);
     const int pol_i = first + wv * 16 + (lane & 15);
     const int pol_n2 = a.n_actions + (a.pol_dueling ? 1 : 0);
@@ -1149,7 +1150,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         const int tid = (int)threadIdx.x;
         uavq::w_issue(vW, a.pol_local);
         const uavq::NetDev nl = uavq::net_view(a.pol_local, pol_n2);
-        pol_b1 = nl.b1[tid < uavq::kHid ? tid : uavq::kHid - 1];
+        uavq::w_issue_sc(pol_sc, a.pol_local, nl.b1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) pol_w2[k] = nl.W2[tid + 256 * k < pol_n2 * uavq::kHid ? tid + 256 * k : 0];
         pol_b2v = nl.b2[tid < pol_n2 ? tid : 0];
@@ -1203,7 +1204,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     pre.moved = false;
     if (POLICY) {                        // policy prologue, part 2: weights into LDS
         const int tid = (int)threadIdx.x;
-        uavq::w_commit(pW1, vW, pol_b1);
+        uavq::w_commit_split(pW1, vW, pol_sc);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (tid + 256 * k < pol_n2 * uavq::kHid) pW2[tid + 256 * k] = pol_w2[k];
@@ -1224,7 +1225,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     const WorldLds<MaskT> w = world_view<MaskT>(smem, a);
     if (POLICY) {                        // policy prologue, part 3: forward, layer 2, epsilon-greedy
         uavq::floatx4 h[4];
-        uavq::fwd_strip_packed(pW1, prow, h);
+        uavq::fwd_strip_split<false>(pW1, prow, h);
         float q[4];
         {
             uavq::W2Frag<4> F;

@@ -63,8 +63,13 @@ def test_fused_act_and_learner_on_packed_rows_equal_the_f32_row_path(kind, net):
         rpk.step_env(auto_reset=True)
         la = float(A.learn_from_ring(r32, 2048, 7, t))
         lb = float(B.learn_from_ring(rpk, 2048, 7, t))
-        assert la == lb, (t, la, lb)
-    assert torch.equal(A.flat, B.flat)
+        # (round 4: on packed rows layer 1 runs in the split form -- the flag columns against fc1 as two f16 terms on the f16
+        # matrix pipe, csrc/qnet_device.hpp -- every product exact, the f32 sums in another order than the f32-row kernels': the two
+        # paths agree to rounding, no longer bit for bit; the actions above still have to be the same ones)
+        assert abs(la - lb) <= 2e-6 * max(1.0, abs(la)), (t, la, lb)
+    dw = (A.flat[0] - B.flat[0]).abs()
+    lr = float(PARAM["LEARNING_RATE"])          # nine Adam steps of lr each: the weight sets stay within a hundredth of ONE step,
+    assert dw.max().item() <= 1e-2 * lr and dw.double().mean().item() <= 1e-5 * lr, (dw.max().item(), dw.double().mean().item())
     # the sampler returns the same transitions, unpacked
     s32, spk = r32.sample(512, 3, 1), rpk.sample(512, 3, 1)
     for k in ("states", "next_states", "actions", "rewards", "dones", "valid"):
