@@ -937,11 +937,17 @@ def run_dqn(args, world_size, rank, dev):
     torch.cuda.synchronize(dev)
     k_b2b_ms = e0.elapsed_time(e1) / it
     kp_b2b_ms = None
+    # the launches as the C loop issues them: on one GPU, packed rows and the f32-MFMA net it stages layer 1 from the image it keeps
+    # (csrc/loop.hip: UavLoop.img); the weights do not change during these legs, so a snapshot is that image
+    loop_image = None
+    if (fused and use_c and not multi and args.sample_lag == 0 and args.obs_dtype == "packed" and getattr(learner, "mfma", "f32") != "f16" and
+            os.environ.get("UAVENV_LOOP_IMAGE", "1") != "0"):
+        loop_image = learner.split_image()
     if fused and use_c and os.environ.get("UAVENV_NO_FUSED_ACT") is None and ring.step_policy(learner, args.eps, seed, 1 << 40):
         torch.cuda.synchronize(dev)
         e0.record()
         for i in range(it):
-            ring.step_policy(learner, args.eps, seed, (1 << 40) + 1 + i)
+            ring.step_policy(learner, args.eps, seed, (1 << 40) + 1 + i, image=loop_image)
         e1.record()
         torch.cuda.synchronize(dev)
         kp_b2b_ms = e0.elapsed_time(e1) / it
@@ -962,9 +968,10 @@ def run_dqn(args, world_size, rank, dev):
         s_ = torch.cuda.current_stream(dev).cuda_stream
 
         def grad(cn):
-            _lib.check(learner.lib.uavenv_dqn_grad(C.byref(ring._c), ring.head, ring.filled, args.batch, seed, cn, None,
-                                                   C.byref(learner.net), kind, learner.gamma, 0, part.data_ptr(), s_),
-                       "uavenv_dqn_grad")
+            _lib.check(learner.lib.uavenv_dqn_grad_img(C.byref(ring._c), ring.head, ring.filled, args.batch, seed, cn, None,
+                                                       C.byref(learner.net), kind, learner.gamma, 0, None, None, part.data_ptr(),
+                                                       None if loop_image is None else loop_image.data_ptr(), s_),
+                       "uavenv_dqn_grad_img")
         for cn in range(5):
             grad(cn)
         torch.cuda.synchronize(dev)

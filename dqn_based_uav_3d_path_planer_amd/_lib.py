@@ -118,6 +118,7 @@ class UavSacAdam(C.Structure):
 SAC_LOOP_MAX_SLOTS = 8
 FED_MAX_BLOCKS = 8
 DRAW_MAX_TRIES = 8
+DQN_IMAGE_FLOATS = 6912      # csrc/dqn_internal.hpp
 
 
 class UavSacLoopSlot(C.Structure):
@@ -322,6 +323,14 @@ def load() -> C.CDLL:
     lib.uavenv_dqn_grad.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, net, i32, f32, i32, vp, vp]
     lib.uavenv_dqn_grad_w.restype = C.c_int
     lib.uavenv_dqn_grad_w.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, net, i32, f32, i32, vp, vp, vp, vp]
+    # not part of the C ABI (csrc/dqn_internal.hpp): the layer-1 image the C loop keeps for its DQN launches, for measurements
+    # of exactly those launches (bench.py's back-to-back legs)
+    lib.uavenv_dqn_split_image.restype = C.c_int
+    lib.uavenv_dqn_split_image.argtypes = [net, vp, vp]
+    lib.uavenv_dqn_grad_img.restype = C.c_int
+    lib.uavenv_dqn_grad_img.argtypes = [C.POINTER(UavReplayRing), i32, i32, i32, u64, u64, vp, net, i32, f32, i32, vp, vp, vp, vp, vp]
+    lib.uavenv_step_policy_img.restype = C.c_int
+    lib.uavenv_step_policy_img.argtypes = [vp, C.POINTER(UavDqnNet), vp, f32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp, vp]
     lib.uavenv_dqn_reduce.restype = C.c_int
     lib.uavenv_dqn_reduce.argtypes = [net, vp, i32, vp, vp]
     lib.uavenv_dqn_adam.restype = C.c_int

@@ -25,6 +25,7 @@
 #include "../../include/uavenv.h"
 #include "uavenv_device.hpp"
 #include "qnet_device.hpp"
+#include "dqn_internal.hpp"
 
 using namespace uav;
 using namespace uavq;
@@ -48,6 +49,7 @@ struct GradArgs {
     // sample s out (ReplayTree.batch_update's input)
     const float *is_w;
     float *abs_td;
+    const float *img;                // nullable: q_local's and q_target's layer 1 in the split form (2 x kSplitF floats, qnet_device.hpp)
 };
 
 #ifdef UAVENV_PHASE_PROFILE
@@ -499,10 +501,9 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     SplitScRegs vSl, vSt;
     float pw[4] = {0, 0, 0, 0}, pt[4] = {0, 0, 0, 0}, pb2 = 0.0f, pb2t = 0.0f;
     if (FIRST) {
-        w_issue(vWl, g.local);
+        if (g.img) img_issue(vWl, g.img); else w_issue(vWl, g.local);
         const NetDev nl = net_view(g.local, n2), nt = net_view(g.target, n2);
-        w_issue_sc(vSl, g.local, nl.b1);
-        w_issue_sc(vSt, g.target, nt.b1);
+        if (!g.img) { w_issue_sc(vSl, g.local, nl.b1); w_issue_sc(vSt, g.target, nt.b1); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = tid + 256 * k < n2 * kHid ? tid + 256 * k : 0;
@@ -532,10 +533,10 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
     const float p_w = g.is_w ? g.is_w[smp] : 1.0f;
     prow_load(Rn, obs + (size_t)row_n * kPackedDwords);
-    if (FIRST) w_issue(vWt, g.target);
+    if (FIRST) { if (g.img) img_issue(vWt, g.img + kSplitF); else w_issue(vWt, g.target); }
 
     if (FIRST) {
-        w_commit_split(w1split_at(L.W1l), vWl, vSl);
+        if (g.img) img_commit(L.W1l, vWl); else w_commit_split(w1split_at(L.W1l), vWl, vSl);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (tid + 256 * k < n2 * kHid) { L.W2l[tid + 256 * k] = pw[k]; L.W2t[tid + 256 * k] = pt[k]; }
@@ -553,7 +554,7 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
     if (gq == 0) prow_store_lds(L.Ps + (wv * 16 + r) * kPackedDwords, Rs);     // the s rows, for the dW1 product
     if (FIRST) {
-        w_commit_split(w1split_at(L.W1t), vWt, vSt);
+        if (g.img) img_commit(L.W1t, vWt); else w_commit_split(w1split_at(L.W1t), vWt, vSt);
         __syncthreads();                      // target weights staged
     }
     L_STAMP(2);
@@ -720,9 +721,9 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     SplitScRegs vS;
     float pw[4] = {0, 0, 0, 0}, pb2 = 0.0f;
     if (FIRST) {                              // group 0 stages q_local's weights, group 1 q_target's
-        w_issue_half(vW, net, t256);
+        if (g.img) img_issue(vW, g.img + (grp == 0 ? 0 : kSplitF)); else w_issue_half(vW, net, t256);
         const NetDev nv = net_view(net, n2);
-        w_issue_sc(vS, net, nv.b1);
+        if (!g.img) w_issue_sc(vS, net, nv.b1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) pw[k] = nv.W2[t256 + 256 * k < n2 * kHid ? t256 + 256 * k : 0];
         pb2 = nv.b2[t256 < n2 ? t256 : 0];
@@ -752,7 +753,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
         p_w = g.is_w ? g.is_w[smp] : 1.0f;
     }
     if (FIRST) {
-        w_commit_split(w1split_at(grp == 0 ? L.W1l : L.W1t), vW, vS);
+        if (g.img) img_commit(grp == 0 ? L.W1l : L.W1t, vW); else w_commit_split(w1split_at(grp == 0 ? L.W1l : L.W1t), vW, vS);
         float *W2 = grp == 0 ? L.W2l : L.W2t, *b2 = grp == 0 ? L.b2l : L.b2t;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1620,7 +1621,7 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
                                                          float *__restrict__ m, float *__restrict__ v, float lr,
                                                          float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
                                                          int hard_update, float *__restrict__ loss, float *__restrict__ raw,
-                                                         const uint32_t *__restrict__ go_word, uint32_t go_value)
+                                                         const uint32_t *__restrict__ go_word, uint32_t go_value, float *__restrict__ img)
 {
     // gated update (uavenv_dqn_reduce_adam_gated): the step kernel of this pass stamps go_word with go_value when it moved at
     // least one agent; a pass in which every agent had already finished leaves the learner exactly as it is (the reference's loop
@@ -1651,6 +1652,10 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
             const float np = w0 - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
             local[p] = np;
             if (hard_update) target[p] = np;
+            if (img) {                        // the C loop's layer-1 image follows the parameters (qnet_device.hpp: img_store_param)
+                img_store_param(img, p, np);
+                if (hard_update) img_store_param(img + kSplitF, p, np);
+            }
         } else if (p == P && loss) {
             *loss = t * inv;
         }
@@ -1666,6 +1671,7 @@ struct ActArgs {
     int32_t *index_out;
     float *steer_out;
     float *q_out;          // nullable [n][A]
+    const float *img;      // nullable: q_local's layer 1 in the split form (packed rows, f32 MFMA)
 };
 
 // Q(s) + epsilon-greedy for a tile of 64 envs (Trainer/DuelingDQN_Trainer.py:86-97), same wave-strip forward as
@@ -1758,9 +1764,8 @@ __global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
     const NetDev nl = net_view(g.local, n2);
     const int i = (int)blockIdx.x * kTile + wv * 16 + r;
     floatx4 vW[kStageIters];
-    w_issue(vW, g.local);
     SplitScRegs vS;
-    w_issue_sc(vS, g.local, nl.b1);
+    if (g.img) img_issue(vW, g.img); else { w_issue(vW, g.local); w_issue_sc(vS, g.local, nl.b1); }
     float pw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) pw[k] = nl.W2[tid + 256 * k < n2 * kHid ? tid + 256 * k : 0];
@@ -1770,7 +1775,7 @@ __global__ void __launch_bounds__(256) k_dqn_act_packed(ActArgs g)
     // the epsilon-greedy draw of this lane's env: a serial chain, computed under the loads' round trip
     const uint4 rn = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)g.counter, (uint32_t)(g.counter >> 32), 0xac7u),
                                    make_uint2((uint32_t)g.seed, (uint32_t)(g.seed >> 32)));
-    w_commit_split(W1, vW, vS);
+    if (g.img) img_commit(lds, vW); else w_commit_split(W1, vW, vS);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (tid + 256 * k < n2 * kHid) W2[tid + 256 * k] = pw[k];
@@ -2040,6 +2045,16 @@ int uavenv_dqn_grad_w(const UavReplayRing *ring, int32_t head, int32_t filled, i
                       uint64_t counter, const int32_t *explicit_idx, const UavDqnNet *net, int32_t kind, float gamma,
                       int32_t huber, const float *is_weights, float *abs_td_out, float *partials, void *stream)
 {
+    return uavenv_dqn_grad_img(ring, head, filled, batch, seed, counter, explicit_idx, net, kind, gamma, huber, is_weights, abs_td_out,
+                               partials, nullptr, stream);
+}
+
+// (internal, csrc/dqn_internal.hpp) image_dev: uavenv_dqn_split_image's output for THIS net as it is now -- packed rings with the
+// f32 MFMA net stage layer 1 of both nets from it; ignored (may be null) everywhere else
+int uavenv_dqn_grad_img(const UavReplayRing *ring, int32_t head, int32_t filled, int32_t batch, uint64_t seed,
+                        uint64_t counter, const int32_t *explicit_idx, const UavDqnNet *net, int32_t kind, float gamma,
+                        int32_t huber, const float *is_weights, float *abs_td_out, float *partials, const float *image_dev, void *stream)
+{
     if (!ring || !ring->obs || !ring->action || !ring->reward || !ring->done || !partials || !net_ok(net) || !net->target)
         return UAVENV_EINVAL;
     if (batch <= 0 || batch % kTile != 0 || ring->frames < 2 || head < 0 || head >= ring->frames) return UAVENV_EINVAL;
@@ -2062,6 +2077,7 @@ int uavenv_dqn_grad_w(const UavReplayRing *ring, int32_t head, int32_t filled, i
     g.dbg = g_learner_dbg;
     g.is_w = is_weights;
     g.abs_td = abs_td_out;
+    g.img = (image_dev && (((uintptr_t)image_dev) & 15u) == 0) ? image_dev : nullptr;
     ga.n_tiles = batch / kTile;
     ga.stride = uavenv_dqn_partial_stride(net);
     const int grid = uavenv_dqn_partial_rows(batch);
@@ -2132,6 +2148,15 @@ int uavenv_dqn_reduce_adam_gated(const UavDqnNet *net, const float *partials, in
                                  float beta2, float eps, int32_t step_t, int32_t hard_update, float *loss_out, float *raw_out,
                                  const uint32_t *go_word_dev, uint32_t go_value, void *stream)
 {
+    return uavenv_dqn_reduce_adam_img(net, partials, n_partials, lr, beta1, beta2, eps, step_t, hard_update, loss_out, raw_out, go_word_dev,
+                                      go_value, nullptr, stream);
+}
+
+int uavenv_dqn_reduce_adam_img(const UavDqnNet *net, const float *partials, int32_t n_partials, float lr, float beta1, float beta2,
+                               float eps, int32_t step_t, int32_t hard_update, float *loss_out, float *raw_out,
+                               const uint32_t *go_word_dev, uint32_t go_value, float *image_dev, void *stream)
+{
+    if (image_dev && (net->w != kW || net->hid != kHid || (((uintptr_t)image_dev) & 15u) != 0)) return UAVENV_EINVAL;
     if (!net_ok(net) || !net->target || !net->m || !net->v || !partials || n_partials <= 0 || step_t <= 0)
         return UAVENV_EINVAL;
     const int P = uavenv_dqn_num_params(net);
@@ -2139,7 +2164,29 @@ int uavenv_dqn_reduce_adam_gated(const UavDqnNet *net, const float *partials, in
     const float bc2 = 1.0f - powf(beta2, (float)step_t);
     hipLaunchKernelGGL(k_dqn_reduce_adam, dim3((P + 2 + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, n_partials,
                        P, uavenv_dqn_partial_stride(net), net->local, net->target, net->m, net->v, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update,
-                       loss_out, raw_out, go_word_dev, go_value);
+                       loss_out, raw_out, go_word_dev, go_value, image_dev);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
+}
+
+// q_local's and q_target's fc1 / b1 -> the split form in memory (workgroup 0 / 1): exactly the staging of the kernels that convert
+// for themselves (w_issue + w_issue_sc + w_commit_split), aimed at memory instead of LDS
+__global__ void __launch_bounds__(256) k_dqn_split_image(const float *__restrict__ local, const float *__restrict__ target,
+                                                         float *__restrict__ img)
+{
+    const float *net = blockIdx.x == 0 ? local : target;
+    floatx4 v[kStageIters];
+    SplitScRegs sc;
+    w_issue(v, net);
+    w_issue_sc(sc, net, net + kHid * kW);
+    w_commit_split(w1split_at(img + (size_t)blockIdx.x * kSplitF), v, sc);
+}
+
+int uavenv_dqn_split_image(const UavDqnNet *net, float *image_dev, void *stream)
+{
+    if (!net_ok(net) || !net->target || !image_dev || net->w != kW || net->hid != kHid || (((uintptr_t)image_dev) & 15u) != 0)
+        return UAVENV_EINVAL;
+    static_assert(UAVENV_DQN_IMAGE_FLOATS == kSplitF, "dqn_internal.hpp");
+    hipLaunchKernelGGL(k_dqn_split_image, dim3(2), dim3(256), 0, (hipStream_t)stream, net->local, net->target, image_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 
@@ -2152,6 +2199,7 @@ int uavenv_dqn_act(const UavDqnNet *net, const void *obs_dev, int32_t obs_dtype,
     g.obs = obs_dev; g.n = n; g.n_actions = net->n_actions; g.dueling = net->dueling;
     g.local = net->local; g.eps = eps; g.seed = seed; g.counter = counter;
     g.index_out = index_out; g.steer_out = steer_out; g.q_out = q_out;
+    g.img = nullptr;
     const int grid = (n + kTile - 1) / kTile;
     hipStream_t s = (hipStream_t)stream;
     const bool small = net->n_actions + (net->dueling ? 1 : 0) <= 4;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/uavenv.h"
+#include "dqn_internal.hpp"
 
 #include <chrono>
 #include <stdio.h>
@@ -37,6 +38,10 @@ struct UavLoop {
     hipStream_t plan = nullptr;
     int32_t replan_next = 0, bank_m = 0;
     uint64_t replan_gen = 0;
+    // fc1 / b1 of q_local and q_target in the split form (csrc/dqn_internal.hpp, qnet_device.hpp): built from the parameters when a
+    // run starts, kept current by the loop's own Adam launches, read by its step-policy and gradient launches instead of converting
+    // fc1 while staging it (packed ring + f32 MFMA net on one GPU; null otherwise)
+    float *img = nullptr;
 };
 
 // Every replan_every passes: hand over the slice whose planning has finished (on the passes' stream: no reset runs meanwhile),
@@ -91,6 +96,13 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
     l->counter = cfg->counter;
     l->per = cfg->per.prio != nullptr;
     l->per_beta = cfg->per_beta;
+    {   // the layer-1 image (see UavLoop.img): one GPU, the serial order, packed rows, the f32-MFMA net of the reference's shape
+        static const bool off = getenv("UAVENV_LOOP_IMAGE") && atoi(getenv("UAVENV_LOOP_IMAGE")) == 0;     // A/B knob
+        if (!off && !cfg->p2p && !cfg->coll && cfg->sample_lag == 0 && cfg->ring.obs_dtype == UAVENV_OBS_PACKED &&
+            cfg->net.mfma_dtype == UAVENV_MFMA_F32 && cfg->net.w == 100 && cfg->net.hid == 64 && cfg->net.local && cfg->net.target) {
+            if (hipMalloc((void **)&l->img, 2 * (size_t)UAVENV_DQN_IMAGE_FLOATS * sizeof(float)) != hipSuccess) { delete l; return UAVENV_ENOMEM; }
+        }
+    }
     if (cfg->sample_lag != 0) {
         if (cfg->sample_lag != 1 || l->per) { delete l; return UAVENV_EINVAL; }
         if (hipStreamCreateWithFlags(&l->aux, hipStreamNonBlocking) != hipSuccess ||
@@ -135,6 +147,7 @@ int uavenv_loop_destroy(UavLoop *l)
         (void)hipStreamDestroy(l->plan);
     }
     for (hipEvent_t e : {l->ev_grad, l->ev_join}) if (e) (void)hipEventDestroy(e);
+    if (l->img) (void)hipFree(l->img);
     delete l;
     return UAVENV_OK;
 }
@@ -188,6 +201,10 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
         if (uavenv_p2p_status(c.p2p, 0, st) == UAVENV_OK && st[0] != 0) return UAVENV_EP2P;
     }
     const bool lag = l->aux != nullptr;
+    if (l->img && n_steps > 0) {              // whatever happened to the parameters since the last run: the image is rebuilt from them
+        const int ri = uavenv_dqn_split_image(&c.net, l->img, s);
+        if (ri != UAVENV_OK) return ri;
+    }
     for (int k = 0; k < n_steps; ++k) {
         const int t = l->head, nxt = t + 1 == R.frames ? 0 : t + 1;
         if (l->plan && l->counter % (uint64_t)c.replan_every == 0) {
@@ -225,8 +242,8 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 e1 = take_event(l);
                 if (e0 && e1) (void)hipEventRecord(e0, s);
             }
-            rc = uavenv_step_policy(c.env, &c.net, obs_t, c.eps, c.seed, l->counter, act_t, obs_n, nullptr, R.reward + (size_t)t * n,
-                                    R.done + (size_t)t * n, nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, s);
+            rc = uavenv_step_policy_img(c.env, &c.net, obs_t, c.eps, c.seed, l->counter, act_t, obs_n, nullptr, R.reward + (size_t)t * n,
+                                        R.done + (size_t)t * n, nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, l->img, s);
             if (rc == UAVENV_EINVAL) l->fuse_act = false;         // not this env / net: the two-launch form from here on
             else if (rc != UAVENV_OK) return rc;
         }
@@ -273,19 +290,19 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 rc = uavenv_per_weights(&c.per, c.per_slots_dev, c.per_prio_dev, c.batch, (int64_t)l->filled * (int64_t)n,
                                         l->per_beta, R.n_agents, c.per_w_dev, c.per_idx_dev, s);
                 if (rc != UAVENV_OK) return rc;
-                rc = uavenv_dqn_grad_w(&R, l->head, l->filled, c.batch, c.seed, l->counter, c.per_idx_dev, &c.net, c.kind, c.gamma,
-                                       c.huber, c.per_w_dev, c.per_abs_dev, c.partials_dev, s);
+                rc = uavenv_dqn_grad_img(&R, l->head, l->filled, c.batch, c.seed, l->counter, c.per_idx_dev, &c.net, c.kind, c.gamma,
+                                         c.huber, c.per_w_dev, c.per_abs_dev, c.partials_dev, l->img, s);
             } else if ((c.step_flags & UAVENV_STEP_SKIP_DONE) != 0 && c.per_idx_dev && R.valid) {
                 // finished agents are skipped, not restarted: their rows stay in the ring with valid = 0 (the reference stores
                 // nothing for them) -- the batch is drawn over the valid rows only and handed to the update as explicit pairs
                 rc = uavenv_replay_draw_valid(R.frames, n, l->head, l->filled, c.batch, 1, 1, 0, R.valid, UAVENV_DRAW_MAX_TRIES, c.seed,
                                               l->counter, c.per_idx_dev, s);
                 if (rc != UAVENV_OK) return rc;
-                rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, c.per_idx_dev, &c.net, c.kind, c.gamma,
-                                     c.huber, c.partials_dev, s);
+                rc = uavenv_dqn_grad_img(&R, l->head, l->filled, c.batch, c.seed, l->counter, c.per_idx_dev, &c.net, c.kind, c.gamma,
+                                         c.huber, nullptr, nullptr, c.partials_dev, l->img, s);
             } else {
-                rc = uavenv_dqn_grad(&R, l->head, l->filled, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
-                                     c.huber, c.partials_dev, s);
+                rc = uavenv_dqn_grad_img(&R, l->head, l->filled, c.batch, c.seed, l->counter, nullptr, &c.net, c.kind, c.gamma,
+                                         c.huber, nullptr, nullptr, c.partials_dev, l->img, s);
             }
             if (rc != UAVENV_OK) return rc;
             if (l->prof) tp2 = std::chrono::steady_clock::now();
@@ -308,9 +325,9 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 rc = uavenv_dqn_adam(&c.net, c.raw_dev, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, s);
             } else {
                 // (moved_dev: no update behind a step that moved nobody -- the word was stamped with this pass's tick by the step)
-                rc = uavenv_dqn_reduce_adam_gated(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2,
-                                                  c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, c.moved_dev,
-                                                  (uint32_t)uavenv_tick(c.env), s);
+                rc = uavenv_dqn_reduce_adam_img(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2,
+                                                c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, c.moved_dev,
+                                                (uint32_t)uavenv_tick(c.env), l->img, s);
             }
             if (rc != UAVENV_OK) return rc;
             if (l->per) {                 // ReplayTree.batch_update (:215-222)
@@ -362,6 +379,7 @@ int uavenv_loop_step_times(UavLoop *l, float *ms_out, int32_t max_n, int32_t *n_
 // plugins/PathPlan_City._run_eposide_fused_sac uses: K steps from here == K steps from there, bit for bit.
 // =====================================================================================================================
 #include "uavenv_device.hpp"
+#include "dqn_internal.hpp"
 
 namespace {
 

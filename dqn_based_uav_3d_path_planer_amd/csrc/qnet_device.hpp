@@ -361,6 +361,43 @@ __device__ __forceinline__ void w_commit_split(const W1Split &S, const floatx4 (
 #pragma unroll
     for (int i = 0; i < 5; ++i) d[i] = R.v[i];
 }
+// A staged layer 1 kept in MEMORY in the split form -- the LDS image, byte for byte (kSplitF floats) -- so that staging it is a
+// straight copy: the conversion above costs a 256-thread staging team ~1.5 k cycles in front of the barrier, as much as the split
+// forward saves a 16-agent strip.  The C loop keeps one image per net (built when a run starts, kept current by its own Adam
+// launches: csrc/loop.hip); every other caller converts while staging -- same values, same results.
+constexpr int kImgPieces = kSplitBytes / 16;                  // 1 728 pieces of 16 bytes: 7 per thread of 256
+static_assert((kImgPieces + 255) / 256 == kStageIters, "the image is staged through the registers of w_issue");
+__device__ __forceinline__ void img_issue(floatx4 (&v)[kStageIters], const float *img)
+{
+    const int tid = (int)threadIdx.x & 255;
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        int c = it * 256 + tid;
+        c = c < kImgPieces ? c : kImgPieces - 1;
+        v[it] = *reinterpret_cast<const floatx4 *>(img + 4 * c);
+    }
+}
+__device__ __forceinline__ void img_commit(float *lds_image, const floatx4 (&v)[kStageIters])
+{
+    const int tid = (int)threadIdx.x & 255;
+#pragma unroll
+    for (int it = 0; it < kStageIters; ++it) {
+        const int c = it * 256 + tid;
+        if (c < kImgPieces) *reinterpret_cast<floatx4 *>(lds_image + 4 * c) = v[it];
+    }
+}
+// parameter p of a flat block (fc1 [64][100] | b1 [64] | ...) = w into an image in memory (the Adam kernels: one thread per parameter)
+__device__ __forceinline__ void img_store_param(float *img, int p, float w)
+{
+    const W1Split S = w1split_at(img);
+    if (p < kHid * kW) {
+        const int row = p / kW;
+        split_store(S, row, p - row * kW, w);
+    } else if (p < kHid * kW + kHid) {
+        S.sc[(p - kHid * kW) * kScK + 15] = w;
+    }
+}
+
 // eight flag bits -> eight halves (0 / 1.0) as the B operand of v_mfma_f32_16x16x32_f16
 __device__ __forceinline__ half8 bits_to_half8(uint32_t byte)
 {

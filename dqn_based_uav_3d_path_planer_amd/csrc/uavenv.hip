@@ -31,6 +31,7 @@
 #include "../../include/uavenv.h"
 #include "uavenv_device.hpp"
 #include "qnet_device.hpp"
+#include "dqn_internal.hpp"
 
 using namespace uav;
 
@@ -133,6 +134,7 @@ struct StepArgs {
     uint64_t seed, tick;
     // the policy in the prologue of k_step_coop (uavenv_step_policy): Q(s) + epsilon-greedy of Trainer/DuelingDQN_Trainer.py:86-97
     const float *pol_local;            // nullable: q_local's flat parameter block
+    const float *pol_img;              // nullable: its layer 1 in the split form (csrc/dqn_internal.hpp; packed rows only)
     const uint32_t *pol_obs;           // rows of the CURRENT frame: [N][20] packed (k_step_coop) or [N][100] halfs (k_step)
     int32_t *pol_act;                  // [N] chosen action indices out (the replay ring's action plane)
     int32_t pol_dueling, pol_off;      // pol_off: LDS byte offset of the policy's tiles
@@ -1148,9 +1150,9 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     const int pol_n2 = a.n_actions + (a.pol_dueling ? 1 : 0);
     if (POLICY) {
         const int tid = (int)threadIdx.x;
-        uavq::w_issue(vW, a.pol_local);
         const uavq::NetDev nl = uavq::net_view(a.pol_local, pol_n2);
-        uavq::w_issue_sc(pol_sc, a.pol_local, nl.b1);
+        if (a.pol_img) uavq::img_issue(vW, a.pol_img);
+        else { uavq::w_issue(vW, a.pol_local); uavq::w_issue_sc(pol_sc, a.pol_local, nl.b1); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) pol_w2[k] = nl.W2[tid + 256 * k < pol_n2 * uavq::kHid ? tid + 256 * k : 0];
         pol_b2v = nl.b2[tid < pol_n2 ? tid : 0];
@@ -1204,7 +1206,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     pre.moved = false;
     if (POLICY) {                        // policy prologue, part 2: weights into LDS
         const int tid = (int)threadIdx.x;
-        uavq::w_commit_split(pW1, vW, pol_sc);
+        if (a.pol_img) uavq::img_commit(reinterpret_cast<float *>(smem + a.pol_off), vW); else uavq::w_commit_split(pW1, vW, pol_sc);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (tid + 256 * k < pol_n2 * uavq::kHid) pW2[tid + 256 * k] = pol_w2[k];
@@ -2254,6 +2256,15 @@ int uavenv_step_policy(UavEnv *e, const UavDqnNet *net, const void *obs_cur, flo
                        int32_t *action_out, void *obs, double *reward64, float *reward32, uint8_t *ret_done, uint8_t *agent_done,
                        uint8_t *info, uint8_t *valid, double *energy64, const uint8_t *active, uint32_t flags, void *stream)
 {
+    return uavenv_step_policy_img(e, net, obs_cur, eps, seed, counter, action_out, obs, reward64, reward32, ret_done, agent_done, info, valid,
+                                  energy64, active, flags, nullptr, stream);
+}
+
+int uavenv_step_policy_img(UavEnv *e, const UavDqnNet *net, const void *obs_cur, float eps, uint64_t seed, uint64_t counter,
+                           int32_t *action_out, void *obs, double *reward64, float *reward32, uint8_t *ret_done, uint8_t *agent_done,
+                           uint8_t *info, uint8_t *valid, double *energy64, const uint8_t *active, uint32_t flags,
+                           const float *image_dev, void *stream)
+{
     if (!e || !net || !net->local || !obs_cur || !action_out) return fail(UAVENV_EINVAL, "null argument");
     if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step_policy before uavenv_set_buildings");
     if ((flags & UAVENV_STEP_AUTO_RESET) && e->bank_m <= 0)
@@ -2290,6 +2301,7 @@ int uavenv_step_policy(UavEnv *e, const UavDqnNet *net, const void *obs_cur, flo
     a.active = active;
     a.flags = flags;
     a.pol_local = net->local;
+    a.pol_img = (coop_packed && image_dev && (((uintptr_t)image_dev) & 15u) == 0) ? image_dev : nullptr;
     a.pol_obs = reinterpret_cast<const uint32_t *>(obs_cur);
     a.pol_act = action_out;
     a.pol_dueling = net->dueling;

@@ -234,6 +234,16 @@ class FusedDQNLearner:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def split_image(self) -> torch.Tensor:
+        """fc1 / b1 of q_local and q_target in the split form the packed-row kernels stage (csrc/qnet_device.hpp), as the C loop
+        keeps it for its own launches (csrc/dqn_internal.hpp): a snapshot of the parameters AS THEY ARE NOW -- for measuring those
+        launches outside the loop; it does not follow later updates."""
+        _lib = self._lib_mod
+        img = torch.empty(2 * _lib.DQN_IMAGE_FLOATS, dtype=torch.float32, device=self.flat.device)
+        s = torch.cuda.current_stream(self.flat.device).cuda_stream
+        _lib.check(self.lib.uavenv_dqn_split_image(self._C.byref(self.net), img.data_ptr(), s), "uavenv_dqn_split_image")
+        return img
+
     def new_partials(self, batch: int) -> torch.Tensor:
         """Scratch for uavenv_dqn_grad: partial_rows(batch) x partial_stride(net) floats."""
         rows = self.lib.uavenv_dqn_partial_rows(int(batch))

@@ -74,7 +74,8 @@ class DeviceReplayRing:
         self.head = nxt
         self.filled = min(self.filled + 1, self.frames - 1)
 
-    def step_policy(self, learner, eps: float, seed: int, counter: int, auto_reset: bool = True, skip_done: bool = None) -> bool:
+    def step_policy(self, learner, eps: float, seed: int, counter: int, auto_reset: bool = True, skip_done: bool = None,
+                    image: torch.Tensor = None) -> bool:
         """get_action + step in ONE launch (uavenv_step_policy: Q(s) + epsilon-greedy in the step kernel's prologue, the
         launch csrc/loop.hip issues per pass).  Returns False -- nothing enqueued -- when this env / net cannot take it
         (the callers then issue learner.act + step_env)."""
@@ -83,11 +84,14 @@ class DeviceReplayRing:
         t, nxt = self.head, (self.head + 1) % self.frames
         n = self.env.N
         flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | self.extra_flags
-        rc = self.env.lib.uavenv_step_policy(self.env._h, C.byref(learner.net), self.obs.data_ptr() + t * self._obs_stride,
-                                             float(eps), int(seed), int(counter), self.action.data_ptr() + t * n * 4,
-                                             self.obs.data_ptr() + nxt * self._obs_stride, None,
-                                             self.reward.data_ptr() + t * n * 4, self.done.data_ptr() + t * n, None, None,
-                                             self.valid.data_ptr() + t * n, None, None, flags, self.env._stream())
+        # (image: learner.split_image() -- the launch as the C loop issues it, csrc/dqn_internal.hpp; same actions)
+        fn = self.env.lib.uavenv_step_policy if image is None else self.env.lib.uavenv_step_policy_img
+        tail = (self.env._stream(),) if image is None else (image.data_ptr(), self.env._stream())
+        rc = fn(self.env._h, C.byref(learner.net), self.obs.data_ptr() + t * self._obs_stride,
+                float(eps), int(seed), int(counter), self.action.data_ptr() + t * n * 4,
+                self.obs.data_ptr() + nxt * self._obs_stride, None,
+                self.reward.data_ptr() + t * n * 4, self.done.data_ptr() + t * n, None, None,
+                self.valid.data_ptr() + t * n, None, None, flags, *tail)
         if rc == _lib.EINVAL:
             return False
         _lib.check(rc, "uavenv_step_policy")
