@@ -305,12 +305,20 @@ __global__ void __launch_bounds__(256) k_p2p_pull_sum(P2PDev d, float *__restric
     }
     __syncthreads();
     if (s_bad) return;
-    const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (p < count) {
-        float sum = 0.0f;
-        for (int r = 0; r < d.world; ++r)
-            sum += __hip_atomic_load(recv_slot(mine, r, d.seq, d.bucket_pad) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        buf[p] = sum;
+    // four floats per thread and trip (the loads of a trip independent and in flight together), a grid-stride walk: the grid is
+    // capped (uavenv_p2p_allreduce) so that the workgroups WAITING above never cover the chip
+    const int count4 = count >> 2;
+    for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x); q < count4; q += (int)(gridDim.x * blockDim.x)) {
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int r = 0; r < d.world; ++r) {
+            const float *src = recv_slot(mine, r, d.seq, d.bucket_pad) + 4 * q;
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += t[e];
+        }
+        *reinterpret_cast<float4 *>(buf + 4 * q) = make_float4(sum[0], sum[1], sum[2], sum[3]);
     }
 }
 
@@ -587,8 +595,13 @@ int uavenv_p2p_allreduce(UavP2P *c, float *buf_dev, int64_t count, void *stream)
         c->seq -= 1;
         return UAVENV_EHIP;
     }
-    hipLaunchKernelGGL(k_p2p_pull_sum, dim3(((int)count + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_view(c, -1, -1), buf_dev,
-                       (int)count);
+    // At most 32 workgroups: every workgroup of this launch sits on its CU until the peers' blocks have arrived, and a CU that
+    // hosts one cannot take a 160 KB-LDS workgroup (the SAC phase kernels).  Two ranks sharing ONE device (the same-device test
+    // runs) deadlocked on that until the wait timed out, about one run in eight: rank A's 340 waiting workgroups covered every CU
+    // while rank B's gradient launch -- whose result A was waiting for -- could not be placed.  On a device of its own the cap
+    // costs nothing: 87 k floats are three trips of 32 x 256 threads x 16 bytes.
+    const int pull_wgs = (count4 + 255) / 256 < 32 ? (count4 + 255) / 256 : 32;
+    hipLaunchKernelGGL(k_p2p_pull_sum, dim3(pull_wgs), dim3(256), 0, (hipStream_t)stream, dev_view(c, -1, -1), buf_dev, (int)count);
     if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
     return *c->host_code ? UAVENV_EP2P : UAVENV_OK;
 }

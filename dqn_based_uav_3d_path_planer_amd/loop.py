@@ -318,8 +318,9 @@ class SACHotLoop:
         rc = self.lib.uavenv_sac_loop_run(self._h, int(n_steps), s)
         if rc == _lib.EP2P:
             self._sync_cursor()          # the steps before the failure are in the ring and in the learners' counters
-            raise P2PExchangeError("the peer exchange of the SAC loop raised its sticky error: stop stepping and re-synchronise "
-                                   "parameters and moments from one rank")
+            raise P2PExchangeError(f"the peer exchange of the SAC loop raised its sticky error ({self.p2p_status(False)}: code 1 = "
+                                   "a peer's block did not arrive in time, 2 = the ranks' weights diverged): stop stepping and "
+                                   "re-synchronise parameters and moments from one rank")
         if rc != 0:
             raise _lib.UavEnvError(f"uavenv_sac_loop_run failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()} / "
                                    f"{self.lib.uavenv_last_error().decode()}")
