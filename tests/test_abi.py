@@ -32,6 +32,20 @@ def test_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libuavenv.so does not export {name}"
 
 
+def test_loop_internal_entry_points_are_exported():
+    """csrc/dqn_internal.hpp: the C loop's image variants of three ABI entry points -- not part of include/uavenv.h, but bench.py
+    times the loop's launches through them and _lib.py binds them: they have to be there, and only there."""
+    lib = _lib.load()
+    text = open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "dqn_internal.hpp")).read()
+    names = sorted(set(re.findall(r"\bint\s+(uavenv_\w+)\s*\(", text)))
+    assert names == ["uavenv_dqn_grad_img", "uavenv_dqn_reduce_adam_img", "uavenv_dqn_split_image", "uavenv_step_policy_img"]
+    declared = set(header_symbols())
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name not in declared
+    assert int(re.search(r"#define UAVENV_DQN_IMAGE_FLOATS (\d+)", text).group(1)) == _lib.DQN_IMAGE_FLOATS
+
+
 def test_config_struct_layout_matches_header():
     # 10 int32 + 5 doubles + 8 doubles + 1 double, naturally aligned
     assert ctypes.sizeof(_lib.UavEnvConfig) == 10 * 4 + 14 * 8

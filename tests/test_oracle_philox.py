@@ -42,3 +42,31 @@ def test_act_draws_range():
     u, r = px.act_draws(4096, seed=7, counter=3, n_actions=3)
     assert u.min() >= 0.0 and u.max() < 1.0 and set(np.unique(r).tolist()) == {0, 1, 2}
     assert abs(u.mean() - 0.5) < 0.03
+
+
+def test_valid_only_draws_reject_over_the_permutation():
+    """replay_draws_valid (the restatement uavenv_replay_draw_valid is tested against on the GPU): draws walk the permutation past
+    rows whose valid flag is 0 -- accepted rows are valid rows of the draw's own slot, distinct within a slot, inside the stored
+    frames; with every row valid they are replay_draws'; a draw that runs out of tries keeps its first row."""
+    frames, n_envs, U, head, filled, batch = 17, 512, 4, 5, 16, 256
+    rng = np.random.default_rng(1)
+    valid = (rng.random((frames, n_envs * U)) >= 0.4).astype(np.uint8)
+    f, e, found = px.replay_draws_valid(batch, U, U, 0, valid, 8, seed=5, counter=2, head=head, filled=filled, frames=frames, n_envs=n_envs)
+    slot = np.arange(U * batch) // batch
+    assert (valid.reshape(frames, n_envs, U)[f, e, slot][found] == 1).all()
+    assert found.mean() > 0.995                                        # 0.4 ** 8 = 7e-4
+    f0, e0 = px.replay_draws(U * batch, 5, 2, head, filled, frames, n_envs)
+    assert (f[~found] == f0[~found]).all() and (e[~found] == e0[~found]).all()
+    back = (head - 1 - f) % frames
+    assert back.max() < filled
+    for j in range(U):
+        m = (slot == j) & found
+        assert len(np.unique(back[m] * n_envs + e[m])) == m.sum()
+    fa, ea, fo = px.replay_draws_valid(batch, U, U, 0, np.ones_like(valid), 8, 5, 2, head, filled, frames, n_envs)
+    assert fo.all() and (fa == f0).all() and (ea == e0).all()
+    # one slot alone, and a ring too small for a second try: positions past filled * n_envs are never looked at
+    f1, e1, fo1 = px.replay_draws_valid(batch, 1, U, 3, valid, 8, 5, 2, head, filled, frames, n_envs)
+    assert (valid.reshape(frames, n_envs, U)[f1, e1, 3][fo1] == 1).all()
+    f2, e2, fo2 = px.replay_draws_valid(filled * n_envs, 1, U, 0, valid, 8, 5, 2, head, filled, frames, n_envs)
+    fs, es = px.replay_draws(filled * n_envs, 5, 2, head, filled, frames, n_envs)
+    assert (f2 == fs).all() and (e2 == es).all()                       # no second position exists: every draw keeps its first row
