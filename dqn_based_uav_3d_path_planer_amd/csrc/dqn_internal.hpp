@@ -25,6 +25,12 @@ int uavenv_dqn_reduce_adam_img(const UavDqnNet *net, const float *partials, int3
                                float eps, int32_t step_t, int32_t hard_update, float *loss_out, float *raw_out,
                                const uint32_t *go_word, uint32_t go_value, float *image_dev, void *stream);
 
+// ... and the Adam launches behind an exchange (csrc/p2p.hip, the RCCL path's uavenv_dqn_adam) do the same.
+int uavenv_dqn_adam_p2p_img(const UavDqnNet *net, struct UavP2P *c, float lr, float beta1, float beta2, float eps, int32_t step_t,
+                            int32_t hard_update, float *loss_out, float *raw_out, float *image_dev, void *stream);
+int uavenv_dqn_adam_img(const UavDqnNet *net, const float *raw, float lr, float beta1, float beta2, float eps, int32_t step_t,
+                        int32_t hard_update, float *loss_out, float *image_dev, void *stream);
+
 // uavenv_step_policy with q_local's image (first half of an image buffer).
 int uavenv_step_policy_img(UavEnv *e, const UavDqnNet *net, const void *obs_cur, float eps, uint64_t seed, uint64_t counter,
                            int32_t *action_out, void *obs, double *reward64, float *reward32, uint8_t *ret_done, uint8_t *agent_done,

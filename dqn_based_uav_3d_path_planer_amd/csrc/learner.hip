@@ -1596,7 +1596,8 @@ __global__ void __launch_bounds__(256) k_dqn_reduce(const float *__restrict__ pa
 // (DQN_Trainer.py:121-130,138-141).  raw[P] = loss sum, raw[P+1] = valid count.
 __global__ void k_dqn_adam(float *__restrict__ local, float *__restrict__ target, float *__restrict__ m,
                            float *__restrict__ v, const float *__restrict__ raw, int P, float lr, float beta1,
-                           float beta2, float eps, float bc1, float bc2_sqrt, int hard_update, float *__restrict__ loss)
+                           float beta2, float eps, float bc1, float bc2_sqrt, int hard_update, float *__restrict__ loss,
+                           float *__restrict__ img)
 {
     const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const float cnt = raw[P + 1];
@@ -1612,6 +1613,10 @@ __global__ void k_dqn_adam(float *__restrict__ local, float *__restrict__ target
     const float np = local[p] - (lr / bc1) * (mp / denom);
     local[p] = np;
     if (hard_update) target[p] = np;
+    if (img) {
+        img_store_param(img, p, np);
+        if (hard_update) img_store_param(img + kSplitF, p, np);
+    }
 }
 
 // Single-GPU fast path: k_dqn_reduce + k_dqn_adam in one launch (each workgroup owns 32 parameters end to end; the
@@ -2127,12 +2132,19 @@ int uavenv_dqn_reduce(const UavDqnNet *net, const float *partials, int32_t n_par
 int uavenv_dqn_adam(const UavDqnNet *net, const float *raw, float lr, float beta1, float beta2, float eps, int32_t step_t,
                     int32_t hard_update, float *loss_out, void *stream)
 {
+    return uavenv_dqn_adam_img(net, raw, lr, beta1, beta2, eps, step_t, hard_update, loss_out, nullptr, stream);
+}
+
+int uavenv_dqn_adam_img(const UavDqnNet *net, const float *raw, float lr, float beta1, float beta2, float eps, int32_t step_t,
+                        int32_t hard_update, float *loss_out, float *image_dev, void *stream)
+{
     if (!net_ok(net) || !net->target || !net->m || !net->v || !raw || step_t <= 0) return UAVENV_EINVAL;
+    if (image_dev && (net->w != kW || net->hid != kHid || (((uintptr_t)image_dev) & 15u) != 0)) return UAVENV_EINVAL;
     const int P = uavenv_dqn_num_params(net);
     const float bc1 = 1.0f - powf(beta1, (float)step_t);
     const float bc2 = 1.0f - powf(beta2, (float)step_t);
     hipLaunchKernelGGL(k_dqn_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, net->local, net->target,
-                       net->m, net->v, raw, P, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update, loss_out);
+                       net->m, net->v, raw, P, lr, beta1, beta2, eps, bc1, sqrtf(bc2), hard_update, loss_out, image_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_EHIP;
 }
 

@@ -40,7 +40,8 @@ struct UavLoop {
     uint64_t replan_gen = 0;
     // fc1 / b1 of q_local and q_target in the split form (csrc/dqn_internal.hpp, qnet_device.hpp): built from the parameters when a
     // run starts, kept current by the loop's own Adam launches, read by its step-policy and gradient launches instead of converting
-    // fc1 while staging it (packed ring + f32 MFMA net on one GPU; null otherwise)
+    // fc1 while staging it (packed ring + f32 MFMA net, the serial order; null otherwise).  Behind an exchange every rank's Adam
+    // launch applies the same summed gradient, so every rank's image follows its own -- identical -- parameters
     float *img = nullptr;
 };
 
@@ -96,9 +97,9 @@ int uavenv_loop_create(const UavLoopConfig *cfg, UavLoop **out)
     l->counter = cfg->counter;
     l->per = cfg->per.prio != nullptr;
     l->per_beta = cfg->per_beta;
-    {   // the layer-1 image (see UavLoop.img): one GPU, the serial order, packed rows, the f32-MFMA net of the reference's shape
+    {   // the layer-1 image (see UavLoop.img): the serial order, packed rows, the f32-MFMA net of the reference's shape
         static const bool off = getenv("UAVENV_LOOP_IMAGE") && atoi(getenv("UAVENV_LOOP_IMAGE")) == 0;     // A/B knob
-        if (!off && !cfg->p2p && !cfg->coll && cfg->sample_lag == 0 && cfg->ring.obs_dtype == UAVENV_OBS_PACKED &&
+        if (!off && cfg->sample_lag == 0 && cfg->ring.obs_dtype == UAVENV_OBS_PACKED &&
             cfg->net.mfma_dtype == UAVENV_MFMA_F32 && cfg->net.w == 100 && cfg->net.hid == 64 && cfg->net.local && cfg->net.target) {
             if (hipMalloc((void **)&l->img, 2 * (size_t)UAVENV_DQN_IMAGE_FLOATS * sizeof(float)) != hipSuccess) { delete l; return UAVENV_ENOMEM; }
         }
@@ -315,14 +316,14 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                     l->counter += 1;
                     return rc;
                 }
-                rc = uavenv_dqn_adam_p2p(&c.net, c.p2p, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, s);
+                rc = uavenv_dqn_adam_p2p_img(&c.net, c.p2p, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, nullptr, l->img, s);
                 if (rc == UAVENV_EP2P) l->counter += 1;   // enqueued, but the kernel keeps the weights frozen
             } else if (c.coll) {              // the same bucket through an RCCL all-reduce enqueued from here (csrc/coll.hip)
                 rc = uavenv_dqn_reduce(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.raw_dev, s);
                 if (rc != UAVENV_OK) return rc;
                 rc = uavenv_coll_allreduce_sum(c.coll, c.raw_dev, (int64_t)uavenv_dqn_num_params(&c.net) + 2, s);
                 if (rc != UAVENV_OK) return rc;
-                rc = uavenv_dqn_adam(&c.net, c.raw_dev, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, s);
+                rc = uavenv_dqn_adam_img(&c.net, c.raw_dev, c.lr, c.beta1, c.beta2, c.adam_eps, l->epoch, hard, c.loss_dev, l->img, s);
             } else {
                 // (moved_dev: no update behind a step that moved nobody -- the word was stamped with this pass's tick by the step)
                 rc = uavenv_dqn_reduce_adam_img(&c.net, c.partials_dev, uavenv_dqn_partial_rows(c.batch), c.lr, c.beta1, c.beta2,

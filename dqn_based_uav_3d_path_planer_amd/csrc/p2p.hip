@@ -29,6 +29,9 @@
 #include <vector>
 
 #include "../../include/uavenv.h"
+#include "uavenv_device.hpp"
+#include "qnet_device.hpp"
+#include "dqn_internal.hpp"
 
 namespace {
 constexpr int kMaxWorld = 16;
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(256) k_p2p_reduce_push(const float *__restrict
 __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restrict__ local, float *__restrict__ target,
                                                        float *__restrict__ m, float *__restrict__ v, float *__restrict__ raw_out,
                                                        int P, float lr, float beta1, float beta2, float eps, float bc1,
-                                                       float bc2_sqrt, int hard_update, float *__restrict__ loss)
+                                                       float bc2_sqrt, int hard_update, float *__restrict__ loss, float *__restrict__ img)
 {
     unsigned char *mine = d.peer[d.rank];
     // Raise flag [rank] = seq at every rank first: this kernel is launched behind k_p2p_reduce_push on the stream, so the
@@ -259,6 +262,10 @@ __global__ void __launch_bounds__(256) k_p2p_pull_adam(P2PDev d, float *__restri
                 np = np - (lr / bc1) * (mp / (sqrtf(vp) / bc2_sqrt + eps));
                 local[p] = np;
                 if (hard_update) target[p] = np;
+                if (img) {                   // the C loop's layer-1 image follows the parameters (csrc/dqn_internal.hpp)
+                    uavq::img_store_param(img, p, np);
+                    if (hard_update) uavq::img_store_param(img + uavq::kSplitF, p, np);
+                }
             }
         }
     }
@@ -529,6 +536,13 @@ int uavenv_dqn_reduce_p2p(const UavDqnNet *net, const float *partials, int32_t n
 int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *c, float lr, float beta1, float beta2, float eps, int32_t step_t,
                         int32_t hard_update, float *loss_out, float *raw_out, void *stream)
 {
+    return uavenv_dqn_adam_p2p_img(net, c, lr, beta1, beta2, eps, step_t, hard_update, loss_out, raw_out, nullptr, stream);
+}
+
+int uavenv_dqn_adam_p2p_img(const UavDqnNet *net, UavP2P *c, float lr, float beta1, float beta2, float eps, int32_t step_t,
+                            int32_t hard_update, float *loss_out, float *raw_out, float *image_dev, void *stream)
+{
+    if (image_dev && (!net || net->w != uavq::kW || net->hid != uavq::kHid || (((uintptr_t)image_dev) & 15u) != 0)) return UAVENV_EINVAL;
     if (!net || !c || !c->connected || c->seq == 0) return UAVENV_EINVAL;
     const int P = uavenv_dqn_num_params(net);
     if (P <= 0 || P + 2 > c->bucket) return UAVENV_EINVAL;
@@ -541,7 +555,7 @@ int uavenv_dqn_adam_p2p(const UavDqnNet *net, UavP2P *c, float lr, float beta1, 
     const int fold_idx = fold ? (int)(c->n_checks & 1u) : -1;
     hipLaunchKernelGGL(k_p2p_pull_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_view(c, c->carry_cur, fold_idx),
                        apply ? net->local : (float *)nullptr, net->target, net->m, net->v, raw_out, P, lr, beta1, beta2, eps,
-                       bc1, sqrtf(bc2), hard_update, loss_out);
+                       bc1, sqrtf(bc2), hard_update, loss_out, apply ? image_dev : (float *)nullptr);
     if (hipGetLastError() != hipSuccess) return UAVENV_EHIP;
     if (fold) {
         c->check_pending = true;

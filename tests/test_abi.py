@@ -38,7 +38,8 @@ def test_loop_internal_entry_points_are_exported():
     lib = _lib.load()
     text = open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "dqn_internal.hpp")).read()
     names = sorted(set(re.findall(r"\bint\s+(uavenv_\w+)\s*\(", text)))
-    assert names == ["uavenv_dqn_grad_img", "uavenv_dqn_reduce_adam_img", "uavenv_dqn_split_image", "uavenv_step_policy_img"]
+    assert names == ["uavenv_dqn_adam_img", "uavenv_dqn_adam_p2p_img", "uavenv_dqn_grad_img", "uavenv_dqn_reduce_adam_img",
+                     "uavenv_dqn_split_image", "uavenv_step_policy_img"]
     declared = set(header_symbols())
     for name in names:
         assert hasattr(lib, name), name
