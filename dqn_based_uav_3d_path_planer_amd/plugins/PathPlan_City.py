@@ -63,6 +63,14 @@ class PathPlan_City:
         # ---- PathPlan_City.__init__ (Envs/PathPlan_City.py:31-103)
         self.eps = float(None2Value(param.get("eps"), 0.1))
         self.Is_On_Policy = int(None2Value(param.get("Is_On_Policy"), 0))
+        if self.Is_On_Policy == 1:
+            # Envs/PathPlan_City.py:419-436 (run_thread_OnPolicy: one thread per UAV per step, the AC-family update after the
+            # episode) is outside this build's path (the off-policy loop :364-385).  Fail closed: raising
+            # here makes EnvFactory.Create_Env print the reason and return None (FactoryClass/EnvFactory.py:21-23) instead of
+            # silently training such a config off-policy.
+            raise NotImplementedError("PathPlan_City: <Is_On_Policy>1</Is_On_Policy> (on-policy sampling, Envs/PathPlan_City.py:"
+                                      "419-436) is not built here; this plugin runs the off-policy loop only "
+                                      "(run_thread_OffPolicy, :364-385).  Set Is_On_Policy to 0 or use the reference's env.")
         self.param = param
         self.buildings = []
         threaten_params = param.get("Obstacles")

@@ -80,6 +80,66 @@ def gen(s, trainer_name, net):
     print(trainer_name, "losses", losses)
 
 
+# The DQN-family updates on PACKED-REPRESENTABLE observations (round 5): rows the reference's own state_PathPlan produced
+# (tests/golden/episodes.npz), so that the bench's learner kernels -- k_dqn_grad_packed8 / k_dqn_grad_packed + k_dqn_reduce_adam,
+# which read 80-byte packed rows -- run on EXACTLY the inputs the executed learn_off_policy / update saw
+# (tests/test_learner_fused_gpu.py::test_packed_row_learner_against_the_executed_reference).  Two 64-sample tiles.
+def gen_packed(s, trainer_name, net):
+    from FactoryClass.TrainerFactory import TrainerFactory
+    Bp = 128
+    param = make_param(net, trainer_name)
+    param["Batch_Size"] = str(Bp)
+    tr = TrainerFactory().Create_Trainer(param)
+    assert tr is not None, trainer_name
+    tr.save = lambda *a, **k: None
+    g = torch.Generator().manual_seed(2468)
+    for netobj, scale in ((tr.q_local, 0.15), (tr.q_target, 0.12)):
+        with torch.no_grad():
+            for p in netobj.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * scale)
+    w_local0, w_target0 = sd_to_np(tr.q_local.state_dict()), sd_to_np(tr.q_target.state_dict())
+    ep = np.load(os.path.join(OUT, "episodes.npz"))
+    obs, outs, off = ep["obs"], ep["outs"], ep["offsets"]
+    rng = np.random.default_rng(13)
+    ok = np.ones(len(obs), bool)
+    ok[off[1:] - 1] = False                                        # s' must be the next record of the same episode
+    pick = rng.choice(np.nonzero(ok)[0], Bp, replace=False)
+    states = obs[pick].astype(np.float32)
+    next_states = obs[pick + 1].astype(np.float32)
+    actions = rng.integers(0, A, Bp).astype(np.int64)
+    rewards = outs[pick, 0].astype(np.float32)
+    dones = (rng.random(Bp) < 0.2).astype(np.float32)
+    losses = []
+    if trainer_name == "DuelingDQN_Trainer":
+        td = {"states": states.tolist(), "actions": tuple(int(a) for a in actions),
+              "rewards": tuple(float(r) for r in rewards), "next_states": next_states.tolist(),
+              "dones": tuple(float(d) for d in dones)}
+        for _ in range(N_UPDATES):
+            tr.update(td)
+            losses.append(float(tr.loss))
+    else:
+        FloatTensor = torch.FloatTensor
+        for i in range(Bp):
+            exp = (FloatTensor(states[i:i + 1]), torch.tensor([[int(actions[i])]]), FloatTensor([[float(rewards[i])]]),
+                   FloatTensor(next_states[i:i + 1]), FloatTensor([[float(dones[i])]]))
+            tr.replay_memory.push(exp, 0)
+        random.seed(7)
+        for _ in range(N_UPDATES):
+            tr.learn_off_policy()                  # random.sample(memory, B) with len(memory) == B: a permutation
+            losses.append(float(tr.loss))
+    out = dict(states=states, next_states=next_states, actions=actions, rewards=rewards, dones=dones,
+               losses=np.array(losses), epoch=int(tr.epoch), episode_rows=pick)
+    for pref, d in (("l0_", w_local0), ("t0_", w_target0), ("l1_", sd_to_np(tr.q_local.state_dict())),
+                    ("t1_", sd_to_np(tr.q_target.state_dict()))):
+        for k, v in d.items():
+            out[pref + k] = v
+    np.savez_compressed(os.path.join(OUT, f"learner_{trainer_name}_packed.npz"), **out)
+    print(trainer_name, "(packed-representable rows) losses", losses)
+
+
+PACKED_CASES = (("DQN_Trainer", "Qnet2"), ("DDQN_Trainer", "Qnet2"), ("DuelingDQN_Trainer", "VAnet2"))
+
+
 def main():
     s = RefSession()
     try:
@@ -88,6 +148,8 @@ def main():
         gen(s, "DuelingDQN_Trainer", "VAnet2")
         gen_sac(s)
         gen_sac_packed(s)
+        for _name, _net in PACKED_CASES:
+            gen_packed(s, _name, _net)
         # epsilon schedule, simulator.py:141-145
         sim = s.sim
         eps = []
@@ -237,6 +299,13 @@ if __name__ == "__main__":
         _s = RefSession()
         try:
             gen_sac_packed(_s)
+        finally:
+            _s.close()
+    elif "--dqn-packed" in sys.argv:
+        _s = RefSession()
+        try:
+            for _name, _net in PACKED_CASES:
+                gen_packed(_s, _name, _net)
         finally:
             _s.close()
     elif "--sac" in sys.argv:

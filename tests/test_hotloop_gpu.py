@@ -228,3 +228,94 @@ def test_loop_that_skips_finished_agents_draws_valid_rows_only():
     loop.close()
     env.close()
     env_b.close()
+
+
+def test_c_loop_at_bench_size_against_the_oracle():
+    """BASELINE configs[1] as bench.py runs it -- uavenv_loop_run at 16 384 envs, batch 16 384, packed ring, f32 DQN: the three
+    launches per pass (k_step_coop<policy> from the loop's layer-1 image, k_dqn_grad_packed8, k_dqn_reduce_adam) enqueued from C --
+    with the rows the loop leaves in the ring checked against oracle/uav_oracle.c DIRECTLY (Agents/UAV.py:397-567,
+    Envs/PathPlan_City.py:364-385): four runs of K = 12 passes; before each run the oracle takes the device's state, then replays
+    the run from the ACTIONS the loop stored -- every agent's reward / done flags and next observation (packed row expanded)
+    pass by pass until its first restart inside the run (the restart draws a scenario the oracle does not know; the next run
+    picks the agent up again from the device's state).  A quarter of the agents is placed 1-25 steps from the Step limit, so
+    restarts happen in every run.  And the same 48 passes issued launch by launch from Python (ring.step_policy +
+    learn_from_ring, the ABI entry points, converting fc1 while staging) leave the same ring and the same weights bit for bit."""
+    import numpy as np
+    from conftest import load_golden
+    from oracle import pyoracle as po
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    from dqn_based_uav_3d_path_planer_amd.loop import HotLoop
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    world = load_golden("world_stock.npz")
+    N, K, RUNS = 16384, 12, 4
+
+    def build():
+        env = make_city26_env(N, obs_dtype="packed")
+        ring = DeviceReplayRing(env, (RUNS * K + 2) * N, discrete=True)          # nothing is overwritten during the test
+        ring.reset(seed=41)
+        torch.manual_seed(6)
+        return env, ring, FusedDQNLearner(dict(PARAM, NetWork="Qnet2"), "dqn", device="cuda:0")
+
+    def inject(env, ring):
+        st, sub, alias = env.get_state(0, N, want_sub=True)
+        rng = np.random.default_rng(9)
+        step = st[:, 9].astype(np.int32)
+        late = rng.random(N) < 0.25
+        step[late] = rng.integers(125, 150, int(late.sum()))
+        env.set_state(0, np.c_[st[:, 0:5], st[:, 6:9]], step, st[:, 11].astype(np.int32), sub, alias=alias)
+        env.observe(ring.obs[ring.head])
+
+    env, ring, L = build()
+    loop = HotLoop(ring, L, N, seed=23, eps=0.2)
+    loop.run(1)                               # pops the start node of every path (zeroes Step, Agents/UAV.py:486)
+    torch.cuda.synchronize()
+    inject(env, ring)
+    batch = po.OracleBatch(po.OracleWorld(world["buildings"]), po.default_uav_params(world), N)
+    bits = np.r_[11:86, 90:95]
+    checked = restarts = 0
+    for run in range(RUNS):
+        st, sub, alias = env.get_state(0, N, want_sub=True)
+        batch.set_from_state16(st, sub, alias)
+        first = ring.head
+        loop.run(K)
+        torch.cuda.synchronize()
+        assert ring.head == first + K
+        alive = np.ones(N, bool)
+        for k in range(K):
+            f = first + k
+            a = ring.action[f].cpu().numpy()
+            r_o, d_o, i_o, obs_o = batch.step(-1.0 + a.astype(np.float64), want_obs=True)
+            r = ring.reward[f].cpu().numpy()
+            want32 = r_o.astype(np.float32)
+            ok = np.abs(r.astype(np.float64) - want32.astype(np.float64)) <= np.spacing(np.abs(want32)).astype(np.float64)
+            assert ok[alive].all(), (run, k)
+            assert np.array_equal(ring.done[f].cpu().numpy()[alive], d_o.astype(np.uint8)[alive]), (run, k)
+            assert np.all(ring.valid[f].cpu().numpy() == 1)
+            ad = batch.view["done"].astype(bool)
+            restarts += int((ad & alive).sum())
+            checked += int(alive.sum())
+            alive &= ~ad                     # the oracle's copy of a restarted agent no longer is the device's agent
+            got = env.unpack(ring.obs[f + 1]).cpu().numpy()[alive]
+            want = obs_o[alive]
+            assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= 2e-6, (run, k)
+            assert np.array_equal(got[:, bits], want[:, bits]), (run, k)
+        assert alive.sum() > N // 2
+    print("C loop at bench size: transitions checked", checked, "restarts seen", restarts)
+    assert checked > 0.8 * RUNS * K * N and restarts > 2000
+    torch.cuda.synchronize()
+    # the same passes, launch by launch from Python
+    env_b, ring_b, Lb = build()
+    for c in range(RUNS * K + 1):
+        if c == 1:
+            inject(env_b, ring_b)
+        assert ring_b.step_policy(Lb, 0.2, 23, c, auto_reset=True)
+        Lb.learn_from_ring(ring_b, N, 23, c)
+    torch.cuda.synchronize()
+    assert (ring_b.head, ring_b.filled, Lb.epoch) == (ring.head, ring.filled, L.epoch)
+    for name in ("obs", "action", "reward", "done", "valid"):
+        assert torch.equal(getattr(ring, name), getattr(ring_b, name)), name
+    assert torch.equal(L.flat, Lb.flat) and float(L.loss) == float(Lb.loss)
+    loop.close()
+    env.close()
+    env_b.close()

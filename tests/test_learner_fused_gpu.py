@@ -56,6 +56,56 @@ def test_fused_updates_match_reference(ref_name, kind, net):
             assert np.abs(v.cpu().numpy() - g[pref + k]).max() <= 5e-6, (pref, k)
 
 
+class HandRingPacked(HandRing):
+    """The same two frames as 80-byte packed rows (UAVENV_OBS_PACKED): what k_dqn_grad_packed8 / k_dqn_grad_packed gather."""
+
+    def __init__(self, states, next_states, actions, rewards, dones):
+        from conftest import pack_obs_rows
+        from dqn_based_uav_3d_path_planer_amd import _lib
+        super().__init__(states, next_states, actions, rewards, dones)
+        n = len(actions)
+        self.obs32 = self.obs
+        self.obs = torch.tensor(np.stack([pack_obs_rows(states), pack_obs_rows(next_states)]), device="cuda").contiguous()
+        self._c = _lib.UavReplayRing(self.obs.data_ptr(), self.action.data_ptr(), self.reward.data_ptr(),
+                                     self.done.data_ptr(), self.valid.data_ptr(), 2, n, _lib.OBS_PACKED, 1)
+
+
+@pytest.mark.parametrize("ref_name,kind,net", CASES)
+def test_packed_row_learner_against_the_executed_reference(ref_name, kind, net):
+    """The bench's learner kernels -- k_dqn_grad_packed8 (<= 4 layer-2 outputs: DQN, DDQN and the 3 + 1 of the dueling net) +
+    k_dqn_reduce_adam, layer 1 in the split form -- on the reference's OWN vectors: tests/golden/learner_*_packed.npz was written
+    by executing Trainer/DQN_Trainer.py:85-136 / DDQN_Trainer.py:72-117 / DuelingDQN_Trainer.py:150-190 on 128 transitions
+    whose observations the reference's state_PathPlan produced (oracle/gen_golden_learner.py: gen_packed), so the packed rows
+    ARE its inputs (they expand back bit for bit).  Same bars as the f32-row test: losses 2e-5 relative, weights 5e-6 after
+    seven updates and two hard target copies."""
+    from dqn_based_uav_3d_path_planer_amd import _lib
+    from dqn_based_uav_3d_path_planer_amd.learner import FusedDQNLearner
+    g = load_golden(f"learner_{ref_name}_packed.npz")
+    B = len(g["actions"])
+    assert B == 128
+    ring = HandRingPacked(g["states"], g["next_states"], g["actions"], g["rewards"], g["dones"])
+    back = torch.empty((2 * B, 100), dtype=torch.float32, device="cuda")
+    lib = _lib.load()
+    assert lib.uavenv_obs_unpack(ring.obs.data_ptr(), 2 * B, back.data_ptr(), _lib.OBS_F32,
+                                 torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.equal(back.view(2, B, 100), ring.obs32)
+    L = FusedDQNLearner(dict(PARAM, NetWork=net), kind, device="cuda:0")
+    _load(L.q_local, g, "l0_")
+    _load(L.q_target, g, "t0_")
+    losses = [float(L.learn_from_ring(ring, B, 0, 0, explicit_idx=ring.idx)) for _ in range(len(g["losses"]))]
+    assert L.epoch == int(g["epoch"])
+    assert np.allclose(losses, g["losses"], rtol=2e-5, atol=0), (losses, g["losses"])
+    worst = 0.0
+    for pref, netobj in (("l1_", L.q_local), ("t1_", L.q_target)):
+        for k, v in netobj.state_dict().items():
+            worst = max(worst, float(np.abs(v.cpu().numpy() - g[pref + k]).max()))
+            assert np.abs(v.cpu().numpy() - g[pref + k]).max() <= 5e-6, (pref, k)
+    print(ref_name, "packed rows vs executed reference: max |dw|", worst, "losses rel",
+          float(np.max(np.abs(np.array(losses) / g["losses"] - 1))))
+    # the same vectors through the C loop's image form of the launches (csrc/dqn_internal.hpp) are covered by
+    # tests/test_hotloop_gpu.py::test_c_loop_at_bench_size_against_the_oracle (image == converting, bit for bit)
+
+
 @pytest.mark.parametrize("kind,net", [("dqn", "Qnet2"), ("ddqn", "Qnet2"), ("dueling", "VAnet2")])
 def test_fused_matches_torch_learner_on_a_real_ring(kind, net):
     from dqn_based_uav_3d_path_planer_amd.data import make_city26_env

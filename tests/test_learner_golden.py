@@ -17,9 +17,10 @@ def _load(net, g, pref):
     net.load_state_dict(sd)
 
 
+@pytest.mark.parametrize("suffix", ["", "_packed"])      # "_packed": rows the reference's own state_PathPlan produced (batch 128)
 @pytest.mark.parametrize("ref_name,kind,net", CASES)
-def test_updates_match_reference(ref_name, kind, net):
-    g = load_golden(f"learner_{ref_name}.npz")
+def test_updates_match_reference(ref_name, kind, net, suffix):
+    g = load_golden(f"learner_{ref_name}{suffix}.npz")
     param = {"NetWork": net, "w": "100", "hiden_dim": "64", "output": "3", "LEARNING_RATE": "0.001",
              "gamma": "0.99", "Update_loop": "3"}
     L = DQNLearner(param, kind, device="cpu")
@@ -36,6 +37,9 @@ def test_updates_match_reference(ref_name, kind, net):
             assert np.abs(v.numpy() - g[pref + k]).max() <= 2e-6, (pref, k)
     # state-dict keys interchange with the reference checkpoints (fc1/fc2 or fc1/fc_A/fc_V)
     assert set(L.q_local.state_dict()) == {k[3:] for k in g if k.startswith("l0_")}
+    if suffix:      # these rows survive the 80-byte packed format unchanged (tests/conftest.py: pack_obs_rows raises otherwise)
+        from conftest import pack_obs_rows
+        assert pack_obs_rows(g["states"]).shape == (128, 20) and pack_obs_rows(g["next_states"]).shape == (128, 20)
 
 
 def test_valid_mask_and_huber_option():

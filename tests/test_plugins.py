@@ -146,6 +146,28 @@ def test_run_eposide_contract_vectorised(cfg_dir):
     assert sim.epoch == 10 and len(sim.infos) == 10 and sim.Max_score >= max(i["average_score"] for i in sim.infos) - 1e-9
 
 
+def test_on_policy_configs_fail_closed(cfg_dir, capsys):
+    """<Is_On_Policy>1</Is_On_Policy> selects the reference's run_thread_OnPolicy branch (Envs/PathPlan_City.py:419-436), which
+    this build does not have: the factory must print the reason and return None (FactoryClass/EnvFactory.py:21-23) -- never
+    run the off-policy loop under that name."""
+    import re
+    xml = driver.make_config_dir(str(cfg_dir), "DQN", num_envs=4)
+    s = open(xml).read()
+    s, n = re.subn(r"<Is_On_Policy>\s*0\s*</Is_On_Policy>", "<Is_On_Policy>1</Is_On_Policy>", s)
+    assert n == 1
+    open(xml, "w").write(s)
+    param = XML2Dict(xml).get("simulator").get("env") if XML2Dict(xml).get("simulator") else None
+    sim = driver.simulator(xml)
+    assert sim.env is None
+    out = capsys.readouterr().out
+    assert "Is_On_Policy" in out and "419-436" in out
+    if param is not None:
+        assert factories.EnvFactory().Create_Env(param) is None
+    # the same file with the flag back at 0 constructs
+    open(xml, "w").write(s.replace("<Is_On_Policy>1</Is_On_Policy>", "<Is_On_Policy>0</Is_On_Policy>"))
+    assert driver.simulator(xml).env is not None
+
+
 def test_run_eposide_with_sac_continuous_actions(cfg_dir):
     """BASELINE config 4's trainer (and the reference's shipped default) through the same episode loop."""
     xml = driver.make_config_dir(str(cfg_dir), "SAC", num_envs=6, num_uav=4)
