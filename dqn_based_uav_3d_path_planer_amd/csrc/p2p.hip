@@ -93,10 +93,14 @@ __device__ uint32_t p2p_wait_once(const P2PDev &d, unsigned char *mine, int P_ch
     uint32_t *verdict = reinterpret_cast<uint32_t *>(mine + (size_t)kMaxWorld * 64);
     const uint32_t tag = d.seq << 2;
     if (blockIdx.x != 0) {
-        uint32_t spins = 0, v;
+        // twice workgroup 0's own worst case (world waits of spin_limit polls each), in 64 bits -- 2 * 2^27 * 16 wrapped a
+        // uint32 to ~1 k polls and raised a spurious sticky timeout -- and at workgroup 0's poll interval
+        const unsigned long long bound = 2ull * (unsigned long long)d.spin_limit * (unsigned long long)d.world + 1024ull;
+        unsigned long long spins = 0;
+        uint32_t v;
         while (((v = __hip_atomic_load(verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) & ~3u) != tag) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > 2u * d.spin_limit * (uint32_t)d.world + 1024u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > bound) {
                 __hip_atomic_fetch_add(d.errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(d.errors + 1, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(d.host_code, (uint32_t)UAVENV_P2P_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

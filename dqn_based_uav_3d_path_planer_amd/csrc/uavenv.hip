@@ -179,6 +179,8 @@ struct UavEnv {
     int rp_wgs = 0;
     bool rp_pending = false;
     hipEvent_t rp_done = nullptr;
+    hipEvent_t rp_committed = nullptr; // recorded behind k_bank_commit: the next planner launch may not touch the staging area before it
+    bool rp_commit_recorded = false;
     int world_gen = 0, rp_world_gen = 0;
     long long rp_calls = 0, rp_rows_planned = 0;
 };
@@ -1764,6 +1766,7 @@ int uavenv_destroy(UavEnv *e)
     (void)hipFree(e->rp_nodes);
     (void)hipFree(e->rp_counters);
     if (e->rp_done) (void)hipEventDestroy(e->rp_done);
+    if (e->rp_committed) (void)hipEventDestroy(e->rp_committed);
     delete e;
     return UAVENV_OK;
 }
@@ -2069,6 +2072,10 @@ int uavenv_replan_begin(UavEnv *e, int32_t first, int32_t count, uint64_t seed, 
         e->rp_wgs = v > 0 && v <= 4096 ? v : 128;
         HIP_TRY(hipMalloc(&e->rp_nodes, (size_t)uavenv_rrt_scratch_bytes(e->rp_wgs)));
     }
+    // The previous slice's k_bank_commit was only ENQUEUED on the step stream (behind whatever backlog of passes that stream
+    // carries) and reads rp_sg / rp_sub / rp_nsub: the planner, which writes a row as soon as its tree is done, must not start
+    // before that kernel has run -- otherwise bank rows are torn and the bank's contents depend on timing.
+    if (e->rp_commit_recorded) HIP_TRY(hipStreamWaitEvent((hipStream_t)plan_stream, e->rp_committed, 0));
     // the Philox stream of row r is keyed by (seed, first + r): every refresh passes its own seed (generation)
     int rc = uavenv_rrt_plan_at(e, first, count, nullptr, nullptr, 0, seed, max_iter, 30.0, 5.0, e->rp_sg, e->rp_sub, e->rp_nsub,
                                 nullptr, e->rp_nodes, e->rp_wgs, plan_stream);
@@ -2109,6 +2116,9 @@ int uavenv_replan_commit(UavEnv *e, int32_t force, void *stream)
     hipLaunchKernelGGL(k_bank_commit, dim3((count + 3) / 4), dim3(256), 0, s, e->bank_sg, e->bank_sub, e->bank_nsub, e->rp_first, count,
                        e->cfg.max_subgoals, e->rp_sg, e->rp_sub, e->rp_nsub, inuse, counters);
     HIP_TRY(hipGetLastError());
+    if (!e->rp_committed) HIP_TRY(hipEventCreateWithFlags(&e->rp_committed, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->rp_committed, s));      // uavenv_replan_begin makes the next planner launch wait for this
+    e->rp_commit_recorded = true;
     return UAVENV_OK;
 }
 

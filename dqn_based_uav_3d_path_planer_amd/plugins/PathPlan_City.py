@@ -138,6 +138,11 @@ class PathPlan_City:
         # <FL_Aggregate>: "reference" (default) = the merge as the reference executes it -- the SUM of the UAVs' models: its
         # division at Envs/PathPlan_City.py:597 never reaches the model -- or "mean" (dqn_based_uav_3d_path_planer_amd/federated.py)
         self.FL_Aggregate = str(None2Value(param.get("FL_Aggregate"), "reference"))
+        # (absent: the actor-critic merge keeps the executed reference's SUM and says so once; the DQN-family merge, for which the
+        # reference has no executed behaviour -- its Federated_Learning raises AttributeError -- takes the mean: a SUM of U
+        # Q-networks scales every Q-value by ~U.  ADVICE r4)
+        self._fl_aggregate_given = param.get("FL_Aggregate") is not None
+        self._fl_warned = False
         from dqn_based_uav_3d_path_planer_amd import federated as _fed
         if self.FL_Aggregate not in _fed.AGGREGATES:
             raise ValueError(f"<FL_Aggregate>{self.FL_Aggregate}</FL_Aggregate>: expected one of {_fed.AGGREGATES}")
@@ -405,6 +410,10 @@ class PathPlan_City:
         """Envs/PathPlan_City.py:590-601: every UAV's actor <- the merge of all UAVs' actors (one launch over the flat
         parameter blocks when the trainers are fused; critics, targets and optimizers untouched)."""
         from dqn_based_uav_3d_path_planer_amd import federated
+        if not self._fl_aggregate_given and not self._fl_warned:
+            self._fl_warned = True
+            print("PathPlan_City: Is_FL = 1 without <FL_Aggregate>: merging the actors as the reference EXECUTES it -- their SUM "
+                  "(the division at Envs/PathPlan_City.py:597 never reaches the model).  <FL_Aggregate>mean</FL_Aggregate> averages.")
         self.fl_merged_on = federated.federated_learning_ac([u.Trainer for u in self.Agents], self.FL_Aggregate)
 
     def Federated_Learning(self):
@@ -412,7 +421,8 @@ class PathPlan_City:
         SPN_param / Update_SPN_Soft, which no trainer in the tree has (AttributeError); the merge of Federated_Learning_AC is
         applied to q_local instead (replace_param, Trainer/DuelingDQN_Trainer.py:204-207)."""
         from dqn_based_uav_3d_path_planer_amd import federated
-        self.fl_merged_on = federated.federated_learning_q([u.Trainer for u in self.Agents], self.FL_Aggregate)
+        self.fl_merged_on = federated.federated_learning_q([u.Trainer for u in self.Agents],
+                                                           self.FL_Aggregate if self._fl_aggregate_given else "mean")
 
     def _federated_merge(self):
         """:469-475, after epoch += 1: every FL_Loop episodes when Is_FL."""
@@ -548,7 +558,8 @@ class PathPlan_City:
         use_c = ((all(p is None for p in self._sac_per) or all_per) and len({t_.Batch_Size for t_ in trs}) == 1 and
                  len({bool(t_.Is_Train) for t_ in trs}) == 1 and U <= _lib.SAC_LOOP_MAX_SLOTS and
                  int(None2Value(self.param.get("sac_c_loop"), 1)) != 0)
-        if use_c and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if use_c and multi:
             use_c = False        # several ranks: the learners of the Python loop exchange per phase (sac.py: _exchange); the C loop's
                                  # on-stream exchange is set up by its owner (loop.SACHotLoop(exchange=...), bench.py --config 4 --gpus N)
         if use_c and getattr(self, "_sac_hot", None) is not None and \
@@ -568,7 +579,14 @@ class PathPlan_City:
         count0 = [(L.epoch, L.adam_steps) for L in Ls]
         beta0 = [None if p is None else p.beta for p in self._sac_per]
         passes = 0
-        if not use_c:
+        # Several ranks: every update sits behind a gradient sum over the ranks, so every rank must take the SAME
+        # updates.  A rank-local gate (this rank's moved word) or a rank-local end of the episode would let rank A skip -- or never
+        # issue -- an update rank B applies: parameters, adam_steps and bias corrections diverge and the exchange loses its partner.
+        # So at world_size > 1 nothing is gated on the device, and the episode ends for every rank at the first step that moved
+        # nobody on ANY rank (one all_gather_object of the per-step moved counts per <done_check> steps); the up to done_check - 1
+        # surplus updates then do happen, identically on every rank, and the counters keep them.
+        gate_local = not use_c and not multi
+        if gate_local:
             if getattr(self, "_sac_moved", None) is None:
                 self._sac_moved = torch.zeros(1, dtype=torch.int32, device=dev)
             _lib.check(lib.uavenv_set_moved_word(self.backend._h, self._sac_moved.data_ptr()), "uavenv_set_moved_word")
@@ -590,7 +608,7 @@ class PathPlan_City:
                 for j, uav in enumerate(self.Agents):
                     uav.Trainer.learner.act_rows(self._flat, t * N + j, U, self.num_envs, act0, act1, eps=za[j])
                 ring.step_env(auto_reset=False, skip_done=True, info=self._info)
-                go = (self._sac_moved.data_ptr(), int(lib.uavenv_tick(self.backend._h)))
+                go = (self._sac_moved.data_ptr(), int(lib.uavenv_tick(self.backend._h))) if gate_local else None
                 for L in Ls:
                     L.go = go
                 for j, per in enumerate(self._sac_per):      # ReplayTree.push(error 0) for the slot's rows of the frame just written
@@ -637,8 +655,13 @@ class PathPlan_City:
             v = ring.valid[fr].bool()
             inf = self._info[fr]
             stats = torch.stack([v.sum(1)] + [((inf == c) & v).sum(1) for c in range(3)], 1).cpu().numpy()   # one sync
+            moved = stats[:, 0]
+            if multi:               # a step counts while ANY rank still moves an agent: the ranks leave the episode together
+                every = [None] * torch.distributed.get_world_size()
+                torch.distributed.all_gather_object(every, [int(x) for x in moved])
+                moved = np.sum(np.asarray(every, dtype=np.int64), axis=0)
             for i in range(k):
-                if stats[i, 0] == 0:
+                if moved[i] == 0:
                     ended = True
                     break
                 n_steps += 1
@@ -649,13 +672,13 @@ class PathPlan_City:
             self._invalidate()
             if self.record_path:
                 self._record_paths(range(U))
-        if not use_c:
+        if gate_local:
             _lib.check(lib.uavenv_set_moved_word(self.backend._h, None), "uavenv_set_moved_word")
-            for L in Ls:
-                L.go = None
+        for L in Ls:
+            L.go = None
         surplus = passes - n_steps
         for j, L in enumerate(Ls):           # the counters follow the device: update() ran once per moving step
-            if surplus > 0:
+            if surplus > 0 and not multi:    # (several ranks: the surplus updates were applied, on every rank alike -- see above)
                 L.epoch -= min(surplus, L.epoch - count0[j][0])
                 L.adam_steps -= min(surplus, L.adam_steps - count0[j][1])
                 if self._sac_per[j] is not None:
@@ -663,7 +686,8 @@ class PathPlan_City:
                     p.beta = min(1.0, beta0[j] + (L.adam_steps - count0[j][1]) * p.beta_inc)
         self.surplus_passes_last_episode = surplus
         if surplus > 0:
-            self._sac_counter -= surplus
+            if not multi:
+                self._sac_counter -= surplus
             if getattr(self, "_sac_hot", None) is not None:
                 self._sac_hot.close()
                 self._sac_hot = None

@@ -206,8 +206,14 @@ class DevicePER:
 
     def update(self, slots: torch.Tensor, abs_errors: torch.Tensor):
         """ReplayTree.batch_update (:215-222)."""
-        slots = slots.to(self.device, torch.int64).contiguous()
+        slots = slots.to(self.device, torch.int64).reshape(-1).contiguous()
         e = abs_errors.detach().to(self.device, torch.float64).reshape(-1).contiguous()
+        # uavenv_per_set resolves a slot listed several times only when the equal entries are ADJACENT (include/uavenv.h); this
+        # entry point takes arbitrary lists, so order them first -- a stable sort keeps the batch order among equal slots, i.e.
+        # the LAST error of a slot still wins, as in the reference's sequential loop (ADVICE r4)
+        if slots.numel() > 1 and bool((slots[1:] < slots[:-1]).any()):
+            slots, order = torch.sort(slots, stable=True)
+            e = e[order].contiguous()
         rc = self.lib.uavenv_per_set(C.byref(self._c), slots.data_ptr(), e.data_ptr(), slots.numel(), self.epsilon,
                                      self.alpha, self.clip, self._stream())
         _lib.check(rc, "uavenv_per_set")

@@ -290,8 +290,10 @@ int uavenv_per_sample(const UavPer *per, int32_t batch, const double *draws_dev,
                       int64_t *out_slot_dev, double *out_prio_dev, void *stream);
 /* prio[slots[i]] = min(|abs_err[i]| + epsilon, clip) ** alpha   (batch_update :215-222; clip <= 0: no clip = push :143).
  * With clip > 0 a slot whose priority is 0 -- an empty leaf: a retired or never-valid ring row -- is left at 0.
- * A slot listed several times takes the LAST of its errors, as the reference's sequential loop does, provided the equal entries
- * are adjacent -- which they are in every list uavenv_per_sample returns (stratified draws come back in prefix order). */
+ * A slot listed several times takes the LAST of its errors, as the reference's sequential loop does.
+ * PRECONDITION: equal entries of slots_dev are ADJACENT -- true of every list uavenv_per_sample returns (stratified draws come
+ * back in prefix order).  Non-adjacent duplicates race (which error wins is undefined): a caller with an arbitrary list sorts it by
+ * slot first, stably (replay.DevicePER.update does). */
 int uavenv_per_set(const UavPer *per, const int64_t *slots_dev, const double *abs_err_dev, int32_t n, double epsilon,
                    double alpha, double clip, void *stream);
 /* prio[first .. first+count) = priority where valid_dev[i] != 0 (or everywhere if NULL), 0 elsewhere: the slots of a

@@ -118,16 +118,21 @@ def test_is_fl_in_a_real_episode_and_off_by_default(tmp_path, monkeypatch):
     assert sim0.env.fl_merges == 0
 
 
-def test_dqn_family_merges_q_local(tmp_path, monkeypatch):
-    """Is_AC = 0: the reference's Federated_Learning cannot run (no trainer has get_policy_DFRL); the same merge on q_local."""
+@pytest.mark.parametrize("tag", ["mean", None])
+def test_dqn_family_merges_q_local(tmp_path, monkeypatch, tag):
+    """Is_AC = 0: the reference's Federated_Learning cannot run (no trainer has get_policy_DFRL); the same merge on q_local.
+    tag None: <FL_Aggregate> absent -- there is no executed behaviour to reproduce here, so the default is the MEAN (a sum of
+    U Q-networks would scale every Q-value by ~U), unlike the actor-critic merge, whose default is the executed reference's sum."""
     import _backend
     monkeypatch.setattr(_backend, "make_backend", lambda n, b, **kw: fake_backend.OracleVecEnv(n, b, **kw))
     monkeypatch.chdir(tmp_path)
     xml = driver.make_config_dir(str(tmp_path), "DuelingDQN", num_envs=2, num_uav=3)
     s = open(xml).read().replace("<Is_FL>0</Is_FL>", "<Is_FL>1</Is_FL>").replace("<FL_Loop>3</FL_Loop>", "<FL_Loop>1</FL_Loop>")
-    s = s.replace("<num_UAV>", "<FL_Aggregate>mean</FL_Aggregate>\n        <num_UAV>", 1)
+    if tag is not None:
+        s = s.replace("<num_UAV>", f"<FL_Aggregate>{tag}</FL_Aggregate>\n        <num_UAV>", 1)
     open(xml, "w").write(s)
     env = driver.simulator(xml).env
+    assert env.FL_Aggregate == ("mean" if tag else "reference") and env._fl_aggregate_given == (tag is not None)
     trs = [u.Trainer for u in env.Agents]
     torch.manual_seed(0)
     with torch.no_grad():
