@@ -171,16 +171,16 @@ def _bench(*extra, timeout=900):
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
            "--no-other-configs", "--envs", "2048", "--batch", "2048", "--replay", "16384", "--env-only-iters", "5", *extra]
+    # NO retry here (round 5): a multi-process leg that fails once in N runs is a defect of the exchange until proven otherwise -- a
+    # silent second attempt is how round 3's same-device deadlock survived.  The one start-up failure that is not this code's (the
+    # rendezvous port taken between the probe and the bind) is handled -- and counted -- by bench.py: spawn_ranks itself.
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    if res.returncode != 0 and "--gpus" in extra:
-        # one retry for the multi-process legs: a rank start-up can fail for reasons outside this code (the rendezvous port
-        # picked by spawn_ranks taken in between; seen once in seven full-suite runs); a defect fails twice
-        print("bench.py failed once, retrying:\n" + res.stderr[-1500:], file=sys.stderr)
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    assert d.get("rendezvous_retries", 0) == 0, d.get("rendezvous_retries")
+    return d
 
 
 def test_bench_starts_its_own_ranks_and_checks_them():
