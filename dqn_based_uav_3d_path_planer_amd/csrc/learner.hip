@@ -54,8 +54,11 @@ struct GradArgs {
 
 #ifdef UAVENV_PHASE_PROFILE
 #define L_STAMP(slot) do { if (g.dbg && threadIdx.x == 0) g.dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// a second bank of eight stamps per workgroup, behind the first (scripts/phase_profile_loop.py allocates both)
+#define L_STAMP2(slot) do { if (g.dbg && threadIdx.x == 0) g.dbg[((size_t)gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define L_STAMP(slot) do { } while (0)
+#define L_STAMP2(slot) do { } while (0)
 #endif
 
 
@@ -169,6 +172,24 @@ __device__ __forceinline__ float row_sum16(float v)
     return v;
 }
 
+// max over the 64 lanes of a wavefront, result in every lane: DPP row rotations inside the 16-lane rows, then the two permlane
+// swaps of group_sum4 (qnet_device.hpp) across the four rows -- no LDS round trip
+__device__ __forceinline__ float wave_max64(float v)
+{
+#define UAV_ROW_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xf, 0xf, false))
+    v = fmaxf(v, UAV_ROW_ROR(v, 8));
+    v = fmaxf(v, UAV_ROW_ROR(v, 4));
+    v = fmaxf(v, UAV_ROW_ROR(v, 2));
+    v = fmaxf(v, UAV_ROW_ROR(v, 1));
+#undef UAV_ROW_ROR
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b);
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
 struct Grad2Args {
     GradArgs g;
     int n_tiles, stride;             // tiles of 64 samples in the batch; floats per partial row (multiple of 4)
@@ -206,9 +227,10 @@ template <int NMAX, bool HALF_T = false>
 __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l, const floatx4 (&hl)[4], const W2Frag<NMAX> &Fl,
                                             const float (&ql)[NMAX], float qn, int p_act, float p_rew,
                                             float p_done, float p_valid, float p_w, int smp, GradAcc<NMAX> &A, float *hrow,
-                                            float *drow, float *dout_row)
+                                            float *drow, float *dout_row, float *lane_amax = nullptr)
 {
     constexpr bool kKeepW2 = NMAX <= 4;
+    float amax = 0.0f;                                // max |dL/dH| of this lane's 16 hidden units (lane_amax != nullptr only)
     const int gq = ((int)threadIdx.x & 63) >> 4;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     // ---- TD target, loss, dL/dout of this lane's sample (Trainer/DQN_Trainer.py:107-119)
@@ -272,6 +294,7 @@ __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l,
         for (int rr = 0; rr < 4; ++rr) {
             hh[rr] = hl[t][rr] > 0.0f ? hl[t][rr] : 0.0f;
             dh[rr] = hl[t][rr] > 0.0f ? dh[rr] : 0.0f;
+            if (lane_amax) amax = fmaxf(amax, fabsf(dh[rr]));
         }
         if (HALF_T) {
             _Float16 *hT = reinterpret_cast<_Float16 *>(hrow), *dT = reinterpret_cast<_Float16 *>(drow);
@@ -297,6 +320,7 @@ __device__ __forceinline__ void td_backward(const GradArgs &g, const float *W2l,
             if ((a >> 2) == gq) d4[a & 3] = dv[a];
         *reinterpret_cast<floatx4 *>(dout_row + 4 * gq) = d4;
     }
+    if (lane_amax) *lane_amax = amax;
 }
 
 // One tile of 64 transitions.  FIRST: also stages the weights (their loads fly together with the observation rows).
@@ -707,7 +731,112 @@ struct GradAcc8 {
     float csum[6];                   // group 0: column sums of dout (NMAX = 4), loss sum, valid count of its strips
 };
 
-template <bool FIRST>
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the weight-gradient products of k_dqn_grad_packed8 in the SPLIT form.
+//   dW1^T[c][j] = sum_s X[s][c] dH[s][j] over the tile's 64 samples.  80 of the 100 columns of X are 0 / 1 flags -- exact in f16 --
+//   so for them the product runs on v_mfma_f32_16x16x32_f16 with dH as TWO f16 terms, hi = f16(dH 2^S) and mid = f16((dH 2^S - hi)
+//   2^11) (22-23 significant bits relative to the tile's largest |dH|; 2^S, a power of two taken from that maximum, puts it at
+//   2^13..2^14: no overflow whatever the loss does, and the scaling is exact): every product is exact, the sums are f32.  The 15
+//   scalar columns (0..10, 86..89) and the ones column (-> db1) form ONE gathered 16-column tile on v_mfma_f32_16x16x4_f32 with the
+//   unscaled f32 dH, as before; the scalar columns' bits are 0 in the packed words, so the f16 products leave exact zeros there.
+//   Per wavefront: 12 f16 MFMAs (16 cycles) + 16 f32 MFMAs (32 cycles) instead of 64 f32 MFMAs -- 1.4 k matrix cycles per SIMD
+//   and tile instead of 4.1 k.
+// K (= sample) index of a lane group: sample(q, g, i) = 32 q + 16 (i >> 2) + 4 g + (i & 3) for f16 step q, K element i of lane
+// group g -- lane groups 4 samples apart are 16 LDS banks apart in the hidden tiles (kLh = 68) and in the packed rows (20 dwords);
+// f32 step kk = 8 q + i takes the same sample, so the lane's sixteen dH values serve both products.
+// Register layout out (the partial-row writer of the split kernel knows it): group 0: acc[0..2] = column tiles 0, 2, 4 (rows
+// 16 u + 4 g + e), acc[3] = the gathered tile (entry 4 g + e: columns 0..10 | 86..89 | ones); group 1: acc[0..2] = tiles 1, 3, 5,
+// acc[3] = dW2^T as before.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ half8 flags_to_half8(const uintx4 (&mk)[8], int w, uint32_t sh)
+{
+    uintx4 d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b0 = (mk[2 * k][w] >> sh) & 1u, b1 = (mk[2 * k + 1][w] >> sh) & 1u;
+        d[k] = (b0 | (b1 << 16)) * 0x3c00u;                  // two halves: 1.0 where the flag is set
+    }
+    return *reinterpret_cast<const half8 *>(&d);
+}
+
+__device__ __forceinline__ void grad_products_split8(const GradLdsP &L, const float *amax4, int grp, int strip, int r, int gq,
+                                                     GradAcc8 &A)
+{
+    // ---- the tile's scale: 2^(13 - e) with e = exponent of max |dH| (clamped: an all-zero or denormal tile scales by 2^113)
+    const float m = fmaxf(fmaxf(amax4[0], amax4[1]), fmaxf(amax4[2], amax4[3]));
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+    e = e < -100 ? -100 : e;
+    const float up = __uint_as_float((uint32_t)(127 + 13 - e) << 23), down = __uint_as_float((uint32_t)(127 - 13 + e) << 23);
+    // ---- every operand of the phase is requested first (one wavefront's dependent LDS round trips are not hidden by anything)
+    const uint32_t *pr = L.Ps + 4 * gq * kPackedDwords;
+    const float *db = L.dHs + 4 * gq * kLh + 16 * strip + r;
+    uintx4 mk[2][8];
+    float dh[2][8], a32[2][8], b32[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+    // group 0: A of the f32 product = entry r of the gathered tile: packed dword 4 + r (columns 0..10), 15 + (r - 11) (86..89); entry
+    // 15 is the ones column (dword 19 is a zero pad: replaced below).  group 1: A = H[s][16 strip + r], B = dout[s][r]
+    const int dsc = r < 15 ? 4 + r : 19;
+    const float *ha = L.Hs + 4 * gq * kLh + 16 * strip + r;
+    const float *ob = L.douts + 4 * gq * kMaxOut + r;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s1 = 32 * q + 16 * (i >> 2) + (i & 3);           // + 4 gq through the base pointers
+            mk[q][i] = *reinterpret_cast<const uintx4 *>(pr + s1 * kPackedDwords);
+            dh[q][i] = db[s1 * kLh];
+            if (grp == 0) {
+                a32[q][i] = __uint_as_float(pr[s1 * kPackedDwords + dsc]);
+            } else {
+                a32[q][i] = ha[s1 * kLh];
+                b32[q][i] = ob[s1 * kMaxOut];
+            }
+        }
+    // ---- B of the f16 products: the lane's sixteen dH values, scaled and split
+    half8 bh[2], bm[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        _Float16 h[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float w = dh[q][i] * up;
+            h[i] = (_Float16)w;
+            l[i] = (_Float16)((w - (float)h[i]) * 2048.0f);
+        }
+        bh[q] = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+        bm[q] = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+    }
+    // ---- the flag columns: tiles u = 2 v + grp, v = 0..2 (columns 16 u + r: word u >> 1, bit 16 (u & 1) + r of the row's flag words)
+    floatx4 ch[3], cm[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) { ch[v] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; cm[v] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const uint32_t sh = (uint32_t)(grp == 0 ? r : 16 + r);            // u & 1 == grp
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const half8 a = flags_to_half8(mk[q], v, sh);             // u >> 1 == v
+            ch[v] = mfma16h(a, bh[q], ch[v]);
+            cm[v] = mfma16h(a, bm[q], cm[v]);
+        }
+    // ---- the f32 product: group 0 the gathered scalar tile x dH, group 1 H x dout (dW2^T)
+    floatx4 c32 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    const bool ones = grp == 0 && r == 15;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            c32 = mfma16(ones ? 1.0f : a32[q][i], grp == 0 ? dh[q][i] : b32[q][i], c32);
+    // ---- into the persistent accumulators: (hi + mid 2^-11) 2^-S, exact scalings
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A.acc[v][k] += fmaf(cm[v][k], 1.0f / 2048.0f, ch[v][k]) * down;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.acc[3][k] += c32[k];
+}
+
+// SPLIT (round 5): the weight-gradient products in the split form -- see grad_products_split8 below.
+template <bool FIRST, bool SPLIT>
 __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradLdsP &L, float *qn_lds, int tile, bool more,
                                                   GradAcc8 &A)
 {
@@ -728,6 +857,10 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
         for (int k = 0; k < 4; ++k) pw[k] = nv.W2[t256 + 256 * k < n2 * kHid ? t256 + 256 * k : 0];
         pb2 = nv.b2[t256 < n2 ? t256 : 0];
     }
+    // (round 5, measured: the weights FIRST -- issuing the row loads ahead of them, so that the rows' HBM round trip runs under the
+    // image's, cost 0.35 us per launch: the CU's vector-memory path is the limit while ~100 KB per workgroup are requested, and the
+    // draw's serial chain hides under the weights' round trip only in this order)
+    L_STAMP2(0);                              // (diagnostics: weight loads issued)
     // ---- this lane's transition: group 0 needs the s row and the transition scalars, group 1 the s' row
     const int smp = tile * kTile + strip * 16 + r;
     int f, agent;
@@ -741,19 +874,23 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     if (fn >= g.ring.frames) fn = 0;
     const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
     const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
+    L_STAMP2(1);                              // (diagnostics: the draw done)
     PRow R;
     prow_load(R, obs + (size_t)(grp == 0 ? row_s : row_n) * kPackedDwords);
     int p_act = 0;
-    float p_rew = 0.0f, p_done = 0.0f, p_valid = 1.0f, p_w = 1.0f;
+    float p_rew = 0.0f, p_w = 1.0f;
+    uint32_t raw_done = 0u, raw_valid = 1u;   // (converted where they are used: a conversion here would wait for every load above)
     if (grp == 0) {
         p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
         p_rew = g.ring.reward[row_s];
-        p_done = (float)g.ring.done[row_s];
-        p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+        raw_done = g.ring.done[row_s];
+        raw_valid = g.ring.valid ? (uint32_t)g.ring.valid[row_s] : 1u;
         p_w = g.is_w ? g.is_w[smp] : 1.0f;
     }
+    L_STAMP(6);                               // (diagnostics: every load of the tile issued)
     if (FIRST) {
         if (g.img) img_commit(grp == 0 ? L.W1l : L.W1t, vW); else w_commit_split(w1split_at(grp == 0 ? L.W1l : L.W1t), vW, vS);
+        L_STAMP(7);                           // (diagnostics: layer 1 committed -- its loads have arrived)
         float *W2 = grp == 0 ? L.W2l : L.W2t, *b2 = grp == 0 ? L.b2l : L.b2t;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -800,13 +937,25 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
         GradAcc<NMAX> T;                              // td_backward's accumulator interface: only csum is used here
 #pragma unroll
         for (int a = 0; a < NMAX + 2; ++a) T.csum[a] = A.csum[a];
+        float amax = 0.0f;
+        const float p_done = (float)raw_done, p_valid = (float)raw_valid;
         td_backward<NMAX>(g, L.W2l, hl, Fl, ql, qn_lds[strip * 16 + r], p_act, p_rew, p_done, p_valid, p_w, smp, T,
-                          L.Hs + (strip * 16 + r) * kLh, L.dHs + (strip * 16 + r) * kLh, L.douts + (strip * 16 + r) * kMaxOut);
+                          L.Hs + (strip * 16 + r) * kLh, L.dHs + (strip * 16 + r) * kLh, L.douts + (strip * 16 + r) * kMaxOut,
+                          SPLIT ? &amax : nullptr);
 #pragma unroll
         for (int a = 0; a < NMAX + 2; ++a) A.csum[a] = T.csum[a];
+        if (SPLIT) {                                  // max |dL/dH| of this strip: the tile's f16 scale is derived from the four
+            amax = wave_max64(amax);
+            if (lane == 0) qn_lds[kTile + strip] = amax;
+        }
     }
     __syncthreads();                                  // H, dH, dout and the packed s rows of all 64 samples visible
     L_STAMP(4);
+    if (SPLIT) {
+        grad_products_split8(L, qn_lds + kTile, grp, strip, r, gq, A);
+        if (more) __syncthreads();
+        return;
+    }
     // ---- weight gradients over the 64 samples (MFMA step kk, lane group gq: sample (kk & 3) + 16 (kk >> 2) + 4 gq);
     // hidden units 16 strip + r; group 0: X columns 16 u + r for u = 0, 2, 4, 6; group 1: u = 1, 3, 5, and dW2^T
     {
@@ -857,6 +1006,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     if (more) __syncthreads();                        // the next tile overwrites Ps / Hs / dHs / douts / qn
 }
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
 {
     constexpr int NMAX = 4;
@@ -886,15 +1036,42 @@ __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
     L_STAMP(0);
     const int step = (int)gridDim.x;
     int tile = (int)blockIdx.x;
-    grad_tile_packed8<true>(g, L, qn_lds, tile, tile + step < ga.n_tiles, A);
+    grad_tile_packed8<true, SPLIT>(g, L, qn_lds, tile, tile + step < ga.n_tiles, A);
     for (tile += step; tile < ga.n_tiles; tile += step)
-        grad_tile_packed8<false>(g, L, qn_lds, tile, tile + step < ga.n_tiles, A);
+        grad_tile_packed8<false, SPLIT>(g, L, qn_lds, tile, tile + step < ga.n_tiles, A);
     L_STAMP(5);
     // ---- the partial-gradient row of this workgroup: dW1 | db1 | dW2 | db2 | loss sum | valid count
     float *out = g.partials + (size_t)blockIdx.x * ga.stride;
     const int oW2 = kHid * kW + kHid, ob2 = oW2 + n2 * kHid;
     const int j = 16 * strip + r;
-    if (grp == 0) {
+    // (round 5, measured: non-temporal stores of the row lengthen this kernel by 0.8 us and shorten the next by as much -- the 6.8 MB
+    // of partial rows cross the memory system once either way)
+#define UAV_ROW_ST4(ptr, val) (*reinterpret_cast<floatx4 *>(ptr) = (val))
+    if (SPLIT) {
+        // (grad_products_split8's register layout) group 0: tiles 0, 2, 4 + the gathered tile, whose entries 0..10 are columns
+        // 0..10 of tile 0 -- held by the same lanes, and exact zeros in the f16 result --, 11..14 columns 86..89 and 15 db1;
+        // group 1: tiles 1, 3, 5 without columns 86..89, and dW2^T.  Columns 96..99 are constant zero in every row.
+        if (grp == 0) {
+            floatx4 t0 = A.acc[0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t0[k] += (4 * gq + k <= 10) ? A.acc[3][k] : 0.0f;
+            UAV_ROW_ST4(out + j * kW + 4 * gq, t0);
+            UAV_ROW_ST4(out + j * kW + 32 + 4 * gq, A.acc[1]);
+            UAV_ROW_ST4(out + j * kW + 64 + 4 * gq, A.acc[2]);
+            if (gq == 2) out[j * kW + 86] = A.acc[3][3];
+            if (gq == 3) { out[j * kW + 87] = A.acc[3][0]; out[j * kW + 88] = A.acc[3][1]; out[j * kW + 89] = A.acc[3][2];
+                           out[kHid * kW + j] = A.acc[3][3]; }
+            if (gq == 0) *reinterpret_cast<floatx4 *>(out + j * kW + 96) = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        } else {
+            UAV_ROW_ST4(out + j * kW + 16 + 4 * gq, A.acc[0]);
+            UAV_ROW_ST4(out + j * kW + 48 + 4 * gq, A.acc[1]);
+            float *t5 = out + j * kW + 80 + 4 * gq;                      // tile 5 = columns 80..95; 86..89 belong to group 0
+            if (gq == 0 || gq == 3) *reinterpret_cast<floatx4 *>(t5) = A.acc[2];
+            else if (gq == 1) { t5[0] = A.acc[2][0]; t5[1] = A.acc[2][1]; }
+            else { t5[2] = A.acc[2][2]; t5[3] = A.acc[2][3]; }
+            if (r < n2) *reinterpret_cast<floatx4 *>(out + oW2 + r * kHid + 16 * strip + 4 * gq) = A.acc[3];      // dW2^T
+        }
+    } else if (grp == 0) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) *reinterpret_cast<floatx4 *>(out + j * kW + 32 * u + 4 * gq) = A.acc[u];     // tiles 0, 2, 4
         if (gq == 0) *reinterpret_cast<floatx4 *>(out + j * kW + 96) = A.acc[3];                                // tile 6: columns 96..99
@@ -918,7 +1095,7 @@ __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
 }
 
 constexpr size_t kGradP8Lds = (size_t)(2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut +
-                                       4 * (kMaxOut + 2) + kTile * kPackedDwords + 4 + kTile) * 4;
+                                       4 * (kMaxOut + 2) + kTile * kPackedDwords + 4 + kTile + 4) * 4;      // (+ 4: the strips' max |dH|)
 
 constexpr size_t kGradPLds = (size_t)(2 * kTileF + 2 * kTile * kLh + kTile * kMaxOut + 2 * kMaxOut * kHid + 2 * kMaxOut +
                                       4 * (kMaxOut + 2) + kTile * kPackedDwords + 4) * 4;
@@ -2101,14 +2278,19 @@ int uavenv_dqn_grad_img(const UavReplayRing *ring, int32_t head, int32_t filled,
     else if (ring->obs_dtype == UAVENV_OBS_PACKED) {
         static const bool four_waves = getenv("UAVENV_GRAD_4WAVES") != nullptr;      // A/B knob
         if (small && !four_waves) {
+            // UAVENV_DW1_F32=1: the round-4 form of the weight-gradient products (all on the f32 matrix pipe) -- A/B knob
+            static const bool dw1_f32 = getenv("UAVENV_DW1_F32") != nullptr;
             static bool attr8 = false;
             if (!attr8) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8),
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradP8Lds) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradP8Lds) != hipSuccess)
                     return UAVENV_EHIP;
                 attr8 = true;
             }
-            hipLaunchKernelGGL(k_dqn_grad_packed8, dim3(grid), dim3(512), kGradP8Lds, s, ga);
+            if (dw1_f32) hipLaunchKernelGGL(k_dqn_grad_packed8<false>, dim3(grid), dim3(512), kGradP8Lds, s, ga);
+            else hipLaunchKernelGGL(k_dqn_grad_packed8<true>, dim3(grid), dim3(512), kGradP8Lds, s, ga);
             rc = UAVENV_OK;
         } else {
             rc = small ? launch_grad_packed<4>(ga, grid, s) : launch_grad_packed<kMaxOut - 2>(ga, grid, s);

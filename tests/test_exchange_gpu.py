@@ -45,7 +45,8 @@ def _worker(rank, world, port, out_dir, scenario):
     ring.reset(seed=4 + rank)
     torch.manual_seed(0)
     L = FusedDQNLearner(dict(PARAM, output="9") if nine else PARAM, "dqn", device="cuda:0")
-    assert L.enable_p2p(check_every=1, spin_limit=1 << 18), "peer-to-peer exchange could not be set up"
+    # (bounded wait: short where the test WANTS a timeout, ~1 s where `world` processes time-slice one GPU and must not see one)
+    assert L.enable_p2p(check_every=1, spin_limit=1 << (18 if scenario == "timeout" else 22)), "peer-to-peer exchange could not be set up"
     hot = HotLoop(ring, L, 256, seed=3 + rank, eps=0.3)
     res = {}
     hot.run(6)
@@ -77,7 +78,7 @@ def _worker(rank, world, port, out_dir, scenario):
     elif scenario == "timeout":
         # rank 1 stops taking part: rank 0's next pull must give up after the spin limit, freeze, and report a timeout
         dist.barrier()
-        if rank == 0:
+        if rank != 1:
             w = L.flat[0].clone()
             raised = False
             try:
@@ -99,26 +100,32 @@ def _worker(rank, world, port, out_dir, scenario):
     env.close()
 
 
-@pytest.mark.parametrize("scenario", ["diverge", "timeout", "healthy9"])
-def test_peer_exchange_raises_a_sticky_error_and_freezes(scenario, tmp_path):
+@pytest.mark.parametrize("scenario,world", [("diverge", 2), ("timeout", 2), ("healthy9", 2),
+                                            ("healthy", 4), ("diverge", 4), ("timeout", 4), ("healthy", 8)])
+def test_peer_exchange_raises_a_sticky_error_and_freezes(scenario, world, tmp_path):
+    """world 4 / 8 (round 5): csrc/p2p.hip's slots, flags, rank-order sums and checksum fan-in with more than two ranks -- all on the
+    one GPU this box has (functional, not a measurement): every rank ends bit-identical; a nudged weight of rank 1 raises
+    DIVERGED on EVERY rank; with rank 1 silent every other rank times out and freezes."""
     import torch.multiprocessing as mp
     from dqn_based_uav_3d_path_planer_amd import _lib
-    mp.spawn(_worker, args=(2, _port(), str(tmp_path), scenario), nprocs=2, join=True)
-    r0 = torch.load(os.path.join(tmp_path, f"{scenario}_r0.pt"))
-    r1 = torch.load(os.path.join(tmp_path, f"{scenario}_r1.pt"))
-    for r in (r0, r1):                      # six healthy updates, a checksum compared at every one from the second on
+    mp.spawn(_worker, args=(world, _port(), str(tmp_path), scenario), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"{scenario}_r{r}.pt")) for r in range(world)]
+    for r in rs:                            # six healthy updates, a checksum compared at every one from the second on
         assert r["healthy"]["code"] == 0 and r["healthy"]["timeouts"] == 0 and r["healthy"]["mismatches"] == 0
         assert r["healthy"]["checks"] >= 5
-    assert r0["sum_healthy"] == r1["sum_healthy"]            # lock-step, bit for bit
-    if scenario == "healthy9":
+    assert len({r["sum_healthy"] for r in rs}) == 1           # lock-step, bit for bit
+    if scenario.startswith("healthy"):
         return
     if scenario == "diverge":
-        for r in (r0, r1):
+        for r in rs:
             assert r["raised"] and r["after"]["code"] == _lib.P2P_ERR_DIVERGED and r["after"]["mismatches"] >= 1
             assert r["rc_after"] == _lib.EP2P and r["frozen"]
     else:
-        assert r0["raised"] and r0["after"]["code"] == _lib.P2P_ERR_TIMEOUT and r0["after"]["timeouts"] >= 1
-        assert r0["frozen"]
+        for k, r in enumerate(rs):
+            if k == 1:
+                continue                    # (the silent rank)
+            assert r["raised"] and r["after"]["code"] == _lib.P2P_ERR_TIMEOUT and r["after"]["timeouts"] >= 1
+            assert r["frozen"]
 
 
 def test_rccl_from_c_world_size_one():
@@ -193,6 +200,37 @@ def test_bench_starts_its_own_ranks_and_checks_them():
     assert d["p2p_checksums_compared"] >= 10
     assert d["ms_per_pass_no_exchange"] > 0 and "peer-to-peer" in d["config"]["parallelism"]
     assert d["config"]["host_loop"].startswith("csrc/loop.hip")
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_dqn_exchange_at_world_4_and_8_on_one_device(world):
+    """`bench.py --gpus 4 | 8 --same-device --envs 512 --batch 512`: the DQN loop's on-stream peer exchange with 4 / 8 ranks (all on
+    this one GPU: functional evidence for kMaxWorld > 2, not a measurement) -- bit-identical ranks, no timeout, no mismatch."""
+    d = _bench("--gpus", str(world), "--same-device", "--dist-backend", "gloo", "--envs", "512", "--batch", "512",
+               "--replay", "8192", "--p2p-check-every", "8", "--no-exchange-leg")
+    assert d["n_gpus"] == world and d["exchange"] == "p2p" and d["ranks_bit_identical"] is True
+    assert d["p2p_timeouts"] == 0 and d["p2p_checksum_mismatches"] == 0 and d["p2p_error_code_max"] == 0
+    assert d["p2p_checksums_compared"] >= 4 and d["links_crossed"] is False and len(d["rank_devices"]) == world
+    assert d["exchange_fallbacks"] == [] and d["rendezvous_retries"] == 0
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_sac_exchange_at_world_4_and_8_on_one_device(world):
+    """`bench.py --config 4 --gpus 4 | 8 --same-device`: uavenv_sac_loop_run's two exchange points per update (all four slots' rows
+    side by side) and its block checksums with 4 / 8 ranks on this one GPU."""
+    d = _bench("--config", "4", "--gpus", str(world), "--same-device", "--dist-backend", "gloo", "--envs", "256", "--batch", "256",
+               "--replay", "8192")
+    assert d["n_gpus"] == world and d["exchange"] == "p2p" and d["ranks_bit_identical"] is True
+    assert d["config"]["slot0_after_run"]["finite"] and d["config"]["slot0_after_run"]["updates"] > 10
+
+
+def test_bench_recovers_at_world_4_when_one_rank_fails():
+    """The fault drill with four ranks: rank 2's exchange raises its sticky error; all four drop to the collective, take rank
+    0's weights and finish bit-identical."""
+    d = _bench("--gpus", "4", "--same-device", "--dist-backend", "gloo", "--envs", "512", "--batch", "512", "--replay", "8192",
+               "--inject-p2p-fault", "2", "--no-exchange-leg")
+    assert d["n_gpus"] == 4 and d["exchange"] == "rccl" and d["ranks_bit_identical"] is True
+    assert any("sticky" in f for f in d["exchange_fallbacks"]) and d["bad_after_recovery"] is False
 
 
 def test_same_device_runs_are_labelled_as_such():

@@ -1,5 +1,6 @@
-"""N > 1 path on CPU: two gloo ranks, each with half of a batch, must apply exactly the update one process applies
-on the concatenated batch (learner._allreduce_grads: flat-bucket all-reduce of the gradients before Adam.step)."""
+"""N > 1 path on CPU: gloo ranks (world sizes 2 and 4), each with its share of a batch, must apply exactly the update one process
+applies on the concatenated batch (learner._allreduce_grads: flat-bucket all-reduce of the gradients before Adam.step)."""
+import pytest
 import os
 import socket
 
@@ -58,19 +59,20 @@ def _single(kind, net):
     return L.q_local.state_dict()
 
 
-def _run(kind, net, tmp_path):
+def _run(kind, net, tmp_path, world=2):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, kind, net, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
-    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    mp.spawn(_worker, args=(world, port, kind, net, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
     ref = _single(kind, net)
     for k in ref:
-        assert torch.equal(r0[k], r1[k]), k                       # ranks stay in lock-step
-        assert (r0[k] - ref[k]).abs().max().item() <= 2e-6, k     # == single process on the concatenated batch
+        for r in rs[1:]:
+            assert torch.equal(rs[0][k], r[k]), k                    # ranks stay in lock-step
+        assert (rs[0][k] - ref[k]).abs().max().item() <= 2e-6, k     # == single process on the concatenated batch
 
 
-def test_two_ranks_equal_one_process_dqn(tmp_path):
-    _run("dqn", "Qnet2", tmp_path)
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_equal_one_process_dqn(tmp_path, world):
+    _run("dqn", "Qnet2", tmp_path, world)
 
 
 def test_two_ranks_equal_one_process_dueling(tmp_path):
@@ -102,25 +104,28 @@ def _fed_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_federated_averaging_every_fl_loop_updates(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_federated_averaging_every_fl_loop_updates(tmp_path, world):
     """sync="fedavg": ranks train alone (different shards -> different weights after update 1) and hold the same,
     averaged weights after every FL_Loop-th update; the average is the mean of what each rank would have had."""
     from dqn_based_uav_3d_path_planer_amd.learner import DQNLearner
     port = _free_port()
-    mp.spawn(_fed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a, b = torch.load(tmp_path / "fed0.pt"), torch.load(tmp_path / "fed1.pt")
+    mp.spawn(_fed_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    snaps = [torch.load(tmp_path / f"fed{r}.pt") for r in range(world)]
+    a = snaps[0]
     k = "fc1.weight"
-    assert not torch.equal(a[0][k], b[0][k])                       # update 1: no exchange
-    assert all(torch.equal(a[1][q], b[1][q]) for q in a[1])        # update 2: averaged
-    assert not torch.equal(a[2][k], b[2][k]) and all(torch.equal(a[3][q], b[3][q]) for q in a[3])
-    # the averaged weights equal the mean of two single-process learners run on the two shards for two updates
+    for b in snaps[1:]:
+        assert not torch.equal(a[0][k], b[0][k])                       # update 1: no exchange
+        assert all(torch.equal(a[1][q], b[1][q]) for q in a[1])        # update 2: averaged
+        assert not torch.equal(a[2][k], b[2][k]) and all(torch.equal(a[3][q], b[3][q]) for q in a[3])
+    # the averaged weights equal the mean of `world` single-process learners run on the shards for two updates
     g = load_golden("learner_DQN_Trainer.npz")
     outs = []
-    for rank in range(2):
+    for rank in range(world):
         L = DQNLearner(dict(PARAM), "dqn", device="cpu")
         L.q_local.load_state_dict({q[3:]: torch.tensor(v) for q, v in g.items() if q.startswith("l0_")})
         L.q_target.load_state_dict({q[3:]: torch.tensor(v) for q, v in g.items() if q.startswith("t0_")})
-        n = len(g["actions"]) // 2
+        n = len(g["actions"]) // world
         sl = slice(rank * n, (rank + 1) * n)
         batch = dict(states=torch.tensor(g["states"][sl]), next_states=torch.tensor(g["next_states"][sl]),
                      actions=torch.tensor(g["actions"][sl].astype(np.int32)), rewards=torch.tensor(g["rewards"][sl]),
@@ -129,7 +134,7 @@ def test_federated_averaging_every_fl_loop_updates(tmp_path):
         L.learn(batch)
         outs.append(L.q_local.state_dict())
     for q in a[1]:
-        assert torch.allclose(a[1][q], (outs[0][q] + outs[1][q]) / 2, rtol=0, atol=1e-7)
+        assert torch.allclose(a[1][q], sum(o[q] for o in outs) / world, rtol=0, atol=2e-7)
 
 
 def _exchange_worker(rank, world, port, out_dir):
