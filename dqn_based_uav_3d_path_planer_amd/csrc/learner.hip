@@ -172,24 +172,6 @@ __device__ __forceinline__ float row_sum16(float v)
     return v;
 }
 
-// max over the 64 lanes of a wavefront, result in every lane: DPP row rotations inside the 16-lane rows, then the two permlane
-// swaps of group_sum4 (qnet_device.hpp) across the four rows -- no LDS round trip
-__device__ __forceinline__ float wave_max64(float v)
-{
-#define UAV_ROW_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xf, 0xf, false))
-    v = fmaxf(v, UAV_ROW_ROR(v, 8));
-    v = fmaxf(v, UAV_ROW_ROR(v, 4));
-    v = fmaxf(v, UAV_ROW_ROR(v, 2));
-    v = fmaxf(v, UAV_ROW_ROR(v, 1));
-#undef UAV_ROW_ROR
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    a = fmaxf(a, b);
-    b = a;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
-}
-
 struct Grad2Args {
     GradArgs g;
     int n_tiles, stride;             // tiles of 64 samples in the batch; floats per partial row (multiple of 4)
@@ -735,7 +717,7 @@ struct GradAcc8 {
 // Round 5: the weight-gradient products of k_dqn_grad_packed8 in the SPLIT form.
 //   dW1^T[c][j] = sum_s X[s][c] dH[s][j] over the tile's 64 samples.  80 of the 100 columns of X are 0 / 1 flags -- exact in f16 --
 //   so for them the product runs on v_mfma_f32_16x16x32_f16 with dH as TWO f16 terms, hi = f16(dH 2^S) and mid = f16((dH 2^S - hi)
-//   2^11) (22-23 significant bits relative to the tile's largest |dH|; 2^S, a power of two taken from that maximum, puts it at
+//   2^11, met by flags worth 2^-11 so that both terms share one accumulator) (22-23 significant bits relative to the tile's largest |dH|; 2^S, a power of two taken from that maximum, puts it at
 //   2^13..2^14: no overflow whatever the loss does, and the scaling is exact): every product is exact, the sums are f32.  The 15
 //   scalar columns (0..10, 86..89) and the ones column (-> db1) form ONE gathered 16-column tile on v_mfma_f32_16x16x4_f32 with the
 //   unscaled f32 dH, as before; the scalar columns' bits are 0 in the packed words, so the f16 products leave exact zeros there.
@@ -748,25 +730,12 @@ struct GradAcc8 {
 // 16 u + 4 g + e), acc[3] = the gathered tile (entry 4 g + e: columns 0..10 | 86..89 | ones); group 1: acc[0..2] = tiles 1, 3, 5,
 // acc[3] = dW2^T as before.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ half8 flags_to_half8(const uintx4 (&mk)[8], int w, uint32_t sh)
-{
-    uintx4 d;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t b0 = (mk[2 * k][w] >> sh) & 1u, b1 = (mk[2 * k + 1][w] >> sh) & 1u;
-        d[k] = (b0 | (b1 << 16)) * 0x3c00u;                  // two halves: 1.0 where the flag is set
-    }
-    return *reinterpret_cast<const half8 *>(&d);
-}
-
 __device__ __forceinline__ void grad_products_split8(const GradLdsP &L, const float *amax4, int grp, int strip, int r, int gq,
                                                      GradAcc8 &A)
 {
-    // ---- the tile's scale: 2^(13 - e) with e = exponent of max |dH| (clamped: an all-zero or denormal tile scales by 2^113)
-    const float m = fmaxf(fmaxf(amax4[0], amax4[1]), fmaxf(amax4[2], amax4[3]));
-    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
-    e = e < -100 ? -100 : e;
-    const float up = __uint_as_float((uint32_t)(127 + 13 - e) << 23), down = __uint_as_float((uint32_t)(127 - 13 + e) << 23);
+    // ---- the tile's scale (qnet_device.hpp: split_scale)
+    float up, down;
+    split_scale(fmaxf(fmaxf(amax4[0], amax4[1]), fmaxf(amax4[2], amax4[3])), up, down);
     // ---- every operand of the phase is requested first (one wavefront's dependent LDS round trips are not hidden by anything)
     const uint32_t *pr = L.Ps + 4 * gq * kPackedDwords;
     const float *db = L.dHs + 4 * gq * kLh + 16 * strip + r;
@@ -794,30 +763,22 @@ __device__ __forceinline__ void grad_products_split8(const GradLdsP &L, const fl
     // ---- B of the f16 products: the lane's sixteen dH values, scaled and split
     half8 bh[2], bm[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        _Float16 h[8], l[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float w = dh[q][i] * up;
-            h[i] = (_Float16)w;
-            l[i] = (_Float16)((w - (float)h[i]) * 2048.0f);
-        }
-        bh[q] = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
-        bm[q] = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
-    }
+    for (int q = 0; q < 2; ++q) split_half8(dh[q], up, bh[q], bm[q]);
     // ---- the flag columns: tiles u = 2 v + grp, v = 0..2 (columns 16 u + r: word u >> 1, bit 16 (u & 1) + r of the row's flag words)
-    floatx4 ch[3], cm[3];
+    floatx4 ch[3];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) { ch[v] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; cm[v] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    for (int v = 0; v < 3; ++v) ch[v] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t sh = (uint32_t)(grp == 0 ? r : 16 + r);            // u & 1 == grp
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+        half8 a1[3], at[3];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const half8 a = flags_to_half8(mk[q], v, sh);             // u >> 1 == v
-            ch[v] = mfma16h(a, bh[q], ch[v]);
-            cm[v] = mfma16h(a, bm[q], cm[v]);
-        }
+        for (int v = 0; v < 3; ++v) flags_to_half8(mk[q], v, sh, a1[v], at[v]);                  // u >> 1 == v
+#pragma unroll
+        for (int v = 0; v < 3; ++v) ch[v] = mfma16h(a1[v], bh[q], ch[v]);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) ch[v] = mfma16h(at[v], bm[q], ch[v]);      // (mid x 2^-11: same accumulator, three MFMAs later)
+    }
     // ---- the f32 product: group 0 the gathered scalar tile x dH, group 1 H x dout (dW2^T)
     floatx4 c32 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     const bool ones = grp == 0 && r == 15;
@@ -830,7 +791,7 @@ __device__ __forceinline__ void grad_products_split8(const GradLdsP &L, const fl
 #pragma unroll
     for (int v = 0; v < 3; ++v)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) A.acc[v][k] += fmaf(cm[v][k], 1.0f / 2048.0f, ch[v][k]) * down;
+        for (int k = 0; k < 4; ++k) A.acc[v][k] += ch[v][k] * down;
 #pragma unroll
     for (int k = 0; k < 4; ++k) A.acc[3][k] += c32[k];
 }

@@ -507,6 +507,68 @@ __device__ __forceinline__ void fwd_strip_split(const W1Split &S, const PRow &R,
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: building blocks of the weight-gradient product dW1^T = X^T dH in the split form (learner.hip: grad_products_split8,
+// sac.hip: wgrad_x_split) -- the flag columns of X against dH as two f16 terms on v_mfma_f32_16x16x32_f16.
+// ---------------------------------------------------------------------------------------------------------------------
+// Max over the 64 lanes of a wavefront, result in every lane: DPP row rotations inside the 16-lane rows, then the two permlane
+// swaps of group_sum4 (qnet_device.hpp) across the four rows -- no LDS round trip
+__device__ __forceinline__ float wave_max64(float v)
+{
+#define UAV_ROW_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xf, 0xf, false))
+    v = fmaxf(v, UAV_ROW_ROR(v, 8));
+    v = fmaxf(v, UAV_ROW_ROR(v, 4));
+    v = fmaxf(v, UAV_ROW_ROR(v, 2));
+    v = fmaxf(v, UAV_ROW_ROR(v, 1));
+#undef UAV_ROW_ROR
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b);
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+// The flag bits of eight samples for one column as the eight halves of an f16 MFMA operand: `one` holds 1.0 where the flag is set,
+// `tiny` 2^-11 (a normal f16 number) -- the operand the MID term of a split value meets, so that hi x one + mid x tiny lands in ONE
+// accumulator in the units of the hi term (mid = (w - hi) 2^11; the products are exact).  mk[i] = the first dwords of sample i's
+// packed row, w = flag word, sh = bit of the column in it.
+template <typename MaskVec>
+__device__ __forceinline__ void flags_to_half8(const MaskVec (&mk)[8], int w, uint32_t sh, half8 &one, half8 &tiny)
+{
+    uintx4 d, t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t pair = ((mk[2 * k][w] >> sh) & 1u) | (((mk[2 * k + 1][w] >> sh) & 1u) << 16);
+        d[k] = pair * 0x3c00u;                               // two halves: 1.0
+        t[k] = pair * 0x1000u;                               // two halves: 2^-11
+    }
+    one = *reinterpret_cast<const half8 *>(&d);
+    tiny = *reinterpret_cast<const half8 *>(&t);
+}
+// The f16 scale of a tile whose largest |dH| is m: up = 2^(13 - e), down = 2^(e - 13), e = exponent of m (clamped: an all-zero or
+// denormal tile scales by 2^113) -- the largest scaled value sits in [2^13, 2^14): no overflow whatever the loss does, exact scaling.
+__device__ __forceinline__ void split_scale(float m, float &up, float &down)
+{
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+    e = e < -100 ? -100 : e;
+    up = __uint_as_float((uint32_t)(127 + 13 - e) << 23);
+    down = __uint_as_float((uint32_t)(127 - 13 + e) << 23);
+}
+// eight f32 values, scaled, as two f16 terms: hi = f16(w up), mid = f16((w up - hi) 2^11)
+__device__ __forceinline__ void split_half8(const float (&w)[8], float up, half8 &hi, half8 &mid)
+{
+    _Float16 h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = w[i] * up;
+        h[i] = (_Float16)v;
+        l[i] = (_Float16)((v - (float)h[i]) * 2048.0f);
+    }
+    hi = half8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+    mid = half8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+}
+
 // LDS of a 64-agent policy team: the fc1 tile in f16 (row stride 104 halfs = 52 dwords: the 16 rows of a ds_read_b128 phase
 // start 4 banks apart and cover all 64), the 64 raw observation rows (200 bytes each, as in memory), 64 x 16 bytes of Q values.
 constexpr int kPolLdW = 104;

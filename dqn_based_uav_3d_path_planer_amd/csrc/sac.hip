@@ -56,6 +56,11 @@ constexpr int kStrideA = UAVENV_SAC_ACTOR_STRIDE;  // kPa + [actor loss sum, sum
 constexpr int kStrideC = UAVENV_SAC_CRITIC_STRIDE; // 2 kPc + [loss 1 sum, loss 2 sum, 0, 0]
 static_assert(kStrideA == kPa + 4 && kStrideC == 2 * kPc + 4, "partial-row strides");
 constexpr int kTMax = 8;                           // tiles per workgroup
+#ifdef UAVENV_SAC_DW1_F32
+constexpr bool kSacSplitDw1 = false;               // A/B build: the round-4 form of dW1 (all on the f32 matrix pipe)
+#else
+constexpr bool kSacSplitDw1 = true;                // dW1 in the split form (wgrad_x_split)
+#endif
 // Tiles per workgroup of a launch that covers n_slots trainers of n_tiles tiles each: as many as it takes to bring the launch
 // down to one workgroup per CU (the staged nets -- ~26 k cycles per workgroup -- and the partial row are paid per workgroup,
 // not per tile), at most kTMax.  BASELINE configs[3]: 4 slots x 512 tiles -> 8 tiles per workgroup, 256 workgroups; one
@@ -463,6 +468,130 @@ __device__ __forceinline__ void wgrad_xf(const float *As, const float *Xs, float
             for (int u = 0; u < 7; ++u) acc[u] = mfma16(a[kk], b[kk][u], acc[u]);
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: dW1 in the SPLIT form (as learner.hip: grad_products_split8).  80 of the 100 observation columns are 0 / 1 flags -- exact
+// in f16 -- so their part of dW1[j][c] = sum_s dH1[s][j] X[s][c] runs on v_mfma_f32_16x16x32_f16 with dH1 as two f16 terms (hi +
+// mid 2^-11 of dH1 2^S; 2^S from the tile's largest |dH1|: no overflow, 22-23 significant bits relative to it; every product
+// exact, f32 sums); the 15 scalar columns and the ones column (-> db1) form one gathered 16-entry tile on v_mfma_f32_16x16x4_f32
+// with the f32 dH1; the critics' two action columns are 32 FMAs per lane.  Per wavefront and tile: 24 f16 MFMAs of 16 cycles + 16
+// f32 MFMAs of 32 instead of 112 f32 MFMAs -- 0.9 k matrix cycles instead of 3.6 k (measured before: 5.5 k cycles per tile for
+// the product on an f32 X tile, 7.5 k with the packed-row decode).
+// A = dH1 (rows = this wavefront's 16 hidden units), B = the flags; sample of K element i, lane group g, step q: 32 q + 16 (i >> 2)
+// + 4 g + (i & 3) -- lane groups 4 samples apart are 16 banks apart in both tiles.  fl[u][reg] = dW1[16 wave + 4 g + reg][16 u + r]
+// (exact zeros at the scalar columns: their bits are 0 in the packed words); sc[reg] = the gathered entry r of those hidden units
+// (entries 0..10 = columns 0..10, 11..14 = 86..89, 15 = ones); act[0 / 1] = this lane's partial sums for hidden unit 16 wave + r
+// and the two action columns (summed over the lane groups at write-out).
+// ---------------------------------------------------------------------------------------------------------------------
+struct Dw1Split {
+    floatx4 fl[6], sc;
+    float act[2];
+};
+__device__ __forceinline__ void dw1_zero(Dw1Split &W)
+{
+#pragma unroll
+    for (int u = 0; u < 6; ++u) W.fl[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    W.sc = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    W.act[0] = W.act[1] = 0.0f;
+}
+// max |dH1| of this wavefront's strip, for the tile's scale: lane 0 leaves it in amax4[wave] (read after the tile's barrier)
+__device__ __forceinline__ void dh_strip_amax(const floatx4 (&dh)[4], float *amax4)
+{
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, fabsf(dh[t][k]));
+    m = wave_max64(m);
+    if (((int)threadIdx.x & 63) == 0) amax4[(int)threadIdx.x >> 6] = m;
+}
+template <bool EXT>
+__device__ __forceinline__ void wgrad_x_split(const float *dHs, const uint32_t *Ps, const float *amax4, Dw1Split &W)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    float up, down;
+    split_scale(fmaxf(fmaxf(amax4[0], amax4[1]), fmaxf(amax4[2], amax4[3])), up, down);
+    const float *ap = dHs + 4 * g * kLh + 16 * wv + r;
+    const uint32_t *pp = Ps + 4 * g * kPsLd;
+    const int dsc = r < 15 ? 4 + r : 20;                        // gathered entry r of a row: dwords 4..18, the ones at dword 20
+    floatx4 ch[6], c32 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 6; ++u) ch[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    float s0 = 0.0f, s1a = 0.0f;
+    // the two K blocks one after the other (both at once: ~180 live registers on top of the phase's persistent accumulators --
+    // the critic kernel spilled 23 of them)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        uintx4 mk[8];
+        float dh[8], xs[8], xa0[8], xa1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s1 = 32 * q + 16 * (i >> 2) + (i & 3);    // + 4 g through the base pointers
+            mk[i] = *reinterpret_cast<const uintx4 *>(pp + s1 * kPsLd);
+            dh[i] = ap[s1 * kLh];
+            xs[i] = __uint_as_float(pp[s1 * kPsLd + dsc]);
+            if (EXT) {
+                xa0[i] = __uint_as_float(pp[s1 * kPsLd + 21]);
+                xa1[i] = __uint_as_float(pp[s1 * kPsLd + 22]);
+            }
+        }
+        half8 ah, am;
+        split_half8(dh, up, ah, am);
+#pragma unroll
+        for (int u0 = 0; u0 < 6; u0 += 3) {                  // three column tiles at a time: six operands live
+            half8 b1[3], bt[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) flags_to_half8(mk, (u0 + k) >> 1, (uint32_t)(16 * ((u0 + k) & 1) + r), b1[k], bt[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ch[u0 + k] = mfma16h(ah, b1[k], ch[u0 + k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ch[u0 + k] = mfma16h(am, bt[k], ch[u0 + k]);    // (mid x 2^-11: same accumulator, three MFMAs later)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c32 = mfma16(dh[i], xs[i], c32);
+        if (EXT) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s0 = fmaf(dh[i], xa0[i], s0); s1a = fmaf(dh[i], xa1[i], s1a); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) W.fl[u][k] += ch[u][k] * down;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) W.sc[k] += c32[k];
+    if (EXT) {
+        W.act[0] += s0;
+        W.act[1] += s1a;
+    }
+}
+// ... -> the partial row (the layout of store_dw1: input column c < 100 at [j][c], b1 at ob1 + j, the action columns at [j][100], [j][101])
+template <bool EXT>
+__device__ __forceinline__ void store_dw1_split(float *out, int in_dim, int ob1, Dw1Split &W)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int c = 16 * u + r;
+        const bool scalar = c <= 10 || (c >= 86 && c <= 89);          // written from the gathered tile below
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            if (!scalar) out[(16 * wv + 4 * g + reg) * in_dim + c] = W.fl[u][reg];
+    }
+    const int cg = r <= 10 ? r : 86 + (r - 11);                       // gathered entry r -> its column (entry 15: b1)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int j = 16 * wv + 4 * g + reg;
+        if (r < 15) out[j * in_dim + cg] = W.sc[reg];
+        else out[ob1 + j] = W.sc[reg];
+        if (r < 4) out[j * in_dim + 96 + r] = 0.0f;                   // columns 96..99 are constant zero in every row
+    }
+    if (EXT) {
+        const float a0 = group_sum4(W.act[0]), a1 = group_sum4(W.act[1]);
+        if (g == 0) { out[(16 * wv + r) * in_dim + kW] = a0; out[(16 * wv + r) * in_dim + kW + 1] = a1; }
+    }
+}
+
 // the critic's other products in one sweep: dW2 = dH2^T H1 (4 tiles), dWout^T = H2^T dq, db2 = column sums of dH2
 __device__ __forceinline__ void wgrad_critic_rest(const float *dH2s, const float *H1s, const float *H2s, const float *dqs,
                                                   floatx4 (&aw2)[4], floatx4 &awo, floatx4 &ab2)
@@ -787,6 +916,8 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
         __syncthreads();
         S_STAMP(3 + 6 * c);
         floatx4 aw1[7], aw2[4], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f}, ab2 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        Dw1Split ws1;
+        dw1_zero(ws1);
 #pragma unroll
         for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -815,11 +946,17 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
             h_strip_store(H2s, h2);
             h_strip_store(dH1s, dh1);
             h_strip_store(dH2s, dh2);
-            x_strip_store(Xs, T.R, T.a0, T.a1);
+            if (kSacSplitDw1) {
+                dh_strip_amax(dh1, red + 48);
+                if (gq == 0) ps_store(reinterpret_cast<uint32_t *>(Xs), 16 * wv + r, T.R, T.a0, T.a1);
+            } else {
+                x_strip_store(Xs, T.R, T.a0, T.a1);
+            }
             if (gq == 0) { dqs[(16 * wv + r) * 4] = dq0; dqs[(16 * wv + r) * 4 + 1] = dq1; }
             __syncthreads();
             if (j == 0) S_STAMP(4 + 6 * c);
-            wgrad_xf(dH1s, Xs, aw1);                   // dW1 (+ db1 as column 100)
+            if (kSacSplitDw1) wgrad_x_split<true>(dH1s, reinterpret_cast<const uint32_t *>(Xs), red + 48, ws1);
+            else wgrad_xf(dH1s, Xs, aw1);              // dW1 (+ db1 as column 100)
             if (j == 0) S_STAMP(5 + 6 * c);
             wgrad_critic_rest(dH2s, H1s, H2s, dqs, aw2, awo, ab2);     // dW2, dWout^T, db2
             __syncthreads();
@@ -828,7 +965,8 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
         }
         S_STAMP(7 + 6 * c);
         float *out = g.partials + (size_t)blockIdx.x * kStrideC + c * kPc;
-        store_dw1(out, kIn, kCob1, aw1);
+        if (kSacSplitDw1) store_dw1_split<true>(out, kIn, kCob1, ws1);
+        else store_dw1(out, kIn, kCob1, aw1);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -898,6 +1036,8 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
     w2_load<2>(Fo2, g.c2 + kCoWo, g.c2 + kCobo, 2);
     __syncthreads();
     floatx4 aw1[7], awo = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    Dw1Split ws1;
+    dw1_zero(ws1);
 #pragma unroll
     for (int u = 0; u < 7; ++u) aw1[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
     float s_b[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s_lp = 0.0f, s_loss = 0.0f, s_cnt = 0.0f;
@@ -975,19 +1115,22 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
             }
         h_strip_store(H1s, h);
         h_strip_store(dH1s, dh);
+        if (kSacSplitDw1) dh_strip_amax(dh, red + 48);
         if (gq == 0) {
             ps_store(Ps, 16 * wv + r, T.R, 0.0f, 0.0f);
 #pragma unroll
             for (int a = 0; a < 4; ++a) { dqs[(16 * wv + r) * 4 + a] = dout[a]; s_b[a] += dout[a]; }
         }
         __syncthreads();
-        wgrad_x<false>(dH1s, Ps, aw1);
+        if (kSacSplitDw1) wgrad_x_split<false>(dH1s, Ps, red + 48, ws1);
+        else wgrad_x<false>(dH1s, Ps, aw1);
         wgrad_small(H1s, dqs, 4, awo);
         __syncthreads();
         T = Tn;
     }
     float *out = g.partials + (size_t)blockIdx.x * kStrideA;
-    store_dw1(out, kW, kHid * kW, aw1);
+    if (kSacSplitDw1) store_dw1_split<false>(out, kW, kHid * kW, ws1);
+    else store_dw1(out, kW, kHid * kW, aw1);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
         if (r < 4) out[kAoW2 + r * kHid + 16 * wv + 4 * gq + reg] = awo[reg];
