@@ -56,6 +56,16 @@ constexpr int kStrideA = UAVENV_SAC_ACTOR_STRIDE;  // kPa + [actor loss sum, sum
 constexpr int kStrideC = UAVENV_SAC_CRITIC_STRIDE; // 2 kPc + [loss 1 sum, loss 2 sum, 0, 0]
 static_assert(kStrideA == kPa + 4 && kStrideC == 2 * kPc + 4, "partial-row strides");
 constexpr int kTMax = 8;                           // tiles per workgroup
+// The 64 -> 64 layer's forward as a three-term f16 product in k_sac_td and the critic phase (layer2_fwd_h): BUILT, MEASURED, OFF.
+// configs[3], one MI355X: 0.4980 ms per pass with the layer on the f32 matrix pipe, 0.5108 ms with the f16 form (all 18 SAC tests
+// green either way) -- 24 f16 MFMAs replace 64 f32 ones, but splitting the lane's 16 activations (max, scale, two conversions each)
+// and the second accumulator's fix-up are ~150 VALU instructions of the SAME wavefront, which do not overlap its MFMAs: with one
+// wavefront per SIMD the phase is bound by its instruction stream, not by the matrix pipe.  -DUAVENV_SAC_W2_HALF builds it.
+#ifdef UAVENV_SAC_W2_HALF
+constexpr bool kSacW2Half = true;
+#else
+constexpr bool kSacW2Half = false;
+#endif
 #ifdef UAVENV_SAC_DW1_F32
 constexpr bool kSacSplitDw1 = false;               // A/B build: the round-4 form of dW1 (all on the f32 matrix pipe)
 #else
@@ -286,6 +296,99 @@ __device__ __forceinline__ void layer2_bwd(const WSet &S, const floatx4 (&dh2)[4
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
             for (int t = 0; t < 4; ++t) w[reg][t] = wn[reg][t];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the 64 -> 64 layer's FORWARD off the f32 matrix pipe.  Neither operand is exact in f16 here, so
+// both are split: fc2 as hi + mid 2^-11 (staged once per workgroup, W2Half), the lane's post-ReLU activations as hi + mid 2^-11 of
+// h 2^S, S from the SAMPLE's largest activation (an MFMA's B column is one sample: a per-sample scale factors out of its output
+// column exactly).  Three v_mfma_f32_16x16x32_f16 per (16 outputs, 32 inputs): hi x hi into one accumulator, mid x hi and hi x mid
+// into a second one worth 2^-11 (mid x mid, 2^-22 relative, is dropped): 24 MFMAs of 16 cycles instead of 64 of 32, sums in f32,
+// ~2^-21 relative per product.  The K index of a lane group keeps the chaining trick of layer2_fwd: element i of lane group g in K
+// block kb is hidden unit 16 (2 kb + (i >> 2)) + 4 g + (i & 3) -- the registers this lane holds.  The staged image is stored in
+// MFMA order, [t2][kb][lane][8 halves]: every A operand is one conflict-free 16-byte read.  Forward only: the backward (W2^T) would
+// need a transposed image the LDS maps have no room for.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kW2hTerm = 4 * 2 * 64 * 8;                   // halves per term: 8 KB; hi + mid = 16 KB (4 096 floats)
+struct W2Half {
+    _Float16 *hi, *mid;
+};
+__device__ __forceinline__ W2Half w2half_at(float *p)
+{
+    W2Half I;
+    I.hi = reinterpret_cast<_Float16 *>(p);
+    I.mid = I.hi + kW2hTerm;
+    return I;
+}
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+// fc2 from the registers of critic_issue (thread tid, piece it: row (it 256 + tid) >> 4, input units 4 q .. 4 q + 3); 256 threads
+__device__ __forceinline__ void layer2_commit_h(const W2Half &I, const CritRegs &C)
+{
+    const int tid = (int)threadIdx.x & 255;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = it * 256 + tid, row = c >> 4, q = c & 15;
+        const int t2 = row >> 4, r = row & 15, t = q >> 2, g = q & 3, kb = t >> 1;
+        const int idx = (((t2 * 2 + kb) * 64 + 16 * g + r) * 8) + 4 * (t & 1);
+        half4v h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float w = C.w2[it][k];
+            h[k] = (_Float16)w;
+            l[k] = (_Float16)((w - (float)h[k]) * 2048.0f);
+        }
+        *reinterpret_cast<half4v *>(I.hi + idx) = h;
+        *reinterpret_cast<half4v *>(I.mid + idx) = l;
+    }
+}
+// max over the four lane groups of a sample (lanes l, l ^ 16, l ^ 32, l ^ 48), in all of them (group_sum4 with max)
+__device__ __forceinline__ float group_max4(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b);
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ void layer2_fwd_h(const W2Half &I, const float *b2s, const floatx4 (&h1)[4], floatx4 (&acc2)[4])
+{
+    const int lane = (int)threadIdx.x & 63, g = lane >> 4;
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, h1[t][k]);                  // (post-ReLU: >= 0)
+    float up, down;
+    split_scale(group_max4(m), up, down);
+    floatx4 cm[4], cc[4];
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) { cm[t2] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; cc[t2] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        half8 ah[4], am[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            ah[t2] = *reinterpret_cast<const half8 *>(I.hi + ((t2 * 2 + kb) * 64 + lane) * 8);
+            am[t2] = *reinterpret_cast<const half8 *>(I.mid + ((t2 * 2 + kb) * 64 + lane) * 8);
+        }
+        const float w[8] = {h1[2 * kb][0], h1[2 * kb][1], h1[2 * kb][2], h1[2 * kb][3],
+                            h1[2 * kb + 1][0], h1[2 * kb + 1][1], h1[2 * kb + 1][2], h1[2 * kb + 1][3]};
+        half8 bh, bm;
+        split_half8(w, up, bh, bm);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) cm[t2] = mfma16h(ah[t2], bh, cm[t2]);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) cc[t2] = mfma16h(am[t2], bh, cc[t2]);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) cc[t2] = mfma16h(ah[t2], bm, cc[t2]);
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) {
+        const floatx4 b = *reinterpret_cast<const floatx4 *>(b2s + 16 * t2 + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc2[t2][k] = fmaf(fmaf(cc[t2][k], 1.0f / 2048.0f, cm[t2][k]), down, b[k]);
     }
 }
 
@@ -693,6 +796,8 @@ struct TdSet {
 };
 constexpr int kTdSetF = kSplitF + kHid * kLh + kHid;
 static_assert(kTdSetF == kTdSetF_, "LDS map");
+static_assert(2 * kW2hTerm / 2 <= kHid * kLh && kTile * kPsLd + 2 * kW2hTerm / 2 <= kTileF,
+              "fc2's f16 image fits where the f32 fc2 tile was (k_sac_td) and behind the packed rows in the critic phase's X area");
 constexpr size_t kSacTdLds = (size_t)(kSplitF + 2 * kTdSetF) * 4;      // actor layer 1 + both target critics: 120 KB
 __device__ __forceinline__ TdSet tdset_at(float *p)
 {
@@ -700,6 +805,8 @@ __device__ __forceinline__ TdSet tdset_at(float *p)
 }
 // critic fc1 (64 x 102: the two action columns -> scalar-block entries 16 / 17, b1 -> 15), fc2, b2 from the registers of
 // critic_issue; 256 threads
+// W2H: fc2 as the f16 image of layer2_fwd_h IN PLACE of the f32 tile (forward-only kernels: k_sac_td)
+template <bool W2H = false>
 __device__ __forceinline__ void critic_commit_split(const TdSet &S, const CritRegs &C)
 {
     const int tid = (int)threadIdx.x;
@@ -717,10 +824,14 @@ __device__ __forceinline__ void critic_commit_split(const TdSet &S, const CritRe
             }
         }
     }
+    if (W2H) {
+        layer2_commit_h(w2half_at(S.W2s), C);
+    } else {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int c = it * 256 + tid, row = c >> 4, q = c & 15;
-        *reinterpret_cast<floatx4 *>(S.W2s + row * kLh + 4 * q) = C.w2[it];
+        for (int it = 0; it < 4; ++it) {
+            const int c = it * 256 + tid, row = c >> 4, q = c & 15;
+            *reinterpret_cast<floatx4 *>(S.W2s + row * kLh + 4 * q) = C.w2[it];
+        }
     }
     if (tid < kHid) {
         float *d = S.W1.sc + tid * kScK;
@@ -728,15 +839,17 @@ __device__ __forceinline__ void critic_commit_split(const TdSet &S, const CritRe
         S.b2s[tid] = C.b2;
     }
 }
+// w2h: the 64 -> 64 layer from this f16 image (layer2_fwd_h) instead of S.W2s on the f32 pipe (nullptr)
 template <bool AHEAD = false>
 __device__ __forceinline__ void critic_fwd_split(const TdSet &S, const PRow &R, float a0, float a1, const W2Frag<2> &Fo,
-                                                 floatx4 (&acc1)[4], floatx4 (&acc2)[4], float (&q)[2])
+                                                 floatx4 (&acc1)[4], floatx4 (&acc2)[4], float (&q)[2], float *w2h = nullptr)
 {
     if (AHEAD) fwd_strip_split_ahead<true>(S.W1, R, acc1, a0, a1);
     else fwd_strip_split<true>(S.W1, R, acc1, a0, a1);
     floatx4 h1[4];
     relu4(acc1, h1);
-    layer2_fwd(WSet{nullptr, S.W2s, S.b2s}, h1, acc2);
+    if (w2h) layer2_fwd_h(w2half_at(w2h), S.b2s, h1, acc2);
+    else layer2_fwd(WSet{nullptr, S.W2s, S.b2s}, h1, acc2);
     q_strip<2>(acc2, Fo, 2, 2, 0, q);
 }
 
@@ -799,8 +912,8 @@ __global__ void __launch_bounds__(512) k_sac_td(SacArgsN slots)
         critic_issue(C1, g.t1);
         critic_issue(C2, g.t2);
         stage_actor_split(Wa, g.actor);
-        critic_commit_split(S1, C1);
-        critic_commit_split(S2, C2);
+        critic_commit_split<kSacW2Half>(S1, C1);
+        critic_commit_split<kSacW2Half>(S2, C2);
     }
     __syncthreads();
     for (int j = half; j < nt; j += 2) {
@@ -821,9 +934,9 @@ __global__ void __launch_bounds__(512) k_sac_td(SacArgsN slots)
         {   // (the two heads' fragments are re-read per use: 64 registers that two wavefronts per SIMD do not have; L1 hits)
             W2Frag<2> Fo;
             w2_load<2>(Fo, g.t1 + kCoWo, g.t1 + kCobo, 2);
-            critic_fwd_split(S1, T.R, a0, a1, Fo, acc, acc2, q1);
+            critic_fwd_split(S1, T.R, a0, a1, Fo, acc, acc2, q1, kSacW2Half ? S1.W2s : nullptr);
             w2_load<2>(Fo, g.t2 + kCoWo, g.t2 + kCobo, 2);
-            critic_fwd_split(S2, T.R, a0, a1, Fo, acc, acc2, q2);
+            critic_fwd_split(S2, T.R, a0, a1, Fo, acc, acc2, q2, kSacW2Half ? S2.W2s : nullptr);
         }
         if (gq < 2)                                // group d writes component d
             g.td[((size_t)(t0 + j) * kTile + 16 * wv + r) * 2 + d] =
@@ -906,10 +1019,14 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
         const float *flat = c ? g.c2 : g.c1;
         TileIn T;
         tile_in<false, true>(g, t0, T);
+        // (split dW1: the f32 X tile is gone, the packed rows take 1 792 of its 6 912 floats -- fc2's f16 image of layer2_fwd_h sits
+        // behind them; the backward keeps the f32 fc2 of SS)
+        float *w2h = (kSacSplitDw1 && kSacW2Half) ? Xs + kTile * kPsLd : nullptr;
         {
             CritRegs C;
             critic_issue(C, flat);
             critic_commit_split(SS, C);
+            if (w2h) layer2_commit_h(w2half_at(w2h), C);
         }
         W2Frag<2> Fo;
         w2_load<2>(Fo, flat + kCoWo, flat + kCobo, 2);
@@ -929,7 +1046,7 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
             const float *td = g.td ? g.td + ((size_t)(t0 + j) * kTile + 16 * wv + r) * 2 : tds + (j * kTile + 16 * wv + r) * 2;
             floatx4 acc1[4], acc2[4];
             float q[2];
-            critic_fwd_split<true>(SS, T.R, T.a0, T.a1, Fo, acc1, acc2, q);
+            critic_fwd_split<true>(SS, T.R, T.a0, T.a1, Fo, acc1, acc2, q, w2h);
             const float e0 = q[0] - td[0], e1 = q[1] - td[1];
             const float ww = T.w * T.isw;                                // validity x importance-sampling weight (1 without PER)
             const float dq0 = ww * e0 * inv_b, dq1 = ww * e1 * inv_b;    // d mean_{[B,2]}(w err^2) / dq = 2 w err / (2 B)
