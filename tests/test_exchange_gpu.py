@@ -228,8 +228,10 @@ def test_bench_sac_exchange_at_world_4_and_8_on_one_device(world):
 def test_bench_recovers_at_world_4_when_one_rank_fails():
     """The fault drill with four ranks: rank 2's exchange raises its sticky error; all four drop to the collective, take rank
     0's weights and finish bit-identical."""
+    # (64 passes per bench step: after the recovery every update is a gloo all-reduce of a device tensor between four processes
+    # -- tens of milliseconds each; the default 1 024 passes per step made this test four minutes long)
     d = _bench("--gpus", "4", "--same-device", "--dist-backend", "gloo", "--envs", "512", "--batch", "512", "--replay", "8192",
-               "--inject-p2p-fault", "2", "--no-exchange-leg")
+               "--inject-p2p-fault", "2", "--no-exchange-leg", "--passes-per-step", "64")
     assert d["n_gpus"] == 4 and d["exchange"] == "rccl" and d["ranks_bit_identical"] is True
     assert any("sticky" in f for f in d["exchange_fallbacks"]) and d["bad_after_recovery"] is False
 
