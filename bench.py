@@ -374,6 +374,7 @@ def run_config4(args, dev, world_size=1, rank=0):
     ring = DeviceReplayRing(env, args.replay, discrete=False)
     ring.reset(seed=1000 + rank)
     a1_plane = torch.zeros((ring.frames, env.N), dtype=torch.float32, device=dev)      # second action component (:444-448)
+    ring.attach_action1(a1_plane)           # recorded with every transition: the fused update gathers one record per sample
     sac_param = {"actor": {"NetWork": "PolicyNetContinuous_SAC", "w": "100", "action_bound": "1", "hiden_dim": "64",
                            "output": "2", "lr": "0.0001"},
                  "critic": {"NetWork": "QValueNetContinuous_SAC", "w": "100", "hiden_dim": "64", "action_dim": "2", "lr": "0.001"},
@@ -395,7 +396,8 @@ def run_config4(args, dev, world_size=1, rank=0):
     flat = ring.obs.view(-1, ring.obs.shape[-1])
     znoise = [None]
     fbatch = [L.make_batch(flat, ring.action.view(-1), a1_plane.view(-1), ring.reward.view(-1), ring.done.view(-1),
-                           valid=ring.valid.view(-1), draws=draws[j], n_agents=env.N, uav_per_env=U, slot=j, frames=ring.frames)
+                           valid=ring.valid.view(-1), draws=draws[j], n_agents=env.N, uav_per_env=U, slot=j, frames=ring.frames,
+                           meta=ring.meta.view(-1, 4))
               for j, L in enumerate(learners)] if fused else None
 
     def update_slot(j):

@@ -8,7 +8,7 @@ from . import _build
 
 OBS_DIM = 100
 MAX_BUILDINGS = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EP2P = 0, -22, -12, -5, -19, -70
 P2P_ERR_TIMEOUT, P2P_ERR_DIVERGED = 1, 2
@@ -18,6 +18,7 @@ INFO_NAMES = ("normal", "success", "lose", "skipped")
 ACT_STEER_F32, ACT_STEER_F64, ACT_INDEX_I32 = 0, 1, 2
 OBS_F32, OBS_F16, OBS_PACKED = 0, 1, 2
 PACKED_DWORDS = 20
+META_BYTES = 16             # one transition record of a ring's `meta` plane (include/uavenv.h: UAVENV_META_BYTES)
 MFMA_F32, MFMA_F16 = 0, 1
 P2P_HANDLE_BYTES = 64
 P2P_CHECK_MAX_BLOCKS = 40
@@ -26,7 +27,7 @@ STEP_AUTO_RESET, STEP_SKIP_DONE, STEP_NO_OBS, STEP_ONE_WAVE, STEP_APF_LANE = 1, 
 # every symbol include/uavenv.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = (
     "uavenv_abi_version", "uavenv_last_error", "uavenv_create", "uavenv_destroy", "uavenv_num_agents",
-    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_replan_begin", "uavenv_replan_ready", "uavenv_replan_commit", "uavenv_replan_stats", "uavenv_bank_read", "uavenv_set_moved_word", "uavenv_tick", "uavenv_dqn_reduce_adam_gated", "uavenv_per_set_f32_gated", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
+    "uavenv_set_buildings", "uavenv_load_scenarios", "uavenv_plan_scenarios", "uavenv_bank_stats", "uavenv_replan_begin", "uavenv_replan_ready", "uavenv_replan_commit", "uavenv_replan_stats", "uavenv_bank_read", "uavenv_set_moved_word", "uavenv_set_step_meta", "uavenv_tick", "uavenv_dqn_reduce_adam_gated", "uavenv_per_set_f32_gated", "uavenv_rrt_plan", "uavenv_reset_all", "uavenv_set_state", "uavenv_get_state",
     "uavenv_step", "uavenv_step_policy", "uavenv_set_debug_buffer", "uavenv_observe", "uavenv_threaten_rate", "uavenv_threaten_rate_allpairs", "uavenv_geometry",
     "uavenv_replay_sample", "uavenv_obs_unpack", "uavenv_replay_draw", "uavenv_replay_draw_valid", "uavenv_select_actions",
     "uavenv_dqn_num_params", "uavenv_dqn_partial_stride", "uavenv_dqn_partial_rows", "uavenv_dqn_set_debug_buffer", "uavenv_dqn_grad", "uavenv_dqn_grad_w", "uavenv_dqn_reduce", "uavenv_dqn_adam", "uavenv_dqn_reduce_adam", "uavenv_dqn_act",
@@ -59,7 +60,7 @@ class UavReplayRing(C.Structure):
     _fields_ = [
         ("obs", C.c_void_p), ("action", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
         ("valid", C.c_void_p), ("frames", C.c_int32), ("n_agents", C.c_int32), ("obs_dtype", C.c_int32),
-        ("action_is_index", C.c_int32),
+        ("action_is_index", C.c_int32), ("meta", C.c_void_p),
     ]
 
 
@@ -106,7 +107,7 @@ class UavSacBatch(C.Structure):
                 ("n_agents", C.c_int32), ("uav_per_env", C.c_int32), ("slot", C.c_int32), ("frames", C.c_int32),
                 ("act0", C.c_void_p), ("act1", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("valid", C.c_void_p),
                 ("eps", C.c_void_p), ("batch", C.c_int32), ("tiles_per_wg", C.c_int32),
-                ("is_weights", C.c_void_p), ("abs_td_out", C.c_void_p), ("td_scratch", C.c_void_p)]
+                ("is_weights", C.c_void_p), ("abs_td_out", C.c_void_p), ("meta", C.c_void_p), ("td_scratch", C.c_void_p)]
 
 
 class UavSacAdam(C.Structure):
@@ -197,6 +198,8 @@ def load() -> C.CDLL:
     lib.uavenv_replan_stats.argtypes = [vp, vp]
     lib.uavenv_set_moved_word.restype = C.c_int
     lib.uavenv_set_moved_word.argtypes = [vp, vp]
+    lib.uavenv_set_step_meta.restype = C.c_int
+    lib.uavenv_set_step_meta.argtypes = [vp, vp, vp]
     lib.uavenv_tick.restype = C.c_uint64
     lib.uavenv_tick.argtypes = [vp]
     lib.uavenv_bank_read.restype = C.c_int

@@ -62,6 +62,26 @@ struct GradArgs {
 #endif
 
 
+// The scalar fields of the transition in ring row `row`: from its ONE 16-byte record when the ring has them (UavReplayRing.meta,
+// ABI 5: {a1, a0, reward, done | valid << 8 | info << 16}, written by the step kernels), else a load each from the action, reward,
+// done and valid planes -- four scattered 128-byte lines per sample, ~45 % of a gradient launch's HBM fetch (round 5 counters).
+// done / valid come back as integers: converted where they are used.
+__device__ __forceinline__ void load_transition(const UavReplayRing &R, uint32_t row, int &act, float &rew, uint32_t &done, uint32_t &valid)
+{
+    if (R.meta) {
+        const uint4 m = reinterpret_cast<const uint4 *>(R.meta)[row];
+        act = (int)m.y;
+        rew = __uint_as_float(m.z);
+        done = m.w & 0xffu;
+        valid = (m.w >> 8) & 0xffu;
+    } else {
+        act = reinterpret_cast<const int32_t *>(R.action)[row];
+        rew = R.reward[row];
+        done = R.done[row];
+        valid = R.valid ? (uint32_t)R.valid[row] : 1u;
+    }
+}
+
 // =====================================================================================================================
 // k_dqn_grad, wave-strip formulation.
 //
@@ -348,10 +368,11 @@ __device__ __forceinline__ void grad_tile(const GradArgs &g, const GradLds &L, i
     x_issue<ObsT>(vXs, obs, row_s);
     // this sample's scalar fields (needed at the TD target; behind the s rows, ahead of everything the first commit
     // does not wait for)
-    const int p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
-    const float p_rew = g.ring.reward[row_s];
-    const float p_done = (float)g.ring.done[row_s];
-    const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    int p_act;
+    float p_rew;
+    uint32_t raw_done, raw_valid;
+    load_transition(g.ring, row_s, p_act, p_rew, raw_done, raw_valid);
+    const float p_done = (float)raw_done, p_valid = (float)raw_valid;
     const float p_w = g.is_w ? g.is_w[smp] : 1.0f;
     x_issue<ObsT>(vXn, obs, row_n);
     if (FIRST) w_issue(vWt, g.target);
@@ -533,10 +554,11 @@ __device__ __forceinline__ void grad_tile_packed(const GradArgs &g, const GradLd
     const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
     PRow Rs, Rn;
     prow_load(Rs, obs + (size_t)row_s * kPackedDwords);
-    const int p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
-    const float p_rew = g.ring.reward[row_s];
-    const float p_done = (float)g.ring.done[row_s];
-    const float p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    int p_act;
+    float p_rew;
+    uint32_t raw_done, raw_valid;
+    load_transition(g.ring, row_s, p_act, p_rew, raw_done, raw_valid);
+    const float p_done = (float)raw_done, p_valid = (float)raw_valid;
     const float p_w = g.is_w ? g.is_w[smp] : 1.0f;
     prow_load(Rn, obs + (size_t)row_n * kPackedDwords);
     if (FIRST) { if (g.img) img_issue(vWt, g.img + kSplitF); else w_issue(vWt, g.target); }
@@ -842,10 +864,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     float p_rew = 0.0f, p_w = 1.0f;
     uint32_t raw_done = 0u, raw_valid = 1u;   // (converted where they are used: a conversion here would wait for every load above)
     if (grp == 0) {
-        p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
-        p_rew = g.ring.reward[row_s];
-        raw_done = g.ring.done[row_s];
-        raw_valid = g.ring.valid ? (uint32_t)g.ring.valid[row_s] : 1u;
+        load_transition(g.ring, row_s, p_act, p_rew, raw_done, raw_valid);
         p_w = g.is_w ? g.is_w[smp] : 1.0f;
     }
     L_STAMP(6);                               // (diagnostics: every load of the tile issued)
@@ -1227,10 +1246,12 @@ __device__ __forceinline__ void tile_issue(const GradArgs &g, int tile, TileLoad
     const uint32_t row_s = (uint32_t)f * (uint32_t)g.ring.n_agents + (uint32_t)agent;
     const uint32_t row_n = (uint32_t)fn * (uint32_t)g.ring.n_agents + (uint32_t)agent;
     xh_issue<KIND>(T.vXs, g.ring.obs, row_s);
-    T.p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
-    T.p_rew = g.ring.reward[row_s];
-    T.p_done = (float)g.ring.done[row_s];
-    T.p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+    {
+        uint32_t raw_done, raw_valid;
+        load_transition(g.ring, row_s, T.p_act, T.p_rew, raw_done, raw_valid);
+        T.p_done = (float)raw_done;
+        T.p_valid = (float)raw_valid;
+    }
     T.p_w = g.is_w ? g.is_w[smp] : 1.0f;
     T.smp = smp;
     xh_issue<KIND>(T.vXn, g.ring.obs, row_n);
@@ -1433,10 +1454,10 @@ __device__ __forceinline__ void tile_issue8(const GradArgs &g, int tile, int grp
     xh_issue<KIND>(T.vX, g.ring.obs, grp == 0 ? row_s : row_n);
     T.p_act = 0; T.p_rew = 0.0f; T.p_done = 0.0f; T.p_valid = 1.0f; T.p_w = 1.0f; T.smp = smp;
     if (grp == 0) {
-        T.p_act = reinterpret_cast<const int32_t *>(g.ring.action)[row_s];
-        T.p_rew = g.ring.reward[row_s];
-        T.p_done = (float)g.ring.done[row_s];
-        T.p_valid = g.ring.valid ? (float)g.ring.valid[row_s] : 1.0f;
+        uint32_t raw_done, raw_valid;
+        load_transition(g.ring, row_s, T.p_act, T.p_rew, raw_done, raw_valid);
+        T.p_done = (float)raw_done;
+        T.p_valid = (float)raw_valid;
         T.p_w = g.is_w ? g.is_w[smp] : 1.0f;
     }
 }
@@ -2204,7 +2225,7 @@ int uavenv_dqn_grad_img(const UavReplayRing *ring, int32_t head, int32_t filled,
     if (!explicit_idx && (filled <= 0 || filled > ring->frames - 1)) return UAVENV_EINVAL;
     if ((uint64_t)ring->frames * (uint64_t)ring->n_agents >= (1ull << 32)) return UAVENV_EINVAL;
     if (!ring->action_is_index) return UAVENV_EINVAL;
-    if ((((uintptr_t)partials | (uintptr_t)net->local | (uintptr_t)net->target) & 15u) != 0) return UAVENV_EINVAL;
+    if ((((uintptr_t)partials | (uintptr_t)net->local | (uintptr_t)net->target | (uintptr_t)ring->meta) & 15u) != 0) return UAVENV_EINVAL;
     Grad2Args ga;
     GradArgs &g = ga.g;
     g.ring = *ring;

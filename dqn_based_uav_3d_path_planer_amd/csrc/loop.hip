@@ -237,12 +237,15 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
         if (l->prof) tp0 = std::chrono::steady_clock::now();
         uint8_t *info_t = c.info_dev ? c.info_dev + (size_t)t * n : nullptr;
         uint8_t *valid_t = R.valid ? R.valid + (size_t)t * n : nullptr;
+        // the transition records of this frame (UavReplayRing.meta): the learner then gathers one record per sample
+        void *meta_t = R.meta ? (unsigned char *)R.meta + (size_t)t * n * UAVENV_META_BYTES : nullptr;
         if (l->fuse_act) {               // Q(s) + epsilon-greedy in the prologue of the step kernel: one launch less
             if (timed) {
                 e0 = take_event(l);
                 e1 = take_event(l);
                 if (e0 && e1) (void)hipEventRecord(e0, s);
             }
+            (void)uavenv_set_step_meta(c.env, meta_t, nullptr);
             rc = uavenv_step_policy_img(c.env, &c.net, obs_t, c.eps, c.seed, l->counter, act_t, obs_n, nullptr, R.reward + (size_t)t * n,
                                         R.done + (size_t)t * n, nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, l->img, s);
             if (rc == UAVENV_EINVAL) l->fuse_act = false;         // not this env / net: the two-launch form from here on
@@ -256,6 +259,7 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 e1 = take_event(l);
                 if (e0 && e1) (void)hipEventRecord(e0, s);
             }
+            (void)uavenv_set_step_meta(c.env, meta_t, nullptr);
             rc = uavenv_step(c.env, act_t, UAVENV_ACT_INDEX_I32, obs_n, nullptr, R.reward + (size_t)t * n, R.done + (size_t)t * n,
                              nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, s);
         }
@@ -537,6 +541,8 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             rc = uavenv_sac_act_multi(actors, R.obs, first, U, envs, eps, c.action_bound, act0, c.act1_plane, U, s);
             if (rc != UAVENV_OK) return rc;
         }
+        (void)uavenv_set_step_meta(c.env, R.meta ? (unsigned char *)R.meta + (size_t)t * n * UAVENV_META_BYTES : nullptr,
+                                   R.meta ? c.act1_plane + (size_t)t * n : nullptr);
         rc = uavenv_step(c.env, act0 + (size_t)t * n, UAVENV_ACT_STEER_F32, (unsigned char *)R.obs + (size_t)nxt * l->obs_row_bytes, nullptr,
                          R.reward + (size_t)t * n, R.done + (size_t)t * n, nullptr, c.info_dev ? c.info_dev + (size_t)t * n : nullptr,
                          R.valid + (size_t)t * n, nullptr, nullptr, c.step_flags, s);
@@ -596,6 +602,7 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             b.draws = draws;
             b.n_agents = R.n_agents; b.uav_per_env = U; b.slot = j; b.frames = R.frames;
             b.act0 = act0; b.act1 = c.act1_plane; b.reward = R.reward; b.done = R.done; b.valid = R.valid;
+            b.meta = R.meta;
             b.batch = B;
             if (l->per) { b.is_weights = sl.per_w_dev; b.abs_td_out = sl.per_abs_dev; }
             b.td_scratch = sl.td_dev;

@@ -96,6 +96,8 @@ struct SacArgs {
     int n_agents, uav, slot, frames;
     const float *act0, *act1, *reward;    // planes indexed by the row of s
     const uint8_t *done, *valid;          // valid nullable (= all 1)
+    const uint4 *meta;                    // nullable: the ring's transition records {a1, a0, reward, done | valid << 8 | info << 16}, indexed
+                                          // by the row of s -- ONE 16-byte gather instead of a line from each of the five planes above
     const float *eps;                     // [batch][2] N(0,1) draws of this phase's rsample()
     int batch, tiles_per_wg;
     const float *actor, *c1, *c2, *t1, *t2, *log_alpha;
@@ -780,12 +782,21 @@ __device__ __forceinline__ void tile_in(const SacArgs &g, int tile, TileIn &T)
     T.a0 = T.a1 = T.rew = T.nd = 0.0f;
     T.w = 1.0f;
     T.isw = (CRITIC && !NEXT && g.is_w) ? g.is_w[smp] : 1.0f;
-    if (CRITIC) {
-        if (NEXT) { T.rew = g.reward[rs]; T.nd = 1.0f - (float)g.done[rs]; }
-        else { T.a0 = g.act0[rs]; T.a1 = g.act1[rs]; }
+    if (g.meta) {                         // the transition's scalars from its one record (include/uavenv.h: UavReplayRing.meta)
+        const uint4 m = g.meta[rs];
+        if (CRITIC) {
+            if (NEXT) { T.rew = __uint_as_float(m.z); T.nd = 1.0f - (float)(m.w & 0xffu); }
+            else { T.a0 = __uint_as_float(m.y); T.a1 = __uint_as_float(m.x); }
+        }
+        if (!NEXT) T.w = (float)((m.w >> 8) & 0xffu);
+    } else {
+        if (CRITIC) {
+            if (NEXT) { T.rew = g.reward[rs]; T.nd = 1.0f - (float)g.done[rs]; }
+            else { T.a0 = g.act0[rs]; T.a1 = g.act1[rs]; }
+        }
+        // rows of agents that were only waiting for their team-mates (valid = 0) are not replay memory: weight 0 in every loss
+        if (!NEXT) T.w = g.valid ? (float)g.valid[rs] : 1.0f;
     }
-    // rows of agents that were only waiting for their team-mates (valid = 0) are not replay memory: weight 0 in every loss
-    if (!NEXT) T.w = g.valid ? (float)g.valid[rs] : 1.0f;
     if (NEXT || !CRITIC) { T.e0 = g.eps[2 * smp]; T.e1 = g.eps[2 * smp + 1]; } else { T.e0 = T.e1 = 0.0f; }
 }
 
@@ -879,8 +890,14 @@ __device__ __forceinline__ void tile_in_s(const SacArgs &g, int tile, int wv, Ti
     uint32_t rs, rn;
     sample_rows(g, smp, rs, rn);
     prow_load(T.R, g.obs + (size_t)rn * kPackedDwords);
-    T.rew = g.reward[rs];
-    T.nd = 1.0f - (float)g.done[rs];
+    if (g.meta) {
+        const uint4 m = g.meta[rs];
+        T.rew = __uint_as_float(m.z);
+        T.nd = 1.0f - (float)(m.w & 0xffu);
+    } else {
+        T.rew = g.reward[rs];
+        T.nd = 1.0f - (float)g.done[rs];
+    }
     T.e0 = g.eps[2 * smp];
     T.e1 = g.eps[2 * smp + 1];
 }
@@ -1451,8 +1468,9 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
         !aligned16(partials) || !aligned16(b->obs_packed))
         return sac_fail(UAVENV_EINVAL, "uavenv_sac: parameter blocks, partial rows and the observation rows must be 16-byte aligned");
     if (b->batch <= 0 || b->batch % kTile) return sac_fail(UAVENV_EINVAL, "uavenv_sac: batch must be a positive multiple of 64");
-    if (!b->obs_packed || !b->act0 || !b->act1 || !b->reward || !b->done || !b->eps)
+    if (!b->obs_packed || !b->eps || (!b->meta && (!b->act0 || !b->act1 || !b->reward || !b->done)))
         return sac_fail(UAVENV_EINVAL, "uavenv_sac: null batch plane");
+    if (!aligned16(b->meta)) return sac_fail(UAVENV_EINVAL, "uavenv_sac: the transition records are 16-byte aligned");
     if (!b->draws && (!b->idx_s || !b->idx_n)) return sac_fail(UAVENV_EINVAL, "uavenv_sac: neither draws nor row indices");
     if (b->draws && (b->n_agents <= 0 || b->uav_per_env <= 0 || b->slot < 0 || b->slot >= b->uav_per_env || b->frames < 2))
         return sac_fail(UAVENV_EINVAL, "uavenv_sac: draws need n_agents / uav_per_env / slot / frames");
@@ -1460,6 +1478,7 @@ int fill_args(const UavSacNets *n, const UavSacBatch *b, float *partials, SacArg
     g.idx_s = b->idx_s; g.idx_n = b->idx_n; g.draws = b->draws;
     g.n_agents = b->n_agents; g.uav = b->uav_per_env; g.slot = b->slot; g.frames = b->frames;
     g.act0 = b->act0; g.act1 = b->act1; g.reward = b->reward; g.done = b->done; g.valid = b->valid;
+    g.meta = reinterpret_cast<const uint4 *>(b->meta);
     g.eps = b->eps;
     g.is_w = b->is_weights;
     g.abs_td = b->abs_td_out;

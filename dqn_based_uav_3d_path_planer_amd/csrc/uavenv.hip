@@ -143,6 +143,9 @@ struct StepArgs {
     // uavenv_set_moved_word: stamped with moved_value by a step launch that moved at least one agent (valid = 1)
     uint32_t *moved_word;
     uint32_t moved_value;
+    // uavenv_set_step_meta: the transition records of this launch ({a1, a0, reward, done | valid << 8 | info << 16}; include/uavenv.h)
+    uint4 *meta;                       // nullable [N]
+    const float *meta_a1;              // nullable [N]: the second action component to record
 };
 
 struct UavEnv {
@@ -170,6 +173,8 @@ struct UavEnv {
     uint64_t seed = 0, tick = 0;
     unsigned long long *dbg = nullptr;
     uint32_t *moved_word = nullptr;    // uavenv_set_moved_word
+    void *step_meta = nullptr;         // uavenv_set_step_meta: consumed by the next step launch
+    const float *step_meta_a1 = nullptr;
     // rolling refresh of the bank (uavenv_replan_*): staged plans of one slice + bookkeeping
     double *rp_sg = nullptr, *rp_sub = nullptr;
     int32_t *rp_nsub = nullptr;        // [cap] staged n_sub, then [cap] in-use flags
@@ -329,6 +334,12 @@ __device__ __forceinline__ bool cal_force(const StepArgs &a, double x, double y,
 struct RawAction {
     uint32_t lo, hi;
 };
+// the action as a transition record keeps it (include/uavenv.h: UavReplayRing.meta): the int32 index or the f32 steer bits as
+// read; an f64 steer is narrowed to f32
+__device__ __forceinline__ uint32_t meta_action_bits(const RawAction &ra, int kind, double a0)
+{
+    return kind == UAVENV_ACT_STEER_F64 ? __float_as_uint((float)a0) : ra.lo;
+}
 __device__ __forceinline__ RawAction load_action_raw(const void *actions, int kind, int i)
 {
     RawAction r;
@@ -966,10 +977,12 @@ __device__ __forceinline__ void k_step_body(const StepArgs &a)
     // issue the first tile's state loads BEFORE the world is staged: their HBM latency overlaps the LDS fill
     Agent g;
     RawAction ra = {0u, 0u};
+    uint32_t meta_a1 = 0u;                                                     // (second action component for the transition record)
     if (i < n_round) {
         const int ii = i < N ? i : N - 1;
         load_agent(S, ii, g);
         if (!POLH) ra = load_action_raw(a.actions, a.action_kind, ii);
+        if (a.meta_a1) meta_a1 = __float_as_uint(a.meta_a1[ii]);
     }
     uint4 pol_rn = make_uint4(0u, 0u, 0u, 0u);
     if (POLH) pol_rn = uavq::policy_philox(i, a.pol_seed, a.pol_counter);       // under the state loads
@@ -1059,6 +1072,9 @@ __device__ __forceinline__ void k_step_body(const StepArgs &a)
             if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
             if (a.info) a.info[i] = (uint8_t)info;
             if (a.valid) a.valid[i] = (uint8_t)valid;
+            if (a.meta)                                                      // the transition record (one 16-byte store per agent)
+                a.meta[i] = make_uint4(meta_a1, meta_action_bits(ra, POLH ? UAVENV_ACT_INDEX_I32 : a.action_kind, a0),
+                                       __float_as_uint((float)r), (uint32_t)ret_done | ((uint32_t)valid << 8) | ((uint32_t)info << 16));
             if (a.moved_word && valid)                                       // (every writer stores the same value)
                 __hip_atomic_store(a.moved_word, a.moved_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.energy64) a.energy64[i] = energy;
@@ -1165,9 +1181,11 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     Agent g;
     RawAction ra = {0u, 0u};
     double head_old = 0.0;
+    uint32_t meta_a1 = 0u;               // (second action component for the transition record)
     if (wv == 0) {                       // the state loads fly while the other three wavefronts stage the world blob
         load_agent(S, ii, g);
         if (!POLICY) ra = load_action_raw(a.actions, a.action_kind, ii);
+        if (a.meta_a1) meta_a1 = __float_as_uint(a.meta_a1[ii]);
     } else if (wv == 2) {                // wave 2 computes the heading after the move (:423): old heading + action only
         head_old = S.F(F_HEAD)[ii];
         if (!POLICY) ra = load_action_raw(a.actions, a.action_kind, ii);
@@ -1335,6 +1353,9 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             if (a.agent_done) a.agent_done[i] = (uint8_t)agent_done;
             if (a.info) a.info[i] = (uint8_t)info;
             if (a.valid) a.valid[i] = (uint8_t)valid;
+            if (a.meta)                                                      // the transition record (one 16-byte store per agent)
+                a.meta[i] = make_uint4(meta_a1, meta_action_bits(ra, POLICY ? UAVENV_ACT_INDEX_I32 : a.action_kind, a0),
+                                       __float_as_uint((float)r), (uint32_t)ret_done | ((uint32_t)valid << 8) | ((uint32_t)info << 16));
             if (a.moved_word && valid)                                       // (every writer stores the same value)
                 __hip_atomic_store(a.moved_word, a.moved_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.energy64) a.energy64[i] = energy;
@@ -1566,6 +1587,8 @@ static StepArgs base_args(const UavEnv *e)
     a.tick = e->tick;
     a.moved_word = e->moved_word;
     a.moved_value = (uint32_t)(e->tick + 1);
+    a.meta = nullptr;                  // (the step entry points hand the pending records over: take_step_meta)
+    a.meta_a1 = nullptr;
     a.dbg = e->dbg;
     return a;
 }
@@ -1615,6 +1638,15 @@ static void launch_geometry(int n, int &block, int &grid)
     block = n <= thr ? 64 : big;
     grid = (n + block - 1) / block;
     if (grid < 1) grid = 1;
+}
+
+// the records asked for by uavenv_set_step_meta go to THIS launch and no further (a stale frame pointer must never be written again)
+static void take_step_meta(UavEnv *e, StepArgs &a)
+{
+    a.meta = reinterpret_cast<uint4 *>(e->step_meta);
+    a.meta_a1 = e->step_meta_a1;
+    e->step_meta = nullptr;
+    e->step_meta_a1 = nullptr;
 }
 
 template <typename MaskT>
@@ -2122,6 +2154,15 @@ int uavenv_replan_commit(UavEnv *e, int32_t force, void *stream)
     return UAVENV_OK;
 }
 
+int uavenv_set_step_meta(UavEnv *e, void *meta_frame_dev, const float *action1_frame_dev)
+{
+    if (!e) return fail(UAVENV_EINVAL, "null env");
+    if ((((uintptr_t)meta_frame_dev) & 15u) != 0) return fail(UAVENV_EINVAL, "uavenv_set_step_meta: records are 16-byte aligned");
+    e->step_meta = meta_frame_dev;
+    e->step_meta_a1 = meta_frame_dev ? action1_frame_dev : nullptr;
+    return UAVENV_OK;
+}
+
 int uavenv_set_moved_word(UavEnv *e, uint32_t *dev_word)
 {
     if (!e) return fail(UAVENV_EINVAL, "null env");
@@ -2255,6 +2296,7 @@ int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, 
     a.energy64 = energy64;
     a.active = active;
     a.flags = flags;
+    take_step_meta(e, a);
     if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
     else launch_step<uint64_t>(e, a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -2318,6 +2360,7 @@ int uavenv_step_policy_img(UavEnv *e, const UavDqnNet *net, const void *obs_cur,
     a.pol_eps = eps;
     a.pol_seed = seed;
     a.pol_counter = counter;
+    take_step_meta(e, a);
     if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
     else launch_step<uint64_t>(e, a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());

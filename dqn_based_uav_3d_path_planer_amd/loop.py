@@ -205,6 +205,7 @@ class SACHotLoop:
         cfg.ring = ring._c
         assert act1_plane.dtype == torch.float32 and tuple(act1_plane.shape) == (ring.frames, env.N) and act1_plane.is_contiguous()
         cfg.act1_plane = act1_plane.data_ptr()
+        ring.attach_action1(act1_plane)      # (Python-issued steps around the loop record the second action component too)
         if info is not None:
             assert info.dtype == torch.uint8 and tuple(info.shape) == (ring.frames, env.N) and info.is_contiguous()
             cfg.info_dev = info.data_ptr()

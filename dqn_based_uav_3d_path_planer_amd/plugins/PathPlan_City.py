@@ -190,6 +190,7 @@ class PathPlan_City:
             ring = self._ring
             self._info = torch.zeros((ring.frames, N), dtype=torch.uint8, device=d)
             self._a1 = torch.zeros((ring.frames, N), dtype=torch.float32, device=d)          # second action component (:444-448)
+            ring.attach_action1(self._a1)                        # ... recorded with every transition (DeviceReplayRing.meta)
             bs = [u.Trainer.Batch_Size for u in self.Agents]
             self._draws_all = torch.empty((sum(bs), 2), dtype=torch.int32, device=d)       # one draw launch per step for all slots
             offs = np.cumsum([0] + bs)
@@ -208,7 +209,8 @@ class PathPlan_City:
                                                               ring.done.view(-1), valid=ring.valid.view(-1), draws=self._draws[j],
                                                               n_agents=N, uav_per_env=self.num_UAV, slot=j, frames=ring.frames,
                                                               is_weights=None if self._sac_per[j] is None else self._sac_per_bufs[j]["w"],
-                                                              abs_td_out=None if self._sac_per[j] is None else self._sac_per_bufs[j]["abs"])
+                                                              abs_td_out=None if self._sac_per[j] is None else self._sac_per_bufs[j]["abs"],
+                                                              meta=ring.meta.view(-1, 4))
                                  for j, u in enumerate(self.Agents)]
             self._sac_counter = 0
             for u in self.Agents:

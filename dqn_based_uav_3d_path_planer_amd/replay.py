@@ -28,11 +28,15 @@ class DeviceReplayRing:
         self.reward = torch.zeros((self.frames, n), dtype=torch.float32, device=d)
         self.done = torch.zeros((self.frames, n), dtype=torch.uint8, device=d)
         self.valid = torch.zeros((self.frames, n), dtype=torch.uint8, device=d)
+        # transition records (ABI 5: UavReplayRing.meta): {a1, a0, reward, done | valid << 8 | info << 16} per (frame, agent), written by
+        # the step kernels next to the planes; the fused learners gather ONE 16-byte record per sample instead of a line from each plane
+        self.meta = torch.zeros((self.frames, n, 4), dtype=torch.int32, device=d)
+        self.action1 = None    # [frames, N] f32, optional: the second action component (SAC) for the records (attach_action1)
         self.head = 0          # frame whose obs is the current state (its action/reward are not written yet)
         self.filled = 0        # complete transitions frames behind head
         self._c = _lib.UavReplayRing(self.obs.data_ptr(), self.action.data_ptr(), self.reward.data_ptr(),
                                      self.done.data_ptr(), self.valid.data_ptr(), self.frames, n,
-                                     env.obs_code, 1 if discrete else 0)
+                                     env.obs_code, 1 if discrete else 0, self.meta.data_ptr())
         self._obs_stride = n * env.obs_width * self.obs.element_size()
         self._batch_bufs = {}
         self.extra_flags = 0           # diagnostics (e.g. _lib.STEP_NO_OBS to time the step without the observation)
@@ -47,6 +51,18 @@ class DeviceReplayRing:
     def reset(self, seed: int = 0):
         self.head, self.filled = 0, 0
         self.env.reset(seed, obs=self.obs[0])
+
+    def attach_action1(self, plane: torch.Tensor):
+        """The plane that holds the second action component of every frame (SAC_Trainer.get_action's action[1], which the env never
+        reads): from now on the step launches copy it into the transition records, so that a learner given `meta` finds both."""
+        assert plane.dtype == torch.float32 and tuple(plane.shape) == (self.frames, self.env.N) and plane.is_contiguous()
+        self.action1 = plane
+
+    def _set_step_meta(self, t: int):
+        n = self.env.N
+        a1 = None if self.action1 is None else self.action1.data_ptr() + t * n * 4
+        _lib.check(self.env.lib.uavenv_set_step_meta(self.env._h, self.meta.data_ptr() + t * n * _lib.META_BYTES, a1),
+                   "uavenv_set_step_meta")
 
     def current_obs(self) -> torch.Tensor:
         return self.obs[self.head]
@@ -67,6 +83,7 @@ class DeviceReplayRing:
         n = self.env.N
         flags = (_lib.STEP_AUTO_RESET if auto_reset else 0) | (_lib.STEP_SKIP_DONE if skip_done else 0) | self.extra_flags
         kind = _lib.ACT_INDEX_I32 if self.discrete else _lib.ACT_STEER_F32
+        self._set_step_meta(t)
         self.env.step_raw(self.action.data_ptr() + t * n * 4, kind, self.obs.data_ptr() + nxt * self._obs_stride,
                           self.reward.data_ptr() + t * n * 4, self.done.data_ptr() + t * n,
                           self.valid.data_ptr() + t * n, flags,
@@ -87,6 +104,7 @@ class DeviceReplayRing:
         # (image: learner.split_image() -- the launch as the C loop issues it, csrc/dqn_internal.hpp; same actions)
         fn = self.env.lib.uavenv_step_policy if image is None else self.env.lib.uavenv_step_policy_img
         tail = (self.env._stream(),) if image is None else (image.data_ptr(), self.env._stream())
+        self._set_step_meta(t)
         rc = fn(self.env._h, C.byref(learner.net), self.obs.data_ptr() + t * self._obs_stride,
                 float(eps), int(seed), int(counter), self.action.data_ptr() + t * n * 4,
                 self.obs.data_ptr() + nxt * self._obs_stride, None,

@@ -203,12 +203,17 @@ class FusedSACLearner:
             raise self._lib.UavEnvError(f"{what} failed with code {rc}: {self.lib.uavenv_sac_last_error().decode()}")
 
     def make_batch(self, obs_packed: torch.Tensor, act0, act1, reward, done, *, valid=None, idx_s=None, idx_n=None,
-                   draws=None, n_agents=0, uav_per_env=1, slot=0, frames=0, is_weights=None, abs_td_out=None, tiles_per_wg=0):
+                   draws=None, n_agents=0, uav_per_env=1, slot=0, frames=0, is_weights=None, abs_td_out=None, tiles_per_wg=0,
+                   meta=None):
         """Describe the sampled transitions in place (see UavSacBatch in include/uavenv.h).  Keeps the tensors alive.
         is_weights / abs_td_out (f32 [batch], prioritised replay): importance weights into the critic losses, and where
         uavenv_sac_critic_grad leaves |min(Q1, Q2) - td_target| per sample.  tiles_per_wg: 0 = chosen per launch; > 0 pins the
-        partition of the partial rows (and with it the summation order) whatever shares the launch."""
-        keep = (obs_packed, act0, act1, reward, done, valid, idx_s, idx_n, draws, is_weights, abs_td_out)
+        partition of the partial rows (and with it the summation order) whatever shares the launch.
+        meta: the ring's transition records (DeviceReplayRing.meta, flattened) -- the kernels then gather one 16-byte record per
+        sample instead of a line from each of act0 / act1 / reward / done / valid.  Only for a ring whose steps recorded the second
+        action component (DeviceReplayRing.attach_action1)."""
+        keep = (obs_packed, act0, act1, reward, done, valid, idx_s, idx_n, draws, is_weights, abs_td_out, meta)
+        assert meta is None or (meta.dtype == torch.int32 and meta.is_contiguous())
         for t in (is_weights, abs_td_out):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
         n = int(draws.shape[0]) if draws is not None else int(idx_s.numel())
@@ -221,7 +226,7 @@ class FusedSACLearner:
         td = torch.empty(2 * n, dtype=torch.float32, device=self.device)      # the td targets of an update (k_sac_td -> k_sac_critic_grad)
         b = self._lib.UavSacBatch(obs_packed.data_ptr(), ptr(idx_s), ptr(idx_n), ptr(draws), int(n_agents), int(uav_per_env),
                                   int(slot), int(frames), act0.data_ptr(), act1.data_ptr(), reward.data_ptr(), done.data_ptr(),
-                                  ptr(valid), None, n, int(tiles_per_wg), ptr(is_weights), ptr(abs_td_out), td.data_ptr())
+                                  ptr(valid), None, n, int(tiles_per_wg), ptr(is_weights), ptr(abs_td_out), ptr(meta), td.data_ptr())
         b._keep = keep + (td,)
         return b
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 4
+#define UAVENV_ABI_VERSION 5
 #define UAVENV_OBS_DIM 100          /* Agents/UAV.py:517  state_map = zeros(1,1,1,100) */
 #define UAVENV_MAX_BUILDINGS 64     /* broad-phase masks are 64-bit */
 
@@ -226,7 +226,19 @@ typedef struct UavReplayRing {
     int32_t n_agents;
     int32_t obs_dtype;
     int32_t action_is_index;
+    void *meta;           /* ABI 5, nullable: frames x N transition records of 16 bytes {a1, a0, reward, flags} -- the action as the step
+                             consumed it (int32 index or f32 steer bits; a1 = the second SAC action component or 0), the f32 reward, and
+                             done | valid << 8 | info << 16 -- written by the step kernels next to the planes above (uavenv_set_step_meta).
+                             A learner that finds it gathers ONE 16-byte record per sample instead of a line each from the action, reward,
+                             done and valid planes (round 5: those four scattered loads were ~45 % of a gradient launch's HBM fetch);
+                             the planes stay the source of truth for everything else.  NULL: the kernels read the planes. */
 } UavReplayRing;
+#define UAVENV_META_BYTES 16
+/* The next step launch of this env (uavenv_step / uavenv_step_policy; ONE launch, then forgotten) also writes the transition records
+ * of its N agents to meta_frame_dev (N x UAVENV_META_BYTES: the frame of a ring's `meta` that its reward / done pointers aim at);
+ * action1_frame_dev (nullable, N floats): the second action component to put into the records (SAC_Trainer.get_action's
+ * action[1], :444-448, which the step itself never reads).  NULL meta: nothing is written (the default). */
+int uavenv_set_step_meta(UavEnv *env, void *meta_frame_dev, const float *action1_frame_dev);
 
 /* ReplayMemory.sample2 = random.sample(memory, batch) (replay_buffer.py:48-51) on device: `batch` DISTINCT stored
  * transitions (frame, agent) out of the `filled` frames preceding `head` -- the first `batch` images of a keyed
@@ -569,6 +581,9 @@ typedef struct UavSacBatch {
      * |min(Q1, Q2)(s, a) - td_target| of output column 0 (:351) -- written by uavenv_sac_critic_grad. */
     const float *is_weights;
     float *abs_td_out;
+    const void *meta;                    /* ABI 5, nullable: the ring's transition records (UavReplayRing.meta), indexed by the row of s:
+                                            when set, a0 / a1 / reward / done / valid of a sample come from its ONE record instead of
+                                            a line each from the five planes above (which may then be NULL) */
     float *td_scratch;                   /* ABI 4, nullable: batch x 2 floats of device scratch.  With it uavenv_sac_critic_grad computes the
                                             td targets (:122-131) in a launch of its own -- two tiles in flight per workgroup, two
                                             wavefronts per SIMD -- and the gradient kernel reads them from here; without it the

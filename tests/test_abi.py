@@ -50,7 +50,7 @@ def test_loop_internal_entry_points_are_exported():
 def test_config_struct_layout_matches_header():
     # 10 int32 + 5 doubles + 8 doubles + 1 double, naturally aligned
     assert ctypes.sizeof(_lib.UavEnvConfig) == 10 * 4 + 14 * 8
-    assert ctypes.sizeof(_lib.UavReplayRing) == 5 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.UavReplayRing) == 5 * 8 + 4 * 4 + 8        # (+ meta, ABI 5)
 
 
 def test_every_struct_layout_matches_the_header_as_gcc_sees_it(tmp_path):
