@@ -1641,12 +1641,16 @@ static void launch_geometry(int n, int &block, int &grid)
 }
 
 // the records asked for by uavenv_set_step_meta go to THIS launch and no further (a stale frame pointer must never be written again)
-static void take_step_meta(UavEnv *e, StepArgs &a)
+struct PendingMeta {
+    void *meta;
+    const float *a1;
+};
+static PendingMeta take_step_meta(UavEnv *e)
 {
-    a.meta = reinterpret_cast<uint4 *>(e->step_meta);
-    a.meta_a1 = e->step_meta_a1;
+    PendingMeta p{e->step_meta, e->step_meta_a1};
     e->step_meta = nullptr;
     e->step_meta_a1 = nullptr;
+    return p;
 }
 
 template <typename MaskT>
@@ -2279,6 +2283,7 @@ int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, 
                 const uint8_t *active, uint32_t flags, void *stream)
 {
     if (!e || !actions) return fail(UAVENV_EINVAL, "null env/actions");
+    const PendingMeta pm = take_step_meta(e);         // (consumed by THIS call, whether or not it gets as far as a launch)
     if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step before uavenv_set_buildings");
     if (action_kind < 0 || action_kind > 2) return fail(UAVENV_EINVAL, "action_kind %d", action_kind);
     if ((flags & UAVENV_STEP_AUTO_RESET) && e->bank_m <= 0)
@@ -2296,7 +2301,8 @@ int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, 
     a.energy64 = energy64;
     a.active = active;
     a.flags = flags;
-    take_step_meta(e, a);
+    a.meta = reinterpret_cast<uint4 *>(pm.meta);
+    a.meta_a1 = pm.a1;
     if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
     else launch_step<uint64_t>(e, a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -2318,6 +2324,7 @@ int uavenv_step_policy_img(UavEnv *e, const UavDqnNet *net, const void *obs_cur,
                            const float *image_dev, void *stream)
 {
     if (!e || !net || !net->local || !obs_cur || !action_out) return fail(UAVENV_EINVAL, "null argument");
+    const PendingMeta pm = take_step_meta(e);         // (consumed by THIS call: a caller that falls back to act + step asks again)
     if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step_policy before uavenv_set_buildings");
     if ((flags & UAVENV_STEP_AUTO_RESET) && e->bank_m <= 0)
         return fail(UAVENV_EINVAL, "AUTO_RESET needs a scenario bank (uavenv_load_scenarios)");
@@ -2360,7 +2367,8 @@ int uavenv_step_policy_img(UavEnv *e, const UavDqnNet *net, const void *obs_cur,
     a.pol_eps = eps;
     a.pol_seed = seed;
     a.pol_counter = counter;
-    take_step_meta(e, a);
+    a.meta = reinterpret_cast<uint4 *>(pm.meta);
+    a.meta_a1 = pm.a1;
     if (e->mask_bytes == 4) launch_step<uint32_t>(e, a, (hipStream_t)stream);
     else launch_step<uint64_t>(e, a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
