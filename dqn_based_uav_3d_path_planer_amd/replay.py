@@ -17,7 +17,9 @@ from .env import VecPathPlanEnv
 
 
 class DeviceReplayRing:
-    def __init__(self, env: VecPathPlanEnv, capacity_transitions: int, discrete: bool = True):
+    def __init__(self, env: VecPathPlanEnv, capacity_transitions: int, discrete: bool = True, records: bool = True):
+        """records: keep the 16-byte transition records next to the planes (what the fused learners gather).  A ring nothing
+        learns from (a rollout-only measurement) can do without them: the step kernels then skip that store."""
         self.env = env
         n = env.N
         self.frames = max(3, -(-int(capacity_transitions) // n) + 1)
@@ -30,13 +32,13 @@ class DeviceReplayRing:
         self.valid = torch.zeros((self.frames, n), dtype=torch.uint8, device=d)
         # transition records (ABI 5: UavReplayRing.meta): {a1, a0, reward, done | valid << 8 | info << 16} per (frame, agent), written by
         # the step kernels next to the planes; the fused learners gather ONE 16-byte record per sample instead of a line from each plane
-        self.meta = torch.zeros((self.frames, n, 4), dtype=torch.int32, device=d)
+        self.meta = torch.zeros((self.frames, n, 4), dtype=torch.int32, device=d) if records else None
         self.action1 = None    # [frames, N] f32, optional: the second action component (SAC) for the records (attach_action1)
         self.head = 0          # frame whose obs is the current state (its action/reward are not written yet)
         self.filled = 0        # complete transitions frames behind head
         self._c = _lib.UavReplayRing(self.obs.data_ptr(), self.action.data_ptr(), self.reward.data_ptr(),
                                      self.done.data_ptr(), self.valid.data_ptr(), self.frames, n,
-                                     env.obs_code, 1 if discrete else 0, self.meta.data_ptr())
+                                     env.obs_code, 1 if discrete else 0, None if self.meta is None else self.meta.data_ptr())
         self._obs_stride = n * env.obs_width * self.obs.element_size()
         self._batch_bufs = {}
         self.extra_flags = 0           # diagnostics (e.g. _lib.STEP_NO_OBS to time the step without the observation)
@@ -59,6 +61,8 @@ class DeviceReplayRing:
         self.action1 = plane
 
     def _set_step_meta(self, t: int):
+        if self.meta is None:
+            return
         n = self.env.N
         a1 = None if self.action1 is None else self.action1.data_ptr() + t * n * 4
         _lib.check(self.env.lib.uavenv_set_step_meta(self.env._h, self.meta.data_ptr() + t * n * _lib.META_BYTES, a1),
