@@ -28,7 +28,7 @@ for PMC in "${SETS[@]}"; do
   (cd /tmp && rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d /tmp/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py $PARGS) > /tmp/pmc_$N.log 2>&1
   F=$(find /tmp/pmc_$N -name "*counter_collection.csv" | head -1)
   python - "$F" "$TAG" <<'PY' | tee -a $OUT/${TAG}_pmc.txt
-import csv, sys, collections
+import csv, sys, collections, re
 f = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 try:
@@ -36,7 +36,9 @@ try:
         k = r.get("Kernel_Name", "")
         for short in ("k_step", "k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam", "k_apf_adjust", "k_sac_critic_grad", "k_sac_actor_grad", "k_sac_reduce_adam", "k_sac"):
             if short in k:
-                if short == "k_step" and (k.rstrip().endswith("true>(StepArgs)") or "k_step_polh" in k):
+                m = re.search(r"k_step_coop<([^>]*)>", k)
+                pol = bool(m) and len(m.group(1).split(",")) >= 4 and m.group(1).split(",")[3].strip() == "true"
+                if short == "k_step" and (pol or "k_step_polh" in k):
                     short = "k_step_policy"          # the step kernel with the policy in its prologue
                 agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 break

@@ -17,11 +17,20 @@ stats = os.path.join(src, f"{tag}_kernel_stats.csv")
 pmc = os.path.join(src, f"{tag}_pmc.txt")
 entry = {"files": f"profiles/{tag}_kernel_stats.csv, profiles/{tag}_pmc.txt"}
 avg = {}
+def coop_has_policy(full):
+    """k_step_coop<MaskT, APF, OBS, POLICY[, PAHEAD]>: is the fourth template argument true?"""
+    m = re.search(r"k_step_coop<([^>]*)>", full)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(1).split(",")]
+    return len(args) >= 4 and args[3] == "true"
+
+
 def short_name(full):
     """kernel family of a rocprofv3 kernel name; the step kernel that carries the policy in its prologue
     (k_step_coop<..., true>) is its own family"""
     if "k_step" in full:
-        return "k_step_policy" if (full.rstrip().endswith("true>(StepArgs)") or "k_step_polh" in full) else "k_step"
+        return "k_step_policy" if (coop_has_policy(full) or "k_step_polh" in full) else "k_step"
     for short in ("k_dqn_grad", "k_dqn_act", "k_dqn_reduce_adam", "k_apf_adjust", "k_sac_critic_grad", "k_sac_actor_grad", "k_sac_reduce_adam"):
         if short in full:
             return short
