@@ -731,7 +731,8 @@ __device__ __forceinline__ void w_issue_half(floatx4 (&v)[kStageIters], const fl
 }
 
 struct GradAcc8 {
-    floatx4 acc[4];                  // group 0: dW1^T k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and the dW2^T tile
+    floatx4 acc[6];                  // group 0: dW1^T k-column tiles 0, 2, 4, 6; group 1: tiles 1, 3, 5 and the dW2^T tile
+                                     // (form B of the split products: group 1 all six flag tiles, group 0 the gathered tile and dW2^T)
     float csum[6];                   // group 0: column sums of dout (NMAX = 4), loss sum, valid count of its strips
 };
 
@@ -818,13 +819,104 @@ __device__ __forceinline__ void grad_products_split8(const GradLdsP &L, const fl
     for (int k = 0; k < 4; ++k) A.acc[3][k] += c32[k];
 }
 
+// Form B of the split products (SPLIT == 2): the two groups' work is not symmetric -- group 0 carries the TD target and dL/dH while
+// group 1 waits -- so group 1 takes ALL six flag tiles and builds their A operands (the flag bits of every sample: they depend on the
+// packed rows only) while group 0 is still in td_backward; behind the barrier group 1 has 24 f16 MFMAs + the split of its sixteen dH
+// values left, group 0 the two f32 products (the gathered scalar tile x dH, H x dout).  Same operands in the same K order per
+// accumulator as form A: bit-identical results.
+struct FlagOps {
+    half8 one[2][6];                 // (the 2^-11 operand of the mid term is derived from it behind the barrier: two instructions per dword)
+};
+__device__ __forceinline__ half8 tiny_of(const half8 &one)
+{
+    uintx4 d = *reinterpret_cast<const uintx4 *>(&one);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = (d[k] << 2) & 0x10001000u;          // 0x3c00 (1.0) -> 0x1000 (2^-11), per half
+    return *reinterpret_cast<const half8 *>(&d);
+}
+__device__ __forceinline__ void flag_ops_build(const GradLdsP &L, int r, int gq, FlagOps &F)
+{
+    const uint32_t *pr = L.Ps + 4 * gq * kPackedDwords;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        uintx4 mk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mk[i] = *reinterpret_cast<const uintx4 *>(pr + (32 * q + 16 * (i >> 2) + (i & 3)) * kPackedDwords);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            half8 tiny;
+            flags_to_half8(mk, u >> 1, (uint32_t)(16 * (u & 1) + r), F.one[q][u], tiny);
+        }
+    }
+}
+__device__ __forceinline__ void grad_products_split8b(const GradLdsP &L, const float *amax4, int grp, int strip, int r, int gq,
+                                                      const FlagOps &F, GradAcc8 &A)
+{
+    const float *db = L.dHs + 4 * gq * kLh + 16 * strip + r;
+    float dh[2][8];
+    if (grp == 1) {
+        float up, down;
+        split_scale(fmaxf(fmaxf(amax4[0], amax4[1]), fmaxf(amax4[2], amax4[3])), up, down);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dh[q][i] = db[(32 * q + 16 * (i >> 2) + (i & 3)) * kLh];
+        floatx4 ch[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) ch[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            half8 bh, bm;
+            split_half8(dh[q], up, bh, bm);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) ch[u] = mfma16h(F.one[q][u], bh, ch[u]);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) ch[u] = mfma16h(tiny_of(F.one[q][u]), bm, ch[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) A.acc[u][k] += ch[u][k] * down;
+        return;
+    }
+    // group 0: the gathered scalar tile (entry r: packed dword 4 + r, 15 = the ones column) x dH, and H x dout (dW2^T)
+    const uint32_t *pr = L.Ps + 4 * gq * kPackedDwords;
+    const int dsc = r < 15 ? 4 + r : 19;
+    const float *ha = L.Hs + 4 * gq * kLh + 16 * strip + r;
+    const float *ob = L.douts + 4 * gq * kMaxOut + r;
+    float xs[2][8], hh[2][8], bo[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s1 = 32 * q + 16 * (i >> 2) + (i & 3);
+            dh[q][i] = db[s1 * kLh];
+            xs[q][i] = __uint_as_float(pr[s1 * kPackedDwords + dsc]);
+            hh[q][i] = ha[s1 * kLh];
+            bo[q][i] = ob[s1 * kMaxOut];
+        }
+    floatx4 csc = floatx4{0.0f, 0.0f, 0.0f, 0.0f}, cw2 = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    const bool ones = r == 15;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            csc = mfma16(ones ? 1.0f : xs[q][i], dh[q][i], csc);
+            cw2 = mfma16(hh[q][i], bo[q][i], cw2);
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { A.acc[0][k] += csc[k]; A.acc[1][k] += cw2[k]; }
+}
+
 // SPLIT (round 5): the weight-gradient products in the split form -- see grad_products_split8 below.
-template <bool FIRST, bool SPLIT>
+template <bool FIRST, int SPLIT>
 __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradLdsP &L, float *qn_lds, int tile, bool more,
                                                   GradAcc8 &A)
 {
     constexpr int NMAX = 4;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    // (the wavefront index through readfirstlane: the compiler then knows that `grp` branches are wavefront-uniform and lets the two
+    // groups' live ranges share registers)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wv >> 2, strip = wv & 3;
     const int r = lane & 15, gq = lane >> 4, t256 = tid & 255;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     const uint32_t *obs = reinterpret_cast<const uint32_t *>(g.ring.obs);
@@ -913,6 +1005,8 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     L_STAMP(2);
     __syncthreads();                                  // bootstrap values handed over
     L_STAMP(3);
+    FlagOps FO;
+    if (SPLIT == 2 && grp == 1) flag_ops_build(L, r, gq, FO);        // (while group 0 is in td_backward)
     if (grp == 0) {
         GradAcc<NMAX> T;                              // td_backward's accumulator interface: only csum is used here
 #pragma unroll
@@ -932,7 +1026,8 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     __syncthreads();                                  // H, dH, dout and the packed s rows of all 64 samples visible
     L_STAMP(4);
     if (SPLIT) {
-        grad_products_split8(L, qn_lds + kTile, grp, strip, r, gq, A);
+        if (SPLIT == 2) grad_products_split8b(L, qn_lds + kTile, grp, strip, r, gq, FO, A);
+        else grad_products_split8(L, qn_lds + kTile, grp, strip, r, gq, A);
         if (more) __syncthreads();
         return;
     }
@@ -986,7 +1081,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
     if (more) __syncthreads();                        // the next tile overwrites Ps / Hs / dHs / douts / qn
 }
 
-template <bool SPLIT>
+template <int SPLIT>
 __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
 {
     constexpr int NMAX = 4;
@@ -1010,7 +1105,7 @@ __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     GradAcc8 A;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) A.acc[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int u = 0; u < 6; ++u) A.acc[u] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int a = 0; a < 6; ++a) A.csum[a] = 0.0f;
     L_STAMP(0);
@@ -1027,7 +1122,29 @@ __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
     // (round 5, measured: non-temporal stores of the row lengthen this kernel by 0.8 us and shorten the next by as much -- the 6.8 MB
     // of partial rows cross the memory system once either way)
 #define UAV_ROW_ST4(ptr, val) (*reinterpret_cast<floatx4 *>(ptr) = (val))
-    if (SPLIT) {
+    if (SPLIT == 2) {
+        // (grad_products_split8b's register layout) group 1: acc[u] = tile u of the flag columns (exact zeros at the scalar columns, which
+        // group 0 stores from its gathered tile: columns 0..10 and 86..89 are left out here); group 0: acc[0] = the gathered tile
+        // (entries 0..10 = columns 0..10, 11..14 = 86..89, 15 = db1), acc[1] = dW2^T; columns 96..99 are constant zero
+        if (grp == 1) {
+            float *t0 = out + j * kW + 4 * gq;
+            if (gq == 3) UAV_ROW_ST4(t0, A.acc[0]);                      // columns 12..15
+            else if (gq == 2) t0[3] = A.acc[0][3];                       // column 11
+#pragma unroll
+            for (int u = 1; u < 5; ++u) UAV_ROW_ST4(out + j * kW + 16 * u + 4 * gq, A.acc[u]);
+            float *t5 = out + j * kW + 80 + 4 * gq;
+            if (gq == 0 || gq == 3) UAV_ROW_ST4(t5, A.acc[5]);
+            else if (gq == 1) { t5[0] = A.acc[5][0]; t5[1] = A.acc[5][1]; }
+            else { t5[2] = A.acc[5][2]; t5[3] = A.acc[5][3]; }
+        } else {
+            const floatx4 sc = A.acc[0];
+            if (gq < 2) UAV_ROW_ST4(out + j * kW + 4 * gq, sc);                                            // columns 0..7
+            else if (gq == 2) { out[j * kW + 8] = sc[0]; out[j * kW + 9] = sc[1]; out[j * kW + 10] = sc[2]; out[j * kW + 86] = sc[3]; }
+            else { out[j * kW + 87] = sc[0]; out[j * kW + 88] = sc[1]; out[j * kW + 89] = sc[2]; out[kHid * kW + j] = sc[3]; }
+            if (gq == 0) UAV_ROW_ST4(out + j * kW + 96, (floatx4{0.0f, 0.0f, 0.0f, 0.0f}));
+            if (r < n2) UAV_ROW_ST4(out + oW2 + r * kHid + 16 * strip + 4 * gq, A.acc[1]);                  // dW2^T
+        }
+    } else if (SPLIT) {
         // (grad_products_split8's register layout) group 0: tiles 0, 2, 4 + the gathered tile, whose entries 0..10 are columns
         // 0..10 of tile 0 -- held by the same lanes, and exact zeros in the f16 result --, 11..14 columns 86..89 and 15 db1;
         // group 1: tiles 1, 3, 5 without columns 86..89, and dW2^T.  Columns 96..99 are constant zero in every row.
@@ -2263,16 +2380,22 @@ int uavenv_dqn_grad_img(const UavReplayRing *ring, int32_t head, int32_t filled,
             // UAVENV_DW1_F32=1: the round-4 form of the weight-gradient products (all on the f32 matrix pipe) -- A/B knob
             static const bool dw1_f32 = getenv("UAVENV_DW1_F32") != nullptr;
             static bool attr8 = false;
+            // form B of the split products (group 1 all six flag tiles, their operands built while group 0 is in td_backward) is the
+            // default: 11.48 -> 10.75 us per launch, 28.76 -> 28.2 us per configs[1] pass; UAVENV_DW1_SPLITA=1 selects form A
+            static const bool dw1_b = getenv("UAVENV_DW1_SPLITA") == nullptr;
             if (!attr8) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8<true>),
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradP8Lds) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8<false>),
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradP8Lds) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dqn_grad_packed8<0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGradP8Lds) != hipSuccess)
                     return UAVENV_EHIP;
                 attr8 = true;
             }
-            if (dw1_f32) hipLaunchKernelGGL(k_dqn_grad_packed8<false>, dim3(grid), dim3(512), kGradP8Lds, s, ga);
-            else hipLaunchKernelGGL(k_dqn_grad_packed8<true>, dim3(grid), dim3(512), kGradP8Lds, s, ga);
+            if (dw1_f32) hipLaunchKernelGGL(k_dqn_grad_packed8<0>, dim3(grid), dim3(512), kGradP8Lds, s, ga);
+            else if (dw1_b) hipLaunchKernelGGL(k_dqn_grad_packed8<2>, dim3(grid), dim3(512), kGradP8Lds, s, ga);
+            else hipLaunchKernelGGL(k_dqn_grad_packed8<1>, dim3(grid), dim3(512), kGradP8Lds, s, ga);
             rc = UAVENV_OK;
         } else {
             rc = small ? launch_grad_packed<4>(ga, grid, s) : launch_grad_packed<kMaxOut - 2>(ga, grid, s);
