@@ -1100,7 +1100,7 @@ __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
     L.red = L.b2t + kMaxOut;
     L.Ps = reinterpret_cast<uint32_t *>(L.red + 4 * (kMaxOut + 2));
     float *qn_lds = reinterpret_cast<float *>(L.Ps + kTile * kPackedDwords + 4);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wv >> 2, strip = wv & 3;
     const int r = lane & 15, gq = lane >> 4;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     GradAcc8 A;
@@ -1583,7 +1583,7 @@ __device__ __forceinline__ void tile_issue8(const GradArgs &g, int tile, int grp
 __device__ __forceinline__ void grad_write_partials8(const GradArgs &g, int stride, float *red, const GradAcc8 &A)
 {
     constexpr int NMAX = 4;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wv >> 2, strip = wv & 3;
     const int r = lane & 15, gq = lane >> 4;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     float *out = g.partials + (size_t)blockIdx.x * stride;
@@ -1639,7 +1639,7 @@ __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
     float *red = b2t + kMaxOut;
     float *qn_lds = red + 4 * (kMaxOut + 2);             // [2][64]
     uint32_t *stage_all = reinterpret_cast<uint32_t *>(qn_lds + 2 * kTile);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv >> 2, strip = wv & 3;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wv >> 2, strip = wv & 3;
     const int r = lane & 15, gq = lane >> 4, t256 = tid & 255;
     const int n2 = g.n_actions + (g.dueling ? 1 : 0);
     _Float16 *x_strip = (grp == 0 ? Xs : Xn) + strip * 16 * kLdH;

@@ -914,7 +914,8 @@ __global__ void __launch_bounds__(512) k_sac_td(SacArgsN slots)
     const SacArgs &g = slots.s[blockIdx.y];
     if ((int)blockIdx.x >= g.grid) return;
     extern __shared__ __align__(16) float lds[];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, half = tid >> 8, r = lane & 15, gq = lane >> 4;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv8 = __builtin_amdgcn_readfirstlane(tid >> 6), wv = wv8 & 3, half = wv8 >> 2,
+              r = lane & 15, gq = lane >> 4;
     const int n_tiles = g.batch / kTile;
     const int t0 = (int)blockIdx.x * g.tiles_per_wg;
     const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
@@ -970,7 +971,7 @@ __global__ void __launch_bounds__(256) k_sac_critic_grad(SacArgsN slots)
     const SacArgs &g = slots.s[blockIdx.y];
     if ((int)blockIdx.x >= g.grid) return;
     extern __shared__ __align__(16) float lds[];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, gq = lane >> 4;
     const int n_tiles = g.batch / kTile;
     const int t0 = (int)blockIdx.x * g.tiles_per_wg;
     const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;
@@ -1141,7 +1142,7 @@ __global__ void __launch_bounds__(256) k_sac_actor_grad(SacArgsN slots)
     const SacArgs &g = slots.s[blockIdx.y];
     if ((int)blockIdx.x >= g.grid) return;
     extern __shared__ __align__(16) float lds[];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, gq = lane >> 4;
     const int n_tiles = g.batch / kTile;
     const int t0 = (int)blockIdx.x * g.tiles_per_wg;
     const int nt = n_tiles - t0 < g.tiles_per_wg ? n_tiles - t0 : g.tiles_per_wg;

@@ -1146,7 +1146,9 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     extern __shared__ __align__(16) unsigned char smem[];
     const DevState &S = a.st;
     const int N = a.N;
-    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    // (the wavefront index through readfirstlane: the four wavefronts of a workgroup do different jobs, and the compiler can only let
+    // their live ranges share registers -- and branch on a scalar -- when it knows the index is wavefront-uniform)
+    const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int first = (int)blockIdx.x * 64;
     const int i = first + lane;
     const bool active = i < N;
