@@ -51,6 +51,113 @@ MFMA_F16_PEAK_TF = 2500.0              # MI355X_MICROARCH.md: bf16/f16 MFMA, den
 PASSES_PER_STEP = 1024                 # hot-path passes per bench step (see module docstring)
 
 
+# ---- the line the driver parses ----------------------------------------------------------------------------------------------
+# BENCH_r05.json: `parsed: null` -- the driver keeps the last 8 081 bytes of stdout and the line had grown to 21 KB.  The LAST stdout
+# line is therefore a whitelisted, bounded summary (< HEADLINE_MAX_BYTES, asserted; tests/test_bench_line.py); everything else -- the
+# prose, the per-config blocks -- goes to side files beside bench.py (and under gpurun_out/ when that directory exists).
+HEADLINE_MAX_BYTES = 6000
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "passes_per_step", "ms_per_pass", "timed_region_ms", "learner_updates_per_s", "learner_samples_per_s",
+             "env_only_steps_per_s", "links_crossed", "ranks_bit_identical", "exchange", "exchange_asked", "exchange_selftest_ms",
+             "p2p_timeouts", "p2p_checksum_mismatches", "p2p_checksums_compared", "ms_per_pass_no_exchange", "rendezvous_retries",
+             "bad_after_recovery")
+_CONFIG_KEYS = ("workload", "envs_per_gpu", "uav_per_env", "learn_batch_per_gpu", "learn_batch_per_slot", "obs_dtype", "host_loop",
+                "learner", "epsilon", "parallelism", "replay", "sample_lag")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_basis", "traffic_stale", "frac_algorithmic",
+              "frac_physical_stored", "frac_physical_counters", "algorithmic_bytes_per_agent_step", "stored_bytes_per_agent_step",
+              "agents_per_launch", "kernel_ms", "kernel_ms_back_to_back", "kernel_ms_rocprofv3_committed", "measured_copy_GBs",
+              "frac_of_measured_copy", "algorithmic_exceeds_measured_copy")
+_LEARN_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "flops_per_sample", "samples_per_launch", "kernel_ms",
+               "kernel_ms_back_to_back", "kernel_ms_rocprofv3_committed", "reduce_adam_ms_rocprofv3_committed", "mfma_busy_frac_pmc",
+               "counters_stale")
+
+
+def _short(v, n=96):
+    """strings are cut to n characters (the full text is in the side file); numbers are rounded to 6 significant digits"""
+    if isinstance(v, str):
+        return v if len(v) <= n else v[:n - 1] + "~"
+    if isinstance(v, float):
+        return float("%.6g" % v)
+    if isinstance(v, (list, tuple)):
+        return [_short(x, n) for x in v][:8]
+    return v
+
+
+def _pick(d, keys, n=96):
+    return {k: _short(d[k], n) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], dict)}
+
+
+def headline_line(full: dict, side_files=None) -> dict:
+    """The bounded summary of a full result dict: the contract's keys, `roofline`, `roofline_learner`, `cpu_baseline`, and one short
+    row per other configuration.  Pure function of `full` (tests/test_bench_line.py feeds it a committed round-5 line)."""
+    out = _pick(full, _TOP_KEYS)
+    cfg = full.get("config") or {}
+    out["config"] = _pick(cfg, _CONFIG_KEYS, 150)
+    rs = cfg.get("resets") or {}
+    if rs:
+        rf = rs.get("refresh") or {}
+        out["config"]["resets"] = dict(_pick(rs, ("consumed_per_s", "episode_end_fraction_of_agent_steps", "planner_rows_per_s")),
+                                       refresh=_pick(rf, ("rows_committed_per_s", "rows_committed", "rows_skipped_in_flight", "slices",
+                                                          "every_passes", "rows_per_slice", "bank_rows", "ms_per_pass_delta")) or None)
+    if "roofline" in full:
+        out["roofline"] = _pick(full["roofline"], _ROOF_KEYS)
+    if "roofline_learner" in full:
+        out["roofline_learner"] = _pick(full["roofline_learner"], _LEARN_KEYS)
+    cb = full.get("cpu_baseline")
+    if cb:
+        o = _pick(cb, ("value", "unit", "cores", "kind", "one_core_value"))
+        o["sample"] = _short(cb.get("sample", ""), 200)
+        rp = cb.get("reference_python") or {}
+        o["reference_python"] = dict(_pick(rp, ("value", "unit", "threads", "with_resets"), 60), measured="committed, build container",
+                                     full_loop_value=(rp.get("full_loop") or {}).get("value"))
+        o["learner"] = _pick(cb.get("learner") or {}, ("value", "unit", "batch", "threads", "kind", "samples_per_s"))
+        out["cpu_baseline"] = o
+    rows = []
+    for r in full.get("other_configs") or []:
+        rr, rl = r.get("roofline") or {}, r.get("roofline_learner") or {}
+        row = {"name": _short(r.get("baseline_config", ""), 44), "value": _short(r.get("value")), "ms_per_pass": _short(r.get("ms_per_pass")),
+               "kernel_ms": _short(rr.get("kernel_ms")), "frac": _short(rr.get("frac")), "frac_algorithmic": _short(rr.get("frac_algorithmic")),
+               "frac_learner": _short(rl.get("frac"))}
+        if "ranks_bit_identical" in r:
+            row["ranks_bit_identical"], row["links_crossed"] = r.get("ranks_bit_identical"), r.get("links_crossed")
+        if r.get("retries"):
+            row["retries"] = r["retries"]
+        if "error" in r:
+            row["error"] = _short(r["error"], 80)
+        rows.append({k: v for k, v in row.items() if v is not None})
+    if rows:
+        out["other_configs"] = rows
+    if side_files:
+        out["side_files"] = side_files
+    line = json.dumps(out)
+    if len(line) >= HEADLINE_MAX_BYTES:                  # never let a driver-facing line outgrow the driver's window again
+        for k in ("other_configs", "roofline_learner"):
+            out.pop(k, None)
+            if len(json.dumps(out)) < HEADLINE_MAX_BYTES:
+                break
+    assert len(json.dumps(out)) < HEADLINE_MAX_BYTES, len(json.dumps(out))
+    return out
+
+
+def write_side_files(full: dict) -> dict:
+    """bench_full.json = the whole result (every prose field), bench_other_configs.json = the per-config blocks; written beside
+    bench.py and, when it exists, under gpurun_out/ (which gpurun merges back).  Returns {name: relative path}; never fatal."""
+    names = {}
+    for name, obj in (("bench_full.json", full), ("bench_other_configs.json", full.get("other_configs"))):
+        if obj is None:
+            continue
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if not os.path.isdir(d):
+                continue
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(obj, f, indent=1)
+                names.setdefault(name.split(".")[0], os.path.relpath(os.path.join(d, name), ROOT))
+            except OSError:
+                pass
+    return names
+
+
 def learner_flops_per_sample(trainer: str, n_actions: int = 3) -> float:
     """Algorithmic FLOPs of one learn_off_policy() per sampled transition for the 100-64-A MLP (2 per multiply-add):
     forward of q_local(s) and q_target(s') (+ q_local(s') for the double-DQN target, + the value head for VAnet2),
@@ -197,6 +304,7 @@ def parse():
     p.add_argument("--p2p-check-every", type=int, default=256, help="N > 1: on-device weight checksum compare every that many updates")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) | gloo (test: several ranks on one GPU)")
     p.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
+    p.add_argument("--full-line", action="store_true", help="print the whole result dict instead of the bounded headline line")
     p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
     p.add_argument("--env-only", action="store_true", help="diagnostic: time only back-to-back k_step launches")
     p.add_argument("--bank", default="gpu", choices=["gpu", "packaged"],
@@ -397,7 +505,7 @@ def run_config4(args, dev, world_size=1, rank=0):
     znoise = [None]
     fbatch = [L.make_batch(flat, ring.action.view(-1), a1_plane.view(-1), ring.reward.view(-1), ring.done.view(-1),
                            valid=ring.valid.view(-1), draws=draws[j], n_agents=env.N, uav_per_env=U, slot=j, frames=ring.frames,
-                           meta=ring.meta.view(-1, 4))
+                           meta=None if ring.meta is None else ring.meta.view(-1, 4))
               for j, L in enumerate(learners)] if fused else None
 
     def update_slot(j):
@@ -657,7 +765,7 @@ def run_child(extra, timeout=600):
     """One more configuration as a child process (its own HIP context: a fault there cannot take the headline line down).
     Returns the child's JSON line as a dict, or {'error': ...}."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs"] + extra
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--full-line"] + extra
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
         lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
@@ -1210,6 +1318,16 @@ def run_dqn(args, world_size, rank, dev):
     return out
 
 
+def emit(full: dict, args) -> None:
+    """Rank 0's output.  Child runs (--full-line: other_configs' children, scripts) print the whole dict; everything else prints the
+    bounded headline as the LAST stdout line, with the whole dict in bench_full.json."""
+    if args.full_line or full.get("mode") == "env-only":
+        print(json.dumps(full), flush=True)
+        return
+    sys.stdout.flush()
+    print(json.dumps(headline_line(full, write_side_files(full))), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1232,7 +1350,7 @@ def main():
     if args.config == 4:
         out4 = run_config4(args, dev, world_size, rank)
         if rank == 0:
-            print(json.dumps(out4))
+            emit(out4, args)
         if world_size > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -1245,7 +1363,7 @@ def main():
             out["other_configs"] = other_configs(args)
         if not args.no_cpu_baseline and world_size == 1 and not args.env_only:
             out["cpu_baseline"] = cpu_baseline(args.envs, args.cpu_seconds)
-        print(json.dumps(out))
+        emit(out, args)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

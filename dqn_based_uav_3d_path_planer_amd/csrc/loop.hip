@@ -245,7 +245,8 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 e1 = take_event(l);
                 if (e0 && e1) (void)hipEventRecord(e0, s);
             }
-            (void)uavenv_set_step_meta(c.env, meta_t, nullptr);
+            rc = uavenv_set_step_meta(c.env, meta_t, nullptr);
+            if (rc != UAVENV_OK) return rc;
             rc = uavenv_step_policy_img(c.env, &c.net, obs_t, c.eps, c.seed, l->counter, act_t, obs_n, nullptr, R.reward + (size_t)t * n,
                                         R.done + (size_t)t * n, nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, l->img, s);
             if (rc == UAVENV_EINVAL) l->fuse_act = false;         // not this env / net: the two-launch form from here on
@@ -259,7 +260,8 @@ int uavenv_loop_run(UavLoop *l, int32_t n_steps, void *stream)
                 e1 = take_event(l);
                 if (e0 && e1) (void)hipEventRecord(e0, s);
             }
-            (void)uavenv_set_step_meta(c.env, meta_t, nullptr);
+            rc = uavenv_set_step_meta(c.env, meta_t, nullptr);
+            if (rc != UAVENV_OK) return rc;
             rc = uavenv_step(c.env, act_t, UAVENV_ACT_INDEX_I32, obs_n, nullptr, R.reward + (size_t)t * n, R.done + (size_t)t * n,
                              nullptr, info_t, valid_t, nullptr, nullptr, c.step_flags, s);
         }
@@ -541,8 +543,9 @@ int uavenv_sac_loop_run(UavSacLoop *l, int32_t n_steps, void *stream)
             rc = uavenv_sac_act_multi(actors, R.obs, first, U, envs, eps, c.action_bound, act0, c.act1_plane, U, s);
             if (rc != UAVENV_OK) return rc;
         }
-        (void)uavenv_set_step_meta(c.env, R.meta ? (unsigned char *)R.meta + (size_t)t * n * UAVENV_META_BYTES : nullptr,
-                                   R.meta ? c.act1_plane + (size_t)t * n : nullptr);
+        rc = uavenv_set_step_meta(c.env, R.meta ? (unsigned char *)R.meta + (size_t)t * n * UAVENV_META_BYTES : nullptr,
+                                  R.meta ? c.act1_plane + (size_t)t * n : nullptr);
+        if (rc != UAVENV_OK) return rc;
         rc = uavenv_step(c.env, act0 + (size_t)t * n, UAVENV_ACT_STEER_F32, (unsigned char *)R.obs + (size_t)nxt * l->obs_row_bytes, nullptr,
                          R.reward + (size_t)t * n, R.done + (size_t)t * n, nullptr, c.info_dev ? c.info_dev + (size_t)t * n : nullptr,
                          R.valid + (size_t)t * n, nullptr, nullptr, c.step_flags, s);

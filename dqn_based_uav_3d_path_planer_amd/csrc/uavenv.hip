@@ -2291,8 +2291,9 @@ int uavenv_step(UavEnv *e, const void *actions, int32_t action_kind, void *obs, 
                 uint8_t *ret_done, uint8_t *agent_done, uint8_t *info, uint8_t *valid, double *energy64,
                 const uint8_t *active, uint32_t flags, void *stream)
 {
-    if (!e || !actions) return fail(UAVENV_EINVAL, "null env/actions");
-    const PendingMeta pm = take_step_meta(e);         // (consumed by THIS call, whether or not it gets as far as a launch)
+    if (!e) return fail(UAVENV_EINVAL, "null env");
+    const PendingMeta pm = take_step_meta(e);         // (consumed by THIS call, whatever it returns: taken before any other check)
+    if (!actions) return fail(UAVENV_EINVAL, "null actions");
     if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step before uavenv_set_buildings");
     if (action_kind < 0 || action_kind > 2) return fail(UAVENV_EINVAL, "action_kind %d", action_kind);
     if ((flags & UAVENV_STEP_AUTO_RESET) && e->bank_m <= 0)
@@ -2332,8 +2333,9 @@ int uavenv_step_policy_img(UavEnv *e, const UavDqnNet *net, const void *obs_cur,
                            uint8_t *info, uint8_t *valid, double *energy64, const uint8_t *active, uint32_t flags,
                            const float *image_dev, void *stream)
 {
-    if (!e || !net || !net->local || !obs_cur || !action_out) return fail(UAVENV_EINVAL, "null argument");
-    const PendingMeta pm = take_step_meta(e);         // (consumed by THIS call: a caller that falls back to act + step asks again)
+    if (!e) return fail(UAVENV_EINVAL, "null env");
+    const PendingMeta pm = take_step_meta(e);         // (consumed by THIS call, whatever it returns: a caller that falls back to act + step asks again)
+    if (!net || !net->local || !obs_cur || !action_out) return fail(UAVENV_EINVAL, "null argument");
     if (!e->have_world) return fail(UAVENV_EINVAL, "uavenv_step_policy before uavenv_set_buildings");
     if ((flags & UAVENV_STEP_AUTO_RESET) && e->bank_m <= 0)
         return fail(UAVENV_EINVAL, "AUTO_RESET needs a scenario bank (uavenv_load_scenarios)");

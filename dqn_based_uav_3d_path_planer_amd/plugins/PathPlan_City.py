@@ -210,7 +210,7 @@ class PathPlan_City:
                                                               n_agents=N, uav_per_env=self.num_UAV, slot=j, frames=ring.frames,
                                                               is_weights=None if self._sac_per[j] is None else self._sac_per_bufs[j]["w"],
                                                               abs_td_out=None if self._sac_per[j] is None else self._sac_per_bufs[j]["abs"],
-                                                              meta=ring.meta.view(-1, 4))
+                                                              meta=None if ring.meta is None else ring.meta.view(-1, 4))
                                  for j, u in enumerate(self.Agents)]
             self._sac_counter = 0
             for u in self.Agents:

@@ -111,7 +111,8 @@ class VecReplayMemory:
 
     def batch_update(self, slots, abs_errors):                                    # ReplayTree.batch_update, :215-222
         if self.per is not None:
-            self.per.update(slots, abs_errors)
+            # the list ReplayTree.sample just returned is in prefix order already (equal slots adjacent): no ordering pass
+            self.per.update(slots, abs_errors, assume_sorted=slots is getattr(self, "_last_slots", None))
 
     def sample2(self, batch_size):                                                # replay_buffer.py:48-51
         b = self.sample_tensors(batch_size)

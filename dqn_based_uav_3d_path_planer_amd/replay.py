@@ -60,6 +60,22 @@ class DeviceReplayRing:
         assert plane.dtype == torch.float32 and tuple(plane.shape) == (self.frames, self.env.N) and plane.is_contiguous()
         self.action1 = plane
 
+    def rewrite_records(self, frames=None):
+        """INVARIANT: the action / reward / done / valid planes (and action1) are written by step launches only, which write the
+        transition record of the same (frame, agent) in the same launch -- the fused learners read the RECORDS.  Code that edits a plane
+        by hand (a test injecting rewards, a tool replaying a log) calls this afterwards: it rebuilds the records of the given frames
+        (default: all) from the planes; the info byte, which has no plane in the ring, is kept."""
+        if self.meta is None:
+            return
+        idx = slice(None) if frames is None else torch.as_tensor(frames, device=self.meta.device, dtype=torch.long).reshape(-1)
+        m = self.meta[idx]
+        a0 = self.action[idx]
+        m[..., 1] = a0 if self.discrete else a0.contiguous().view(torch.int32)
+        m[..., 0] = 0 if self.action1 is None else self.action1[idx].contiguous().view(torch.int32)
+        m[..., 2] = self.reward[idx].contiguous().view(torch.int32)
+        m[..., 3] = (m[..., 3] & 0x00FF0000) | self.done[idx].int() | (self.valid[idx].int() << 8)
+        self.meta[idx] = m
+
     def _set_step_meta(self, t: int):
         if self.meta is None:
             return
@@ -226,14 +242,16 @@ class DevicePER:
         self.fill(ring.head * n, n, zero=True)
         self.n_entries = ring.filled * n
 
-    def update(self, slots: torch.Tensor, abs_errors: torch.Tensor):
-        """ReplayTree.batch_update (:215-222)."""
+    def update(self, slots: torch.Tensor, abs_errors: torch.Tensor, assume_sorted: bool = False):
+        """ReplayTree.batch_update (:215-222).  assume_sorted: the list comes from uavenv_per_sample (prefix order: equal slots are
+        adjacent already) -- nothing to order.  Otherwise the list is stably sorted ON THE DEVICE, unconditionally: asking whether it
+        needs sorting would be a device-to-host round trip per priority update."""
         slots = slots.to(self.device, torch.int64).reshape(-1).contiguous()
         e = abs_errors.detach().to(self.device, torch.float64).reshape(-1).contiguous()
         # uavenv_per_set resolves a slot listed several times only when the equal entries are ADJACENT (include/uavenv.h); this
         # entry point takes arbitrary lists, so order them first -- a stable sort keeps the batch order among equal slots, i.e.
         # the LAST error of a slot still wins, as in the reference's sequential loop (ADVICE r4)
-        if slots.numel() > 1 and bool((slots[1:] < slots[:-1]).any()):
+        if slots.numel() > 1 and not assume_sorted:
             slots, order = torch.sort(slots, stable=True)
             e = e[order].contiguous()
         rc = self.lib.uavenv_per_set(C.byref(self._c), slots.data_ptr(), e.data_ptr(), slots.numel(), self.epsilon,

@@ -17,13 +17,13 @@ for t in range(30):
     L.act(ring.current_obs(), 0.1, 1, t, index_out=ring.current_action())
     ring.step_env(auto_reset=True)
 nb = min(B // 64, 256)
-buf = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(2 * nb * 8, dtype=torch.int64, device="cuda")      # two stamp banks (csrc/learner.hip: L_STAMP2 writes the second)
 env.lib.uavenv_dqn_set_debug_buffer(buf.data_ptr())
 rows = []
 for t in range(20):
     L.learn_from_ring(ring, B, 3, t)
     torch.cuda.synchronize()
-    rows.append(buf.cpu().numpy().reshape(nb, 8).astype(np.float64))
+    rows.append(buf.cpu().numpy()[:nb * 8].reshape(nb, 8).astype(np.float64))
 env.lib.uavenv_dqn_set_debug_buffer(None)
 R = np.stack(rows)
 print("h8 kernels: tile start -> rows committed:", (R[:, :, 7] - R[:, :, 6]).mean(), " -> next tile issued:", (R[:, :, 1] - R[:, :, 7]).mean(), " prev tile end -> tile start (sync):", (R[:, :, 6] - R[:, :, 5]).mean())

@@ -178,7 +178,7 @@ def _bench(*extra, timeout=900):
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-           "--no-other-configs", "--envs", "2048", "--batch", "2048", "--replay", "16384", "--env-only-iters", "5", *extra]
+           "--no-other-configs", "--full-line", "--envs", "2048", "--batch", "2048", "--replay", "16384", "--env-only-iters", "5", *extra]
     # NO retry here (round 5): a multi-process leg that fails once in N runs is a defect of the exchange until proven otherwise -- a
     # silent second attempt is how round 3's same-device deadlock survived.  The one start-up failure that is not this code's (the
     # rendezvous port taken between the probe and the bind) is handled -- and counted -- by bench.py: spawn_ranks itself.
@@ -291,6 +291,28 @@ def test_bench_one_gpu_line_has_the_in_loop_roofline():
     assert d["roofline"]["kernel_ms_back_to_back"] > 0 and d["roofline"]["k_step_alone"]["kernel_ms_back_to_back"] > 0
     assert 0 < d["roofline"]["frac"] < 1 and 0 < d["roofline_learner"]["frac"] < 1
     assert "3 launches" in d["config"]["host_loop"]
+
+
+def test_bench_headline_line_is_bounded_and_carries_the_contract():
+    """Without --full-line (what the driver runs) the LAST stdout line is the bounded summary: it parses, stays under bench.py's
+    HEADLINE_MAX_BYTES (BENCH_r05.json was `parsed: null` because the line had outgrown the driver's 8 081-byte window), and carries the
+    contract's keys plus `roofline`; the whole dict is in bench_full.json."""
+    import bench
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-other-configs", "--envs", "2048", "--batch", "2048", "--replay", "16384", "--env-only-iters", "5"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    last = res.stdout.strip().splitlines()[-1]
+    assert len(last) < bench.HEADLINE_MAX_BYTES
+    d = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_learner"):
+        assert k in d, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert "workload" in d["config"] and d["value"] > 0
+    full = json.load(open(os.path.join(ROOT, d["side_files"]["bench_full"])))
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and "k_step_alone" in full["roofline"]
 
 
 def test_bench_legs_run_small():
