@@ -15,6 +15,8 @@ What pins what (reference file:line):
   episodes.npz         Agents/UAV.py:397-567 whole episodes from reset, scripted actions
   injected.npz         Agents/UAV.py:397-567 single steps from injected states (all branches)
   apf.npz              Agents/UAV.py:156-210,448-453 with building.v injected
+  apf_episodes.npz     the same, WHOLE episodes from uav.reset() with APF_Enabled = 1: every step's outputs, state and the
+                       full sub-goal list (Adjust_subgoal shifts every sub-goal every step: accumulated drift is compared)
 """
 from __future__ import annotations
 
@@ -320,6 +322,94 @@ def gen_apf(s, out, n, kmax=8):
                         sub_goals_after=np.array(subs_after))
 
 
+def run_apf_episode(s, seed, policy, kmax):
+    """Whole episode from uav.reset() with APF on (env.buildings already carry .v).  Returns None when the reference raises at
+    UAV.py:205-208 (cum_force > 100 -> Cal_SubTask_Dynamic() without its arguments -> TypeError)."""
+    uav, cm = s.uav, s.CalMod
+    random.seed(seed)
+    uav.reset()
+    if len(uav.sub_goals) > kmax:
+        return None
+    init = uav_state_vec(uav) + [f(uav.V_dir)]
+    sub0 = subgoals_arr(uav, kmax)
+    alias0 = int(len(uav.sub_goals) > 0 and uav.sub_goals[0] is uav.position)
+    obs0 = np.array(uav.state(), dtype=np.float64)
+    prng = random.Random(seed * 104729 + 71)
+    acts, outs, states, obss, subs, nsubs = [], [], [], [], [], []
+    for t in range(4000):
+        if policy == "random":
+            a = prng.uniform(-1, 1)
+        elif policy == "seek":
+            a = seek_action(uav, cm, prng.gauss(0, 0.05))
+        else:
+            a = seek_action(uav, cm, prng.gauss(0, 0.3)) if prng.random() < 0.7 else prng.uniform(-1, 1)
+        try:
+            r, d, info = uav.update([a, 0.0])
+        except TypeError:
+            return None
+        o = uav.state()
+        acts.append(a)
+        outs.append([f(r), f(d), f(uav.done), f(INFO[info])])
+        states.append(uav_state_vec(uav))
+        obss.append(np.array(o, dtype=np.float64))
+        subs.append(subgoals_arr(uav, kmax))
+        nsubs.append(len(uav.sub_goals))
+        if uav.done:
+            break
+    return dict(init=np.array(init), sub_goals=sub0, alias0=alias0, obs0=obs0, actions=np.array(acts), outs=np.array(outs),
+                states=np.array(states), obs=np.array(obss), subs=np.array(subs), nsubs=np.array(nsubs, dtype=np.int32))
+
+
+def gen_apf_episodes(s, out, kmax=48):
+    """APF-on trajectories WITHOUT re-synchronisation.  Every building that gen_apf moves moves here too (the same
+    seeded velocities); whole episodes from uav.reset(); seeds where the reference raises (UAV.py:205-208) are skipped and listed."""
+    uav, env, Loc = s.uav, s.env, s.CalMod.Loc
+    rng = random.Random(4242)
+    nb = len(env.buildings)
+    vel = np.zeros((nb, 3))
+    for i in range(nb):
+        if i % 3 != 0:
+            vel[i] = (rng.uniform(-1, 1), rng.uniform(-1, 1), 0.0)
+    for i, t in enumerate(env.buildings):
+        t.v = Loc(float(vel[i][0]), float(vel[i][1]), float(vel[i][2]))
+    uav.APF_Enabled = 1
+    plan = ([(k, "seek") for k in range(300, 324)] + [(k, "random") for k in (5, 11, 23)] + [(k, "mixed") for k in (201, 202, 203, 204, 205)])
+    eps, used, skipped = [], [], []
+    n_success = n_lose = 0
+    for seed, pol in plan:
+        e = run_apf_episode(s, seed, pol, kmax)
+        if e is None:
+            skipped.append(seed)
+            continue
+        final = int(e["outs"][-1][3])
+        # keep every random / mixed episode; of the seeking ones at most six successes and four time-outs
+        if pol == "seek":
+            if final == 1 and n_success >= 6:
+                continue
+            if final != 1 and n_lose >= 4:
+                continue
+        n_success += final == 1
+        n_lose += final != 1
+        eps.append(e)
+        used.append((seed, pol))
+    uav.APF_Enabled = 0
+    for t in env.buildings:
+        del t.v
+    offs = np.cumsum([0] + [len(e["actions"]) for e in eps])
+    pol_code = {"random": 0, "seek": 1, "mixed": 2}
+    np.savez_compressed(
+        os.path.join(out, "apf_episodes.npz"), velocities=vel,
+        seeds=np.array([u[0] for u in used], dtype=np.int64), policy=np.array([pol_code[u[1]] for u in used], dtype=np.int32),
+        skipped_seeds=np.array(skipped, dtype=np.int64), offsets=offs.astype(np.int64),
+        init=np.array([e["init"] for e in eps]), sub_goals=np.array([e["sub_goals"] for e in eps]),
+        alias0=np.array([e["alias0"] for e in eps], dtype=np.int32), obs0=np.array([e["obs0"] for e in eps]),
+        actions=np.concatenate([e["actions"] for e in eps]), outs=np.concatenate([e["outs"] for e in eps]),
+        states=np.concatenate([e["states"] for e in eps]), obs=np.concatenate([e["obs"] for e in eps]),
+        subs=np.concatenate([e["subs"] for e in eps]), nsubs=np.concatenate([e["nsubs"] for e in eps]))
+    print("apf_episodes", len(eps), "steps", int(offs[-1]), "final infos", [int(e["outs"][-1][3]) for e in eps],
+          "lens", [len(e["actions"]) for e in eps], "skipped seeds (reference raised)", skipped)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     s = RefSession()
@@ -331,6 +421,7 @@ def main():
         gen_episodes(s, OUT)
         gen_injected(s, OUT, 3000)
         gen_apf(s, OUT, 600)
+        gen_apf_episodes(s, OUT)
     finally:
         s.close()
 
