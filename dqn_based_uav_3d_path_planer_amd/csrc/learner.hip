@@ -1084,6 +1084,7 @@ __device__ __forceinline__ void grad_tile_packed8(const GradArgs &g, const GradL
 template <int SPLIT>
 __global__ void __launch_bounds__(512) k_dqn_grad_packed8(Grad2Args ga)
 {
+    UAV_HOT_PRIO();
     constexpr int NMAX = 4;
     const GradArgs &g = ga.g;
     extern __shared__ __align__(16) float lds[];
@@ -1907,6 +1908,7 @@ __global__ void __launch_bounds__(256) k_dqn_reduce_adam(const float *__restrict
     // gated update (uavenv_dqn_reduce_adam_gated): the step kernel of this pass stamps go_word with go_value when it moved at
     // least one agent; a pass in which every agent had already finished leaves the learner exactly as it is (the reference's loop
     // has left run_eposide by then, Envs/PathPlan_City.py:456-459)
+    UAV_HOT_PRIO();
     if (go_word && __hip_atomic_load(go_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != go_value) return;
     __shared__ float cnt_part[4];
     const int tid = (int)threadIdx.x;

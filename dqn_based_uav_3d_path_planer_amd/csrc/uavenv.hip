@@ -1143,6 +1143,7 @@ struct CoopLds {
 template <typename MaskT, bool APF, int OBS, bool POLICY = false, bool PAHEAD = false>
 __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
 {
+    UAV_HOT_PRIO();
     extern __shared__ __align__(16) unsigned char smem[];
     const DevState &S = a.st;
     const int N = a.N;

@@ -6,6 +6,17 @@
 // libm differences (OCML vs glibc atan2/sin/cos), far inside the 1e-5 parity tolerance.
 // Only the stored observation is narrowed (f32 / f16).
 #pragma once
+#ifndef UAVENV_HOT_PRIO_DEFINED
+#define UAVENV_HOT_PRIO_DEFINED
+// Wave priority of the loop's own kernels (s_setprio, 0..3; the hardware's default is 0).  The background planner that turns the
+// reset bank over (k_rrt_plan<.., false>, csrc/rrt.hip) shares SIMDs with them: a step / gradient launch is as long as its slowest
+// workgroup, so a planner wavefront taking every other issue slot of ONE SIMD stretches the whole launch.  At priority 3 the loop's
+// wavefronts issue first and the planner fills the slots they leave (round 6: see DESIGN 3.5 for the measured difference).
+#ifndef UAVENV_HOT_PRIO
+#define UAVENV_HOT_PRIO 3
+#endif
+#define UAV_HOT_PRIO() __builtin_amdgcn_s_setprio(UAVENV_HOT_PRIO)
+#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
