@@ -64,7 +64,7 @@ _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_ste
 _CONFIG_KEYS = ("workload", "envs_per_gpu", "uav_per_env", "learn_batch_per_gpu", "learn_batch_per_slot", "obs_dtype", "host_loop",
                 "learner", "epsilon", "parallelism", "replay", "sample_lag")
 _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_basis", "traffic_stale", "frac_algorithmic",
-              "frac_physical_stored", "frac_physical_counters", "algorithmic_bytes_per_agent_step", "stored_bytes_per_agent_step",
+              "frac_physical_stored", "frac_physical_counters", "algorithmic_bytes_per_agent_step", "moved_bytes_per_agent_step", "counters_over_model",
               "agents_per_launch", "kernel_ms", "kernel_ms_back_to_back", "kernel_ms_rocprofv3_committed", "measured_copy_GBs",
               "frac_of_measured_copy", "algorithmic_exceeds_measured_copy")
 _LEARN_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "flops_per_sample", "samples_per_launch", "kernel_ms",
@@ -167,6 +167,33 @@ def learner_flops_per_sample(trainer: str, n_actions: int = 3) -> float:
     n_fwd = 2 if trainer == "dqn" else 3
     bwd = 2 * (64 * 100) + 2 * (64 * n2) * 2
     return float(n_fwd * fwd + bwd)
+
+
+# ---- the bytes a step launch moves, plane by plane (round 6: reconciled with the counters) -------------------------------------
+# profiles/r06_counter_calibration.txt: on gfx950 WRITE_SIZE x 1024 = the bytes written, exactly, for every pattern the step kernel uses
+# (f64 / i32 / 1-byte planes, 80-byte rows, 16-byte records), and FETCH_SIZE x 1024 = exactly HALF the bytes read (8-, 4-, 16-byte and
+# row reads alike).  The counters of the committed profile therefore ARE the traffic; what was short was the model: SURVEY 8(d)'s 604 B
+# count the planes update_PathPlan CHANGES (pos, V_vector, V, Step, sub_idx ...), the kernels load and store the agent's WHOLE state
+# record -- 19 f64 + 6 i32 planes = 176 B each way (csrc/uavenv.hip: load_agent / store_agent; goal, the sub-goal window, score /
+# total / path_len, cached heading, scenario id and epoch ride along).
+STATE_PLANE_BYTES = 19 * 8 + 6 * 4          # per agent, read AND written every step
+
+
+def step_bytes_model(row_bytes: int, n_agents: int, *, policy: bool, records: bool, world_bytes: int = 8704, apf_pairs: float = 0.0) -> dict:
+    """Bytes per agent-step of one step launch as the kernels issue them.  Per-launch shared reads (the world blob, the copy-out
+    table, with `policy` the staged layer-1 image + fc2) are L2 hits after the first workgroup of an XCD: counted once per XCD."""
+    shared = 8 * (world_bytes + 13 * 64 * 8 + (27648 + 16 * 64 * 4 + 64 if policy else 0))
+    rd = {"state planes (19 f64 + 6 i32)": STATE_PLANE_BYTES, "action / policy row of the current frame": row_bytes if policy else 4,
+          "per-XCD shared (world blob, copy-out table%s)" % (", layer-1 image + fc2" if policy else ""): shared / float(n_agents)}
+    wr = {"state planes (19 f64 + 6 i32)": STATE_PLANE_BYTES, "observation row of frame t+1": row_bytes, "reward f32": 4, "done + valid bytes": 2}
+    if records:
+        wr["transition record"] = 16
+    if policy:
+        wr["action (int32, written by the policy)"] = 4
+    if apf_pairs:
+        rd["sub-goal lists (APF)"] = wr["sub-goal lists (APF)"] = apf_pairs * 24
+    r, w = sum(rd.values()), sum(wr.values())
+    return {"read": rd, "written": wr, "read_bytes": r, "written_bytes": w, "total": r + w}
 
 
 def physical_view(algo_bytes: int, moved_bytes: int, n_agents: int, kernel_ms: float, traffic, copy_gbs) -> dict:
@@ -654,7 +681,8 @@ def run_config4(args, dev, world_size=1, rank=0):
         tr4 += prof["k_apf_adjust_traffic_bytes_per_launch"]
     k_use = max(k_ms, k_prof or 0.0)
     algo = ALGO_BYTES_PER_AGENT_STEP + 2 * 20 * 24      # APF on adds 2 * n_sub * 24 B (~20 sub-goals)
-    moved = algo - 400 + ring.obs.shape[-1] * ring.obs.element_size()          # packed rows: 80 B instead of the 400-B f32 row
+    model4 = step_bytes_model(ring.obs.shape[-1] * ring.obs.element_size(), env.N, policy=False, records=ring.meta is not None, apf_pairs=2 * 20)
+    moved = int(round(model4["total"]))          # whole state records + packed rows + ~20 sub-goals read and written (k_apf_adjust)
     copy_gbs = measure_copy_gbs(dev) if rank == 0 else None
     out = {"metric": "env-steps/sec + learner updates/sec, PathPlan_City SAC", "value": n_pass * env.N * world_size / dt,
            "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -685,6 +713,8 @@ def run_config4(args, dev, world_size=1, rank=0):
     out["rendezvous_retries"] = int(os.environ.get("UAVENV_RDZV_RETRIES", "0"))
     if multi:
         out["exchange"] = exchange_used
+        from dqn_based_uav_3d_path_planer_amd import exchange as _ex
+        out["exchange_selftest_ms"] = _ex.selftest_ms[0]
         out["ranks_bit_identical"] = ident
         out["links_crossed"], out["rank_devices"] = len(set(rank_devs)) > 1, rank_devs     # False: every rank on one GPU, NOT row-e evidence
         out["config"]["parallelism"] = "env-shard x%d + per-phase gradient sum of all slots: %s" % (world_size, exchange_used)
@@ -794,6 +824,16 @@ def other_configs(args):
               "--steps", "12", "--warmup", "2"]),
             ("env-only 65536 agents/launch", ["--env-only", "--envs", "65536", "--steps", "40"]),
             ("env-only 262144 agents/launch", ["--env-only", "--envs", "262144", "--steps", "20"])]
+    if torch.cuda.device_count() >= 2:
+        # a box with two visible GPUs: the N > 1 path with one rank per DEVICE, as part of the default command (what
+        # tests/test_exchange_gpu.py::test_two_ranks_on_two_devices asserts, without pytest): the peer exchange over mapped peer HBM,
+        # then the RCCL communicator driven from C -- links_crossed must read true in both rows
+        runs += [("row e on TWO devices: peer exchange over HIP-IPC-mapped HBM (csrc/p2p.hip)",
+                  ["--gpus", "2", "--steps", "8", "--warmup", "2", "--p2p-check-every", "16"]),
+                 ("row e on TWO devices: RCCL all-reduce enqueued from C (csrc/coll.hip)",
+                  ["--gpus", "2", "--exchange", "coll", "--steps", "8", "--warmup", "2"]),
+                 ("row e on TWO devices, SAC loop (configs[3] at 8192 envs x 4 UAVs per rank)",
+                  ["--config", "4", "--gpus", "2", "--envs", "8192", "--batch", "8192", "--steps", "12", "--warmup", "2"])]
     out = []
     for name, extra in runs:
         t0 = time.perf_counter()
@@ -821,7 +861,8 @@ def other_configs(args):
                         "ms_per_pass": d.get("ms_per_pass"), "timed_region_ms": d.get("timed_region_ms"),
                         "learner_updates_per_s": d.get("learner_updates_per_s"),
                         **{k: d[k] for k in ("n_gpus", "ranks_bit_identical", "exchange", "exchange_fallbacks", "p2p_timeouts",
-                                             "p2p_checksum_mismatches", "p2p_checksums_compared", "ms_per_pass_no_exchange") if k in d},
+                                             "p2p_checksum_mismatches", "p2p_checksums_compared", "ms_per_pass_no_exchange",
+                                             "exchange_selftest_ms") if k in d},
                         **{k: d[k] for k in ("links_crossed", "rank_devices") if k in d},
                         "rendezvous_retries": d.get("rendezvous_retries", 0),
                         "roofline": {k: r.get(k) for k in ("kernel", "kernel_ms", "achieved", "unit", "frac", "frac_basis", "agents_per_launch",
@@ -878,13 +919,15 @@ def run_dqn(args, world_size, rank, dev):
         ms = e0.elapsed_time(e1) / iters
         algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
         gbs = algo * env.N / (ms * 1e-3) / 1e9
-        stored = algo - (200 if args.obs_dtype == "f16" else 400) + ring.obs.shape[-1] * ring.obs.element_size()
+        model = step_bytes_model(ring.obs.shape[-1] * ring.obs.element_size(), env.N, policy=False, records=False)
+        stored = int(round(model["total"]))
         prof = committed_profile(args, env_only=True)
         copy_gbs = measure_copy_gbs(dev)
         k_prof = prof.get("k_step_ms")
         out = {"mode": "env-only", "envs": env.N, "k_step_ms_back_to_back": ms, "timed_region_ms": ms * iters,
                "env_steps_per_s": env.N / (ms * 1e-3), "achieved_GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS,
-               "obs_dtype": args.obs_dtype, "replay_frames": ring.frames, "measured_copy_GBs": copy_gbs,
+               "obs_dtype": args.obs_dtype, "replay_frames": ring.frames, "measured_copy_GBs": copy_gbs, "records": False,
+               "bytes_model": model,
                "k_step_ms_rocprofv3_committed": k_prof, "traffic": prof.get("k_step_traffic_bytes_per_launch"),
                "traffic_stale": prof.get("stale") if prof.get("k_step_traffic_bytes_per_launch") else None,
                "traffic_source": prof.get("source") if prof.get("k_step_traffic_bytes_per_launch") else None,
@@ -1079,7 +1122,10 @@ def run_dqn(args, world_size, rank, dev):
                         "exchange": exchange["used"], "exchange_asked": exchange["asked"], "exchange_fallbacks": exchange["fallbacks"],
                         "p2p_error_code_max": max(int(x[0]) for x in allst), "p2p_timeouts": sum(int(x[1]) for x in allst),
                         "p2p_checksum_mismatches": sum(int(x[2]) for x in allst), "p2p_checksums_compared": int(allst[0][3]),
-                        "bad_after_recovery": bool(bad)}
+                        "bad_after_recovery": bool(bad),
+                        # wall time of the start-up self-test of the peer exchange (four exchanges of a random multi-KB payload, both
+                        # receive slots twice, each checked against torch.distributed's all-reduce: learner.enable_p2p)
+                        "exchange_selftest_ms": getattr(learner, "p2p_selftest_ms", None)}
         # the same loop without any exchange (the ranks drift apart from here on: last thing this run does with them)
         if not args.no_exchange_leg and exchange["used"] in ("p2p", "coll", "rccl") and args.host_loop == "c":
             saved = (getattr(learner, "_p2p", None), getattr(learner, "_coll", None), exchange["used"])
@@ -1207,9 +1253,10 @@ def run_dqn(args, world_size, rank, dev):
         # packed rows are a lossless image of the f32 row, so they are priced as f32 and simply move fewer bytes
         algo = 404 if args.obs_dtype == "f16" else ALGO_BYTES_PER_AGENT_STEP
         row_bytes = ring.obs.shape[-1] * ring.obs.element_size()
-        stored = algo - (200 if args.obs_dtype == "f16" else 400) + row_bytes
         in_loop_policy = kp_ms is not None               # the loop's launch is k_step_coop<policy>; else act + k_step
-        moved = stored + (row_bytes + 4 if in_loop_policy else 0)      # the policy reads the current row and writes the action
+        model = step_bytes_model(row_bytes, n_agents, policy=in_loop_policy, records=ring.meta is not None)
+        moved = int(round(model["total"]))               # everything the loop's step launch reads and writes, per agent-step
+        stored = int(round(step_bytes_model(row_bytes, n_agents, policy=False, records=ring.meta is not None)["total"]))   # k_step alone
         r_ms = kp_ms if in_loop_policy else k_ms
         achieved = algo * n_agents / (r_ms * 1e-3) / 1e9
         traffic = prof.get("k_step_policy_traffic_bytes_per_launch" if in_loop_policy else "k_step_traffic_bytes_per_launch")
@@ -1273,7 +1320,8 @@ def run_dqn(args, world_size, rank, dev):
                          "traffic": traffic, "traffic_stale": prof.get("stale") if traffic else None,
                          "traffic_source": prof.get("source") if traffic else None,
                          "algorithmic_bytes_per_agent_step": algo, "stored_bytes_per_agent_step": stored,
-                         "agents_per_launch": n_agents,
+                         "agents_per_launch": n_agents, "bytes_model": model,
+                         "counters_over_model": None if not traffic else traffic / float(moved * n_agents),
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          **physical_view(algo, moved, n_agents, r_ms, traffic, copy_gbs),
                          "kernel_ms": r_ms,

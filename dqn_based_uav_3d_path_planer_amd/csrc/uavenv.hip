@@ -948,6 +948,16 @@ __device__ __forceinline__ void step_agent(const StepArgs &a, const WorldLds<Mas
 #define UAV_STAMP(slot) do { } while (0)
 #define UAV_DRAIN() do { } while (0)
 #endif
+// -DUAVENV_PHASE_PROFILE -DUAVENV_PHASE_POLICY: slots 1..5 of k_step_coop hold the stages of the POLICY prologue instead of the
+// step's own phases (scripts/phase_profile_coop.py, POLICY=2): 1 after the staging barrier, 2 after the layer-1 forward, 3 after layer
+// 2 + epsilon-greedy, 4 after the action barrier, 5 after step_pre; 0 = start, 6 = update_PathPlan done (wave 0), 7 = end
+#if defined(UAVENV_PHASE_PROFILE) && defined(UAVENV_PHASE_POLICY)
+#define UAV_PSTAMP(slot) UAV_STAMP(slot)
+#define UAV_CSTAMP(slot) do { if ((slot) == 0 || (slot) == 7) UAV_STAMP(slot); else if ((slot) == 2) UAV_STAMP(6); } while (0)
+#else
+#define UAV_PSTAMP(slot) do { } while (0)
+#define UAV_CSTAMP(slot) UAV_STAMP(slot)
+#endif
 
 #ifndef UAVENV_KSTEP_WAVES
 #define UAVENV_KSTEP_WAVES 1      // min waves per SIMD the register allocator must leave room for (A/B knob)
@@ -1157,7 +1167,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     CoopLds *C = reinterpret_cast<CoopLds *>(smem + a.obsq_off);
     const bool want_obs = a.obs && !(a.flags & UAVENV_STEP_NO_OBS);
     const bool auto_reset = (a.flags & UAVENV_STEP_AUTO_RESET) != 0;
-    UAV_STAMP(0);
+    UAV_CSTAMP(0);
 
     // ---- policy prologue, part 1: fc1 + the packed row of this lane's agent (strip wv, row lane & 15) in flight
     const uavq::W1Split pW1 = uavq::w1split_at(reinterpret_cast<float *>(smem + a.pol_off));      // fc1 + b1, split form (kTileF floats)
@@ -1249,6 +1259,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         }
     }
     __syncthreads();                                                         // world (and fc1) staged
+    UAV_PSTAMP(1);
     const WorldLds<MaskT> w = world_view<MaskT>(smem, a);
     if (POLICY) {                        // policy prologue, part 3: forward, layer 2, epsilon-greedy
         uavq::floatx4 h[4];
@@ -1256,6 +1267,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         // 29.08 us per configs[1] pass with the operands requested first)
         if (PAHEAD) uavq::fwd_strip_split_ahead<false>(pW1, prow, h);
         else uavq::fwd_strip_split<false>(pW1, prow, h);
+        UAV_PSTAMP(2);
         float q[4];
         {
             uavq::W2Frag<4> F;
@@ -1277,14 +1289,17 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             pact[wv * 16 + lane] = act;
             if (pol_i < N) a.pol_act[pol_i] = act;
         }
+        UAV_PSTAMP(3);
         __syncthreads();                                                     // the 64 actions of the workgroup are known
+        UAV_PSTAMP(4);
         if (wv == 0 || wv == 2) ra.lo = (uint32_t)pact[lane];
         if (wv == 0) {
             a0 = decode_action(ra, UAVENV_ACT_INDEX_I32, a.n_actions);
             if (!skip) step_pre(a, a0, g, pre);
         }
     }
-    UAV_STAMP(1);
+    UAV_PSTAMP(5);
+    UAV_CSTAMP(1);
 
     if (wv == 1 && auto_reset) {
         if (cand_want) {
@@ -1311,9 +1326,9 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         C->pos[lane][2] = g.o.pz;
         C->done[lane] = g.done;
     }
-    UAV_STAMP(2);
+    UAV_CSTAMP(2);
     __syncthreads();                                                         // candidates ready, step done
-    UAV_STAMP(3);
+    UAV_CSTAMP(3);
     // ---- auto reset: the env restarts when ALL of its U agents are done (PathPlan_City.py:252-259,416-417).  Every
     // wave takes the decision from the same LDS data.
     bool will_reset = false;
@@ -1351,7 +1366,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         }
     }
     if (fallback) __syncthreads();
-    UAV_STAMP(4);
+    UAV_CSTAMP(4);
     if (wv == 0) {
         if (active) {
             // ---- outputs of the transition
@@ -1397,9 +1412,9 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         if (m1) atomicOr(&trow[1], m1);
         if (m2) atomicOr(&trow[2], m2);
     }
-    UAV_STAMP(5);
+    UAV_CSTAMP(5);
     __syncthreads();                                                         // tile complete
-    UAV_STAMP(6);
+    UAV_CSTAMP(6);
     if (want_obs && OBS == OBS_KIND_PACKED) {
         // packed rows: the 64 x 80 B image of the tile is 320 16-byte chunks, 5 KiB contiguous: two store instructions
         const int nv = N - first < 64 ? N - first : 64;
@@ -1425,7 +1440,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
             if (wv == 0) ctile_emit_lut<F16>(a.obs, first, nv, C->tile, 6, lut[6], true);
         }
     }
-    UAV_STAMP(7);
+    UAV_CSTAMP(7);
 }
 
 // state_PathPlan only

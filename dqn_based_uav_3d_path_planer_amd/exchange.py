@@ -57,18 +57,30 @@ def open_p2p(lib, device: torch.device, bucket_floats: int, check_every: int = 2
     return h
 
 
-def verify_p2p_allreduce(lib, h, device: torch.device, n: int, stream) -> bool:
-    """One uavenv_p2p_allreduce of a known vector against torch.distributed's result, on every rank."""
+def verify_p2p_allreduce(lib, h, device: torch.device, n: int, stream, iters: int = 4) -> bool:
+    """`iters` uavenv_p2p_allreduce calls back to back (both receive slots, twice each) of a payload that is random per rank and per
+    iteration, each against torch.distributed's result, on every rank.  selftest_ms[0] = the wall time of the last call of this."""
+    import time
     world, rank = dist.get_world_size(), dist.get_rank()
     n = max(4, (int(n) // 4) * 4)
-    t = torch.arange(n, device=device, dtype=torch.float32) * 1e-3 + (rank + 1)
-    want = t.clone()
-    dist.all_reduce(want, op=dist.ReduceOp.SUM)
-    rc = lib.uavenv_p2p_allreduce(h, t.data_ptr(), n, stream)
+    gen = torch.Generator(device="cpu").manual_seed(0x51AC + 7919 * rank)
+    ok = True
     torch.cuda.synchronize(device)
-    err = C.c_int32(0)
-    lib.uavenv_p2p_errors(h, C.byref(err))
-    return _all(rc == 0 and err.value == 0 and bool(torch.allclose(t, want, rtol=1e-6, atol=1e-6)), world)
+    t0 = time.perf_counter()
+    for _ in range(max(1, iters)):
+        t = (torch.rand(n, generator=gen) * 2.0 - 1.0).to(device)
+        want = t.clone()
+        dist.all_reduce(want, op=dist.ReduceOp.SUM)
+        rc = lib.uavenv_p2p_allreduce(h, t.data_ptr(), n, stream)
+        torch.cuda.synchronize(device)
+        err = C.c_int32(0)
+        lib.uavenv_p2p_errors(h, C.byref(err))
+        ok = ok and rc == 0 and err.value == 0 and bool(torch.allclose(t, want, rtol=1e-5, atol=1e-5 * world))
+    selftest_ms[0] = (time.perf_counter() - t0) * 1e3
+    return _all(ok, world)
+
+
+selftest_ms = [None]
 
 
 def open_coll(lib, device: torch.device, verify_floats: int, stream):

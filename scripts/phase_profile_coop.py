@@ -7,7 +7,7 @@ from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
 from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-POLICY = os.environ.get("POLICY") == "1"         # the launch the C loop issues: get_action in the step kernel's prologue
+POLICY = os.environ.get("POLICY") in ("1", "2")      # 2: a -DUAVENV_PHASE_POLICY build, the stages of the policy prologue         # the launch the C loop issues: get_action in the step kernel's prologue
 env = make_city26_env(n, obs_dtype="packed" if POLICY else torch.float32)
 ring = DeviceReplayRing(env, 8 * n)
 if POLICY:
@@ -34,9 +34,12 @@ env.lib.uavenv_set_debug_buffer(env._h, None)
 t = np.stack(rows)                       # [iters, blocks, wave, 8]
 t0 = t[:, :, :, 0].min(axis=2, keepdims=True)
 names = ["start", "staged", "own work done", "after barrier 1", "after barrier 2", "own obs part done", "after barrier 3", "end"]
+if os.environ.get("POLICY") == "2":
+    names = ["start", "world + fc1 staged (barrier)", "layer-1 forward done", "layer 2 + eps-greedy done", "action barrier passed",
+             "step_pre done", "update_PathPlan done (w0)", "end"]
 print(f"{n} envs, {nb} workgroups x 4 waves; cycles since the workgroup's first stamp (mean over workgroups and 20 launches | p95)")
 for k, nm in enumerate(names):
     x = t[:, :, :, k] - t0
-    print(f"  {nm:20s} " + "  ".join(f"w{w}: {x[:, :, w].mean():7.0f} | {np.percentile(x[:, :, w], 95):7.0f}" for w in range(4)))
+    print(f"  {nm:30s} " + "  ".join(f"w{w}: {x[:, :, w].mean():7.0f} | {np.percentile(x[:, :, w], 95):7.0f}" for w in range(4)))
 tot = (t[:, :, :, 7].max(axis=2) - t[:, :, :, 0].min(axis=2)).ravel()
 print(f"  workgroup lifetime: mean {tot.mean():.0f}  p95 {np.percentile(tot, 95):.0f}  max {tot.max():.0f}")
