@@ -120,6 +120,9 @@ def headline_line(full: dict, side_files=None) -> dict:
                "frac_learner": _short(rl.get("frac"))}
         if "ranks_bit_identical" in r:
             row["ranks_bit_identical"], row["links_crossed"] = r.get("ranks_bit_identical"), r.get("links_crossed")
+        rf_ = (r.get("resets") or {}).get("refresh")
+        if rf_:
+            row["fresh_plans_per_s"], row["resets_per_s"] = _short(rf_.get("rows_committed_per_s")), _short(r["resets"].get("consumed_per_s"))
         if r.get("retries"):
             row["retries"] = r["retries"]
         if "error" in r:
@@ -320,7 +323,7 @@ def parse():
     p.add_argument("--replan-every", type=int, default=0,
                    help="rolling refresh of the reset bank (the reference plans a fresh path at every reset): every that many passes "
                         "the C loop commits the slice planned in the background and starts the next one (0 = the bank stays as planned)")
-    p.add_argument("--replan-count", type=int, default=4096,
+    p.add_argument("--replan-count", type=int, default=16384,
                    help="bank rows per refresh slice.  A slice lasts as long as its longest tree (~20-25 ms: a few reset scenarios "
                         "need thousands of RRT iterations), so the refresh rate is rows per slice / that time: large slices")
     p.add_argument("--bank-size", type=int, default=0,
@@ -813,6 +816,8 @@ def other_configs(args):
             ("configs[3]", ["--config", "4", "--steps", "8", "--warmup", "2"]),
             ("configs[4] (one GPU's 32768-env share of the 8-GPU run)", ["--config", "5", "--steps", "12", "--warmup", "3"]),
             ("configs[1] with prioritised replay (IsPriority_Replay = 1) on the fused path", ["--per", "--steps", "8", "--warmup", "2"]),
+            ("configs[1] with the reset bank turning over in the background (--replan-every 256 --replan-count 16384: fresh RRT plans "
+             "committed per second against resets consumed per second)", ["--replan-every", "256", "--replan-count", "16384", "--steps", "12", "--warmup", "3"]),
             ("EXPERIMENT on configs[1] (not the benchmark's semantics): sample_lag = 1 -- update t samples transitions <= t - 1, "
              "its gradient kernel on a second stream beside step t", ["--sample-lag", "1", "--steps", "12", "--warmup", "2"]),
             ("row e on ONE GPU (NOT a multi-GPU measurement): two ranks sharing this device, 16384 envs each, gradient bucket "
@@ -860,6 +865,7 @@ def other_configs(args):
             row.update({"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                         "ms_per_pass": d.get("ms_per_pass"), "timed_region_ms": d.get("timed_region_ms"),
                         "learner_updates_per_s": d.get("learner_updates_per_s"),
+                        **({"resets": d["config"]["resets"]} if (d["config"].get("resets") or {}).get("refresh") else {}),
                         **{k: d[k] for k in ("n_gpus", "ranks_bit_identical", "exchange", "exchange_fallbacks", "p2p_timeouts",
                                              "p2p_checksum_mismatches", "p2p_checksums_compared", "ms_per_pass_no_exchange",
                                              "exchange_selftest_ms") if k in d},
@@ -1227,13 +1233,16 @@ def run_dqn(args, world_size, rank, dev):
     # rolling refresh: rows committed during this run)
     p_reset = None
     if rank == 0:
+        # (2 048 extra steps, the count accumulated on the device: episodes last ~2 500 steps and their ends cluster in time after a
+        # common start, so the 64-step window of round 5 read anything between 0.2 and 0.6 of the long-run rate)
         o_ = env.alloc_out()
         o_.obs = None
-        tot = 0
-        for _ in range(64):
+        tot = torch.zeros((), dtype=torch.int64, device=dev)
+        n_extra = 2048
+        for _ in range(n_extra):
             env.step(ring.action[0], o_, auto_reset=True)
-            tot += int(o_.agent_done.sum())
-        p_reset = tot / (64.0 * env.N)
+            tot += o_.agent_done.sum()
+        p_reset = int(tot.item()) / (float(n_extra) * env.N)
     refresh = env.replan_stats() if (rank == 0 and args.replan_every > 0) else None
     planner_rows_per_s = None
     if rank == 0:                      # the planner by itself (csrc/rrt.hip, the two LDS tiers): 16 384 fresh scenarios
