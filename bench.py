@@ -1233,16 +1233,19 @@ def run_dqn(args, world_size, rank, dev):
     # rolling refresh: rows committed during this run)
     p_reset = None
     if rank == 0:
-        # (2 048 extra steps, the count accumulated on the device: episodes last ~2 500 steps and their ends cluster in time after a
-        # common start, so the 64-step window of round 5 read anything between 0.2 and 0.6 of the long-run rate)
-        o_ = env.alloc_out()
-        o_.obs = None
+        # Episode ends per agent-step UNDER THE POLICY the loop runs (get_action inside the step launch, epsilon as in the timed region),
+        # counted on the device over 1 024 extra passes.  (Round 5 stepped 64 times with one frozen action frame: a constant steer never
+        # reaches a sub-goal, every agent times out after Max_Step = 150 steps, and the window read whatever part of that it caught.)
+        done_ = torch.zeros(env.N, dtype=torch.uint8, device=dev)
         tot = torch.zeros((), dtype=torch.int64, device=dev)
-        n_extra = 2048
-        for _ in range(n_extra):
-            env.step(ring.action[0], o_, auto_reset=True)
-            tot += o_.agent_done.sum()
-        p_reset = int(tot.item()) / (float(n_extra) * env.N)
+        n_extra, ok_ = 1024, fused
+        for i_ in range(n_extra if ok_ else 0):
+            if not ring.step_policy(learner, args.eps, seed, (1 << 41) + i_, agent_done=done_):
+                ok_ = False
+                break
+            tot += done_.sum()
+        if ok_:
+            p_reset = int(tot.item()) / (float(n_extra) * env.N)
     refresh = env.replan_stats() if (rank == 0 and args.replan_every > 0) else None
     planner_rows_per_s = None
     if rank == 0:                      # the planner by itself (csrc/rrt.hip, the two LDS tiers): 16 384 fresh scenarios

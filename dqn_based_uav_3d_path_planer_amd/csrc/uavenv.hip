@@ -540,20 +540,29 @@ struct PreStep {
     bool moved;                // false: :400-406, no sub-goal left -- nothing moves
 };
 
-__device__ __forceinline__ void step_pre(const StepArgs &a, double a0, Agent &g, PreStep &P)
+// step_pre in two pieces, so that the policy form of the cooperative kernel can take the action-INdependent half in front of its
+// staging barrier, while the weights are in flight (k_step_coop<POLICY>).  (Round 6 also had the helper wavefronts evaluate the
+// sincos and the heading after the move for every discrete action speculatively -- bit-identical, all parity tests green, and
+// SLOWER: 10.9 -> 11.95 us per launch.  No wavefront of the workgroup idles in front of the action barrier -- each runs a strip of
+// the forward -- so the 1.8 k cycles of f64 moved the staging barrier by as much: profiles/r06_phase_k_step_coop_policy.txt.)
+//   step_pre_dists   what does not depend on the action: :400-406's "nothing left", the old position, dis_old, g_old (:409-413)
+//   step_pre_move    everything behind sincos(seta_new) (:415-422), given that sine and cosine
+// step_pre = dists, sincos, move: the same operations on the same operands in the same order, whoever evaluates the sincos.
+__device__ __forceinline__ void step_pre_dists(Agent &g, PreStep &P)
 {
     ObsIn &o = g.o;
     P.moved = g.sub_idx < g.n_total;
     P.ox = o.px; P.oy = o.py; P.oz = o.pz;                                     // :409
     P.dis_old = P.g_old = P.tgx = P.tgy = 0.0;
     if (!P.moved) return;
-    o.step += 1;                                                               // :408
-    const double seta_old = g.head;                                            // :411 (cached: same V_vector)
     P.dis_old = dist3(o.px, o.py, o.pz, o.s0x, o.s0y, o.s0z);                  // :412
     P.g_old = dist3(o.px, o.py, o.pz, o.gx, o.gy, o.gz);                       // :413
-    const double seta_new = seta_old + a0 * a.steer;                           // :414
-    double sn, cs;
-    sincos(seta_new, &sn, &cs);
+}
+__device__ __forceinline__ void step_pre_move(const StepArgs &a, Agent &g, PreStep &P, double sn, double cs)
+{
+    ObsIn &o = g.o;
+    if (!P.moved) return;
+    o.step += 1;                                                               // :408
     o.vx = a.max_v * cs;                                                       // :415
     o.vy = a.max_v * sn;                                                       // :416
     o.V = calc_v(o.vx, o.vy, a.max_v);                                         // :417
@@ -563,6 +572,15 @@ __device__ __forceinline__ void step_pre(const StepArgs &a, double a0, Agent &g,
     // :422-428  tri_goal = angle(sub0 - pos), tri_V = angle(V) -- or angle(sub0 - old pos) after a collision.  Only
     // cos|tri_goal - tri_V| is ever used, so the vectors are kept and cos_between() replaces two atan2 chains.
     P.tgx = o.s0x - o.px; P.tgy = o.s0y - o.py;                                // :422
+}
+__device__ __forceinline__ void step_pre(const StepArgs &a, double a0, Agent &g, PreStep &P)
+{
+    step_pre_dists(g, P);
+    if (!P.moved) return;
+    const double seta_new = g.head + a0 * a.steer;                             // :411 (cached: same V_vector), :414
+    double sn, cs;
+    sincos(seta_new, &sn, &cs);
+    step_pre_move(a, g, P, sn, cs);
 }
 
 // The heading after the move, :423 (and obs[7], and the next step's :411): depends on the OLD heading and the action
@@ -1256,6 +1274,8 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         if (!POLICY) {
             a0 = decode_action(ra, a.action_kind, a.n_actions);
             if (!skip) step_pre(a, a0, g, pre);
+        } else if (!skip) {
+            step_pre_dists(g, pre);      // the action-independent half, while the policy's weights are still in flight
         }
     }
     __syncthreads();                                                         // world (and fc1) staged
@@ -1263,17 +1283,15 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
     const WorldLds<MaskT> w = world_view<MaskT>(smem, a);
     if (POLICY) {                        // policy prologue, part 3: forward, layer 2, epsilon-greedy
         uavq::floatx4 h[4];
+        uavq::W2Frag<4> F;
         // (bit-identical either way: the same MFMAs in the same order per accumulator; measured at 16 384 agents, round 5: 29.26 ->
         // 29.08 us per configs[1] pass with the operands requested first)
         if (PAHEAD) uavq::fwd_strip_split_ahead<false>(pW1, prow, h);
         else uavq::fwd_strip_split<false>(pW1, prow, h);
         UAV_PSTAMP(2);
         float q[4];
-        {
-            uavq::W2Frag<4> F;
-            uavq::w2_load<4>(F, pW2, pb2, pol_n2);
-            uavq::q_strip<4>(h, F, pol_n2, a.n_actions, a.pol_dueling, q);
-        }
+        uavq::w2_load<4>(F, pW2, pb2, pol_n2);     // (requested in front of the forward it costs 52 registers across it: 227 + 32 -> 255 + 76, and the forward 1.2 k cycles)
+        uavq::q_strip<4>(h, F, pol_n2, a.n_actions, a.pol_dueling, q);
         if (lane < 16) {
             const float sample = (float)(pol_rn.x >> 8) * (1.0f / 16777216.0f);
             int act;
@@ -1295,7 +1313,11 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         if (wv == 0 || wv == 2) ra.lo = (uint32_t)pact[lane];
         if (wv == 0) {
             a0 = decode_action(ra, UAVENV_ACT_INDEX_I32, a.n_actions);
-            if (!skip) step_pre(a, a0, g, pre);
+            if (!skip && pre.moved) {    // (step_pre's other half: the distances were taken in front of the staging barrier)
+                double sn, cs;
+                sincos(g.head + a0 * a.steer, &sn, &cs);
+                step_pre_move(a, g, pre, sn, cs);
+            }
         }
     }
     UAV_PSTAMP(5);

@@ -112,7 +112,7 @@ class DeviceReplayRing:
         self.filled = min(self.filled + 1, self.frames - 1)
 
     def step_policy(self, learner, eps: float, seed: int, counter: int, auto_reset: bool = True, skip_done: bool = None,
-                    image: torch.Tensor = None) -> bool:
+                    image: torch.Tensor = None, agent_done: torch.Tensor = None) -> bool:
         """get_action + step in ONE launch (uavenv_step_policy: Q(s) + epsilon-greedy in the step kernel's prologue, the
         launch csrc/loop.hip issues per pass).  Returns False -- nothing enqueued -- when this env / net cannot take it
         (the callers then issue learner.act + step_env)."""
@@ -128,7 +128,8 @@ class DeviceReplayRing:
         rc = fn(self.env._h, C.byref(learner.net), self.obs.data_ptr() + t * self._obs_stride,
                 float(eps), int(seed), int(counter), self.action.data_ptr() + t * n * 4,
                 self.obs.data_ptr() + nxt * self._obs_stride, None,
-                self.reward.data_ptr() + t * n * 4, self.done.data_ptr() + t * n, None, None,
+                self.reward.data_ptr() + t * n * 4, self.done.data_ptr() + t * n,
+                None if agent_done is None else agent_done.data_ptr(), None,      # (agent_done: uint8 [N], which agents ended an episode)
                 self.valid.data_ptr() + t * n, None, None, flags, *tail)
         if rc == _lib.EINVAL:
             return False

@@ -19,15 +19,17 @@ PMC_SETS=traffic bash scripts/profile_round.sh ${TAG}_config4 --config 4 > $O/${
 python scripts/summarize_profile.py ${TAG}_config4 envs32768_batch32768_sac_packed >> $O/${TAG}_summary_entry.json 2>&1
 cp profiles/summary.json $O/${TAG}_summary.json
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+cp bench_full.json $O/${TAG}_bench_full.json; cp bench_other_configs.json $O/${TAG}_bench_other_configs.json
 rm -rf /tmp/prof_apf; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_apf -o bench -- python $GRAFT_REPO_ROOT/bench.py --env-only --envs 32768 --uav-per-env 4 --apf --no-cpu-baseline --steps 1) > /tmp/apf.log 2>&1
 find /tmp/prof_apf -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_apf_envonly_kernel_stats.csv
 # two ranks sharing this GPU (bench.py starts them itself): the peer exchange with its in-run no-exchange leg; the fault drill
 python bench.py --gpus 2 --same-device --dist-backend gloo --no-cpu-baseline --steps 8 --warmup 2 > $O/${TAG}_2rank_samedev_p2p.json 2> $O/${TAG}_2rank.err
 python bench.py --gpus 2 --same-device --dist-backend gloo --no-cpu-baseline --inject-p2p-fault 1 --no-exchange-leg --steps 8 --warmup 2 > $O/${TAG}_2rank_samedev_fault_drill.json 2>> $O/${TAG}_2rank.err
-python bench.py --no-cpu-baseline --no-other-configs --replan-every 64 --replan-count 256 --steps 20 --warmup 4 2>/dev/null > $O/${TAG}_replan_bench.json
+python bench.py --no-cpu-baseline --no-other-configs --full-line --replan-every 256 --replan-count 16384 --steps 20 --warmup 4 2>/dev/null > $O/${TAG}_replan_bench.json
+bash scripts/calib/run_calibration.sh ${TAG} > /dev/null 2>&1
 python -c "
 import json
-d=json.loads(open('$O/${TAG}_bench.json').read().strip().splitlines()[-1])
+d=json.load(open('$O/${TAG}_bench_full.json'))
 r=d['roofline']
 print('headline', d['value'], d['ms_per_pass'], r['frac'], r['frac_physical_stored'], r['frac_physical_counters'], r.get('traffic_stale'), d['roofline_learner']['frac'])
 for r in d.get('other_configs', []):
