@@ -334,6 +334,9 @@ def parse():
     p.add_argument("--p2p-check-every", type=int, default=256, help="N > 1: on-device weight checksum compare every that many updates")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) | gloo (test: several ranks on one GPU)")
     p.add_argument("--same-device", action="store_true", help="test only: every rank uses cuda:0")
+    p.add_argument("--no-reset-count", action="store_true",
+                   help="skip the 1 024 extra policy + step launches that count episode ends (scripts/profile_round.sh: under rocprofv3 "
+                        "they would enter the kernel's average -- each follows a torch reduction, not a learner launch)")
     p.add_argument("--full-line", action="store_true", help="print the whole result dict instead of the bounded headline line")
     p.add_argument("--no-obs", action="store_true", help="diagnostic (env-only): skip the observation")
     p.add_argument("--env-only", action="store_true", help="diagnostic: time only back-to-back k_step launches")
@@ -1238,7 +1241,7 @@ def run_dqn(args, world_size, rank, dev):
         # reaches a sub-goal, every agent times out after Max_Step = 150 steps, and the window read whatever part of that it caught.)
         done_ = torch.zeros(env.N, dtype=torch.uint8, device=dev)
         tot = torch.zeros((), dtype=torch.int64, device=dev)
-        n_extra, ok_ = 1024, fused
+        n_extra, ok_ = 1024, fused and not args.no_reset_count
         for i_ in range(n_extra if ok_ else 0):
             if not ring.step_policy(learner, args.eps, seed, (1 << 41) + i_, agent_done=done_):
                 ok_ = False

@@ -6,13 +6,13 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
-ARGS="--steps ${PROF_STEPS:-2} --warmup 1 --no-cpu-baseline --no-other-configs --env-only-iters 50 $*"
+ARGS="--steps ${PROF_STEPS:-2} --warmup 1 --no-cpu-baseline --no-other-configs --no-reset-count --env-only-iters 50 $*"
 rm -rf /tmp/prof_$TAG
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS) > $OUT/${TAG}_stats.log 2>&1
 find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
 tail -1 $OUT/${TAG}_stats.log > $OUT/${TAG}_bench_under_rocprof.json
 head -12 $OUT/${TAG}_kernel_stats.csv
-PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --env-only-iters 20 $*"
+PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --no-reset-count --env-only-iters 20 $*"
 : > $OUT/${TAG}_pmc.txt
 # PMC_SETS=traffic: only the two HBM-traffic passes (FETCH_SIZE, WRITE_SIZE: separate passes, MI355X_MICROARCH.md)
 if [ "$PMC_SETS" = "traffic" ]; then
