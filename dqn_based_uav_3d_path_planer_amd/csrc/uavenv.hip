@@ -1274,9 +1274,12 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         if (!POLICY) {
             a0 = decode_action(ra, a.action_kind, a.n_actions);
             if (!skip) step_pre(a, a0, g, pre);
-        } else if (!skip) {
+        }
+#ifndef UAVENV_PRE_DISTS_LATE            // (A/B knob: the round-5 placement, all of step_pre behind the action barrier)
+        else if (!skip) {
             step_pre_dists(g, pre);      // the action-independent half, while the policy's weights are still in flight
         }
+#endif
     }
     __syncthreads();                                                         // world (and fc1) staged
     UAV_PSTAMP(1);
@@ -1313,11 +1316,15 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         if (wv == 0 || wv == 2) ra.lo = (uint32_t)pact[lane];
         if (wv == 0) {
             a0 = decode_action(ra, UAVENV_ACT_INDEX_I32, a.n_actions);
+#ifdef UAVENV_PRE_DISTS_LATE
+            if (!skip) step_pre(a, a0, g, pre);
+#else
             if (!skip && pre.moved) {    // (step_pre's other half: the distances were taken in front of the staging barrier)
                 double sn, cs;
                 sincos(g.head + a0 * a.steer, &sn, &cs);
                 step_pre_move(a, g, pre, sn, cs);
             }
+#endif
         }
     }
     UAV_PSTAMP(5);
