@@ -63,14 +63,9 @@ class PathPlan_City:
         # ---- PathPlan_City.__init__ (Envs/PathPlan_City.py:31-103)
         self.eps = float(None2Value(param.get("eps"), 0.1))
         self.Is_On_Policy = int(None2Value(param.get("Is_On_Policy"), 0))
-        if self.Is_On_Policy == 1:
-            # Envs/PathPlan_City.py:419-436 (run_thread_OnPolicy: one thread per UAV per step, the AC-family update after the
-            # episode) is outside this build's path (the off-policy loop :364-385).  Fail closed: raising
-            # here makes EnvFactory.Create_Env print the reason and return None (FactoryClass/EnvFactory.py:21-23) instead of
-            # silently training such a config off-policy.
-            raise NotImplementedError("PathPlan_City: <Is_On_Policy>1</Is_On_Policy> (on-policy sampling, Envs/PathPlan_City.py:"
-                                      "419-436) is not built here; this plugin runs the off-policy loop only "
-                                      "(run_thread_OffPolicy, :364-385).  Set Is_On_Policy to 0 or use the reference's env.")
+        # Is_On_Policy = 1 (Envs/PathPlan_City.py:386-436): every UAV collects its whole episode in transition_dict (nothing goes to the
+        # replay memory) and trains ONCE after the episode -- the general per-step path here (_run_eposide_on_policy); the fused loops
+        # are the off-policy ones (run_thread_OffPolicy, :364-385) and stay off for such a config.
         self.param = param
         self.buildings = []
         threaten_params = param.get("Obstacles")
@@ -104,6 +99,8 @@ class PathPlan_City:
                                int(None2Value(sacp.get("IS_Continuous"), 0)) == 1 and param.get("obs_dtype") is None and
                                int(None2Value(tcfg.get("Batch_Size"), 128)) % 64 == 0 and
                                int(None2Value(tcfg.get("fused"), 1)) != 0 and torch.cuda.is_available())
+        if self.Is_On_Policy == 1:
+            self._want_fast = self._want_fast_sac = False
         if self._want_fast or self._want_fast_sac:
             obs_dtype = "packed"
         fp = (uav_params.get("Power_param") or {}).get("Fly_power") or {}
@@ -717,9 +714,68 @@ class PathPlan_City:
         self._federated_merge()
         return self.result
 
+    def _run_eposide_on_policy(self, eps_rate=0.1):
+        """PathPlan_City.py:419-436 + run_thread_OnPolicy (:386-406), for all vectorised envs at once: per time step every UAV that is
+        not done acts (Choose_Action2 -> Trainer.get_action, :338-346), moves, and APPENDS the transition to its own transition_dict;
+        nothing is pushed to a replay memory and nothing is learnt until every agent is done -- then ONE update() (:436), i.e. one
+        Train_nn per UAV on its whole episode.  (The reference starts one thread per UAV per step and joins them all: the UAVs do not
+        interact, so the result is that of the loop below.)"""
+        self.Reset_Result(eps_rate)
+        self.Scene_Random_Reset()
+        names = ("normal", "success", "lose")
+        keys = ("states", "actions", "next_states", "rewards", "dones")
+        acc = [{k: [] for k in keys} for _ in self.Agents]
+        while True:
+            self.run()
+            states = self._obs
+            s_view = states.view(self.num_envs, self.num_UAV, -1)
+            chosen = [uav.Trainer.get_action_batch(s_view[:, j], eps_rate).to(states.device) for j, uav in enumerate(self.Agents)]
+            continuous = any(c.dim() == 2 for c in chosen)
+            actions = torch.zeros((self.num_envs, self.num_UAV), dtype=torch.float32 if continuous else torch.int32, device=states.device)
+            for j, c in enumerate(chosen):
+                if c.dim() == 2:
+                    actions[:, j] = c[:, 0].float()
+                elif continuous:
+                    actions[:, j] = -1.0 + 2.0 * c.float() / (self.Agents[j].Trainer.act_num - 1)
+                else:
+                    actions[:, j] = c.to(torch.int32)
+            out = self.backend.step(actions.reshape(-1).contiguous(), skip_done=True)     # `if uav.done: return` (:388-389)
+            self._obs = out.obs
+            self._invalidate()
+            self._record_paths(range(self.num_UAV))
+            info = out.info.view(self.num_envs, self.num_UAV)
+            valid = out.valid.view(self.num_envs, self.num_UAV).bool()
+            for k, nm in enumerate(names):
+                self.result[nm] += int(((info == k) & valid).sum().item())                # Run_statistics (:395)
+            n_view = out.obs.view(self.num_envs, self.num_UAV, -1)
+            r_view = out.reward32.view(self.num_envs, self.num_UAV)
+            d_view = out.ret_done.view(self.num_envs, self.num_UAV)
+            for j in range(self.num_UAV):
+                keep = valid[:, j]
+                a = acc[j]
+                a["states"].append(s_view[keep, j].float())
+                a["actions"].append(chosen[j][keep])
+                a["next_states"].append(n_view[keep, j].float())
+                a["rewards"].append(r_view[keep, j].float())
+                a["dones"].append(d_view[keep, j].float())
+            if self.Check_uav_Done():
+                break
+        for j, uav in enumerate(self.Agents):
+            uav.transition_dict = {k: torch.cat(acc[j][k]) for k in keys}
+        train_info = self.update()                                                        # :436, after the episode
+        self.Train_statistics(train_info)
+        self.epoch += 1
+        if self.epoch % self.print_loop == 0:
+            for uav in self.Agents:
+                uav.record_list()
+        self._federated_merge()
+        return self.result
+
     def run_eposide(self, eps_rate=0.1):
         """PathPlan_City.py:410-478 (off-policy branch) for all vectorised envs at once: reset, then
         act -> step -> store -> sample -> learn per time step until every agent of every env is done."""
+        if self.Is_On_Policy == 1:
+            return self._run_eposide_on_policy(eps_rate)
         if self.fast:
             return self._run_eposide_fused(eps_rate)
         if self.fast_sac:

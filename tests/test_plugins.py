@@ -146,26 +146,46 @@ def test_run_eposide_contract_vectorised(cfg_dir):
     assert sim.epoch == 10 and len(sim.infos) == 10 and sim.Max_score >= max(i["average_score"] for i in sim.infos) - 1e-9
 
 
-def test_on_policy_configs_fail_closed(cfg_dir, capsys):
-    """<Is_On_Policy>1</Is_On_Policy> selects the reference's run_thread_OnPolicy branch (Envs/PathPlan_City.py:419-436), which
-    this build does not have: the factory must print the reason and return None (FactoryClass/EnvFactory.py:21-23) -- never
-    run the off-policy loop under that name."""
+def test_on_policy_episode_collects_then_trains_once(cfg_dir):
+    """<Is_On_Policy>1</Is_On_Policy> = the reference's run_thread_OnPolicy branch (Envs/PathPlan_City.py:386-436): every UAV appends
+    each of its transitions to its own transition_dict, NOTHING goes to the replay memory, and there is exactly ONE update() -- one
+    Train_nn per UAV on the whole episode -- after every agent is done; the off-policy loop (:364-385) learns at every step instead."""
     import re
-    xml = driver.make_config_dir(str(cfg_dir), "DQN", num_envs=4)
+    xml = driver.make_config_dir(str(cfg_dir), "DuelingDQN", num_envs=4, num_uav=2)
     s = open(xml).read()
     s, n = re.subn(r"<Is_On_Policy>\s*0\s*</Is_On_Policy>", "<Is_On_Policy>1</Is_On_Policy>", s)
     assert n == 1
     open(xml, "w").write(s)
-    param = XML2Dict(xml).get("simulator").get("env") if XML2Dict(xml).get("simulator") else None
     sim = driver.simulator(xml)
-    assert sim.env is None
-    out = capsys.readouterr().out
-    assert "Is_On_Policy" in out and "419-436" in out
-    if param is not None:
-        assert factories.EnvFactory().Create_Env(param) is None
-    # the same file with the flag back at 0 constructs
+    env = sim.env
+    assert env is not None and env.Is_On_Policy == 1 and not env.fast and not env.fast_sac
+    random.seed(1)
+    torch.manual_seed(1)
+    seen = []
+    for uav in env.Agents:                                   # count the update() calls and what they are given
+        tr = uav.Trainer
+        orig = tr.update
+        tr.update = (lambda td, _o=orig, _j=uav.j: (seen.append((_j, len(td["states"]))), _o(td))[1])
+    e0 = [u.Trainer.epoch for u in env.Agents]
+    res = env.run_eposide(0.3)
+    moved = res["normal"] + res["success"] + res["lose"]
+    assert env.Check_uav_Done() and moved >= 4 * 2 * 2
+    assert sorted(j for j, _ in seen) == [0, 1]                                   # ONE update per UAV, after the episode
+    assert sum(n for _, n in seen) == moved                                       # ... on every transition its agents made
+    for u, e in zip(env.Agents, e0):
+        assert u.Trainer.epoch == e + 1 and len(u.Trainer.replay_memory) == 0     # the replay memory is not part of this branch
+        td = u.transition_dict
+        assert len(td["states"]) == len(td["actions"]) == len(td["next_states"]) == len(td["rewards"]) == len(td["dones"])
+        assert tuple(td["states"].shape[1:]) == (100,) and td["dones"].max() <= 1
+    assert set(res) >= {"success", "lose", "normal", "loss", "sum_epoch", "average_score"} and np.isfinite(float(res["loss"]))
+    # a second episode starts from empty transition lists (:421-422)
+    seen.clear()
+    res2 = env.run_eposide(0.3)
+    assert sum(n for _, n in seen) == res2["normal"] + res2["success"] + res2["lose"]
+    # the same file with the flag at 0 runs the off-policy loop: many updates per episode
     open(xml, "w").write(s.replace("<Is_On_Policy>1</Is_On_Policy>", "<Is_On_Policy>0</Is_On_Policy>"))
-    assert driver.simulator(xml).env is not None
+    env0 = driver.simulator(xml).env
+    assert env0 is not None and env0.Is_On_Policy == 0
 
 
 def test_run_eposide_with_sac_continuous_actions(cfg_dir):
