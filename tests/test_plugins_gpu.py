@@ -43,6 +43,31 @@ def test_run_eposide_on_device(tmp_path, monkeypatch):
     assert np.isfinite(res["loss"])
 
 
+def test_on_policy_episode_on_device(tmp_path, monkeypatch):
+    """Is_On_Policy = 1 (Envs/PathPlan_City.py:386-436) on the real backend: 256 envs x 2 UAVs collect their episode, the fused
+    trainers take ONE update each on it (an arbitrary batch through FusedDQNLearner.learn), the replay memories stay empty."""
+    import re
+    from dqn_based_uav_3d_path_planer_amd import driver
+    monkeypatch.chdir(tmp_path)
+    xml = driver.make_config_dir(str(tmp_path), "DuelingDQN", num_envs=256, num_uav=2)
+    s = open(xml).read()
+    s, n = re.subn(r"<Is_On_Policy>\s*0\s*</Is_On_Policy>", "<Is_On_Policy>1</Is_On_Policy>", s)
+    assert n == 1
+    open(xml, "w").write(s)
+    env = driver.simulator(xml).env
+    assert env is not None and env.Is_On_Policy == 1 and not env.fast and type(env.backend).__name__ == "VecPathPlanEnv"
+    torch.manual_seed(0)
+    w0 = [u.Trainer.q_local.state_dict()["fc1.weight"].clone() for u in env.Agents]
+    res = env.run_eposide(0.5)
+    moved = res["normal"] + res["success"] + res["lose"]
+    assert env.Check_uav_Done() and res["lose"] + res["success"] >= 512
+    assert sum(len(u.transition_dict["states"]) for u in env.Agents) == moved
+    for u, w in zip(env.Agents, w0):
+        assert u.Trainer.epoch == 1 and len(u.Trainer.replay_memory) == 0
+        assert not torch.equal(u.Trainer.q_local.state_dict()["fc1.weight"], w)      # the one update moved the weights
+    assert np.isfinite(float(res["loss"]))
+
+
 def _set_xml(path, **tags):
     import re
     s = path.read_text()
