@@ -420,6 +420,17 @@ __device__ __forceinline__ int flag_aoff(int kk, int g)
 }
 // the pre-activations of layer 1 for this lane's sample (the C/D layout of fwd_strip_packed: registers = hidden units
 // 16 t + 4 g + reg).  EXT: scalar-block entries 16 / 17 carry the critics' action columns.
+// x[4 i + g] for a lane's group g = lane >> 4 (the K index of the f32 MFMA step i): a four-way select on per-lane data.  Written as
+// nested ?: it compiles to DIVERGENT CONTROL FLOW on gfx950 (s_and_saveexec / s_cbranch_execz / v_mov per arm: ~15 instructions
+// per select, sixteen selects per strip); as two levels of bit-field inserts it is three v_bfi_b32.  m1 / m2 = all ones where bit 0 /
+// bit 1 of g is set.
+__device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, uint32_t m1, uint32_t m2)
+{
+    const uint32_t lo = (__float_as_uint(a1) & m1) | (__float_as_uint(a0) & ~m1);
+    const uint32_t hi = (__float_as_uint(a3) & m1) | (__float_as_uint(a2) & ~m1);
+    return __uint_as_float((hi & m2) | (lo & ~m2));
+}
+
 template <bool EXT>
 __device__ __forceinline__ void fwd_strip_split_ahead(const W1Split &S, const PRow &R, floatx4 (&acc)[4], float e0 = 0.0f, float e1 = 0.0f)
 {
@@ -447,8 +458,9 @@ __device__ __forceinline__ void fwd_strip_split_ahead(const W1Split &S, const PR
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) b[kk] = bits_to_half8(flag_byte(R, kk, g));
     float bv[NS];
+    const uint32_t gm1 = 0u - (uint32_t)(g & 1), gm2 = 0u - (uint32_t)(g >> 1);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) bv[i] = g == 0 ? x[4 * i] : (g == 1 ? x[4 * i + 1] : (g == 2 ? x[4 * i + 2] : x[4 * i + 3]));
+    for (int i = 0; i < NS; ++i) bv[i] = sel4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3], gm1, gm2);
     floatx4 am[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { acc[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; am[t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f}; }
@@ -493,7 +505,7 @@ __device__ __forceinline__ void fwd_strip_split(const W1Split &S, const PRow &R,
                            R.sg[0], R.sg[1], R.sg[2], R.sg[3], 1.0f, EXT ? e0 : 0.0f, EXT ? e1 : 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < (EXT ? 5 : 4); ++i) {
-        const float bv = g == 0 ? x[4 * i] : (g == 1 ? x[4 * i + 1] : (g == 2 ? x[4 * i + 2] : x[4 * i + 3]));
+        const float bv = sel4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3], 0u - (uint32_t)(g & 1), 0u - (uint32_t)(g >> 1));
         float a[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) a[t] = S.sc[(16 * t + r) * kScK + 4 * i + g];

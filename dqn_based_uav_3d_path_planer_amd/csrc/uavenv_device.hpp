@@ -363,22 +363,22 @@ __device__ __forceinline__ ObsBits obs_bits_queued(const WorldLds<MaskT> &w, Obs
         const bool have = m != 0;
         const int b = have ? ctz_mask(m) : 0;
         if (have) m &= (MaskT)(m - 1);
-        bool full[3] = {false, false, false};
-        if (have) {
+        bool full[3];
+        {   // (predicated, not branched: the if / else-if ladder per stencil compiled to one divergent branch per arm, ~20 cycles each
+            // with one wavefront per SIMD; a lane without a candidate reads cylinder 0 and masks everything with `have`)
             const BldLds B = w.b[b];
             const BldAux X = w.aux[b];
             const double dcx = px - B.cx, dcy = py - B.cy;
             const double dc2 = dcx * dcx + dcy * dcy;
-            if (need_below & (dc2 < B.thr)) {
+            const bool under = have & need_below & (dc2 < B.thr);
 #pragma unroll
-                for (int k = 1; k <= 5; ++k) bl |= !((pz - (double)k) > B.H) ? (1u << (k - 1)) : 0u;
-            }
-            if (!(pz > B.H)) {
+            for (int k = 1; k <= 5; ++k) bl |= (under & !((pz - (double)k) > B.H)) ? (1u << (k - 1)) : 0u;
+            const bool low = have & !(pz > B.H);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    if (dc2 < X.acc2[k]) bits[k] = 0x1FFFFFFu;          // stencil entirely inside the disc
-                    else if (dc2 < X.rej2[k]) full[k] = true;           // can touch: needs the 25 exact tests
-                }
+            for (int k = 0; k < 3; ++k) {
+                const bool in = dc2 < X.acc2[k];                           // stencil entirely inside the disc
+                bits[k] |= (low & in) ? 0x1FFFFFFu : 0u;
+                full[k] = low & !in & (dc2 < X.rej2[k]);                   // can touch: needs the 25 exact tests
             }
         }
 #pragma unroll
@@ -441,18 +441,18 @@ __device__ __forceinline__ ObsBits obs_cand_queued(const WorldLds<MaskT> &w, Obs
         m &= (MaskT)(m - 1);                         // this candidate, and the two the other phases take
         m &= (MaskT)(m - 1);
         m &= (MaskT)(m - 1);
-        bool full[3] = {false, false, false};
-        if (have) {
+        bool full[3];
+        {   // (predicated, not branched: see obs_bits_queued)
             const BldLds B = w.b[b];
             const BldAux X = w.aux[b];
             const double dcx = px - B.cx, dcy = py - B.cy;
             const double dc2 = dcx * dcx + dcy * dcy;
-            if (!(pz > B.H)) {
+            const bool low = have & !(pz > B.H);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    if (dc2 < X.acc2[k]) bits[k] = 0x1FFFFFFu;          // stencil entirely inside the disc
-                    else if (dc2 < X.rej2[k]) full[k] = true;           // can touch: needs the 25 exact tests
-                }
+            for (int k = 0; k < 3; ++k) {
+                const bool in = dc2 < X.acc2[k];                           // stencil entirely inside the disc
+                bits[k] |= (low & in) ? 0x1FFFFFFu : 0u;
+                full[k] = low & !in & (dc2 < X.rej2[k]);                   // can touch: needs the 25 exact tests
             }
         }
 #pragma unroll
