@@ -102,7 +102,21 @@ struct W2Frag {
 };
 
 template <int NMAX>
+__device__ __forceinline__ void w2_load_n(W2Frag<NMAX> &F, const float *W2, const float *b2, int n2);
+template <int NMAX>
+__device__ __forceinline__ void q_strip_n(const floatx4 (&acc)[4], const W2Frag<NMAX> &F, int n2, int n_actions, int dueling, float (&q)[NMAX]);
+
+// n2 (the number of layer-2 rows) is a run-time value, so every `a < n2` below is a scalar compare + branch -- dozens per gradient
+// launch.  The reference's own shape (three actions, no value head: Qnet2 100-64-3) takes a copy in which it is a constant.
+template <int NMAX>
 __device__ __forceinline__ void w2_load(W2Frag<NMAX> &F, const float *W2, const float *b2, int n2)
+{
+    if (NMAX >= 3 && n2 == 3) w2_load_n<NMAX>(F, W2, b2, 3);
+    else w2_load_n<NMAX>(F, W2, b2, n2);
+}
+
+template <int NMAX>
+__device__ __forceinline__ void w2_load_n(W2Frag<NMAX> &F, const float *W2, const float *b2, int n2)
 {
     const int g = ((int)threadIdx.x & 63) >> 4;
 #pragma unroll
@@ -122,6 +136,14 @@ __device__ __forceinline__ void w2_load(W2Frag<NMAX> &F, const float *W2, const 
 template <int NMAX>
 __device__ __forceinline__ void q_strip(const floatx4 (&acc)[4], const W2Frag<NMAX> &F, int n2, int n_actions, int dueling,
                                         float (&q)[NMAX])
+{
+    if (NMAX >= 3 && n2 == 3 && n_actions == 3 && dueling == 0) q_strip_n<NMAX>(acc, F, 3, 3, 0, q);
+    else q_strip_n<NMAX>(acc, F, n2, n_actions, dueling, q);
+}
+
+template <int NMAX>
+__device__ __forceinline__ void q_strip_n(const floatx4 (&acc)[4], const W2Frag<NMAX> &F, int n2, int n_actions, int dueling,
+                                          float (&q)[NMAX])
 {
     floatx4 h[4];
 #pragma unroll

@@ -213,9 +213,9 @@ __device__ __forceinline__ void stage_copy(unsigned char *smem, const StepArgs &
         for (int r = 0; r < kInFlight; ++r)           // pin the loads here: keeps hipcc from sinking each one into
             asm volatile("" : "+v"(tmp[r].x), "+v"(tmp[r].y), "+v"(tmp[r].z), "+v"(tmp[r].w));   // its guarded store
 #pragma unroll
-        for (int r = 0; r < kInFlight; ++r) {
-            const int k = base + r * nthr + tid;
-            if (k < n16) dst[k] = tmp[r];
+        for (int r = 0; r < kInFlight; ++r) {         // unconditional too: a piece past the end was loaded from the last piece and is
+            const int k = base + r * nthr + tid;      // stored onto it (same bytes) -- a guarded store is a divergent branch each
+            dst[k < n16 ? k : n16 - 1] = tmp[r];
         }
     }
 }
@@ -1205,7 +1205,7 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         if (a.pol_img) uavq::img_issue(vW, a.pol_img);
         else { uavq::w_issue(vW, a.pol_local); uavq::w_issue_sc(pol_sc, a.pol_local, nl.b1); }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pol_w2[k] = nl.W2[tid + 256 * k < pol_n2 * uavq::kHid ? tid + 256 * k : 0];
+        for (int k = 0; k < 4; ++k) pol_w2[k] = nl.W2[tid + 256 * k < pol_n2 * uavq::kHid ? tid + 256 * k : pol_n2 * uavq::kHid - 1];
         pol_b2v = nl.b2[tid < pol_n2 ? tid : 0];
         uavq::prow_load(prow, a.pol_obs + (size_t)(pol_i < N ? pol_i : N - 1) * kPackedDwords);
         pol_rn = philox4x32_10(make_uint4((uint32_t)pol_i, (uint32_t)a.pol_counter, (uint32_t)(a.pol_counter >> 32), 0xac7u),
@@ -1261,8 +1261,10 @@ __global__ void __launch_bounds__(256) k_step_coop(StepArgs a)
         const int tid = (int)threadIdx.x;
         if (a.pol_img) uavq::img_commit(reinterpret_cast<float *>(smem + a.pol_off), vW); else uavq::w_commit_split(pW1, vW, pol_sc);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (tid + 256 * k < pol_n2 * uavq::kHid) pW2[tid + 256 * k] = pol_w2[k];
+        for (int k = 0; k < 4; ++k) {    // (clamped like the loads: past the end, the last element onto itself -- no guarded stores)
+            const int at = tid + 256 * k < pol_n2 * uavq::kHid ? tid + 256 * k : pol_n2 * uavq::kHid - 1;
+            pW2[at] = pol_w2[k];
+        }
         if (tid < pol_n2) pb2[tid] = pol_b2v;
     }
     if (wv >= 2) {                       // the world blob comes in through waves 2 and 3 (wave 1's loads depend on
