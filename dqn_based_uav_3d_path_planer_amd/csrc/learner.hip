@@ -1421,9 +1421,9 @@ __device__ __forceinline__ void grad_tile_h(const GradArgs &g, const GradLdsH &L
     floatx4 hl[4];
     fwd_strip_h(L.W1l, xs_strip, hl);
     W2Frag<NMAX> Fl;
-    w2_load<NMAX>(Fl, L.W2l, L.b2l, n2);
+    w2_load<NMAX, 3>(Fl, L.W2l, L.b2l, n2);
     float ql[NMAX];
-    q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+    q_strip<NMAX, 3>(hl, Fl, n2, g.n_actions, g.dueling, ql);
     xh_commit<KIND>(xn_strip, T.vXn, stage, nullptr);
     if (FIRST) {
         wh_commit(L.W1t, vWt, pb1t);
@@ -1437,7 +1437,7 @@ __device__ __forceinline__ void grad_tile_h(const GradArgs &g, const GradLdsH &L
     if (g.kind == 1) {                        // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
         fwd_strip_h(L.W1l, xn_strip, ht);
         float qn_l[NMAX];
-        q_strip<NMAX>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
+        q_strip<NMAX, 3>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
         float bq = qn_l[0];
 #pragma unroll
         for (int a = 1; a < NMAX; ++a)
@@ -1447,8 +1447,8 @@ __device__ __forceinline__ void grad_tile_h(const GradArgs &g, const GradLdsH &L
     float qt[NMAX];
     {
         W2Frag<NMAX> Ft;
-        w2_load<NMAX>(Ft, L.W2t, L.b2t, n2);
-        q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+        w2_load<NMAX, 3>(Ft, L.W2t, L.b2t, n2);
+        q_strip<NMAX, 3>(ht, Ft, n2, g.n_actions, g.dueling, qt);
     }
     L_STAMP(3);
     __syncthreads();                                  // every wave is done with its s' rows: HT / dHT overwrite that tile
@@ -1696,17 +1696,17 @@ __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
         if (grp == 0) {
             fwd_strip_h(W1l, x_strip, hl);
             W2Frag<NMAX> Fl;
-            w2_load<NMAX>(Fl, W2l, b2l, n2);
-            q_strip<NMAX>(hl, Fl, n2, g.n_actions, g.dueling, ql);
+            w2_load<NMAX, 3>(Fl, W2l, b2l, n2);
+            q_strip<NMAX, 3>(hl, Fl, n2, g.n_actions, g.dueling, ql);
         } else {
             int best = 0;
             floatx4 ht[4];
             if (g.kind == 1) {                // double DQN: a* = argmax_a Q_local(s', a)   (DDQN_Trainer.py:94)
                 fwd_strip_h(W1l, x_strip, ht);
                 W2Frag<NMAX> Fl;
-                w2_load<NMAX>(Fl, W2l, b2l, n2);
+                w2_load<NMAX, 3>(Fl, W2l, b2l, n2);
                 float qn_l[NMAX];
-                q_strip<NMAX>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
+                q_strip<NMAX, 3>(ht, Fl, n2, g.n_actions, g.dueling, qn_l);
                 float bq = qn_l[0];
 #pragma unroll
                 for (int a = 1; a < NMAX; ++a)
@@ -1714,9 +1714,9 @@ __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
             }
             fwd_strip_h(W1t, x_strip, ht);
             W2Frag<NMAX> Ft;
-            w2_load<NMAX>(Ft, W2t, b2t, n2);
+            w2_load<NMAX, 3>(Ft, W2t, b2t, n2);
             float qt[NMAX];
-            q_strip<NMAX>(ht, Ft, n2, g.n_actions, g.dueling, qt);
+            q_strip<NMAX, 3>(ht, Ft, n2, g.n_actions, g.dueling, qt);
             if (gq == 0) qn_lds[(i & 1) * kTile + strip * 16 + r] = pick_qn<NMAX>(g, qt, best);
             wave_lds_sync();                  // (the strip is rewritten by this wavefront's next commit)
         }
@@ -1731,7 +1731,7 @@ __global__ void __launch_bounds__(512) k_dqn_grad_h8(Grad2Args ga)
             for (int a = 0; a < NMAX + 2; ++a) Tc.csum[a] = A.csum[a];
             const int s = strip * 16 + r;
             W2Frag<NMAX> Fl;
-            w2_load<NMAX>(Fl, W2l, b2l, n2);
+            w2_load<NMAX, 3>(Fl, W2l, b2l, n2);
             td_backward<NMAX, true>(g, W2l, hl, Fl, ql, qn_lds[(i & 1) * kTile + s], p_act, p_rew, p_done, p_valid, p_w, smp, Tc,
                                     reinterpret_cast<float *>(HT + s), reinterpret_cast<float *>(dHT + s),
                                     reinterpret_cast<float *>(doutT + s));
@@ -2151,7 +2151,7 @@ __global__ void __launch_bounds__(256) k_dqn_act_h(ActArgs g)
     }
     __syncthreads();
     W2Frag<NMAX> F;
-    w2_load<NMAX>(F, W2, b2, n2);
+    w2_load<NMAX, 3>(F, W2, b2, n2);
     for (; tile < n_tiles; tile += (int)gridDim.x) {
         const int i = tile * kTile + wv * 16 + r;
         xh_commit<KIND>(strip, vX, stage + wv * kStageW, nullptr);
@@ -2162,7 +2162,7 @@ __global__ void __launch_bounds__(256) k_dqn_act_h(ActArgs g)
         floatx4 h[4];
         fwd_strip_h(W1, strip, h);
         float q[NMAX];
-        q_strip<NMAX>(h, F, n2, g.n_actions, g.dueling, q);
+        q_strip<NMAX, 3>(h, F, n2, g.n_actions, g.dueling, q);
         if (lane < 16 && i < g.n) {
             if (g.q_out) {
 #pragma unroll

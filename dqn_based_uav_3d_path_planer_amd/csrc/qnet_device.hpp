@@ -108,10 +108,14 @@ __device__ __forceinline__ void q_strip_n(const floatx4 (&acc)[4], const W2Frag<
 
 // n2 (the number of layer-2 rows) is a run-time value, so every `a < n2` below is a scalar compare + branch -- dozens per gradient
 // launch.  The reference's own shape (three actions, no value head: Qnet2 100-64-3) takes a copy in which it is a constant.
-template <int NMAX>
+// SPEC: which shapes get their own copy -- bit 0: Qnet2 100-64-3; bit 1: VAnet2 with three actions (3 + the value head), taken by the
+// f16 kernels of BASELINE configs[2] only: a third copy in the f32 kernels of configs[1] cost them more in code size than the branches
+// it removes (k_step_coop<policy> 10.05 -> 10.4 us), while configs[2] gained 1.5 us per pass.
+template <int NMAX, int SPEC = 1>
 __device__ __forceinline__ void w2_load(W2Frag<NMAX> &F, const float *W2, const float *b2, int n2)
 {
-    if (NMAX >= 3 && n2 == 3) w2_load_n<NMAX>(F, W2, b2, 3);
+    if ((SPEC & 1) && NMAX >= 3 && n2 == 3) w2_load_n<NMAX>(F, W2, b2, 3);
+    else if ((SPEC & 2) && NMAX >= 4 && n2 == 4) w2_load_n<NMAX>(F, W2, b2, 4);
     else w2_load_n<NMAX>(F, W2, b2, n2);
 }
 
@@ -133,11 +137,12 @@ __device__ __forceinline__ void w2_load_n(W2Frag<NMAX> &F, const float *W2, cons
 }
 
 // layer 2 + (dueling) Q for this lane's sample from its registers: q[a], a < n_actions.  acc holds pre-activations.
-template <int NMAX>
+template <int NMAX, int SPEC = 1>
 __device__ __forceinline__ void q_strip(const floatx4 (&acc)[4], const W2Frag<NMAX> &F, int n2, int n_actions, int dueling,
                                         float (&q)[NMAX])
 {
-    if (NMAX >= 3 && n2 == 3 && n_actions == 3 && dueling == 0) q_strip_n<NMAX>(acc, F, 3, 3, 0, q);
+    if ((SPEC & 1) && NMAX >= 3 && n2 == 3 && n_actions == 3 && dueling == 0) q_strip_n<NMAX>(acc, F, 3, 3, 0, q);
+    else if ((SPEC & 2) && NMAX >= 4 && n2 == 4 && n_actions == 3 && dueling != 0) q_strip_n<NMAX>(acc, F, 4, 3, 1, q);
     else q_strip_n<NMAX>(acc, F, n2, n_actions, dueling, q);
 }
 
@@ -674,7 +679,7 @@ __device__ __forceinline__ void polh_wave(int p, const float *flat, int n_action
         }
     }
     W2Frag<4> F;
-    w2_load<4>(F, nl.W2, nl.b2, n2);             // fc2 fragments straight from memory (16-byte aligned: 6 464 floats in)
+    w2_load<4, 3>(F, nl.W2, nl.b2, n2);          // fc2 fragments straight from memory (16-byte aligned: 6 464 floats in)
     __syncthreads();                             // fc1 tile complete (both halves); the agent wavefront: world staged
     POL_STAMP(2);
     const _Float16 z = (_Float16)0.0f;
@@ -711,7 +716,7 @@ __device__ __forceinline__ void polh_wave(int p, const float *flat, int n_action
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         float q[4];
-        q_strip<4>(acc[st], F, n2, n_actions, dueling, q);
+        q_strip<4, 3>(acc[st], F, n2, n_actions, dueling, q);
         if (lane < 16) qs[16 * st + lane] = floatx4{q[0], q[1], q[2], q[3]};
     }
     POL_STAMP(4);
