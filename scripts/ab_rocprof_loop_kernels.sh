@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B under rocprofv3 --kernel-trace --stats: the step / grad / reduce averages of the configs[1] loop for four builds
+# (wave priority on / off x the placement of step_pre's distances).  Round 6: profiles/r06_ab_prio_and_step_pre_under_rocprof.txt
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out; mkdir -p $O
 one() { rm -rf /tmp/prof_ab; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ab -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-reset-count --env-only-iters 50) > /tmp/ab.log 2>&1; f=$(find /tmp/prof_ab -name "*kernel_stats.csv" | head -1); python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --no-reset-count --full-line 2>/dev/null | tail -1 > /tmp/ab_un.json; python - "$f" "$1" <<'PY'
 import csv, sys, json

@@ -1,4 +1,6 @@
 #!/bin/bash
+# On the GPU box: the counter calibration, the reset-bank refresh sweep (slice size x planner wavefronts: fresh plans per second
+# against the pass time) and the env-only sweep over agents per launch.  Round 6: profiles/r06_replan_sweep.txt, r06_envonly_sweep.txt.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out; mkdir -p $O
 bash scripts/calib/run_calibration.sh r06 > /dev/null 2>&1
 : > $O/r06c_sweep.jsonl
