@@ -60,3 +60,19 @@ def test_side_files_hold_the_whole_result(tmp_path, monkeypatch):
     names = bench.write_side_files(full)
     assert json.load(open(tmp_path / names["bench_full"])) == full
     assert json.load(open(tmp_path / names["bench_other_configs"])) == full["other_configs"]
+
+
+def test_step_bytes_model_adds_up_to_what_the_counters_saw():
+    """bench.step_bytes_model: the per-plane bytes of a step launch.  Written bytes at configs[1] = the 282 B per agent-step that
+    WRITE_SIZE reported (profiles/r06_pmc.txt; the counter is exact on gfx950: profiles/r06_counter_calibration.txt); the totals stay
+    within 10 % of the counted traffic at every size a profile was committed for."""
+    m = bench.step_bytes_model(80, 16384, policy=True, records=True)
+    assert m["written_bytes"] == 176 + 80 + 16 + 4 + 2 + 4 == 282
+    assert abs(sum(m["read"].values()) - m["read_bytes"]) < 1e-9 and abs(m["total"] - m["read_bytes"] - m["written_bytes"]) < 1e-9
+    summ = json.load(open(os.path.join(ROOT, "profiles", "summary.json")))
+    got = summ["envs16384_batch16384_dqn_packed"]
+    assert got["k_step_policy_WRITE_SIZE_KB"] * 1024 / 16384 == pytest.approx(282, rel=0.01)
+    assert got["k_step_policy_traffic_bytes_per_launch"] / 16384 == pytest.approx(m["total"], rel=0.10)
+    for key, n in (("envonly65536_packed", 65536), ("envonly262144_packed", 262144)):
+        e = bench.step_bytes_model(80, n, policy=False, records=False)
+        assert summ[key]["k_step_traffic_bytes_per_launch"] / n == pytest.approx(e["total"], rel=0.10), key

@@ -120,3 +120,49 @@ def test_the_f16_policy_step_kernel_writes_the_records():
     torch.cuda.synchronize()
     _check(ring, slice(0, 5))
     env.close()
+
+
+@pytest.mark.parametrize("discrete", [True, False])
+def test_rewrite_records_follows_hand_edited_planes(discrete):
+    """DeviceReplayRing.rewrite_records: the fused learners read the RECORDS, so code that edits an action / reward / done /
+    valid plane by hand rebuilds them from the planes afterwards -- for the given frames only, the info byte (which has no plane in the
+    ring) kept, a second action component taken from the attached plane."""
+    from dqn_based_uav_3d_path_planer_amd.data import make_city26_env
+    from dqn_based_uav_3d_path_planer_amd.replay import DeviceReplayRing
+    n = 512
+    env = make_city26_env(n, obs_dtype="packed")
+    ring = DeviceReplayRing(env, 12 * n, discrete=discrete)
+    ring.reset(seed=9)
+    a1 = None
+    if not discrete:
+        a1 = torch.rand((ring.frames, n), device="cuda") * 2 - 1
+        ring.attach_action1(a1)
+    info = torch.zeros((ring.frames, n), dtype=torch.uint8, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for _ in range(8):
+        if discrete:
+            ring.current_action().copy_(torch.randint(0, 3, (n,), generator=gen, device="cuda", dtype=torch.int32))
+        else:
+            ring.current_action().copy_(torch.rand(n, generator=gen, device="cuda") * 2 - 1)
+        ring.step_env(auto_reset=True, info=info)
+    torch.cuda.synchronize()
+    _check(ring, slice(0, 8), info=info, a1=a1)
+    before = ring.meta.clone()
+    # hand-edit frames 2 and 5: rewards, dones, a block of actions, a few valid bytes
+    ring.reward[2] += 1.5
+    ring.done[5] ^= 1
+    ring.valid[5, :7] = 0
+    if discrete:
+        ring.action[2, :64] = 2
+    else:
+        ring.action[2, :64] = 0.25
+    assert not torch.equal(ring.meta[2][..., 2], ring.reward[2].view(torch.int32))          # the records are stale now
+    ring.rewrite_records([2, 5])
+    torch.cuda.synchronize()
+    _check(ring, slice(0, 8), info=info, a1=a1)                                             # planes == records again, info kept
+    untouched = [f for f in range(ring.frames) if f not in (2, 5)]
+    assert torch.equal(ring.meta[untouched], before[untouched])
+    ring.reward[:] = 0.0
+    ring.rewrite_records()                                                                  # all frames
+    assert int(ring.meta[..., 2].abs().max()) == 0
+    env.close()
