@@ -825,13 +825,16 @@ __device__ __forceinline__ uint4 ctile_packed_chunk(const uint32_t *tile, int ch
     const int r = chunk / 5, part = chunk - r * 5;
     const uint32_t *src = tile + r * kCTileLd;
     // part 0: masks | part 1: cols 0..3 | part 2: cols 4..7 | part 3: cols 8, 9, 10, 86 | part 4: cols 87, 88, 89, 0
-    const int b0 = part == 0 ? 0 : part == 1 ? 3 : part == 2 ? 7 : part == 3 ? 11 : 18;
+    // (arithmetic + an unconditional fourth load: the five-way ?: and the conditional load were a divergent branch each, in every
+    // packed-row step kernel's copy-out; b3 <= 21 stays inside the row of kCTileLd = 23 dwords)
+    const int b0 = 4 * part - (part != 0 ? 1 : 0) + (part == 4 ? 3 : 0);          // 0, 3, 7, 11, 18
     const int b3 = part == 3 ? 17 : b0 + 3;
     uint4 v;
     v.x = src[b0];
     v.y = src[b0 + 1];
     v.z = src[b0 + 2];
-    v.w = (part == 0 || part == 4) ? 0u : src[b3];
+    const uint32_t w3 = src[b3];
+    v.w = (part == 0 || part == 4) ? 0u : w3;
     return v;
 }
 
@@ -840,6 +843,11 @@ __device__ __forceinline__ void ctile_emit_packed_wave(void *obs_base, int64_t f
 {
     const int lane = (int)threadIdx.x & 63;
     uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(obs_base) + first_agent * kPackedDwords);
+    if (n_valid >= 64) {                  // wavefront-uniform: every wavefront but a launch's last stores unguarded
+#pragma unroll
+        for (int it = 0; it < 5; ++it) dst[it * 64 + lane] = ctile_packed_chunk(tile, it * 64 + lane);
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
         const int chunk = it * 64 + lane;
